@@ -1,0 +1,168 @@
+/*
+ * lto.h -- C ABI of liblto_hip.so: the MI355X (gfx950) multiple-shooting segment propagator.
+ *
+ * This is the drop-in boundary for the one data-parallel hot path of
+ * travelingspaceman/LowThrustOpt: the `defectCalc` / `jacobianCalc` closures nested inside
+ *   multiShoot_CRTBP_indirect  (src/multiShoot_CRTBP_indirect.jl:63-90, :93-146)
+ *   multiShoot_CRTBP_direct    (src/multiShoot_CRTBP_direct.jl:66-109, :111-166, tf partial :503-516)
+ * The reference has no FFI of its own (pure Julia); these entry points are what a `ccall` from the
+ * two Julia drivers binds instead of running the closures' serial `for i = 1:n_nodes-1` loops
+ * (INTEGRATION.md shows the Julia side).  Plain C: pointers, ints and doubles only.
+ *
+ * Conventions
+ *   - All floating point data is binary64.  Host arrays use the reference's Julia layouts
+ *     (column-major): XC_all is [ndim x n_nodes], defect is [ndim x (n_nodes-1)], ...
+ *   - `n_batch` independent trajectories (line-search trial points, homotopy levels) can be swept by
+ *     one call; host arrays then carry a trailing batch dimension.
+ *   - Return value: 0 = ok; < 0 = API misuse; > 0 = runtime failure (see LTO_E*).  Non-finite
+ *     results are not errors: NaN/Inf propagate into the outputs so the caller's driver reproduces the
+ *     reference's status_flag = 2 path (src/multiShoot_CRTBP_indirect.jl:339-341).
+ *   - The library never throws across the ABI, installs no signal handlers and keeps no host pointer
+ *     after a call returns.  One thread per context at a time; distinct contexts are independent.
+ */
+#ifndef LTO_H
+#define LTO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTO_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define LTO_OK 0
+#define LTO_EINVAL (-1)       /* bad dimension / count / enum                                   */
+#define LTO_ENULL (-2)        /* required pointer is NULL                                        */
+#define LTO_EUNSUPPORTED (-3) /* valid request this build does not implement                     */
+#define LTO_EHIP 1            /* HIP runtime error (message in lto_last_error)                   */
+#define LTO_EBADP 2           /* reference: error("Invalid value of p!") stateCostate_deriv.jl:52 */
+#define LTO_ENODEVICE 3       /* no usable gfx950 device                                         */
+
+/* Integrators.  RK4 = GeneralCode/ode.jl:21-73; RKF78_FIXED = ode7_8, ode.jl:773-953 (the direct
+ * path's integrator); RKF78_ADAPTIVE = ode78, ode.jl:364-544; DOP853_ADAPTIVE = order-8 adaptive pair
+ * standing in for OrdinaryDiffEq's Vern8() at reltol=abstol=1e-13 (multiShoot_CRTBP_indirect.jl:79). */
+#define LTO_RK4 0
+#define LTO_RKF78_FIXED 1
+#define LTO_RKF78_ADAPTIVE 2
+#define LTO_DOP853_ADAPTIVE 3
+
+typedef struct lto_ctx lto_ctx;
+typedef struct lto_indirect_plan lto_indirect_plan;
+typedef struct lto_direct_plan lto_direct_plan;
+
+typedef struct lto_integrator {
+  int method;    /* LTO_RK4 ...                                                        */
+  int steps;     /* fixed-step methods: number of equal steps per segment              */
+  double rtol;   /* adaptive methods (RKF78_ADAPTIVE uses rtol as ode78's `tol`)        */
+  double atol;
+  int max_steps; /* adaptive methods: per-segment cap on accepted+rejected steps (0 = 100000) */
+} lto_integrator;
+
+/* The reference's `params` tuple, src/multiShoot_CRTBP_indirect.jl:260 /
+ * src/CRTBP_stateCostate_deriv.jl:13, field for field. */
+typedef struct lto_params {
+  double MU, DU, TU, thrustLimit, mass, time_direction, p, rho;
+} lto_params;
+
+/* Arguments the direct closures forward to ode7_8 / CRTBP_prop_EP_deriv
+ * (src/multiShoot_CRTBP_direct.jl:86: MU, DU, TU, Isp). */
+typedef struct lto_direct_params {
+  double MU, DU, TU, Isp;
+} lto_direct_params;
+
+/* ------------------------------------------------------------------------------- context */
+/* One context per GPU (one process per GPU under torch.distributed / one Julia task).  device_id
+ * is the HIP ordinal.  Owns a stream and grow-only device staging buffers. */
+int lto_create(lto_ctx** out, int device_id);
+void lto_destroy(lto_ctx* ctx);
+const char* lto_last_error(const lto_ctx* ctx);
+int lto_version(void);
+/* When enabled, every sweep brackets its dominant kernel with HIP events on the launch stream;
+ * lto_last_kernel_ms blocks on the stop event and returns that kernel's duration. */
+int lto_set_timing(lto_ctx* ctx, int enabled);
+double lto_last_kernel_ms(lto_ctx* ctx);
+
+/* --------------------------------------------------------- host-pointer API (what Julia ccalls) */
+
+/* Replaces defectCalc of multiShoot_CRTBP_indirect (src/multiShoot_CRTBP_indirect.jl:63-90).
+ *   XC      [ndim x n_nodes x n_batch]   ndim = 12 (state+costate; 14 reserved)
+ *   t       [n_nodes x n_tgrids]         n_tgrids = 1 (shared grid) or n_batch
+ *   prm     [n_prm]                      n_prm = 1 or n_batch
+ *   defect  [ndim x (n_nodes-1) x n_batch]  = x(t_{i+1}; XC[:,i]) - XC[:,i+1]          (:82)
+ *   errors  [(n_nodes-1) x n_batch] or NULL: 0 for RK4 / adaptive (reference: always 0, :85),
+ *           RKF7(8) 8th-order estimate for RKF78_FIXED. */
+int lto_indirect_defect(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, const double* XC, const double* t,
+                        int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ, double* defect,
+                        double* errors);
+
+/* Replaces jacobianCalc of multiShoot_CRTBP_indirect (:93-146), compact form:
+ *   Phi     [ndim x ndim x (n_nodes-1) x n_batch], Phi[:,:,i] = d x(t_{i+1}) / d XC[:,i]
+ *           (= ForwardDiff.jacobian(f, x0), :121).  The caller forms [Phi_i | -I] (:123), the band
+ *           scatter (:128-138) and the fixed-endpoint column mask (:141-142).
+ *   defect  as above, or NULL. */
+int lto_indirect_jacobian(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, const double* XC, const double* t,
+                          int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ, double* Phi,
+                          double* defect);
+
+/* Replaces defectCalc of multiShoot_CRTBP_direct (src/multiShoot_CRTBP_direct.jl:66-109).
+ *   X [nstate x n_nodes x n_batch] (nstate = 6 or 7), U [3 x n_nodes x n_batch] thrust in N,
+ *   nsteps = points of the half-segment grid, i.e. nsteps-1 RKF7(8) steps per half (:84).
+ *   defect [nstate x (n_nodes-1) x n_batch], errors [(n_nodes-1) x n_batch] (:104). */
+int lto_direct_defect(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, const double* X, const double* U,
+                      const double* t, int n_tgrids, int nsteps, const lto_direct_params* prm, double* defect,
+                      double* errors);
+
+/* Replaces jacobianCalc of multiShoot_CRTBP_direct (:111-143) and the tf partial (:503-516).
+ *   Jac_temp    [nstate x nvar x (n_nodes-1) x n_batch], nvar = 2(nstate+3); block i is
+ *               d defect_i / d [x_i; x_{i+1}; u_i; u_{i+1}] (variable order of :125), computed from
+ *               the variational equations instead of the reference's forward differences.
+ *   ddefect_dtf [nstate x (n_nodes-1) x n_batch] or NULL (last column of Jac_full, :516)
+ *   defect, errors as lto_direct_defect, or NULL. */
+int lto_direct_jacobian(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, const double* X, const double* U,
+                        const double* t, int n_tgrids, int nsteps, const lto_direct_params* prm, double* Jac_temp,
+                        double* ddefect_dtf, double* defect, double* errors);
+
+/* ------------------------------------------------- device-resident API (operands already in HBM)
+ * Struct-of-arrays, segment/node index fastest, so that a wavefront's 64 lanes read 512
+ * contiguous bytes per component.  With J = n_nodes*n_batch nodes and S = (n_nodes-1)*n_batch
+ * segments (node j = b*n_nodes + k, segment s = b*(n_nodes-1) + i):
+ *   X[c*ldx + j]  t[g*n_nodes + k]  defect[c*ldd + s]  Phi[(col*ndim+row)*ldp + s]  errors[s]
+ *   U[c*ldu + j]  Jac[(col*nstate+row)*ldj + s]  dtf[c*ldd + s]
+ * Launches are asynchronous on `stream` (a hipStream_t; NULL = the context's stream). */
+int lto_indirect_plan_create(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
+                             const lto_integrator* integ, lto_indirect_plan** out);
+void lto_indirect_plan_destroy(lto_indirect_plan* plan);
+int lto_indirect_defect_dev(lto_indirect_plan* plan, void* stream, const double* X, long ldx, const double* t,
+                            int n_tgrids, double* defect, long ldd, double* errors);
+int lto_indirect_jacobian_dev(lto_indirect_plan* plan, void* stream, const double* X, long ldx, const double* t,
+                              int n_tgrids, double* Phi, long ldp, double* defect, long ldd);
+/* Per-segment accepted / rejected step counts of the last adaptive sweep (device pointers owned by the
+ * plan, S ints each; NULL for fixed-step plans). */
+const int* lto_indirect_plan_steps_accepted(const lto_indirect_plan* plan);
+const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* plan);
+/* Tuning knob: STM columns integrated per lane (1, 2, 3, 4, 6 or 12); 0 = choose from S. */
+int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);
+
+int lto_direct_plan_create(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, int nsteps,
+                           const lto_direct_params* prm, lto_direct_plan** out);
+void lto_direct_plan_destroy(lto_direct_plan* plan);
+int lto_direct_defect_dev(lto_direct_plan* plan, void* stream, const double* X, long ldx, const double* U, long ldu,
+                          const double* t, int n_tgrids, double* defect, long ldd, double* errors);
+int lto_direct_jacobian_dev(lto_direct_plan* plan, void* stream, const double* X, long ldx, const double* U,
+                            long ldu, const double* t, int n_tgrids, double* Jac, long ldj, double* dtf,
+                            double* defect, long ldd, double* errors);
+
+/* Layout kernels: Julia column-major [ndim x count] (node-contiguous) <-> SoA [ndim][ld]. */
+int lto_pack_soa_dev(lto_ctx* ctx, void* stream, const double* aos, int ndim, long count, double* soa, long ld);
+int lto_unpack_soa_dev(lto_ctx* ctx, void* stream, const double* soa, long ld, int ndim, long count, double* aos);
+
+/* Per-trajectory reductions the drivers take of a defect array (line search cost sum(defect.^2),
+ * src/multiShoot_CRTBP_indirect.jl:240; convergence test norm(defect[:], Inf), :331):
+ *   sumsq[b], maxabs[b] for b < n_batch over the ndim x seg_per_traj block of trajectory b. */
+int lto_defect_norms_dev(lto_ctx* ctx, void* stream, const double* defect, long ldd, int ndim, int seg_per_traj,
+                         int n_batch, double* sumsq, double* maxabs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTO_H */

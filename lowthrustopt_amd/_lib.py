@@ -1,0 +1,90 @@
+"""ctypes binding of liblto_hip.so (the C ABI declared in include/lto.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no GPU is visible the calls
+raise.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblto_hip.so")
+
+LTO_OK, LTO_EINVAL, LTO_ENULL, LTO_EUNSUPPORTED = 0, -1, -2, -3
+LTO_EHIP, LTO_EBADP, LTO_ENODEVICE = 1, 2, 3
+
+
+class LtoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lto error %d: %s" % (code, msg))
+        self.code = code
+
+
+class LtoIntegrator(C.Structure):
+    _fields_ = [("method", C.c_int), ("steps", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
+                ("max_steps", C.c_int)]
+
+
+class LtoParams(C.Structure):
+    """The reference's params tuple (src/multiShoot_CRTBP_indirect.jl:260)."""
+    _fields_ = [(n, C.c_double) for n in ("MU", "DU", "TU", "thrustLimit", "mass", "time_direction", "p", "rho")]
+
+
+class LtoDirectParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("MU", "DU", "TU", "Isp")]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); one entry per symbol declared in include/lto.h
+SIGNATURES = {
+    "lto_version": (C.c_int, []),
+    "lto_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "lto_destroy": (None, [_vp]),
+    "lto_last_error": (C.c_char_p, [_vp]),
+    "lto_set_timing": (C.c_int, [_vp, C.c_int]),
+    "lto_last_kernel_ms": (C.c_double, [_vp]),
+    "lto_indirect_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
+                                      C.POINTER(LtoIntegrator), _vp, _vp]),
+    "lto_indirect_jacobian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
+                                        C.POINTER(LtoIntegrator), _vp, _vp]),
+    "lto_direct_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                                    C.POINTER(LtoDirectParams), _vp, _vp]),
+    "lto_direct_jacobian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                                      C.POINTER(LtoDirectParams), _vp, _vp, _vp, _vp]),
+    "lto_indirect_plan_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(LtoParams), C.c_int,
+                                           C.POINTER(LtoIntegrator), C.POINTER(_vp)]),
+    "lto_indirect_plan_destroy": (None, [_vp]),
+    "lto_indirect_defect_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp]),
+    "lto_indirect_jacobian_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp, C.c_long]),
+    "lto_indirect_plan_steps_accepted": (_vp, [_vp]),
+    "lto_indirect_plan_steps_rejected": (_vp, [_vp]),
+    "lto_indirect_plan_set_cols_per_lane": (C.c_int, [_vp, C.c_int]),
+    "lto_direct_plan_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LtoDirectParams),
+                                         C.POINTER(_vp)]),
+    "lto_direct_plan_destroy": (None, [_vp]),
+    "lto_direct_defect_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp]),
+    "lto_direct_jacobian_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp, _vp,
+                                          C.c_long, _vp]),
+    "lto_pack_soa_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_long, _vp, C.c_long]),
+    "lto_unpack_soa_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, C.c_int, C.c_long, _vp]),
+    "lto_defect_norms_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def load_library():
+    """dlopen liblto_hip.so and attach prototypes.  Raises if the library has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise LtoError(LTO_ENODEVICE, "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB

@@ -1,0 +1,260 @@
+// dynamics.hpp -- CRTBP right-hand sides and their variational coefficients, gfx950 device code.
+//
+// fp64 VALU only (no MFMA: every product here is a register-resident 3x3 against a 3-vector).
+// Formulas: reference src/CRTBP_stateCostate_deriv.jl:9-90 (state+costate, "A1") and
+// src/CRTBP_prop_EP_deriv.jl:8-61 (given thrust, "A2"), restated through the symmetric gravity
+// gradient G (the reference's longhand costate rows :83-85 are exactly -G*lambda_v).  The variational
+// coefficients (H = d(G lambda_v)/dr, U = du/dlambda_v) do not exist in the reference, which
+// differentiates by ForwardDiff / finite differences (multiShoot_CRTBP_indirect.jl:121,
+// multiShoot_CRTBP_direct.jl:123-143); they are the same mathematical object.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lto {
+
+// Control-law modes of CRTBP_stateCostate_deriv! (stateCostate_deriv.jl:36-53).
+enum PMode : int { PM_P0 = 0, PM_P1 = 1, PM_P2 = 2, PM_PGEN = 3, PM_MIXED = 4 };
+
+// Per-trajectory constants, precomputed on the host in the reference's operation order.
+struct TrajParams {
+  double accel_limit;  // thrustLimit / mass / 1e3 * TU^2 / DU        (stateCostate_deriv.jl:33)
+  double inv_2rho;     // 1 / (2 rho)                                   (:43)
+  double al_over_rho;  // accel_limit / rho  (prefactor of d umag / d|lambda_v| for p = 1)
+  double p;            // control-law exponent
+  double inv_p;        // 1 / p
+  double inv_pm1;      // 1 / (p - 1)   (p > 1 only)
+  double omega;        // time_direction
+  double MU;           // CRTBP mass ratio
+};
+
+// 1/sqrt(x) to ~1 ulp: v_rsq_f64 seed (~2^-23 relative) + two second-order Newton steps.
+// Arguments here are squared distances / squared norms of O(1e-6 .. 1e2): no range scaling needed.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = __builtin_fma(-x * y, y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  e = __builtin_fma(-x * y, y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  return y;
+}
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps.
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return y;
+}
+
+// Coefficients one STM column needs at an RK stage of the 12-dim system:
+//   F = [0 I 0 0; G 2wJ 0 U; -H 0 0 -G; 0 0 -I 2wJ],  U d = -ua d + ub (l.d) l.
+struct VarCoef12 {
+  double Gxx, Gyy, Gzz, Gxy, Gxz, Gyz;
+  double Hxx, Hyy, Hzz, Hxy, Hxz, Hyz;
+  double ua, ub, lx, ly, lz;
+};
+
+// Thrust magnitude m(n), n = |lambda_v|, and (if VAR) m' = dm/dn, for one control-law mode.
+// Returns through references; `inv_n` is 1/n (0 when n == 0, the reference's NaN guard :59-64).
+template <int PM, bool VAR>
+__device__ __forceinline__ void control_law(const TrajParams& tp, double n, double inv_n, double& m, double& ua,
+                                            double& ub) {
+  const double aL = tp.accel_limit;
+  if (PM == PM_P0) {  // :36-39  umag = accelLimit
+    m = aL;
+    ua = aL * inv_n;
+    ub = ua;  // m' = 0
+  } else if (PM == PM_P1) {  // :41-43  umag = 1/2 (1 + tanh(g / (2 rho))) accelLimit, g = n - 1
+    // 1/2 (1 + tanh x) = 1 / (1 + exp(-2x)): evaluated without cancellation or overflow for any rho.
+    const double x = (n - 1.0) * tp.inv_2rho;
+    const double e = exp(-2.0 * fabs(x));
+    const double q = rcp_nr(1.0 + e);
+    const double sig = (x >= 0.0) ? q : e * q;
+    m = aL * sig;
+    ua = m * inv_n;
+    // m' = aL/(4 rho) sech^2 x = (aL / rho) e q^2
+    ub = VAR ? ua - tp.al_over_rho * (e * q) * q : 0.0;
+  } else if (PM == PM_P2) {  // :45-50 with p = 2: umag = n / 2, clamped at accelLimit
+    const double mu = 0.5 * n;
+    if (mu > aL) { m = aL; ua = aL * inv_n; ub = ua; }
+    else { m = mu; ua = 0.5; ub = 0.0; }  // u = -lambda_v / 2  =>  U = -I / 2 (also at n = 0)
+  } else {  // PM_PGEN :45-50  umag = (n / p)^(1 / (p - 1)), clamped
+    const double mu = pow(tp.inv_p * n, tp.inv_pm1);
+    if (mu > aL) { m = aL; ua = aL * inv_n; ub = ua; }
+    else { m = mu; ua = mu * inv_n; ub = VAR ? ua - ua * tp.inv_pm1 : 0.0; }  // m' = m / ((p-1) n)
+  }
+}
+
+// A1: ydot for y = (r, v, lambda_r, lambda_v); optionally the column coefficients.
+// y, dy are fully unrolled register arrays.
+template <int PM, bool VAR>
+__device__ __forceinline__ void rhs12(const double (&y)[12], const TrajParams& tp, double (&dy)[12], VarCoef12& vc) {
+  const double MU = tp.MU;
+  const double x = y[0], yy = y[1], z = y[2];
+  const double w2 = 2.0 * tp.omega;
+  const double a = x + MU, b = a - 1.0;
+  const double yz2 = __builtin_fma(yy, yy, z * z);
+  const double d1 = __builtin_fma(a, a, yz2), d2 = __builtin_fma(b, b, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
+  const double cs = c1 + c2;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double ee = e1 + e2;
+  const double sa = e1 * a, tb = e2 * b;
+  const double st = sa + tb;
+  // gravity-gradient + centrifugal matrix G (symmetric)
+  const double Gxx = __builtin_fma(sa, a, __builtin_fma(tb, b, 1.0 - cs));
+  const double Gyy = __builtin_fma(ee * yy, yy, 1.0 - cs);
+  const double Gzz = __builtin_fma(ee * z, z, -cs);
+  const double Gxy = st * yy, Gxz = st * z, Gyz = ee * yy * z;
+
+  // control  u = -m(n) lambda_v / n
+  const double lx0 = y[9], ly0 = y[10], lz0 = y[11];
+  const double n2 = __builtin_fma(lx0, lx0, __builtin_fma(ly0, ly0, lz0 * lz0));
+  const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
+  const double n = n2 * inv_n;
+  double m, ua, ub;
+  if (PM == PM_MIXED) {
+    if (tp.p == 1.0) control_law<PM_P1, VAR>(tp, n, inv_n, m, ua, ub);
+    else if (tp.p == 2.0) control_law<PM_P2, VAR>(tp, n, inv_n, m, ua, ub);
+    else if (tp.p == 0.0) control_law<PM_P0, VAR>(tp, n, inv_n, m, ua, ub);
+    else control_law<PM_PGEN, VAR>(tp, n, inv_n, m, ua, ub);
+  } else {
+    control_law<PM, VAR>(tp, n, inv_n, m, ua, ub);
+  }
+  const double lhx = lx0 * inv_n, lhy = ly0 * inv_n, lhz = lz0 * inv_n;
+
+  dy[0] = y[3]; dy[1] = y[4]; dy[2] = y[5];                                   // :78
+  dy[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))) - m * lhx;   // :79
+  dy[4] = __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)) - m * lhy;                       // :80
+  dy[5] = __builtin_fma(-cs, z, -m * lhz);                                                     // :81
+  // lambda_r dot = -G lambda_v                                                                 // :83-85
+  dy[6] = -__builtin_fma(Gxx, lx0, __builtin_fma(Gxy, ly0, Gxz * lz0));
+  dy[7] = -__builtin_fma(Gxy, lx0, __builtin_fma(Gyy, ly0, Gyz * lz0));
+  dy[8] = -__builtin_fma(Gxz, lx0, __builtin_fma(Gyz, ly0, Gzz * lz0));
+  dy[9] = __builtin_fma(w2, ly0, -y[6]);                                      // :86
+  dy[10] = __builtin_fma(-w2, lx0, -y[7]);                                    // :87
+  dy[11] = -y[8];                                                             // :88
+
+  if (VAR) {
+    vc.Gxx = Gxx; vc.Gyy = Gyy; vc.Gzz = Gzz; vc.Gxy = Gxy; vc.Gxz = Gxz; vc.Gyz = Gyz;
+    vc.ua = ua; vc.ub = ub; vc.lx = lhx; vc.ly = lhy; vc.lz = lhz;
+    // H = d(G lambda_v)/dr = sum_bodies e (s I + rho l^T + l rho^T) - f s rho rho^T,
+    //   e = 3 kappa / d^{5/2}, f = 5 e / d, s = rho . lambda_v
+    const double s1 = __builtin_fma(a, lx0, __builtin_fma(yy, ly0, z * lz0));
+    const double s2 = __builtin_fma(b, lx0, __builtin_fma(yy, ly0, z * lz0));
+    const double q1 = 5.0 * e1 * i1s * s1, q2 = 5.0 * e2 * i2s * s2;
+    const double es = __builtin_fma(e1, s1, e2 * s2);   // e1 s1 + e2 s2
+    const double qq = q1 + q2;
+    const double qa = __builtin_fma(q1, a, q2 * b);     // q1 a + q2 b
+    // diagonal: e(s + 2 rho_i l_i) - q rho_i^2
+    vc.Hxx = es + 2.0 * st * lx0 - __builtin_fma(q1 * a, a, q2 * b * b);
+    vc.Hyy = es + 2.0 * ee * yy * ly0 - qq * yy * yy;
+    vc.Hzz = es + 2.0 * ee * z * lz0 - qq * z * z;
+    // off-diagonal: e(rho_i l_j + rho_j l_i) - q rho_i rho_j
+    vc.Hxy = __builtin_fma(st, ly0, ee * yy * lx0) - qa * yy;
+    vc.Hxz = __builtin_fma(st, lz0, ee * z * lx0) - qa * z;
+    vc.Hyz = ee * __builtin_fma(yy, lz0, z * ly0) - qq * yy * z;
+  }
+}
+
+// One STM column c = (a, b, g, d) of the 12-dim system: cdot = F c.
+__device__ __forceinline__ void var_col12(const VarCoef12& vc, const double w2, const double (&c)[12], double (&dc)[12]) {
+  const double ax = c[0], ay = c[1], az = c[2];
+  const double dx = c[9], dyv = c[10], dz = c[11];
+  dc[0] = c[3]; dc[1] = c[4]; dc[2] = c[5];
+  const double ld = __builtin_fma(vc.lx, dx, __builtin_fma(vc.ly, dyv, vc.lz * dz));
+  const double tl = vc.ub * ld;
+  // b dot = G a + 2w J b + U d
+  dc[3] = __builtin_fma(vc.Gxx, ax, __builtin_fma(vc.Gxy, ay, __builtin_fma(vc.Gxz, az,
+          __builtin_fma(w2, c[4], __builtin_fma(-vc.ua, dx, tl * vc.lx)))));
+  dc[4] = __builtin_fma(vc.Gxy, ax, __builtin_fma(vc.Gyy, ay, __builtin_fma(vc.Gyz, az,
+          __builtin_fma(-w2, c[3], __builtin_fma(-vc.ua, dyv, tl * vc.ly)))));
+  dc[5] = __builtin_fma(vc.Gxz, ax, __builtin_fma(vc.Gyz, ay, __builtin_fma(vc.Gzz, az,
+          __builtin_fma(-vc.ua, dz, tl * vc.lz))));
+  // g dot = -H a - G d
+  dc[6] = -__builtin_fma(vc.Hxx, ax, __builtin_fma(vc.Hxy, ay, __builtin_fma(vc.Hxz, az,
+           __builtin_fma(vc.Gxx, dx, __builtin_fma(vc.Gxy, dyv, vc.Gxz * dz)))));
+  dc[7] = -__builtin_fma(vc.Hxy, ax, __builtin_fma(vc.Hyy, ay, __builtin_fma(vc.Hyz, az,
+           __builtin_fma(vc.Gxy, dx, __builtin_fma(vc.Gyy, dyv, vc.Gyz * dz)))));
+  dc[8] = -__builtin_fma(vc.Hxz, ax, __builtin_fma(vc.Hyz, ay, __builtin_fma(vc.Hzz, az,
+           __builtin_fma(vc.Gxz, dx, __builtin_fma(vc.Gyz, dyv, vc.Gzz * dz)))));
+  // d dot = -g + 2w J d
+  dc[9] = __builtin_fma(w2, dyv, -c[6]);
+  dc[10] = __builtin_fma(-w2, dx, -c[7]);
+  dc[11] = -c[8];
+}
+
+// ------------------------------------------------------------------------------ A2 (direct path)
+// Per-lane constants of one half-segment propagation (prop_EP_deriv.jl:8-61).
+struct DirectLane {
+  double MU;
+  double w2;       // 2 * time_direction
+  double cx, cy, cz;  // control [N]
+  double kk;       // TU^2 / DU / 1e3: thrust [N] / mass [kg] -> DU/TU^2        (:32)
+  double mdot;     // -time_direction * |control| / (Isp * 9.81) * TU           (:41-42)
+};
+
+struct VarCoef6 {
+  double Gxx, Gyy, Gzz, Gxy, Gxz, Gyz;
+  double k_over_m;      // dv/dcontrol = kk / m
+  double dvdm_x, dvdm_y, dvdm_z;  // dv/dm = -control * kk / m^2 (7-state only)
+};
+
+// xdot for x = (r, v[, m]).  NS = 6: mass literal 1000.0 (:20); NS = 7: mass = x[6].
+template <int NS, bool VAR>
+__device__ __forceinline__ void rhs_direct(const double (&x)[NS], const DirectLane& L, double (&dx)[NS], VarCoef6& vc) {
+  const double X = x[0], Y = x[1], Z = x[2];
+  const double a = X + L.MU, b = a - 1.0;
+  const double yz2 = __builtin_fma(Y, Y, Z * Z);
+  const double d1 = __builtin_fma(a, a, yz2), d2 = __builtin_fma(b, b, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - L.MU) * (i1s * i1), c2 = L.MU * (i2s * i2);
+  const double cs = c1 + c2;
+  const double inv_m = (NS == 7) ? rcp_nr(x[NS - 1]) : 1e-3;  // 1 / 1000.0
+  const double k = L.kk * inv_m;
+  dx[0] = x[3]; dx[1] = x[4]; dx[2] = x[5];
+  dx[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(L.w2, x[4], X))) + L.cx * k;  // :48
+  dx[4] = __builtin_fma(-cs, Y, __builtin_fma(-L.w2, x[3], Y)) + L.cy * k;                        // :49
+  dx[5] = __builtin_fma(-cs, Z, L.cz * k);                                                        // :50
+  if (NS == 7) dx[NS - 1] = L.mdot;
+  if (VAR) {
+    const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+    const double ee = e1 + e2;
+    const double sa = e1 * a, tb = e2 * b;
+    const double st = sa + tb;
+    vc.Gxx = __builtin_fma(sa, a, __builtin_fma(tb, b, 1.0 - cs));
+    vc.Gyy = __builtin_fma(ee * Y, Y, 1.0 - cs);
+    vc.Gzz = __builtin_fma(ee * Z, Z, -cs);
+    vc.Gxy = st * Y; vc.Gxz = st * Z; vc.Gyz = ee * Y * Z;
+    vc.k_over_m = k;
+    if (NS == 7) {
+      const double km = -k * inv_m;
+      vc.dvdm_x = L.cx * km; vc.dvdm_y = L.cy * km; vc.dvdm_z = L.cz * km;
+    }
+  }
+}
+
+// One sensitivity column of the direct system: c = d x / d p for p an initial state component or a
+// control component.  forcing_v = d vdot / d p (explicit), forcing_m = d mdot / d p (explicit).
+template <int NS>
+__device__ __forceinline__ void var_col_direct(const VarCoef6& vc, const double w2, const double (&c)[NS],
+                                               const double fvx, const double fvy, const double fvz, const double fm,
+                                               double (&dc)[NS]) {
+  dc[0] = c[3]; dc[1] = c[4]; dc[2] = c[5];
+  double bx = __builtin_fma(vc.Gxx, c[0], __builtin_fma(vc.Gxy, c[1], __builtin_fma(vc.Gxz, c[2], __builtin_fma(w2, c[4], fvx))));
+  double by = __builtin_fma(vc.Gxy, c[0], __builtin_fma(vc.Gyy, c[1], __builtin_fma(vc.Gyz, c[2], __builtin_fma(-w2, c[3], fvy))));
+  double bz = __builtin_fma(vc.Gxz, c[0], __builtin_fma(vc.Gyz, c[1], __builtin_fma(vc.Gzz, c[2], fvz)));
+  if (NS == 7) {
+    bx = __builtin_fma(vc.dvdm_x, c[NS - 1], bx);
+    by = __builtin_fma(vc.dvdm_y, c[NS - 1], by);
+    bz = __builtin_fma(vc.dvdm_z, c[NS - 1], bz);
+    dc[NS - 1] = fm;
+  }
+  dc[3] = bx; dc[4] = by; dc[5] = bz;
+}
+
+}  // namespace lto

@@ -1,0 +1,51 @@
+// kernels.hpp -- argument blocks and launch entry points shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dynamics.hpp"
+
+namespace lto {
+
+// integrator ids (== LTO_* in include/lto.h)
+enum Method : int { M_RK4 = 0, M_RKF78_FIXED = 1, M_RKF78_ADAPTIVE = 2, M_DOP853_ADAPTIVE = 3 };
+
+// Device layout (include/lto.h, "device-resident API"): node j = b*n_nodes + k, segment
+// s = b*seg_per_traj + i, component-major with leading dimensions ld*.
+struct IndirectArgs {
+  const double* X; long ldx;       // [12][ldx] nodes
+  const double* t; int t_stride;   // t[b*t_stride + k]; t_stride = n_nodes (per-trajectory grids) or 0 (shared)
+  const TrajParams* tp; int tp_stride;  // tp[b*tp_stride]; 1 or 0
+  int n_nodes, seg_per_traj, S;
+  int steps;                       // fixed-step methods
+  double rtol, atol; int max_steps;  // adaptive methods
+  double* defect; long ldd;        // [12][ldd] or null
+  double* errors;                  // [S] or null
+  double* Phi; long ldp;           // [144][ldp] (col*12+row) or null
+  int* nacc; int* nrej;            // [S] adaptive step counters or null
+};
+
+struct DirectArgs {
+  const double* X; long ldx;       // [nstate][ldx]
+  const double* U; long ldu;       // [3][ldu]  thrust, N
+  const double* t; int t_stride;
+  double MU, kk, isp_g0, TU;       // kk = TU^2/DU/1e3; isp_g0 = Isp * 9.81
+  int n_nodes, seg_per_traj, S;
+  int half_steps;                  // nsteps - 1 RKF7(8) steps per half segment
+  double* defect; long ldd;        // [nstate][ldd] or null
+  double* errors;                  // [S] or null
+  double* Jac; long ldj;           // [nstate*nvar][ldj] (col*nstate+row) or null
+  double* dtf;                     // [nstate][ldd] or null
+};
+
+// Launchers return hipSuccess or the launch error.  `pm` is a PMode, `method` a Method.
+hipError_t launch_indirect_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
+// cols_per_lane in {1,2,3}; 0 = choose from S.
+hipError_t launch_indirect_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
+hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
+hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
+
+hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st);
+hipError_t launch_unpack_soa(const double* soa, long ld, int ndim, long count, double* aos, hipStream_t st);
+hipError_t launch_defect_norms(const double* defect, long ldd, int ndim, int seg_per_traj, int n_batch, double* sumsq,
+                               double* maxabs, hipStream_t st);
+
+}  // namespace lto

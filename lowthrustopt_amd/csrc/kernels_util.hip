@@ -1,0 +1,120 @@
+// kernels_util.hip -- layout and reduction kernels around the propagators (HBM-bound, trivial work).
+//
+//  pack / unpack : Julia column-major [ndim x count] (node-contiguous AoS, 8*ndim bytes per node)
+//                  <-> component-major SoA [ndim][ld].  A tile of up to 256 nodes is staged through LDS so both
+//                  the HBM reads and the HBM writes are unit-stride across the wavefront.
+//  defect_norms  : per trajectory sum(defect.^2) (line-search cost, multiShoot_CRTBP_indirect.jl:240,
+//                  multiShoot_CRTBP_direct.jl:424) and max|defect| (convergence test, :331 / :588).
+#include "kernels.hpp"
+
+namespace lto {
+
+constexpr int THREADS = 256;
+constexpr int MAXDIM = 512;
+constexpr int LDS_BUDGET_DOUBLES = 8192;  // 64 KiB tile
+
+// nodes per tile: as many as fit the LDS budget, at most 256, a multiple of 32 when possible
+static int tile_nodes(int ndim) {
+  int n = LDS_BUDGET_DOUBLES / (ndim + 1);
+  if (n > 256) n = 256;
+  if (n >= 32) n &= ~31;
+  return n < 1 ? 1 : n;
+}
+
+// LDS tile [tn][ndim+1]: the +1 pad breaks the regular row stride (bank conflicts).
+__global__ __launch_bounds__(THREADS) void k_pack(const double* __restrict__ aos, int ndim, long count,
+                                                  double* __restrict__ soa, long ld, int tn) {
+  extern __shared__ double tile[];
+  const long j0 = (long)blockIdx.x * tn;
+  const int nj = (int)((count - j0 < tn) ? (count - j0) : tn);
+  const int pitch = ndim + 1;
+  const double* src = aos + j0 * ndim;
+  for (int e = threadIdx.x; e < nj * ndim; e += THREADS) {  // unit-stride HBM read
+    const int j = e / ndim, c = e - j * ndim;
+    tile[j * pitch + c] = src[e];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nj * ndim; e += THREADS) {  // runs of nj contiguous doubles per component
+    const int c = e / nj, j = e - c * nj;
+    soa[c * ld + j0 + j] = tile[j * pitch + c];
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void k_unpack(const double* __restrict__ soa, long ld, int ndim, long count,
+                                                    double* __restrict__ aos, int tn) {
+  extern __shared__ double tile[];
+  const long j0 = (long)blockIdx.x * tn;
+  const int nj = (int)((count - j0 < tn) ? (count - j0) : tn);
+  const int pitch = ndim + 1;
+  for (int e = threadIdx.x; e < nj * ndim; e += THREADS) {
+    const int c = e / nj, j = e - c * nj;
+    tile[j * pitch + c] = soa[c * ld + j0 + j];
+  }
+  __syncthreads();
+  double* dst = aos + j0 * ndim;
+  for (int e = threadIdx.x; e < nj * ndim; e += THREADS) {
+    const int j = e / ndim, c = e - j * ndim;
+    dst[e] = tile[j * pitch + c];
+  }
+}
+
+// One workgroup per trajectory; NaN-propagating max (a NaN defect must surface, status_flag = 2 path).
+__global__ __launch_bounds__(256) void k_defect_norms(const double* __restrict__ defect, long ldd, int ndim,
+                                                      int seg_per_traj, double* __restrict__ sumsq,
+                                                      double* __restrict__ maxabs) {
+  const int b = blockIdx.x;
+  double ss = 0.0, mx = 0.0;
+  bool bad = false;
+  for (int c = 0; c < ndim; ++c)
+    for (int i = threadIdx.x; i < seg_per_traj; i += 256) {
+      const double v = defect[c * ldd + (long)b * seg_per_traj + i];
+      ss = __builtin_fma(v, v, ss);
+      bad |= (v != v);
+      mx = fmax(mx, fabs(v));
+    }
+  __shared__ double s_ss[4], s_mx[4];
+  __shared__ int s_bad[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o);
+    mx = fmax(mx, __shfl_xor(mx, o));
+    bad |= (bool)__shfl_xor((int)bad, o);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_ss[w] = ss; s_mx[w] = mx; s_bad[w] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
+    double m = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3]));
+    const bool any_bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+    if (sumsq) sumsq[b] = t;
+    if (maxabs) maxabs[b] = any_bad ? __builtin_nan("") : m;
+  }
+}
+
+hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  if (ndim < 1 || ndim > MAXDIM) return hipErrorInvalidValue;
+  const int tn = tile_nodes(ndim);
+  const unsigned blocks = (unsigned)((count + tn - 1) / tn);
+  hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(THREADS), sizeof(double) * tn * (ndim + 1), st, aos, ndim, count, soa, ld, tn);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_soa(const double* soa, long ld, int ndim, long count, double* aos, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  if (ndim < 1 || ndim > MAXDIM) return hipErrorInvalidValue;
+  const int tn = tile_nodes(ndim);
+  const unsigned blocks = (unsigned)((count + tn - 1) / tn);
+  hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(THREADS), sizeof(double) * tn * (ndim + 1), st, soa, ld, ndim, count, aos, tn);
+  return hipGetLastError();
+}
+
+hipError_t launch_defect_norms(const double* defect, long ldd, int ndim, int seg_per_traj, int n_batch, double* sumsq,
+                               double* maxabs, hipStream_t st) {
+  if (n_batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_defect_norms, dim3(n_batch), dim3(256), 0, st, defect, ldd, ndim, seg_per_traj, sumsq, maxabs);
+  return hipGetLastError();
+}
+
+}  // namespace lto

@@ -1,0 +1,591 @@
+// lto_api.hip -- the C ABI of include/lto.h: contexts, plans, host-pointer and device-resident sweeps.
+//
+// No C++ exception crosses the ABI (everything below is noexcept by construction: no STL that
+// throws on the hot path, allocation failures are turned into LTO_EHIP).  No signal handlers, no
+// global state besides what HIP itself keeps.  A context belongs to one device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/lto.h"
+#include "kernels.hpp"
+
+using namespace lto;
+
+struct lto_ctx {
+  int device;
+  hipStream_t stream;
+  bool timing;
+  hipEvent_t ev0, ev1;
+  bool ev_valid;
+  // grow-only device arena for the host-pointer API
+  char* arena;
+  size_t arena_bytes;
+  size_t arena_top;
+  char err[512];
+};
+
+struct lto_indirect_plan {
+  lto_ctx* ctx;
+  int ndim, n_nodes, n_batch, S;
+  int pm;           // PMode
+  int n_prm;        // 1 or n_batch
+  lto_integrator integ;
+  TrajParams* d_tp;
+  int* d_nacc;
+  int* d_nrej;
+  int cols_per_lane;
+};
+
+struct lto_direct_plan {
+  lto_ctx* ctx;
+  int nstate, n_nodes, n_batch, S, nsteps;
+  lto_direct_params prm;
+};
+
+namespace {
+
+int set_err(lto_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    if (e != hipSuccess) std::snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+    else std::snprintf(c->err, sizeof c->err, "%s", what);
+  }
+  return code;
+}
+
+#define LTO_HIP(c, call)                                              \
+  do {                                                                \
+    hipError_t e_ = (call);                                           \
+    if (e_ != hipSuccess) return set_err((c), LTO_EHIP, #call, e_);   \
+  } while (0)
+
+int bind_device(lto_ctx* c) {
+  LTO_HIP(c, hipSetDevice(c->device));
+  return LTO_OK;
+}
+
+// ---- arena: reset at the start of each host-pointer call, bump-allocated, 256-B aligned
+int arena_reserve(lto_ctx* c, size_t bytes) {
+  if (bytes <= c->arena_bytes) return LTO_OK;
+  if (c->arena) { LTO_HIP(c, hipStreamSynchronize(c->stream)); LTO_HIP(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+  size_t want = bytes + bytes / 4 + (1u << 20);
+  LTO_HIP(c, hipMalloc((void**)&c->arena, want));
+  c->arena_bytes = want;
+  return LTO_OK;
+}
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+template <class T>
+T* arena_take(lto_ctx* c, size_t count) {
+  T* p = (T*)(c->arena + c->arena_top);
+  c->arena_top += al256(count * sizeof(T));
+  return p;
+}
+
+// Reference validity rule for p (stateCostate_deriv.jl:36-53): p == 0, p == 1 or p > 1.
+bool p_valid(double p) { return p == 0.0 || p == 1.0 || p > 1.0; }
+
+int make_traj_params(lto_ctx* c, const lto_params* prm, int n, TrajParams* out, int* pm_out) {
+  int pm = -1;
+  for (int i = 0; i < n; ++i) {
+    const lto_params& q = prm[i];
+    if (!p_valid(q.p)) return set_err(c, LTO_EBADP, "Invalid value of p!");
+    TrajParams t;
+    t.accel_limit = q.thrustLimit / q.mass / 1e3 * (q.TU * q.TU) / q.DU;  // stateCostate_deriv.jl:33
+    t.inv_2rho = 1.0 / (2.0 * q.rho);
+    t.al_over_rho = t.accel_limit / q.rho;
+    t.p = q.p;
+    t.inv_p = (q.p != 0.0) ? 1.0 / q.p : 0.0;
+    t.inv_pm1 = (q.p > 1.0) ? 1.0 / (q.p - 1.0) : 0.0;
+    t.omega = q.time_direction;
+    t.MU = q.MU;
+    out[i] = t;
+    const int m = (q.p == 1.0) ? PM_P1 : (q.p == 2.0) ? PM_P2 : PM_MIXED;
+    pm = (pm < 0 || pm == m) ? m : PM_MIXED;
+  }
+  *pm_out = pm < 0 ? PM_MIXED : pm;
+  return LTO_OK;
+}
+
+int check_integ(lto_ctx* c, const lto_integrator* ig) {
+  if (!ig) return set_err(c, LTO_ENULL, "integrator is NULL");
+  switch (ig->method) {
+    case LTO_RK4:
+    case LTO_RKF78_FIXED:
+      if (ig->steps < 1) return set_err(c, LTO_EINVAL, "fixed-step integrator needs steps >= 1");
+      return LTO_OK;
+    case LTO_RKF78_ADAPTIVE:
+      if (!(ig->rtol > 0.0)) return set_err(c, LTO_EINVAL, "adaptive integrator needs rtol > 0");
+      return LTO_OK;
+    case LTO_DOP853_ADAPTIVE:
+      if (!(ig->rtol > 0.0) || !(ig->atol >= 0.0)) return set_err(c, LTO_EINVAL, "adaptive integrator needs rtol > 0, atol >= 0");
+      return LTO_OK;
+  }
+  return set_err(c, LTO_EINVAL, "unknown integrator method");
+}
+
+void timing_begin(lto_ctx* c, hipStream_t st) {
+  if (c->timing) { (void)hipEventRecord(c->ev0, st); }
+}
+void timing_end(lto_ctx* c, hipStream_t st) {
+  if (c->timing) { (void)hipEventRecord(c->ev1, st); c->ev_valid = true; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lto_version(void) { return LTO_VERSION; }
+
+int lto_create(lto_ctx** out, int device_id) {
+  if (!out) return LTO_ENULL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LTO_ENODEVICE;
+  if (device_id < 0 || device_id >= n) return LTO_EINVAL;
+  lto_ctx* c = new (std::nothrow) lto_ctx();
+  if (!c) return LTO_EHIP;
+  std::memset(c, 0, sizeof *c);
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return LTO_EHIP;
+  }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LTO_EHIP;
+  }
+  *out = c;
+  return LTO_OK;
+}
+
+void lto_destroy(lto_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->arena) (void)hipFree(c->arena);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* lto_last_error(const lto_ctx* c) { return c ? c->err : "null context"; }
+
+int lto_set_timing(lto_ctx* c, int enabled) {
+  if (!c) return LTO_ENULL;
+  c->timing = enabled != 0;
+  c->ev_valid = false;
+  return LTO_OK;
+}
+
+double lto_last_kernel_ms(lto_ctx* c) {
+  if (!c || !c->ev_valid) return -1.0;
+  float ms = -1.0f;
+  if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+/* ------------------------------------------------------------------------------ indirect plans */
+int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
+                             const lto_integrator* integ, lto_indirect_plan** out) {
+  if (!c || !out) return LTO_ENULL;
+  *out = nullptr;
+  if (!prm) return set_err(c, LTO_ENULL, "prm is NULL");
+  if (ndim == 14) return set_err(c, LTO_EUNSUPPORTED, "ndim = 14 (mass + mass costate) is not built yet");
+  if (ndim != 12) return set_err(c, LTO_EINVAL, "ndim must be 12");
+  if (n_nodes < 2 || n_batch < 1) return set_err(c, LTO_EINVAL, "need n_nodes >= 2 and n_batch >= 1");
+  if (n_prm != 1 && n_prm != n_batch) return set_err(c, LTO_EINVAL, "n_prm must be 1 or n_batch");
+  if ((long)(n_nodes - 1) * n_batch > 0x7fffffffL) return set_err(c, LTO_EINVAL, "too many segments");
+  int rc = check_integ(c, integ);
+  if (rc) return rc;
+  rc = bind_device(c);
+  if (rc) return rc;
+  TrajParams* h = (TrajParams*)std::malloc(sizeof(TrajParams) * (size_t)n_prm);
+  if (!h) return set_err(c, LTO_EHIP, "host allocation failed");
+  int pm = PM_MIXED;
+  rc = make_traj_params(c, prm, n_prm, h, &pm);
+  if (rc) { std::free(h); return rc; }
+  lto_indirect_plan* p = new (std::nothrow) lto_indirect_plan();
+  if (!p) { std::free(h); return set_err(c, LTO_EHIP, "host allocation failed"); }
+  std::memset(p, 0, sizeof *p);
+  p->ctx = c; p->ndim = ndim; p->n_nodes = n_nodes; p->n_batch = n_batch; p->S = (n_nodes - 1) * n_batch;
+  p->pm = pm; p->n_prm = n_prm; p->integ = *integ;
+  if (p->integ.max_steps <= 0) p->integ.max_steps = 100000;
+  hipError_t e = hipMalloc((void**)&p->d_tp, sizeof(TrajParams) * (size_t)n_prm);
+  if (e == hipSuccess) e = hipMemcpy(p->d_tp, h, sizeof(TrajParams) * (size_t)n_prm, hipMemcpyHostToDevice);
+  std::free(h);
+  const bool adaptive = integ->method == LTO_RKF78_ADAPTIVE || integ->method == LTO_DOP853_ADAPTIVE;
+  if (e == hipSuccess && adaptive) {
+    e = hipMalloc((void**)&p->d_nacc, sizeof(int) * (size_t)p->S);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_nrej, sizeof(int) * (size_t)p->S);
+  }
+  if (e != hipSuccess) {
+    lto_indirect_plan_destroy(p);
+    return set_err(c, LTO_EHIP, "plan allocation", e);
+  }
+  *out = p;
+  return LTO_OK;
+}
+
+void lto_indirect_plan_destroy(lto_indirect_plan* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  if (p->d_tp) (void)hipFree(p->d_tp);
+  if (p->d_nacc) (void)hipFree(p->d_nacc);
+  if (p->d_nrej) (void)hipFree(p->d_nrej);
+  delete p;
+}
+
+const int* lto_indirect_plan_steps_accepted(const lto_indirect_plan* p) { return p ? p->d_nacc : nullptr; }
+const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* p) { return p ? p->d_nrej : nullptr; }
+
+int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
+  if (!p) return LTO_ENULL;
+  if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2 or 3");
+  p->cols_per_lane = cols;
+  return LTO_OK;
+}
+
+static int fill_indirect_args(lto_indirect_plan* p, const double* X, long ldx, const double* t, int n_tgrids,
+                              IndirectArgs* a) {
+  lto_ctx* c = p->ctx;
+  if (!X || !t) return set_err(c, LTO_ENULL, "X or t is NULL");
+  const long J = (long)p->n_nodes * p->n_batch;
+  if (ldx < J) return set_err(c, LTO_EINVAL, "ldx smaller than n_nodes*n_batch");
+  if (n_tgrids != 1 && n_tgrids != p->n_batch) return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
+  std::memset(a, 0, sizeof *a);
+  a->X = X; a->ldx = ldx; a->t = t; a->t_stride = (n_tgrids == 1) ? 0 : p->n_nodes;
+  a->tp = p->d_tp; a->tp_stride = (p->n_prm == 1) ? 0 : 1;
+  a->n_nodes = p->n_nodes; a->seg_per_traj = p->n_nodes - 1; a->S = p->S;
+  a->steps = p->integ.steps; a->rtol = p->integ.rtol; a->atol = p->integ.atol; a->max_steps = p->integ.max_steps;
+  a->nacc = p->d_nacc; a->nrej = p->d_nrej;
+  return LTO_OK;
+}
+
+int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X, long ldx, const double* t,
+                            int n_tgrids, double* defect, long ldd, double* errors) {
+  if (!p) return LTO_ENULL;
+  lto_ctx* c = p->ctx;
+  IndirectArgs a;
+  int rc = fill_indirect_args(p, X, ldx, t, n_tgrids, &a);
+  if (rc) return rc;
+  if (!defect) return set_err(c, LTO_ENULL, "defect is NULL");
+  if (ldd < p->S) return set_err(c, LTO_EINVAL, "ldd smaller than the segment count");
+  a.defect = defect; a.ldd = ldd; a.errors = errors;
+  rc = bind_device(c);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  timing_begin(c, st);
+  hipError_t e = launch_indirect_defect(p->pm, p->integ.method, a, st);
+  timing_end(c, st);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_defect", e);
+  return LTO_OK;
+}
+
+int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* X, long ldx, const double* t,
+                              int n_tgrids, double* Phi, long ldp, double* defect, long ldd) {
+  if (!p) return LTO_ENULL;
+  lto_ctx* c = p->ctx;
+  IndirectArgs a;
+  int rc = fill_indirect_args(p, X, ldx, t, n_tgrids, &a);
+  if (rc) return rc;
+  if (!Phi) return set_err(c, LTO_ENULL, "Phi is NULL");
+  if (ldp < p->S || (defect && ldd < p->S)) return set_err(c, LTO_EINVAL, "ldp/ldd smaller than the segment count");
+  a.Phi = Phi; a.ldp = ldp; a.defect = defect; a.ldd = ldd;
+  rc = bind_device(c);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  timing_begin(c, st);
+  hipError_t e = launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
+  timing_end(c, st);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
+  return LTO_OK;
+}
+
+/* ------------------------------------------------------------------------------ direct plans */
+int lto_direct_plan_create(lto_ctx* c, int nstate, int n_nodes, int n_batch, int nsteps, const lto_direct_params* prm,
+                           lto_direct_plan** out) {
+  if (!c || !out) return LTO_ENULL;
+  *out = nullptr;
+  if (!prm) return set_err(c, LTO_ENULL, "prm is NULL");
+  if (nstate != 6 && nstate != 7) return set_err(c, LTO_EINVAL, "nstate must be 6 or 7");
+  if (n_nodes < 2 || n_batch < 1) return set_err(c, LTO_EINVAL, "need n_nodes >= 2 and n_batch >= 1");
+  if (nsteps < 2) return set_err(c, LTO_EINVAL, "nsteps (grid points per half segment) must be >= 2");
+  if ((long)(n_nodes - 1) * n_batch > 0x3fffffffL) return set_err(c, LTO_EINVAL, "too many segments");
+  lto_direct_plan* p = new (std::nothrow) lto_direct_plan();
+  if (!p) return set_err(c, LTO_EHIP, "host allocation failed");
+  p->ctx = c; p->nstate = nstate; p->n_nodes = n_nodes; p->n_batch = n_batch; p->S = (n_nodes - 1) * n_batch;
+  p->nsteps = nsteps; p->prm = *prm;
+  *out = p;
+  return LTO_OK;
+}
+
+void lto_direct_plan_destroy(lto_direct_plan* p) { delete p; }
+
+static int fill_direct_args(lto_direct_plan* p, const double* X, long ldx, const double* U, long ldu, const double* t,
+                            int n_tgrids, DirectArgs* a) {
+  lto_ctx* c = p->ctx;
+  if (!X || !U || !t) return set_err(c, LTO_ENULL, "X, U or t is NULL");
+  const long J = (long)p->n_nodes * p->n_batch;
+  if (ldx < J || ldu < J) return set_err(c, LTO_EINVAL, "ldx/ldu smaller than n_nodes*n_batch");
+  if (n_tgrids != 1 && n_tgrids != p->n_batch) return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
+  std::memset(a, 0, sizeof *a);
+  a->X = X; a->ldx = ldx; a->U = U; a->ldu = ldu; a->t = t; a->t_stride = (n_tgrids == 1) ? 0 : p->n_nodes;
+  a->MU = p->prm.MU;
+  a->kk = (p->prm.TU * p->prm.TU) / p->prm.DU / 1e3;  // N/kg -> DU/TU^2   (prop_EP_deriv.jl:32)
+  a->isp_g0 = p->prm.Isp * 9.81;                       // prop_EP_deriv.jl:41-42
+  a->TU = p->prm.TU;
+  a->n_nodes = p->n_nodes; a->seg_per_traj = p->n_nodes - 1; a->S = p->S;
+  a->half_steps = p->nsteps - 1;
+  return LTO_OK;
+}
+
+int lto_direct_defect_dev(lto_direct_plan* p, void* stream, const double* X, long ldx, const double* U, long ldu,
+                          const double* t, int n_tgrids, double* defect, long ldd, double* errors) {
+  if (!p) return LTO_ENULL;
+  lto_ctx* c = p->ctx;
+  DirectArgs a;
+  int rc = fill_direct_args(p, X, ldx, U, ldu, t, n_tgrids, &a);
+  if (rc) return rc;
+  if (!defect) return set_err(c, LTO_ENULL, "defect is NULL");
+  if (ldd < p->S) return set_err(c, LTO_EINVAL, "ldd smaller than the segment count");
+  a.defect = defect; a.ldd = ldd; a.errors = errors;
+  rc = bind_device(c);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  timing_begin(c, st);
+  hipError_t e = launch_direct_defect(p->nstate, a, st);
+  timing_end(c, st);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_direct_defect", e);
+  return LTO_OK;
+}
+
+int lto_direct_jacobian_dev(lto_direct_plan* p, void* stream, const double* X, long ldx, const double* U, long ldu,
+                            const double* t, int n_tgrids, double* Jac, long ldj, double* dtf, double* defect, long ldd,
+                            double* errors) {
+  if (!p) return LTO_ENULL;
+  lto_ctx* c = p->ctx;
+  DirectArgs a;
+  int rc = fill_direct_args(p, X, ldx, U, ldu, t, n_tgrids, &a);
+  if (rc) return rc;
+  if (!Jac) return set_err(c, LTO_ENULL, "Jac is NULL");
+  if (ldj < p->S || ((defect || dtf) && ldd < p->S)) return set_err(c, LTO_EINVAL, "ldj/ldd smaller than the segment count");
+  a.Jac = Jac; a.ldj = ldj; a.dtf = dtf; a.defect = defect; a.ldd = ldd; a.errors = errors;
+  rc = bind_device(c);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  timing_begin(c, st);
+  hipError_t e = launch_direct_jacobian(p->nstate, a, st);
+  timing_end(c, st);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_direct_jacobian", e);
+  return LTO_OK;
+}
+
+/* ------------------------------------------------------------------------------ utilities */
+int lto_pack_soa_dev(lto_ctx* c, void* stream, const double* aos, int ndim, long count, double* soa, long ld) {
+  if (!c) return LTO_ENULL;
+  if (!aos || !soa) return set_err(c, LTO_ENULL, "aos or soa is NULL");
+  if (ndim < 1 || count < 0 || ld < count) return set_err(c, LTO_EINVAL, "bad pack dimensions");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  hipError_t e = launch_pack_soa(aos, ndim, count, soa, ld, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_pack_soa", e);
+  return LTO_OK;
+}
+
+int lto_unpack_soa_dev(lto_ctx* c, void* stream, const double* soa, long ld, int ndim, long count, double* aos) {
+  if (!c) return LTO_ENULL;
+  if (!aos || !soa) return set_err(c, LTO_ENULL, "aos or soa is NULL");
+  if (ndim < 1 || count < 0 || ld < count) return set_err(c, LTO_EINVAL, "bad unpack dimensions");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  hipError_t e = launch_unpack_soa(soa, ld, ndim, count, aos, stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_unpack_soa", e);
+  return LTO_OK;
+}
+
+int lto_defect_norms_dev(lto_ctx* c, void* stream, const double* defect, long ldd, int ndim, int seg_per_traj,
+                         int n_batch, double* sumsq, double* maxabs) {
+  if (!c) return LTO_ENULL;
+  if (!defect) return set_err(c, LTO_ENULL, "defect is NULL");
+  if (ndim < 1 || seg_per_traj < 1 || n_batch < 1 || ldd < (long)seg_per_traj * n_batch)
+    return set_err(c, LTO_EINVAL, "bad norm dimensions");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  hipError_t e = launch_defect_norms(defect, ldd, ndim, seg_per_traj, n_batch, sumsq, maxabs,
+                                     stream ? (hipStream_t)stream : c->stream);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_defect_norms", e);
+  return LTO_OK;
+}
+
+/* ------------------------------------------------------------------------------ host-pointer API
+ * H2D (Julia layout) -> pack to SoA -> sweep -> unpack -> D2H, all on the context's stream, then one
+ * stream synchronise.  The caller's buffers are only touched inside the call. */
+
+int lto_indirect_defect(lto_ctx* c, int ndim, int n_nodes, int n_batch, const double* XC, const double* t, int n_tgrids,
+                        const lto_params* prm, int n_prm, const lto_integrator* integ, double* defect, double* errors) {
+  if (!c) return LTO_ENULL;
+  if (!XC || !t || !defect) return set_err(c, LTO_ENULL, "XC, t or defect is NULL");
+  lto_indirect_plan* p = nullptr;
+  int rc = lto_indirect_plan_create(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);
+  if (rc) return rc;
+  if (n_tgrids != 1 && n_tgrids != n_batch) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
+  const long J = (long)n_nodes * n_batch, S = p->S;
+  const size_t need = al256(sizeof(double) * ndim * J) * 2 + al256(sizeof(double) * n_nodes * n_tgrids) +
+                      al256(sizeof(double) * ndim * S) * 2 + al256(sizeof(double) * S) + 4096;
+  rc = arena_reserve(c, need);
+  if (rc) { lto_indirect_plan_destroy(p); return rc; }
+  c->arena_top = 0;
+  double* d_aos = arena_take<double>(c, (size_t)ndim * J);
+  double* d_X = arena_take<double>(c, (size_t)ndim * J);
+  double* d_t = arena_take<double>(c, (size_t)n_nodes * n_tgrids);
+  double* d_def = arena_take<double>(c, (size_t)ndim * S);
+  double* d_def_aos = arena_take<double>(c, (size_t)ndim * S);
+  double* d_err = arena_take<double>(c, (size_t)S);
+  hipStream_t st = c->stream;
+  hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * ndim * J, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
+  if (e != hipSuccess) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, errors ? d_err : nullptr);
+  if (rc == LTO_OK) {
+    e = launch_unpack_soa(d_def, S, ndim, S, d_def_aos, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * ndim * S, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && errors) e = hipMemcpyAsync(errors, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  lto_indirect_plan_destroy(p);
+  return rc;
+}
+
+int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const double* XC, const double* t, int n_tgrids,
+                          const lto_params* prm, int n_prm, const lto_integrator* integ, double* Phi, double* defect) {
+  if (!c) return LTO_ENULL;
+  if (!XC || !t || !Phi) return set_err(c, LTO_ENULL, "XC, t or Phi is NULL");
+  lto_indirect_plan* p = nullptr;
+  int rc = lto_indirect_plan_create(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);
+  if (rc) return rc;
+  if (n_tgrids != 1 && n_tgrids != n_batch) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
+  const long J = (long)n_nodes * n_batch, S = p->S;
+  const int nn = ndim * ndim;
+  const size_t need = al256(sizeof(double) * ndim * J) * 2 + al256(sizeof(double) * n_nodes * n_tgrids) +
+                      al256(sizeof(double) * ndim * S) * 2 + al256(sizeof(double) * nn * S) * 2 + 4096;
+  rc = arena_reserve(c, need);
+  if (rc) { lto_indirect_plan_destroy(p); return rc; }
+  c->arena_top = 0;
+  double* d_aos = arena_take<double>(c, (size_t)ndim * J);
+  double* d_X = arena_take<double>(c, (size_t)ndim * J);
+  double* d_t = arena_take<double>(c, (size_t)n_nodes * n_tgrids);
+  double* d_def = arena_take<double>(c, (size_t)ndim * S);
+  double* d_def_aos = arena_take<double>(c, (size_t)ndim * S);
+  double* d_phi = arena_take<double>(c, (size_t)nn * S);
+  double* d_phi_aos = arena_take<double>(c, (size_t)nn * S);
+  hipStream_t st = c->stream;
+  hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * ndim * J, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
+  if (e != hipSuccess) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
+  if (rc == LTO_OK) {
+    e = launch_unpack_soa(d_phi, S, nn, S, d_phi_aos, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(Phi, d_phi_aos, sizeof(double) * nn * S, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && defect) {
+      e = launch_unpack_soa(d_def, S, ndim, S, d_def_aos, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * ndim * S, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  lto_indirect_plan_destroy(p);
+  return rc;
+}
+
+static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const double* X, const double* U, const double* t,
+                       int n_tgrids, int nsteps, const lto_direct_params* prm, double* Jac_temp, double* ddefect_dtf,
+                       double* defect, double* errors, bool want_jac) {
+  lto_direct_plan* p = nullptr;
+  int rc = lto_direct_plan_create(c, nstate, n_nodes, n_batch, nsteps, prm, &p);
+  if (rc) return rc;
+  if (n_tgrids != 1 && n_tgrids != n_batch) { lto_direct_plan_destroy(p); return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
+  const long J = (long)n_nodes * n_batch, S = p->S;
+  const int nvar = 2 * (nstate + 3), nj = nstate * nvar;
+  size_t need = al256(sizeof(double) * nstate * J) * 2 + al256(sizeof(double) * 3 * J) * 2 +
+                al256(sizeof(double) * n_nodes * n_tgrids) + al256(sizeof(double) * nstate * S) * 4 +
+                al256(sizeof(double) * S) + 8192;
+  if (want_jac) need += al256(sizeof(double) * nj * S) * 2;
+  rc = arena_reserve(c, need);
+  if (rc) { lto_direct_plan_destroy(p); return rc; }
+  c->arena_top = 0;
+  double* d_xa = arena_take<double>(c, (size_t)nstate * J);
+  double* d_X = arena_take<double>(c, (size_t)nstate * J);
+  double* d_ua = arena_take<double>(c, (size_t)3 * J);
+  double* d_U = arena_take<double>(c, (size_t)3 * J);
+  double* d_t = arena_take<double>(c, (size_t)n_nodes * n_tgrids);
+  double* d_def = arena_take<double>(c, (size_t)nstate * S);
+  double* d_def_aos = arena_take<double>(c, (size_t)nstate * S);
+  double* d_dtf = arena_take<double>(c, (size_t)nstate * S);
+  double* d_dtf_aos = arena_take<double>(c, (size_t)nstate * S);
+  double* d_err = arena_take<double>(c, (size_t)S);
+  double* d_jac = want_jac ? arena_take<double>(c, (size_t)nj * S) : nullptr;
+  double* d_jac_aos = want_jac ? arena_take<double>(c, (size_t)nj * S) : nullptr;
+  hipStream_t st = c->stream;
+  hipError_t e = hipMemcpyAsync(d_xa, X, sizeof(double) * nstate * J, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ua, U, sizeof(double) * 3 * J, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_pack_soa(d_xa, nstate, J, d_X, J, st);
+  if (e == hipSuccess) e = launch_pack_soa(d_ua, 3, J, d_U, J, st);
+  if (e != hipSuccess) { lto_direct_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  if (want_jac)
+    rc = lto_direct_jacobian_dev(p, st, d_X, J, d_U, J, d_t, n_tgrids, d_jac, S, d_dtf, d_def, S, d_err);
+  else
+    rc = lto_direct_defect_dev(p, st, d_X, J, d_U, J, d_t, n_tgrids, d_def, S, d_err);
+  if (rc == LTO_OK) {
+    if (defect) {
+      e = launch_unpack_soa(d_def, S, nstate, S, d_def_aos, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * nstate * S, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess && errors) e = hipMemcpyAsync(errors, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && want_jac) {
+      e = launch_unpack_soa(d_jac, S, nj, S, d_jac_aos, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(Jac_temp, d_jac_aos, sizeof(double) * nj * S, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess && ddefect_dtf) {
+        e = launch_unpack_soa(d_dtf, S, nstate, S, d_dtf_aos, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(ddefect_dtf, d_dtf_aos, sizeof(double) * nstate * S, hipMemcpyDeviceToHost, st);
+      }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  lto_direct_plan_destroy(p);
+  return rc;
+}
+
+int lto_direct_defect(lto_ctx* c, int nstate, int n_nodes, int n_batch, const double* X, const double* U, const double* t,
+                      int n_tgrids, int nsteps, const lto_direct_params* prm, double* defect, double* errors) {
+  if (!c) return LTO_ENULL;
+  if (!X || !U || !t || !defect) return set_err(c, LTO_ENULL, "X, U, t or defect is NULL");
+  return direct_host(c, nstate, n_nodes, n_batch, X, U, t, n_tgrids, nsteps, prm, nullptr, nullptr, defect, errors, false);
+}
+
+int lto_direct_jacobian(lto_ctx* c, int nstate, int n_nodes, int n_batch, const double* X, const double* U, const double* t,
+                        int n_tgrids, int nsteps, const lto_direct_params* prm, double* Jac_temp, double* ddefect_dtf,
+                        double* defect, double* errors) {
+  if (!c) return LTO_ENULL;
+  if (!X || !U || !t || !Jac_temp) return set_err(c, LTO_ENULL, "X, U, t or Jac_temp is NULL");
+  return direct_host(c, nstate, n_nodes, n_batch, X, U, t, n_tgrids, nsteps, prm, Jac_temp, ddefect_dtf, defect, errors, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,350 @@
+"""Host-side mirror of the reference's hot-path closures, calling the HIP library through its C ABI.
+
+Reference seam (there is no FFI in the reference; the seam is created at these four closures):
+  indirect defectCalc    src/multiShoot_CRTBP_indirect.jl:63-90
+  indirect jacobianCalc  src/multiShoot_CRTBP_indirect.jl:93-146
+  direct   defectCalc    src/multiShoot_CRTBP_direct.jl:66-109
+  direct   jacobianCalc  src/multiShoot_CRTBP_direct.jl:111-166  (+ tf partial :503-516)
+
+Names, argument meaning and return shapes follow the Julia closures; arrays are numpy in the reference's
+(column-major) shapes, e.g. XC_all is (12, n_nodes).  The Julia glue that binds the same C ABI is
+julia/LowThrustOptHIP.jl.  Nothing here computes on the CPU: without the HIP
+library and a GPU every call raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .constants import RK4, RKF78_FIXED, RKF78_ADAPTIVE, DOP853_ADAPTIVE  # noqa: F401
+from ._lib import LtoError, LtoIntegrator, LtoParams, LtoDirectParams
+
+
+def integrator(method=DOP853_ADAPTIVE, steps=0, rtol=1e-13, atol=1e-13, max_steps=0):
+    """lto_integrator.  Default = adaptive order-8 pair at reltol = abstol = 1e-13, the reference's
+    Vern8 setting (src/multiShoot_CRTBP_indirect.jl:79)."""
+    return LtoIntegrator(int(method), int(steps), float(rtol), float(atol), int(max_steps))
+
+
+def make_params(MU, DU, TU, thrustLimit, mass, time_direction, p, rho):
+    """The reference's `params` tuple (src/multiShoot_CRTBP_indirect.jl:260)."""
+    return LtoParams(float(MU), float(DU), float(TU), float(thrustLimit), float(mass), float(time_direction), float(p),
+                     float(rho))
+
+
+def _params_array(params):
+    if isinstance(params, LtoParams):
+        params = [params]
+    params = [p if isinstance(p, LtoParams) else make_params(*p) for p in params]
+    arr = (LtoParams * len(params))(*params)
+    return arr, len(params)
+
+
+def _f64(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One lto_ctx = one GPU (one process per GPU)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load_library()
+        h = C.c_void_p()
+        rc = self.lib.lto_create(C.byref(h), int(device))
+        if rc != 0:
+            raise LtoError(rc, "lto_create failed (no gfx950 device visible?)")
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lto_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.lto_last_error(self.handle)
+            raise LtoError(rc, msg.decode() if msg else "")
+
+    def set_timing(self, on):
+        self.check(self.lib.lto_set_timing(self.handle, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        return float(self.lib.lto_last_kernel_ms(self.handle))
+
+
+_DEFAULT_CTX = {}
+
+
+def default_context(device=0):
+    if device not in _DEFAULT_CTX:
+        _DEFAULT_CTX[device] = Context(device)
+    return _DEFAULT_CTX[device]
+
+
+# ------------------------------------------------------------------------------------------------
+# Host-pointer operators (numpy in / numpy out; data crosses PCIe inside the call)
+# ------------------------------------------------------------------------------------------------
+
+def _batch_dims(XC):
+    if XC.ndim == 2:
+        return XC.shape[0], XC.shape[1], 1, False
+    if XC.ndim == 3:
+        return XC.shape[0], XC.shape[1], XC.shape[2], True
+    raise ValueError("expected [ndim x n_nodes] or [ndim x n_nodes x n_batch]")
+
+
+def _tgrids(t, n_nodes, n_batch):
+    t = _f64(t)
+    if t.ndim == 1:
+        if t.shape[0] != n_nodes:
+            raise ValueError("t_TU must have n_nodes entries")
+        return t, 1
+    if t.shape != (n_nodes, n_batch):
+        raise ValueError("t_TU must be [n_nodes] or [n_nodes x n_batch]")
+    return t, n_batch
+
+
+def indirect_defectCalc(XC_all, t_TU, params, integ=None, ctx=None):
+    """defectCalc of multiShoot_CRTBP_indirect (:63-90): returns (defect[12 x (n-1)], errors[n-1]).
+    A trailing batch axis on XC_all sweeps several trajectories (line-search trial points, homotopy levels)
+    in one launch; params may then be one tuple or one per trajectory."""
+    ctx = ctx or default_context()
+    integ = integ or integrator()
+    XC = _f64(XC_all)
+    ndim, n, B, batched = _batch_dims(XC)
+    t, ntg = _tgrids(t_TU, n, B)
+    prm, nprm = _params_array(params)
+    defect = np.zeros((ndim, n - 1, B), order="F")
+    errors = np.zeros((n - 1, B), order="F")
+    ctx.check(ctx.lib.lto_indirect_defect(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
+                                          _ptr(defect), _ptr(errors)))
+    if not batched:
+        return defect[:, :, 0], errors[:, 0]
+    return defect, errors
+
+
+def indirect_stm(XC_all, t_TU, params, integ=None, ctx=None):
+    """Compact Jacobian blocks: Phi[12 x 12 x (n-1)] with Phi[:,:,i] = d x(t_{i+1}) / d XC_all[:,i]
+    (the ForwardDiff.jacobian(f, x0) of :121), plus the defect."""
+    ctx = ctx or default_context()
+    integ = integ or integrator()
+    XC = _f64(XC_all)
+    ndim, n, B, batched = _batch_dims(XC)
+    t, ntg = _tgrids(t_TU, n, B)
+    prm, nprm = _params_array(params)
+    Phi = np.zeros((ndim, ndim, n - 1, B), order="F")
+    defect = np.zeros((ndim, n - 1, B), order="F")
+    ctx.check(ctx.lib.lto_indirect_jacobian(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
+                                            _ptr(Phi), _ptr(defect)))
+    if not batched:
+        return Phi[:, :, :, 0], defect[:, :, 0]
+    return Phi, defect
+
+
+def indirect_scatter(Phi, sparse=False):
+    """Band scatter of jacobianCalc (:123-142): row block i = [Phi_i | -I] at columns 12(i-1)+(1:24)
+    (1-based), then columns 1:6 and (end-11):(end-6) zeroed (fixed end states)."""
+    nd, _, S = Phi.shape
+    ns = nd // 2
+    n = S + 1
+    if sparse:
+        import scipy.sparse as sp
+        rows = (np.arange(S)[:, None, None] * nd + np.arange(nd)[None, :, None] + np.zeros((1, 1, nd), int)).ravel()
+        cols = (np.arange(S)[:, None, None] * nd + np.zeros((1, nd, 1), int) + np.arange(nd)[None, None, :]).ravel()
+        vals = np.transpose(Phi, (2, 0, 1)).ravel()
+        ir = (np.arange(S)[:, None] * nd + np.arange(nd)[None, :]).ravel()
+        ic = ir + nd
+        J = sp.coo_matrix((np.concatenate([vals, -np.ones(S * nd)]),
+                           (np.concatenate([rows, ir]), np.concatenate([cols, ic]))), shape=(nd * S, nd * n)).tolil()
+        J[:, 0:ns] = 0.0
+        J[:, nd * n - nd:nd * n - ns] = 0.0
+        return J.tocsc()
+    J = np.zeros((nd * S, nd * n))
+    for i in range(S):
+        J[nd * i:nd * (i + 1), nd * i:nd * (i + 1)] = Phi[:, :, i]
+        J[nd * i:nd * (i + 1), nd * (i + 1):nd * (i + 2)] = -np.eye(nd)
+    J[:, 0:ns] = 0.0
+    J[:, nd * n - nd:nd * n - ns] = 0.0
+    return J
+
+
+def indirect_jacobianCalc(XC_all, t_TU, params, integ=None, ctx=None, sparse=False):
+    """jacobianCalc of multiShoot_CRTBP_indirect (:93-146): Jac_full [12(n-1) x 12n]."""
+    Phi, _ = indirect_stm(XC_all, t_TU, params, integ, ctx)
+    return indirect_scatter(Phi, sparse=sparse)
+
+
+def direct_defectCalc(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
+    """defectCalc of multiShoot_CRTBP_direct (:66-109): returns (defect[nstate x (n-1)], errors[n-1])."""
+    ctx = ctx or default_context()
+    X = _f64(X_all)
+    U = _f64(u_all)
+    ns, n, B, batched = _batch_dims(X)
+    t, ntg = _tgrids(t_TU, n, B)
+    prm = LtoDirectParams(float(MU), float(DU), float(TU), float(Isp))
+    defect = np.zeros((ns, n - 1, B), order="F")
+    errors = np.zeros((n - 1, B), order="F")
+    ctx.check(ctx.lib.lto_direct_defect(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
+                                        _ptr(defect), _ptr(errors)))
+    if not batched:
+        return defect[:, :, 0], errors[:, 0]
+    return defect, errors
+
+
+def direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
+    """Compact direct Jacobian: (Jac_temp[nstate x nvar x (n-1)], ddefect_dtf[nstate x (n-1)], defect, errors);
+    nvar = 2(nstate+3), variable order [x_i; x_{i+1}; u_i; u_{i+1}] (:125)."""
+    ctx = ctx or default_context()
+    X = _f64(X_all)
+    U = _f64(u_all)
+    ns, n, B, batched = _batch_dims(X)
+    nvar = 2 * (ns + 3)
+    t, ntg = _tgrids(t_TU, n, B)
+    prm = LtoDirectParams(float(MU), float(DU), float(TU), float(Isp))
+    Jt = np.zeros((ns, nvar, n - 1, B), order="F")
+    dtf = np.zeros((ns, n - 1, B), order="F")
+    defect = np.zeros((ns, n - 1, B), order="F")
+    errors = np.zeros((n - 1, B), order="F")
+    ctx.check(ctx.lib.lto_direct_jacobian(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
+                                          _ptr(Jt), _ptr(dtf), _ptr(defect), _ptr(errors)))
+    if not batched:
+        return Jt[:, :, :, 0], dtf[:, :, 0], defect[:, :, 0], errors[:, 0]
+    return Jt, dtf, defect, errors
+
+
+def direct_scatter(Jac_temp, ddefect_dtf=None):
+    """Band scatter of the direct jacobianCalc (:146-162) and the tf column (:516):
+    Jac_full [nstate(n-1) x n(nstate+3) (+1)]; state columns node-major, then control columns."""
+    ns, nvar, S = Jac_temp.shape
+    n = S + 1
+    ncol = n * (ns + 3) + (1 if ddefect_dtf is not None else 0)
+    J = np.zeros((ns * S, ncol))
+    for i in range(S):
+        r = slice(ns * i, ns * (i + 1))
+        J[r, ns * i:ns * i + 2 * ns] = Jac_temp[:, :2 * ns, i]
+        J[r, ns * n + 3 * i:ns * n + 3 * i + 6] = Jac_temp[:, 2 * ns:, i]
+    if ddefect_dtf is not None:
+        J[:, -1] = np.asarray(ddefect_dtf).reshape(-1, order="F")
+    return J
+
+
+def direct_jacobianCalc(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None, with_tf=True):
+    """jacobianCalc (+ tf partial) of multiShoot_CRTBP_direct: Jac_full [nstate(n-1) x n(nstate+3)+1]."""
+    Jt, dtf, _, _ = direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx)
+    return direct_scatter(Jt, dtf if with_tf else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# Device-resident plans (operands stay in HBM; SoA layouts of include/lto.h)
+# ------------------------------------------------------------------------------------------------
+
+def _dptr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream (so torch events / collectives order against our launches)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class IndirectPlan:
+    """lto_indirect_plan: per-trajectory parameters uploaded once, then repeated asynchronous sweeps."""
+
+    def __init__(self, ctx, n_nodes, n_batch, params, integ, ndim=12):
+        self.ctx = ctx
+        self.n_nodes, self.n_batch, self.ndim = int(n_nodes), int(n_batch), int(ndim)
+        self.S = (self.n_nodes - 1) * self.n_batch
+        prm, nprm = _params_array(params)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.lto_indirect_plan_create(ctx.handle, self.ndim, self.n_nodes, self.n_batch, prm, nprm,
+                                                   C.byref(integ), C.byref(h)))
+        self.handle = h
+
+    def set_cols_per_lane(self, cols):
+        self.ctx.check(self.ctx.lib.lto_indirect_plan_set_cols_per_lane(self.handle, int(cols)))
+
+    def defect(self, X, ldx, t, n_tgrids, defect, ldd, errors=None, stream=None):
+        self.ctx.check(self.ctx.lib.lto_indirect_defect_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(t), int(n_tgrids),
+                                                            _dptr(defect), int(ldd), _dptr(errors)))
+
+    def jacobian(self, X, ldx, t, n_tgrids, Phi, ldp, defect=None, ldd=0, stream=None):
+        self.ctx.check(self.ctx.lib.lto_indirect_jacobian_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(t),
+                                                              int(n_tgrids), _dptr(Phi), int(ldp), _dptr(defect), int(ldd)))
+
+    def steps_accepted_ptr(self):
+        return self.ctx.lib.lto_indirect_plan_steps_accepted(self.handle)
+
+    def steps_rejected_ptr(self):
+        return self.ctx.lib.lto_indirect_plan_steps_rejected(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.lto_indirect_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DirectPlan:
+    def __init__(self, ctx, nstate, n_nodes, n_batch, nsteps, MU, DU, TU, Isp):
+        self.ctx = ctx
+        self.nstate, self.n_nodes, self.n_batch, self.nsteps = int(nstate), int(n_nodes), int(n_batch), int(nsteps)
+        self.S = (self.n_nodes - 1) * self.n_batch
+        prm = LtoDirectParams(float(MU), float(DU), float(TU), float(Isp))
+        h = C.c_void_p()
+        ctx.check(ctx.lib.lto_direct_plan_create(ctx.handle, self.nstate, self.n_nodes, self.n_batch, self.nsteps,
+                                                 C.byref(prm), C.byref(h)))
+        self.handle = h
+
+    def defect(self, X, ldx, U, ldu, t, n_tgrids, defect, ldd, errors=None, stream=None):
+        self.ctx.check(self.ctx.lib.lto_direct_defect_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(U), int(ldu),
+                                                          _dptr(t), int(n_tgrids), _dptr(defect), int(ldd), _dptr(errors)))
+
+    def jacobian(self, X, ldx, U, ldu, t, n_tgrids, Jac, ldj, dtf=None, defect=None, ldd=0, errors=None, stream=None):
+        self.ctx.check(self.ctx.lib.lto_direct_jacobian_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(U), int(ldu),
+                                                            _dptr(t), int(n_tgrids), _dptr(Jac), int(ldj), _dptr(dtf),
+                                                            _dptr(defect), int(ldd), _dptr(errors)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.lto_direct_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_soa(ctx, aos, ndim, count, soa, ld, stream=None):
+    ctx.check(ctx.lib.lto_pack_soa_dev(ctx.handle, stream, _dptr(aos), int(ndim), int(count), _dptr(soa), int(ld)))
+
+
+def unpack_soa(ctx, soa, ld, ndim, count, aos, stream=None):
+    ctx.check(ctx.lib.lto_unpack_soa_dev(ctx.handle, stream, _dptr(soa), int(ld), int(ndim), int(count), _dptr(aos)))
+
+
+def defect_norms(ctx, defect, ldd, ndim, seg_per_traj, n_batch, sumsq, maxabs, stream=None):
+    ctx.check(ctx.lib.lto_defect_norms_dev(ctx.handle, stream, _dptr(defect), int(ldd), int(ndim), int(seg_per_traj),
+                                           int(n_batch), _dptr(sumsq), _dptr(maxabs)))
