@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- segment-integrations/s of the multiple-shooting hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU (RCCL).
+Rank 0 prints ONE JSON line.
+
+Workload (default `c2`, BASELINE.json configs[1]): indirect method, 12-dim state+costate PLUS the 12x12 STM
+(the metric's "state+costate+STM" unit), 4 096 shooting segments per GPU, fixed-step RK4, 64 steps per
+segment, fp64, p = 1, rho = 1, thrust 0.05 N -- i.e. one `jacobianCalc` sweep (which also emits the defect) of
+src/multiShoot_CRTBP_indirect.jl:93-146 per step.  Inputs are synthetic halo->halo stacked trajectories
+(lowthrustopt_amd/synth.py) resident in HBM (struct-of-arrays) before the timed region starts.
+N > 1: weak scaling -- every rank sweeps its own 4 096 segments, then one RCCL all-gather of the per-rank
+defect slabs (12 x 4096 doubles = 393 KB per rank) gives every rank the full defect vector.
+
+Other workloads (`--workload c3|c4|c5|hbm`) are measurement aids for DESIGN.md, not the contract line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_TFLOPS = 78.6   # MI355X vector (= matrix) FP64 peak
+PEAK_HBM_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+# Algorithmic work per unit (DESIGN.md "Roofline"): flops = steps*(stages*F_rhs + C_tab*dim)
+WORK = {
+    # name: (flops per segment, algorithmic bytes per segment)
+    "c2": (64 * (4 * 1070 + 14 * 156), 1456),       # 12-dim + 12x12 STM, RK4 x 64
+    "c2_defect": (64 * (4 * 95 + 14 * 12), 304),
+    "c3": (18 * (13 * 232 + 132 * 60), 1080 + 48),   # direct 6-dim + Phi + Psi, RKF7(8) 9 steps x 2 halves
+    "hbm": (1 * (4 * 1070 + 14 * 156), 1456),        # 1 RK4 step + full STM output: the HBM evidence point
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2_defect", "c3", "c4", "c5", "hbm"])
+    ap.add_argument("--segments", type=int, default=0, help="segments per GPU (default: the workload's)")
+    ap.add_argument("--cols", type=int, default=0, help="STM columns per lane (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, seconds):
+    """Oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    import lowthrustopt_amd as lto
+    from lowthrustopt_amd import synth
+    prm = [lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+    if workload == "c3":
+        X, U, T = synth.direct_problem(65, seed=0)
+        X, U, t = X[:, :, 0], U[:, :, 0], T[:, 0]
+
+        def run():
+            d, e = O.direct_defect(X, U, t, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+            O.direct_jacobian_fd(X, U, t, d, 10, lto.MU, lto.DU, lto.TU, 2000.0)   # the reference's FD Jacobian
+            O.direct_dtf_fd(X, U, t, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        per_call = 64
+        what = "direct defect + 18-column forward-difference Jacobian + tf partial (the reference's method), RKF7(8) nsteps=10"
+    else:
+        XC, T = synth.indirect_problem(65, seed=0)
+        XC, t = XC[:, :, 0], T[:, 0]
+
+        def run():
+            O.indirect_jacobian(XC, t, prm, O.RK4, 64)
+        per_call = 64
+        what = "indirect 12-dim + 12x12 STM by dual numbers through RK4 x 64 (same discrete map as the GPU run)"
+    O.lib()
+    run()
+    t0 = time.perf_counter()
+    calls = 0
+    while True:
+        run()
+        calls += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": per_call * calls / el, "unit": "segment-integrations/s", "cores": 1, "kind": "port",
+            "sample": "%d segments x %d sweeps in %.1f s; %s; host has %d cores" % (per_call, calls, el, what, os.cpu_count() or 0)}
+
+
+def main():
+    a = parse()
+    import torch
+    import lowthrustopt_amd as lto
+    from lowthrustopt_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    ctx = lto.Context(local_rank)
+    st = lto.current_stream_ptr()
+
+    wl = a.workload
+    prm1 = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    extra = {}
+    if wl in ("c2", "c2_defect", "hbm", "c5"):
+        S = a.segments or (65536 // max(world, 1) if wl == "c5" else 4096)
+        n = S + 1
+        if wl == "c5":
+            XC, T = synth.indirect_problem(n, seed=1 + rank, dt_range=(0.05, 0.5))
+            prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1e-3)
+            integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13)
+            desc = "C5: indirect 12-dim defect, adaptive DOP853 rtol=atol=1e-13, dt_seg~U[0.05,0.5], rho=1e-3"
+        else:
+            XC, T = synth.indirect_problem(n, seed=rank)
+            prm = prm1
+            steps = 1 if wl == "hbm" else 64
+            integ = lto.integrator(lto.RK4, steps=steps)
+            desc = {"c2": "C2: indirect 12-dim state+costate + 12x12 STM, RK4 x 64 steps, fp64, p=1 rho=1 thrust 0.05 N",
+                    "c2_defect": "C2 (defect only): indirect 12-dim state+costate, RK4 x 64 steps",
+                    "hbm": "HBM evidence point: indirect 12-dim + 12x12 STM, ONE RK4 step per segment"}[wl]
+        X = torch.from_numpy(synth.to_soa_nodes(XC)).to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).to(dev)
+        plan = lto.IndirectPlan(ctx, n, 1, prm, integ)
+        if a.cols:
+            plan.set_cols_per_lane(a.cols)
+        defect = torch.zeros(12, S, **f64)
+        Phi = torch.zeros(144, S, **f64)
+        if wl in ("c2", "hbm"):
+            def sweep():
+                plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)
+        else:
+            def sweep():
+                plan.defect(X, n, t, 1, defect, S, stream=st)
+        n_traj, gather_rows = 1, 12
+    elif wl == "c4":
+        levels = 256 // max(world, 1) if not a.segments else max(1, a.segments // 1024)
+        spt = 1024
+        n = spt + 1
+        S = levels * spt
+        XC, T = synth.indirect_problem(n, n_batch=levels, seed=10 + rank)
+        rhos = synth.homotopy_rhos(256)[rank * levels:(rank + 1) * levels] if world * levels == 256 else synth.homotopy_rhos(levels)
+        prm = [lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, r) for r in rhos]
+        integ = lto.integrator(lto.RK4, steps=64)
+        X = torch.from_numpy(synth.to_soa_nodes(XC)).to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(T.T)).to(dev)   # [levels][n]
+        plan = lto.IndirectPlan(ctx, n, levels, prm, integ)
+        if a.cols:
+            plan.set_cols_per_lane(a.cols)
+        defect = torch.zeros(12, S, **f64)
+        Phi = torch.zeros(144, S, **f64)
+
+        def sweep():
+            plan.jacobian(X, n * levels, t, levels, Phi, S, defect, S, stream=st)
+        desc = "C4: homotopy sweep, %d rho levels x 1024 segments per GPU, 12-dim + STM, RK4 x 64" % levels
+        gather_rows = 12
+    else:  # c3
+        S = a.segments or 16384
+        n = S + 1
+        Xd, Ud, Td = synth.direct_problem(n, seed=rank)
+        X = torch.from_numpy(synth.to_soa_nodes(Xd)).to(dev)
+        U = torch.from_numpy(synth.to_soa_nodes(Ud)).to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(Td[:, 0])).to(dev)
+        plan = lto.DirectPlan(ctx, 6, n, 1, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        defect = torch.zeros(6, S, **f64)
+        errs = torch.zeros(S, **f64)
+        Jac = torch.zeros(108, S, **f64)
+        dtf = torch.zeros(6, S, **f64)
+
+        def sweep():
+            plan.jacobian(X, n, U, n, t, 1, Jac, S, dtf, defect, S, errs, stream=st)
+        desc = "C3: direct 6-dim, RKF7(8) nsteps=10 per half, on-device Jacobian blocks 6x18 + tf column + defect + errors"
+        gather_rows = 6
+
+    gathered = torch.zeros(world, gather_rows, S, **f64) if world > 1 else None
+
+    def step():
+        sweep()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, defect)   # RCCL over xGMI, same stream order
+
+    for _ in range(a.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()
+        sweep()
+        ev[k][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, defect)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kt = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+        kern_ms = float(kt.item())
+
+    # sanity: the sweep produced finite numbers (a failed launch would leave zeros / raise earlier)
+    assert bool(torch.isfinite(defect).all()), "non-finite defect in benchmark sweep"
+
+    if rank == 0:
+        value = world * S * a.steps / elapsed
+        out = {
+            "metric": "segment-integrations/sec (state+costate+STM)" if wl in ("c2", "c4", "hbm") else "segment-integrations/sec",
+            "value": value, "unit": "segment-integrations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
+                       "collective": "rccl all_gather(defect)" if world > 1 else "none", "integrator": "see workload"},
+        }
+        if wl in WORK:
+            flops, nbytes = WORK[wl]
+            dur = kern_ms * 1e-3
+            ach_tf = flops * S / dur / 1e12
+            ach_gb = nbytes * S / dur / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % wl)
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "bound": "fp64_valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
+                "kernel_ms": kern_ms, "flops_per_segment": flops, "bytes_per_segment": nbytes,
+                "hbm": {"achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBS},
+                "note": "register-resident fp64 ODE integration: bound by the FP64 vector pipe (no MFMA issued; MI355X "
+                        "FP64 matrix peak equals the vector peak), not by HBM -- see DESIGN.md 'Roofline'",
+            }
+        if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm"):
+            out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

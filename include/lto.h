@@ -77,6 +77,7 @@ int lto_create(lto_ctx** out, int device_id);
 void lto_destroy(lto_ctx* ctx);
 const char* lto_last_error(const lto_ctx* ctx);
 int lto_version(void);
+void* lto_ctx_stream(lto_ctx* ctx); /* the context's own non-blocking hipStream_t */
 /* When enabled, every sweep brackets its dominant kernel with HIP events on the launch stream;
  * lto_last_kernel_ms blocks on the stop event and returns that kernel's duration. */
 int lto_set_timing(lto_ctx* ctx, int enabled);
@@ -128,7 +129,8 @@ int lto_direct_jacobian(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, cons
  * segments (node j = b*n_nodes + k, segment s = b*(n_nodes-1) + i):
  *   X[c*ldx + j]  t[g*n_nodes + k]  defect[c*ldd + s]  Phi[(col*ndim+row)*ldp + s]  errors[s]
  *   U[c*ldu + j]  Jac[(col*nstate+row)*ldj + s]  dtf[c*ldd + s]
- * Launches are asynchronous on `stream` (a hipStream_t; NULL = the context's stream). */
+ * Launches are asynchronous on `stream`, a hipStream_t taken literally (NULL = HIP's default stream,
+ * which is also PyTorch's default current stream); lto_ctx_stream() returns the context's own stream. */
 int lto_indirect_plan_create(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
                              const lto_integrator* integ, lto_indirect_plan** out);
 void lto_indirect_plan_destroy(lto_indirect_plan* plan);

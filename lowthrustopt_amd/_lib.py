@@ -42,6 +42,7 @@ SIGNATURES = {
     "lto_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "lto_destroy": (None, [_vp]),
     "lto_last_error": (C.c_char_p, [_vp]),
+    "lto_ctx_stream": (_vp, [_vp]),
     "lto_set_timing": (C.c_int, [_vp, C.c_int]),
     "lto_last_kernel_ms": (C.c_double, [_vp]),
     "lto_indirect_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,

@@ -176,6 +176,8 @@ void lto_destroy(lto_ctx* c) {
 
 const char* lto_last_error(const lto_ctx* c) { return c ? c->err : "null context"; }
 
+void* lto_ctx_stream(lto_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
 int lto_set_timing(lto_ctx* c, int enabled) {
   if (!c) return LTO_ENULL;
   c->timing = enabled != 0;
@@ -280,7 +282,7 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   a.defect = defect; a.ldd = ldd; a.errors = errors;
   rc = bind_device(c);
   if (rc) return rc;
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
   hipError_t e = launch_indirect_defect(p->pm, p->integ.method, a, st);
   timing_end(c, st);
@@ -300,7 +302,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   a.Phi = Phi; a.ldp = ldp; a.defect = defect; a.ldd = ldd;
   rc = bind_device(c);
   if (rc) return rc;
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
   hipError_t e = launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);
@@ -358,7 +360,7 @@ int lto_direct_defect_dev(lto_direct_plan* p, void* stream, const double* X, lon
   a.defect = defect; a.ldd = ldd; a.errors = errors;
   rc = bind_device(c);
   if (rc) return rc;
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
   hipError_t e = launch_direct_defect(p->nstate, a, st);
   timing_end(c, st);
@@ -379,7 +381,7 @@ int lto_direct_jacobian_dev(lto_direct_plan* p, void* stream, const double* X, l
   a.Jac = Jac; a.ldj = ldj; a.dtf = dtf; a.defect = defect; a.ldd = ldd; a.errors = errors;
   rc = bind_device(c);
   if (rc) return rc;
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
   hipError_t e = launch_direct_jacobian(p->nstate, a, st);
   timing_end(c, st);
@@ -394,7 +396,7 @@ int lto_pack_soa_dev(lto_ctx* c, void* stream, const double* aos, int ndim, long
   if (ndim < 1 || count < 0 || ld < count) return set_err(c, LTO_EINVAL, "bad pack dimensions");
   int rc = bind_device(c);
   if (rc) return rc;
-  hipError_t e = launch_pack_soa(aos, ndim, count, soa, ld, stream ? (hipStream_t)stream : c->stream);
+  hipError_t e = launch_pack_soa(aos, ndim, count, soa, ld, (hipStream_t)stream);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_pack_soa", e);
   return LTO_OK;
 }
@@ -405,7 +407,7 @@ int lto_unpack_soa_dev(lto_ctx* c, void* stream, const double* soa, long ld, int
   if (ndim < 1 || count < 0 || ld < count) return set_err(c, LTO_EINVAL, "bad unpack dimensions");
   int rc = bind_device(c);
   if (rc) return rc;
-  hipError_t e = launch_unpack_soa(soa, ld, ndim, count, aos, stream ? (hipStream_t)stream : c->stream);
+  hipError_t e = launch_unpack_soa(soa, ld, ndim, count, aos, (hipStream_t)stream);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_unpack_soa", e);
   return LTO_OK;
 }
@@ -419,7 +421,7 @@ int lto_defect_norms_dev(lto_ctx* c, void* stream, const double* defect, long ld
   int rc = bind_device(c);
   if (rc) return rc;
   hipError_t e = launch_defect_norms(defect, ldd, ndim, seg_per_traj, n_batch, sumsq, maxabs,
-                                     stream ? (hipStream_t)stream : c->stream);
+                                     (hipStream_t)stream);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_defect_norms", e);
   return LTO_OK;
 }

@@ -79,6 +79,11 @@ template <int N> inline Dual<N> o_tanh(const Dual<N>& a) { Dual<N> r; r.v = std:
 template <int N> inline double o_val(const Dual<N>& a) { return a.v; }
 template <int N> inline bool o_isnan(const Dual<N>& a) { return std::isnan(a.v); }
 
+/* x^e with the exponent carried in the scalar type (binary128 runs keep 1/(p-1) in binary128) */
+inline double o_powT(double x, double e) { return std::pow(x, e); }
+inline quad o_powT(quad x, quad e) { return powq(x, e); }
+template <int N> inline Dual<N> o_powT(const Dual<N>& a, const Dual<N>& e) { return o_pow(a, e.v); }
+
 /* Euclidean norm of a 3-vector.  For duals at the origin the two-sided derivative does not exist; the
  * one-sided directional derivative |dc| is returned, which is what the reference's forward finite
  * difference sees when the nominal control is exactly zero (src/multiShoot_CRTBP_direct.jl:129-140). */
@@ -112,23 +117,26 @@ template <int N> inline double o_sumsq(const Dual<N>& a) { double s = a.v * a.v;
  * Returns 0, or 1 for the reference's error("Invalid value of p!") (:52). */
 template <class T>
 int rhs_state_costate(const T* y, const double* prm, T* dy) {
-  const double MU = prm[0], DU = prm[1], TU = prm[2], thrustLimit = prm[3], mass = prm[4];
+  /* MU is carried in T so that the binary128 instantiation evaluates (1-MU) etc. in binary128 */
+  const T MU = T(prm[0]);
+  const double DU = prm[1], TU = prm[2], thrustLimit = prm[3], mass = prm[4];
   const double time_direction = prm[5], p = prm[6], rho = prm[7];
   const T X1 = y[0], X2 = y[1], X3 = y[2], X4 = y[3], X5 = y[4], X6 = y[5];
   const T L1 = y[6], L2 = y[7], L3 = y[8], L4 = y[9], L5 = y[10], L6 = y[11];
   (void)X6;
 
-  const double accelLimit = thrustLimit / mass / 1e3 * (TU * TU) / DU; /* :33 */
+  /* :33 -- same operation order as the reference; carried in T (identical in binary64) */
+  const T accelLimit = T(thrustLimit) / mass / 1e3 * (T(TU) * T(TU)) / DU;
   const T nlv = o_sqrt(L4 * L4 + L5 * L5 + L6 * L6);                  /* norm(λv) */
   T umag;
   if (p == 0.0) {
-    umag = T(accelLimit);                                              /* :36-39 */
+    umag = accelLimit;                                                 /* :36-39 */
   } else if (p == 1.0) {
     T g = nlv - 1.0;                                                   /* :42 */
-    umag = 0.5 * (1.0 + o_tanh(g / (2.0 * rho))) * accelLimit;         /* :43 */
+    umag = 0.5 * (1.0 + o_tanh(g / (2.0 * T(rho)))) * accelLimit;      /* :43 */
   } else if (p > 1.0) {
-    umag = o_pow(1.0 / p * nlv, 1.0 / (p - 1.0));                      /* :46 */
-    if (umag > accelLimit) umag = T(accelLimit);                       /* :48-50 */
+    umag = o_powT(T(1.0) / T(p) * nlv, T(1.0) / (T(p) - 1.0));         /* :46 */
+    if (umag > accelLimit) umag = accelLimit;                          /* :48-50 */
   } else {
     return 1;                                                          /* :52 */
   }

@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Mint the golden vectors under tests/golden/ (run once in the build container; output committed).
+
+The reference (Julia) cannot run here and ships no tests or golden vectors, so these vectors come from
+restatements that are INDEPENDENT of both the C++ oracle (oracle/lto_oracle.cpp) and the HIP kernels:
+
+  rhs_state_costate.json   CRTBP_stateCostate_deriv! (src/CRTBP_stateCostate_deriv.jl:9-90) evaluated with
+                           mpmath at 40 digits.  The costate rows are NOT transcribed from the reference's
+                           longhand (:83-85) nor from the G-matrix form used on the GPU: they are obtained as
+                           lambda_r_dot = -grad_r( grad(Omega)(r) . lambda_v ) by high-order numerical
+                           differentiation of the CRTBP pseudo-potential Omega.
+  rhs_prop_ep.json         CRTBP_prop_EP_deriv (src/CRTBP_prop_EP_deriv.jl:8-61), mpmath 40 digits.
+  flows_taylor.json        final states (and one STM by central differences) of a few demo-sized segments
+                           integrated with mpmath's Taylor-series ODE solver at 30 digits.
+  flows_scipy.json         32 segments with scipy DOP853 at rtol = atol = 1e-13 (the reference's tolerance,
+                           src/multiShoot_CRTBP_indirect.jl:79).
+  direct_numpy.json        mid-point defects and maxErr of 8 segments from a numpy transliteration of ode7_8
+                           (GeneralCode/ode.jl:875-952, with the same `f*beta_[:,j]` matrix-vector form) and of
+                           the two-sided shooting of src/multiShoot_CRTBP_direct.jl:77-105.
+  halo_kat.json            facts about the reference's own data files (Jacobi constant per column,
+                           column->column propagation residuals) computed with scipy.
+
+Usage: python tests/golden/gen_golden.py
+"""
+import json
+import os
+import sys
+
+import mpmath as mp
+import numpy as np
+from scipy.integrate import solve_ivp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from lowthrustopt_amd import synth  # noqa: E402
+from lowthrustopt_amd.constants import MU, DU, TU  # noqa: E402
+
+mp.mp.dps = 40
+
+
+# ---------------------------------------------------------------------------------------------- mpmath RHS
+def mp_control(lv, thrustLimit, mass, p, rho):
+    """Control law, stateCostate_deriv.jl:33-64."""
+    accelLimit = mp.mpf(thrustLimit) / mass / 1000 * mp.mpf(TU) ** 2 / mp.mpf(DU)
+    n = mp.sqrt(sum(x * x for x in lv))
+    if p == 0:
+        umag = accelLimit
+    elif p == 1:
+        umag = mp.mpf(1) / 2 * (1 + mp.tanh((n - 1) / (2 * mp.mpf(rho)))) * accelLimit
+    elif p > 1:
+        umag = (n / mp.mpf(p)) ** (1 / (mp.mpf(p) - 1))
+        if umag > accelLimit:
+            umag = accelLimit
+    else:
+        raise ValueError("Invalid value of p!")
+    if n == 0:
+        return [mp.mpf(0)] * 3
+    return [-umag * x / n for x in lv]
+
+
+def mp_grad_omega(r, mu):
+    """Gradient of the CRTBP pseudo-potential Omega = (x^2+y^2)/2 + (1-mu)/r1 + mu/r2."""
+    x, y, z = r
+    r1 = mp.sqrt((x + mu) ** 2 + y ** 2 + z ** 2)
+    r2 = mp.sqrt((x + mu - 1) ** 2 + y ** 2 + z ** 2)
+    return [x - (1 - mu) * (x + mu) / r1 ** 3 - mu * (x + mu - 1) / r2 ** 3,
+            y - (1 - mu) * y / r1 ** 3 - mu * y / r2 ** 3,
+            -(1 - mu) * z / r1 ** 3 - mu * z / r2 ** 3]
+
+
+def mp_hessian_omega(r, mu):
+    """Hessian of Omega in closed form (textbook tidal tensor), used where mp.diff would be too slow/inexact."""
+    x, y, z = r
+    out = [[mp.mpf(0)] * 3 for _ in range(3)]
+    out[0][0] = mp.mpf(1); out[1][1] = mp.mpf(1)
+    for kappa, rho in ((1 - mu, [x + mu, y, z]), (mu, [x + mu - 1, y, z])):
+        d = mp.sqrt(sum(v * v for v in rho))
+        for i in range(3):
+            out[i][i] -= kappa / d ** 3
+            for j in range(3):
+                out[i][j] += 3 * kappa * rho[i] * rho[j] / d ** 5
+    return out
+
+
+def mp_rhs_state_costate(y, prm, numeric_hessian=True):
+    MUq, _, _, thrustLimit, mass, td, p, rho = prm
+    mu = mp.mpf(MUq)
+    y = [mp.mpf(v) for v in y]
+    r, v, lr, lv = y[0:3], y[3:6], y[6:9], y[9:12]
+    g = mp_grad_omega(r, mu)
+    u = mp_control(lv, thrustLimit, mass, p, rho)
+    td = mp.mpf(td)
+    dv = [g[0] + 2 * td * v[1] + u[0], g[1] - 2 * td * v[0] + u[1], g[2] + u[2]]
+
+    def phi(*rr):
+        gg = mp_grad_omega(list(rr), mu)
+        return gg[0] * lv[0] + gg[1] * lv[1] + gg[2] * lv[2]
+
+    if numeric_hessian:
+        # numerical differentiation at 3x the working precision: error far below 1e-25
+        old = mp.mp.dps
+        mp.mp.dps = 3 * old
+        try:
+            dlr = [-mp.diff(phi, tuple(r), n=tuple(1 if k == i else 0 for k in range(3))) for i in range(3)]
+        finally:
+            mp.mp.dps = old
+        dlr = [+v for v in dlr]
+    else:
+        Hs = mp_hessian_omega(r, mu)
+        dlr = [-(Hs[i][0] * lv[0] + Hs[i][1] * lv[1] + Hs[i][2] * lv[2]) for i in range(3)]
+    dlv = [2 * lv[1] * td - lr[0], -lr[1] - 2 * lv[0] * td, -lr[2]]
+    return v + dv + dlr + dlv
+
+
+def mp_rhs_prop_ep(s, Isp, control, td):
+    s = [mp.mpf(v) for v in s]
+    c = [mp.mpf(v) for v in control]
+    mu = mp.mpf(MU)
+    m = s[6] if len(s) == 7 else mp.mpf(1000)
+    g = mp_grad_omega(s[0:3], mu)
+    nc = mp.sqrt(sum(x * x for x in c))
+    Tmag = nc / m / 1000 * mp.mpf(TU) ** 2 / mp.mpf(DU)
+    T = c if nc == 0 else [x / nc * Tmag for x in c]
+    td = mp.mpf(td)
+    out = s[3:6] + [g[0] + 2 * td * s[4] + T[0], g[1] - 2 * td * s[3] + T[1], g[2] + T[2]]
+    if len(s) == 7:
+        out.append(-td * nc / (mp.mpf(Isp) * mp.mpf("9.81")) * mp.mpf(TU))
+    return out
+
+
+def f64(v):
+    return [float(x) for x in v]
+
+
+# ---------------------------------------------------------------------------------------------- fixtures
+def gen_rhs():
+    rng = np.random.default_rng(11)
+    H1, H2 = synth.halo_orbits()
+    cases = []
+    combos = [(1.0, 1.0, 0.05, 1.0), (1.0, 1e-2, 0.05, 1.0), (1.0, 1e-4, 0.05, 1.0), (2.0, 1.0, 10.0, 1.0),
+              (2.0, 1.0, 0.05, 1.0), (1.5, 1.0, 10.0, 1.0), (1.5, 1.0, 0.001, 1.0), (0.0, 1.0, 0.05, 1.0),
+              (1.0, 1.0, 0.05, -1.0), (2.0, 1.0, 10.0, -1.0), (1.0, 1e-3, 10.0, 1.0), (1.2, 0.5, 10.0, -1.0)]
+    for k, (p, rho, thr, td) in enumerate(combos):
+        for rep in range(2):
+            tab = H1 if (k + rep) % 2 == 0 else H2
+            y = np.concatenate([tab[:, rng.integers(0, 99)] + 1e-3 * rng.standard_normal(6),
+                                (0.1 if rep == 0 else 1.2) * rng.standard_normal(6)])
+            prm = [MU, DU, TU, thr, 1000.0, td, p, rho]
+            cases.append({"y": f64(y), "prm": prm, "dy": [mp.nstr(v, 25) for v in mp_rhs_state_costate(y, prm)]})
+    # lambda_v == 0 guard (stateCostate_deriv.jl:59-64) and |lambda_v| == 1 exactly (tanh argument 0)
+    y = np.concatenate([H1[:, 5], [0.01, -0.02, 0.03, 0.0, 0.0, 0.0]])
+    for p in (0.0, 1.0, 2.0):
+        prm = [MU, DU, TU, 0.05, 1000.0, 1.0, p, 1.0]
+        cases.append({"y": f64(y), "prm": prm, "dy": [mp.nstr(v, 25) for v in mp_rhs_state_costate(y, prm)]})
+    y = np.concatenate([H2[:, 40], [0.3, 0.1, -0.2, 0.6, 0.0, 0.8]])
+    prm = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1e-3]
+    cases.append({"y": f64(y), "prm": prm, "dy": [mp.nstr(v, 25) for v in mp_rhs_state_costate(y, prm)]})
+    json.dump({"doc": "mpmath 40-digit CRTBP_stateCostate_deriv!, 25 significant digits", "cases": cases},
+              open(os.path.join(HERE, "rhs_state_costate.json"), "w"), indent=0)
+
+    cases = []
+    for k in range(10):
+        tab = H1 if k % 2 == 0 else H2
+        n = 6 if k < 6 else 7
+        s = list(tab[:, rng.integers(0, 99)] + 1e-3 * rng.standard_normal(6))
+        if n == 7:
+            s.append(1000.0 - 3.0 * k)
+        control = [0.0, 0.0, 0.0] if k in (2, 7) else list(0.05 * rng.standard_normal(3))
+        td = 1.0 if k % 3 else -1.0
+        cases.append({"s": f64(s), "Isp": 2000.0, "control": f64(control), "td": td,
+                      "ds": [mp.nstr(v, 25) for v in mp_rhs_prop_ep(s, 2000.0, control, td)]})
+    json.dump({"doc": "mpmath 40-digit CRTBP_prop_EP_deriv, 25 significant digits", "cases": cases},
+              open(os.path.join(HERE, "rhs_prop_ep.json"), "w"), indent=0)
+
+
+def gen_flows_taylor():
+    mp.mp.dps = 30
+    XC, T = synth.indirect_problem(30, seed=3)
+    span = float(T[1, 0] - T[0, 0])
+    cases = []
+    for (node, p, rho, thr) in ((4, 1.0, 1.0, 0.05), (20, 2.0, 1.0, 10.0), (11, 1.0, 1e-2, 0.05)):
+        y0 = XC[:, node, 0]
+        prm = [MU, DU, TU, thr, 1000.0, 1.0, p, rho]
+
+        def flow(yy):
+            sol = mp.odefun(lambda t, y: mp_rhs_state_costate(y, prm, numeric_hessian=False), 0, [mp.mpf(float(v)) for v in yy], tol=mp.mpf(10) ** -26)
+            return sol(mp.mpf(span))
+
+        yf = flow(y0)
+        case = {"y0": f64(y0), "prm": prm, "span": span, "yf": [mp.nstr(v, 22) for v in yf]}
+        if node == 4:  # STM by 4th-order central differences of the Taylor flow
+            d = 1e-6
+            Phi = np.zeros((12, 12))
+            for c in range(12):
+                fs = {}
+                for k in (-2, -1, 1, 2):
+                    yp = np.array(y0, dtype=np.float64)
+                    yp[c] = yp[c] + k * d
+                    fs[k] = (flow(yp), mp.mpf(float(yp[c])) - mp.mpf(float(y0[c])))
+                for r in range(12):
+                    # Richardson on possibly slightly unequal perturbations (they are exact doubles)
+                    d1 = (fs[1][0][r] - fs[-1][0][r]) / (fs[1][1] - fs[-1][1])
+                    d2 = (fs[2][0][r] - fs[-2][0][r]) / (fs[2][1] - fs[-2][1])
+                    Phi[r, c] = float((4 * d1 - d2) / 3)
+            case["Phi_rowmajor"] = Phi.reshape(-1).tolist()
+        cases.append(case)
+        print("taylor flow node", node, "done", flush=True)
+    mp.mp.dps = 40
+    json.dump({"doc": "mpmath Taylor-series flows of CRTBP_stateCostate_deriv! over one demo segment, 22 digits",
+               "cases": cases}, open(os.path.join(HERE, "flows_taylor.json"), "w"), indent=0)
+
+
+def np_rhs_state_costate(y, prm):
+    """numpy restatement through the pseudo-potential Hessian (independent of the oracle's longhand rows)."""
+    MUq, DUq, TUq, thrustLimit, mass, td, p, rho = prm
+    x, yy, z = y[0:3]
+    lv = y[9:12]
+    aL = thrustLimit / mass / 1e3 * TUq ** 2 / DUq
+    n = np.linalg.norm(lv)
+    if p == 0:
+        umag = aL
+    elif p == 1:
+        umag = 0.5 * (1 + np.tanh((n - 1) / (2 * rho))) * aL
+    else:
+        umag = min((n / p) ** (1 / (p - 1)), aL)
+    u = -umag * lv / n if n > 0 else np.zeros(3)
+    r1v = np.array([x + MUq, yy, z]); r2v = np.array([x + MUq - 1, yy, z])
+    r1 = np.linalg.norm(r1v); r2 = np.linalg.norm(r2v)
+    g = np.array([x, yy, 0.0]) - (1 - MUq) * r1v / r1 ** 3 - MUq * r2v / r2 ** 3
+    Hs = (np.diag([1.0, 1.0, 0.0]) - ((1 - MUq) / r1 ** 3 + MUq / r2 ** 3) * np.eye(3)
+          + 3 * (1 - MUq) * np.outer(r1v, r1v) / r1 ** 5 + 3 * MUq * np.outer(r2v, r2v) / r2 ** 5)
+    dv = g + 2 * td * np.array([y[4], -y[3], 0.0]) + u
+    dlr = -Hs @ lv
+    dlv = np.array([2 * lv[1] * td - y[6], -y[7] - 2 * lv[0] * td, -y[8]])
+    return np.concatenate([y[3:6], dv, dlr, dlv])
+
+
+def gen_flows_scipy():
+    XC, T = synth.indirect_problem(33, seed=5)
+    cases = []
+    combos = [(1.0, 1.0, 0.05), (2.0, 1.0, 10.0), (1.0, 1e-2, 0.05), (1.5, 1.0, 10.0), (0.0, 1.0, 0.05), (1.0, 1e-3, 10.0)]
+    for i in range(32):
+        p, rho, thr = combos[i % len(combos)]
+        prm = [MU, DU, TU, thr, 1000.0, 1.0, p, rho]
+        y0 = XC[:, i, 0]
+        span = float(T[i + 1, 0] - T[i, 0])
+        sol = solve_ivp(lambda t, y: np_rhs_state_costate(y, prm), (0.0, span), y0, method="DOP853", rtol=1e-13, atol=1e-13)
+        cases.append({"y0": f64(y0), "prm": prm, "span": span, "yf": f64(sol.y[:, -1]), "nfev": int(sol.nfev)})
+    json.dump({"doc": "scipy DOP853 rtol=atol=1e-13 flows of the numpy pseudo-potential restatement", "cases": cases},
+              open(os.path.join(HERE, "flows_scipy.json"), "w"), indent=0)
+
+
+# ---------------------------------------------------------------------------------------------- direct path (numpy)
+def np_prop_ep(t, state, MUq, DUq, TUq, Isp, control, td):
+    """CRTBP_prop_EP_deriv, src/CRTBP_prop_EP_deriv.jl:8-61, statement by statement."""
+    x, y, z, xdot, ydot, zdot = state[0:6]
+    m = state[6] if len(state) == 7 else 1000.0
+    r1 = np.sqrt((x + MUq) ** 2 + y ** 2 + z ** 2)
+    r2 = np.sqrt((x + MUq - 1) ** 2 + y ** 2 + z ** 2)
+    r1_3 = r1 ** 3
+    r2_3 = r2 ** 3
+    nc = np.linalg.norm(control)
+    T_mag = nc / m / 1e3 * TUq ** 2 / DUq
+    T = control if nc == 0 else control / nc * T_mag
+    mdot = -td * nc / (Isp * 9.81) * TUq
+    xdd = -(1 - MUq) * (x + MUq) / r1_3 - MUq * (x - 1 + MUq) / r2_3 + 2 * td * ydot + x + T[0]
+    ydd = -(1 - MUq) * y / r1_3 - MUq * y / r2_3 - 2 * td * xdot + y + T[1]
+    zdd = -(1 - MUq) * z / r1_3 - MUq * z / r2_3 + T[2]
+    out = [xdot, ydot, zdot, xdd, ydd, zdd]
+    if len(state) == 7:
+        out.append(mdot)
+    return np.array(out)
+
+
+def np_ode7_8(odefun, tspan, x0, *args):
+    """ode7_8, GeneralCode/ode.jl:773-953 (coefficients :875-892, loop :924-949)."""
+    alpha = np.array([2. / 27., 1 / 9, 1 / 6, 5 / 12, 0.5, 5 / 6, 1 / 6, 2 / 3, 1 / 3, 1, 0, 1])
+    beta = np.zeros((13, 12))
+    cols = [[2 / 27], [1 / 36, 1 / 12], [1 / 24, 0, 1 / 8], [5 / 12, 0, -25 / 16, 25 / 16], [0.05, 0, 0, 0.25, 0.2],
+            [-25 / 108, 0, 0, 125 / 108, -65 / 27, 125 / 54], [31 / 300, 0, 0, 0, 61 / 225, -2 / 9, 13 / 900],
+            [2, 0, 0, -53 / 6, 704 / 45, -107 / 9, 67 / 90, 3],
+            [-91 / 108, 0, 0, 23 / 108, -976 / 135, 311 / 54, -19 / 60, 17 / 6, -1 / 12],
+            [2383 / 4100, 0, 0, -341 / 164, 4496 / 1025, -301 / 82, 2133 / 4100, 45 / 82, 45 / 164, 18 / 41],
+            [3 / 205, 0, 0, 0, 0, -6 / 41, -3 / 205, -3 / 41, 3 / 41, 6 / 41],
+            [-1777 / 4100, 0, 0, -341 / 164, 4496 / 1025, -289 / 82, 2193 / 4100, 51 / 82, 33 / 164, 12 / 41, 0, 1]]
+    for j, c in enumerate(cols):
+        beta[:len(c), j] = c
+    chi = np.array([0, 0, 0, 0, 0, 34 / 105, 9 / 35, 9 / 35, 9 / 280, 9 / 280, 0, 41 / 840, 41 / 840])
+    psi = np.array([1., 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, -1, -1])
+    h = np.diff(tspan)
+    neq = len(x0)
+    N = len(tspan)
+    Xout = np.zeros((neq, N))
+    f = np.zeros((neq, 13))
+    Xout[:, 0] = x0
+    maxErr = 0.0
+    for ind in range(1, N):
+        ti = tspan[ind - 1]
+        hi = h[ind - 1]
+        xi = Xout[:, ind - 1].copy()
+        f[:, 0] = odefun(ti, xi, *args)
+        for j in range(12):
+            f[:, j + 1] = odefun(ti + alpha[j] * hi, xi + hi * f @ beta[:, j], *args)
+        Xout[:, ind] = xi + hi * f @ chi
+        gamma1 = hi * 41 / 840 * f @ psi
+        delta = np.linalg.norm(gamma1, np.inf)
+        if delta > maxErr:
+            maxErr = delta
+    return Xout, maxErr
+
+
+def np_direct_defect(X_all, u_all, t_TU, nstate, n_nodes, nsteps, Isp):
+    """defectCalc, src/multiShoot_CRTBP_direct.jl:66-109."""
+    t_mid = t_TU[:-1] + np.diff(t_TU) / 2
+    defect = np.zeros((nstate, n_nodes - 1))
+    errors = np.zeros(n_nodes - 1)
+    for i in range(n_nodes - 1):
+        tspan = np.linspace(t_TU[i], t_mid[i], nsteps)
+        sf, ef = np_ode7_8(np_prop_ep, tspan, X_all[:, i].copy(), MU, DU, TU, Isp, u_all[:, i].copy(), 1.0)
+        x0 = X_all[:, i + 1].copy()
+        x0[3:6] = -x0[3:6]
+        sb, eb = np_ode7_8(np_prop_ep, tspan, x0, MU, DU, TU, Isp, u_all[:, i + 1].copy(), -1.0)
+        xb = sb[:, -1].copy()
+        xb[3:6] = -xb[3:6]
+        defect[:, i] = sf[:, -1] - xb
+        errors[i] = max(ef, eb)
+    return defect, errors
+
+
+def gen_direct():
+    out = {"doc": "numpy transliteration of ode7_8 + direct defectCalc, nsteps=10", "cases": []}
+    for nstate, seed in ((6, 0), (7, 1)):
+        X, U, T = synth.direct_problem(9, seed=seed, nstate=nstate)
+        X, U, t = X[:, :, 0], U[:, :, 0], T[:, 0]
+        if nstate == 6:
+            U[:, 3] = 0.0  # exercise the zero-control branch (prop_EP_deriv.jl:35-36)
+        d, e = np_direct_defect(X, U, t, nstate, 9, 10, 2000.0)
+        out["cases"].append({"nstate": nstate, "nsteps": 10, "Isp": 2000.0, "X": X.T.tolist(), "U": U.T.tolist(),
+                             "t": t.tolist(), "defect": d.T.tolist(), "errors": e.tolist()})
+    json.dump(out, open(os.path.join(HERE, "direct_numpy.json"), "w"), indent=0)
+
+
+def gen_halo():
+    H = synth.halo_orbits()
+    out = {"doc": "facts about the reference's L2_Anderson_{1,2}.txt", "orbits": []}
+    for k in (0, 1):
+        tab = H[k]
+        r1 = np.sqrt((tab[0] + MU) ** 2 + tab[1] ** 2 + tab[2] ** 2)
+        r2 = np.sqrt((tab[0] + MU - 1) ** 2 + tab[1] ** 2 + tab[2] ** 2)
+        C = tab[0] ** 2 + tab[1] ** 2 + 2 * (1 - MU) / r1 + 2 * MU / r2 - (tab[3] ** 2 + tab[4] ** 2 + tab[5] ** 2)
+        res = []
+        for c in range(0, 99, 11):
+            sol = solve_ivp(lambda t, s: np_prop_ep(t, s, MU, DU, TU, 2000.0, np.zeros(3), 1.0), (0, synth.HALO_DT[k]),
+                            tab[:, c], method="DOP853", rtol=1e-13, atol=1e-13)
+            res.append(float(np.abs(sol.y[:, -1] - tab[:, c + 1]).max()))
+        out["orbits"].append({"dt": synth.HALO_DT[k], "closure": float(np.abs(tab[:, 0] - tab[:, 99]).max()),
+                              "jacobi_mean": float(C.mean()), "jacobi_spread": float(C.max() - C.min()),
+                              "col_to_col_residual_max": max(res)})
+    json.dump(out, open(os.path.join(HERE, "halo_kat.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rhs", "scipy", "direct", "halo", "taylor"]
+    if "rhs" in which:
+        gen_rhs(); print("rhs done", flush=True)
+    if "scipy" in which:
+        gen_flows_scipy(); print("scipy done", flush=True)
+    if "direct" in which:
+        gen_direct(); print("direct done", flush=True)
+    if "halo" in which:
+        gen_halo(); print("halo done", flush=True)
+    if "taylor" in which:
+        gen_flows_taylor(); print("taylor done", flush=True)

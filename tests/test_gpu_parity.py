@@ -1,0 +1,368 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes -- through
+size-independent properties (symplectic STM, det = 1, exact-node defect = 0, batch == singles).
+
+Tolerances (binary64, same tableau and step grid on both sides => differences are round-off only):
+  defect  : relative L2 error ||d_gpu - d_oracle|| / ||x_oracle(t1)|| <= 1e-10   (north_star bar; observed ~1e-14)
+  STM     : max |Phi_gpu - Phi_oracle| / max|Phi_oracle| <= 1e-10 for fixed-step methods (observed ~1e-13),
+            <= 1e-8 for adaptive methods (both converge to the flow at tol 1e-13 but take different steps)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lowthrustopt_amd as lto
+from lowthrustopt_amd import synth
+from lowthrustopt_amd.constants import MU, DU, TU
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+P_CASES = {  # name: (p, rho, thrustLimit, lambda scale)
+    "p1_rho1": (1.0, 1.0, 0.05, 0.1),
+    "p1_rho1e-3": (1.0, 1e-3, 0.05, 1.0),
+    "p1_rho1e-4_saturated": (1.0, 1e-4, 10.0, 1.0),
+    "p2_unclamped": (2.0, 1.0, 10.0, 0.1),
+    "p2_clamped": (2.0, 1.0, 0.05, 1.0),
+    "p1.5": (1.5, 1.0, 10.0, 0.3),
+    "p0": (0.0, 1.0, 0.05, 0.1),
+}
+METHODS = {
+    "rk4x64": (lto.RK4, 64),
+    "rkf78x8": (lto.RKF78_FIXED, 8),
+    "rkf78_adaptive": (lto.RKF78_ADAPTIVE, 0),
+    "dop853_adaptive": (lto.DOP853_ADAPTIVE, 0),
+}
+
+
+def rel_l2(d_gpu, d_ref, x1):
+    return np.linalg.norm(d_gpu - d_ref) / np.linalg.norm(d_ref + x1)
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("pcase", list(P_CASES))
+@pytest.mark.parametrize("mname", list(METHODS))
+def test_indirect_defect_vs_oracle(gpu_ctx, oracle, pcase, mname):
+    p, rho, thr, lam = P_CASES[pcase]
+    method, steps = METHODS[mname]
+    XC, T = synth.indirect_problem(30, seed=1, lam_sigma=lam)
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, thr, 1000.0, 1.0, p, rho)
+    d, e = lto.indirect_defectCalc(XC, t, prm, lto.integrator(method, steps=steps), ctx=gpu_ctx)
+    d_o, e_o, rc = oracle.indirect_defect(XC, t, [MU, DU, TU, thr, 1000.0, 1.0, p, rho], method, steps)
+    assert rc == 0
+    assert d.shape == (12, 29) and e.shape == (29,)
+    assert rel_l2(d, d_o, XC[:, 1:]) < 1e-10
+    if method != lto.RKF78_FIXED:
+        assert np.all(e == 0.0)      # reference: errors[i] = 0.  (indirect.jl:85)
+
+
+@pytest.mark.parametrize("n_nodes", [2, 3, 64, 65, 66, 131])
+def test_indirect_ragged_sizes(gpu_ctx, oracle, n_nodes):
+    """Wavefront-boundary sizes: 1, 2, 63, 64, 65, 130 segments."""
+    XC, T = synth.indirect_problem(n_nodes, seed=n_nodes)
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    integ = lto.integrator(lto.RK4, steps=16)
+    Phi, d = lto.indirect_stm(XC, t, prm, integ, ctx=gpu_ctx)
+    Phi_o, d_o, rc = oracle.indirect_jacobian(XC, t, [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0], oracle.RK4, 16)
+    assert Phi.shape == (12, 12, n_nodes - 1)
+    assert rel_l2(d, d_o, XC[:, 1:]) < 1e-10
+    assert np.abs(Phi - Phi_o).max() < 1e-10 * np.abs(Phi_o).max()
+
+
+@pytest.mark.parametrize("pcase", list(P_CASES))
+@pytest.mark.parametrize("mname", ["rk4x64", "rkf78x8"])
+def test_indirect_stm_fixed_vs_oracle_duals(gpu_ctx, oracle, pcase, mname):
+    """Variational-equation STM (HIP) == dual numbers pushed through the same discrete map (oracle),
+    the mechanism of ForwardDiff.jacobian at indirect.jl:121."""
+    p, rho, thr, lam = P_CASES[pcase]
+    method, steps = METHODS[mname]
+    XC, T = synth.indirect_problem(30, seed=2, lam_sigma=lam)
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, thr, 1000.0, 1.0, p, rho)
+    Phi, d = lto.indirect_stm(XC, t, prm, lto.integrator(method, steps=steps), ctx=gpu_ctx)
+    Phi_o, d_o, rc = oracle.indirect_jacobian(XC, t, [MU, DU, TU, thr, 1000.0, 1.0, p, rho], method, steps)
+    assert rc == 0
+    assert rel_l2(d, d_o, XC[:, 1:]) < 1e-10
+    assert np.abs(Phi - Phi_o).max() < 1e-10 * np.abs(Phi_o).max()
+
+
+@pytest.mark.parametrize("mname", ["rkf78_adaptive", "dop853_adaptive"])
+def test_indirect_stm_adaptive_vs_oracle(gpu_ctx, oracle, mname):
+    method, steps = METHODS[mname]
+    XC, T = synth.indirect_problem(30, seed=3)
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    Phi, d = lto.indirect_stm(XC, t, prm, lto.integrator(method), ctx=gpu_ctx)
+    Phi_o, d_o, rc = oracle.indirect_jacobian(XC, t, [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0], oracle.DOP853_ADAPTIVE)
+    assert rel_l2(d, d_o, XC[:, 1:]) < 1e-10
+    assert np.abs(Phi - Phi_o).max() < 1e-8 * np.abs(Phi_o).max()
+
+
+@pytest.mark.parametrize("cols", [1, 2, 3])
+def test_indirect_stm_cols_per_lane_agree(gpu_ctx, cols):
+    """All column-group mappings (1, 2, 3 STM columns per lane) produce the same Phi to round-off."""
+    import torch
+    n = 200
+    XC, T = synth.indirect_problem(n, seed=4)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    S = n - 1
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, prm, lto.integrator(lto.RK4, steps=32))
+    out = {}
+    for c in (1, cols):
+        plan.set_cols_per_lane(c)
+        Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(X, n, t, 1, Phi, S, d, S)
+        torch.cuda.synchronize()
+        out[c] = (Phi.cpu().numpy(), d.cpu().numpy())
+    assert np.abs(out[cols][0] - out[1][0]).max() < 1e-12 * np.abs(out[1][0]).max()
+    assert np.abs(out[cols][1] - out[1][1]).max() < 1e-13
+
+
+def test_indirect_golden_scipy_flows(gpu_ctx):
+    """HIP adaptive integrators vs the committed scipy DOP853 (1e-13) vectors: 5e-13 absolute."""
+    cases = load("flows_scipy.json")["cases"]
+    for method in (lto.DOP853_ADAPTIVE, lto.RKF78_ADAPTIVE):
+        for c in cases:
+            XC = np.zeros((12, 2)); XC[:, 0] = c["y0"]
+            prm = lto.make_params(*c["prm"])
+            d, _ = lto.indirect_defectCalc(XC, [0.0, c["span"]], prm, lto.integrator(method), ctx=gpu_ctx)
+            assert np.abs(d[:, 0] - np.array(c["yf"])).max() < 5e-13
+
+
+def test_indirect_golden_taylor_flows(gpu_ctx):
+    """HIP vs mpmath Taylor-series flows (30 digits) incl. one STM by high-precision central differences."""
+    for c in load("flows_taylor.json")["cases"]:
+        XC = np.zeros((12, 2)); XC[:, 0] = c["y0"]
+        prm = lto.make_params(*c["prm"])
+        ref = np.array([float(v) for v in c["yf"]])
+        Phi, d = lto.indirect_stm(XC, [0.0, c["span"]], prm, lto.integrator(lto.DOP853_ADAPTIVE), ctx=gpu_ctx)
+        assert np.abs(d[:, 0] - ref).max() < 3e-13
+        d8, _ = lto.indirect_defectCalc(XC, [0.0, c["span"]], prm, lto.integrator(lto.RKF78_FIXED, steps=24), ctx=gpu_ctx)
+        assert np.abs(d8[:, 0] - ref).max() < 3e-13
+        if "Phi_rowmajor" in c:
+            Phi_ref = np.array(c["Phi_rowmajor"]).reshape(12, 12)
+            assert np.abs(Phi[:, :, 0] - Phi_ref).max() < 1e-9 * np.abs(Phi_ref).max()
+
+
+def test_indirect_batch_homotopy_levels(gpu_ctx):
+    """n_batch trajectories with per-trajectory (rho, thrust, p) and time grids == the singles."""
+    B, n = 5, 17
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=6, dt_range=(0.05, 0.3))
+    rhos = synth.homotopy_rhos(B)
+    prms = [lto.make_params(MU, DU, TU, 0.05 * (1 + b), 1000.0, 1.0, 1.0 if b != 3 else 2.0, rhos[b]) for b in range(B)]
+    integ = lto.integrator(lto.RKF78_FIXED, steps=6)
+    Phi, d = lto.indirect_stm(XC, T, prms, integ, ctx=gpu_ctx)
+    dd, ee = lto.indirect_defectCalc(XC, T, prms, integ, ctx=gpu_ctx)
+    assert Phi.shape == (12, 12, n - 1, B) and d.shape == (12, n - 1, B)
+    for b in range(B):
+        Phi1, d1 = lto.indirect_stm(XC[:, :, b], T[:, b], prms[b], integ, ctx=gpu_ctx)
+        assert np.array_equal(d[:, :, b], d1) and np.array_equal(Phi[:, :, :, b], Phi1)
+        assert np.abs(dd[:, :, b] - d1).max() < 1e-13
+    # shared grid + shared params (the line-search batch: 20 trial points, indirect.jl:227-241)
+    XC2 = np.repeat(XC[:, :, :1], 4, axis=2) * (1 + 1e-3 * np.arange(4))[None, None, :]
+    d2, _ = lto.indirect_defectCalc(XC2, T[:, 0], prms[0], integ, ctx=gpu_ctx)
+    for b in range(4):
+        d1, _ = lto.indirect_defectCalc(XC2[:, :, b], T[:, 0], prms[0], integ, ctx=gpu_ctx)
+        assert np.array_equal(d2[:, :, b], d1)
+
+
+def test_indirect_backward_time_direction(gpu_ctx, oracle):
+    XC, T = synth.indirect_problem(12, seed=8)
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, -1.0, 1.0, 0.5)
+    Phi, d = lto.indirect_stm(XC, t, prm, lto.integrator(lto.RK4, steps=32), ctx=gpu_ctx)
+    Phi_o, d_o, rc = oracle.indirect_jacobian(XC, t, [MU, DU, TU, 0.05, 1000.0, -1.0, 1.0, 0.5], oracle.RK4, 32)
+    assert rel_l2(d, d_o, XC[:, 1:]) < 1e-10 and np.abs(Phi - Phi_o).max() < 1e-10 * np.abs(Phi_o).max()
+
+
+def test_indirect_lambda_v_zero_and_nan(gpu_ctx, oracle):
+    """lambda_v == 0: control zeroed (stateCostate_deriv.jl:59-64), finite results equal to the oracle's;
+    NaN inputs are not an error: they propagate (status_flag = 2 path, indirect.jl:339-341)."""
+    XC, T = synth.indirect_problem(6, seed=9)
+    XC, t = XC[:, :, 0].copy(), T[:, 0]
+    XC[9:12, 2] = 0.0
+    for p in (0.0, 1.0, 2.0):
+        prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, p, 1.0)
+        d, _ = lto.indirect_defectCalc(XC, t, prm, lto.integrator(lto.RK4, steps=1), ctx=gpu_ctx)
+        d_o, _, rc = oracle.indirect_defect(XC, t, [MU, DU, TU, 0.05, 1000.0, 1.0, p, 1.0], oracle.RK4, 1)
+        assert np.all(np.isfinite(d)) and np.abs(d - d_o).max() < 1e-13
+    XC[0, 3] = np.nan
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    d, _ = lto.indirect_defectCalc(XC, t, prm, lto.integrator(lto.RK4, steps=4), ctx=gpu_ctx)
+    assert np.all(np.isnan(d[:, 3])) and np.all(np.isfinite(d[:, 0]))
+    assert np.isnan(d[0, 2])        # defect_2 = x(t_3) - XC[:,3]
+
+
+def test_indirect_error_behaviour(gpu_ctx):
+    """Reference error("Invalid value of p!") -> LTO_EBADP; API misuse -> negative codes."""
+    XC, T = synth.indirect_problem(4)
+    XC, t = XC[:, :, 0], T[:, 0]
+    integ = lto.integrator(lto.RK4, steps=4)
+    for bad_p in (-1.0, 0.5, float("nan")):
+        with pytest.raises(lto.LtoError) as ei:
+            lto.indirect_defectCalc(XC, t, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, bad_p, 1.0), integ, ctx=gpu_ctx)
+        assert ei.value.code == 2 and "Invalid value of p" in str(ei.value)
+    with pytest.raises(lto.LtoError) as ei:
+        lto.indirect_defectCalc(np.zeros((13, 4)), t, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), integ, ctx=gpu_ctx)
+    assert ei.value.code == -1
+    with pytest.raises(lto.LtoError) as ei:
+        lto.indirect_defectCalc(XC, t, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0),
+                                lto.integrator(lto.RK4, steps=0), ctx=gpu_ctx)
+    assert ei.value.code == -1
+
+
+def test_indirect_full_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[1] size (4 096 segments, RK4 x 64, + STM): every Phi is symplectic with det 1;
+    a 64-segment sample matches the oracle; defect of exactly propagated nodes vanishes."""
+    import torch
+    S = 4096
+    n = S + 1
+    XC, T = synth.indirect_problem(n, seed=0)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, prm, lto.integrator(lto.RK4, steps=64))
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+    d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(X, n, t, 1, Phi, S, d, S)
+    torch.cuda.synchronize()
+    P = Phi.cpu().numpy().reshape(12, 12, S).transpose(1, 0, 2)   # [row, col, s]
+    Om = np.block([[np.zeros((6, 6)), np.eye(6)], [-np.eye(6), np.zeros((6, 6))]])
+    PtOP = np.einsum("ris,rq,qjs->ijs", P, Om, P)
+    scale = np.maximum(1.0, np.abs(P).max(axis=(0, 1)) ** 2)
+    assert (np.abs(PtOP - Om[:, :, None]).max(axis=(0, 1)) / scale).max() < 1e-9
+    dets = np.linalg.det(P.transpose(2, 0, 1))
+    assert np.abs(dets - 1.0).max() < 1e-7
+    idx = np.arange(0, S, 64)
+    dn = d.cpu().numpy()
+    for i in idx:
+        y, Phi_o, rc, _, _ = oracle.flow_stm_state_costate(XC[:, i, 0], [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0],
+                                                           T[i + 1, 0] - T[i, 0], oracle.RK4, 64)
+        assert np.abs(P[:, :, i] - Phi_o).max() < 1e-10 * np.abs(Phi_o).max()
+        assert np.linalg.norm(dn[:, i] - (y - XC[:, i + 1, 0])) < 1e-10 * np.linalg.norm(y)
+    # exact-node property: replace node i+1 by the propagated node i  ->  defect == 0 (to round-off)
+    X2 = X.clone()
+    X2[:, 1:] = X[:, 1:] + d          # x(t_{i+1}; node_i)
+    X3 = torch.cat([X[:, :1], X2[:, 1:]], dim=1).contiguous()
+    d2 = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    # only segment 0 starts from an unchanged node: check it, and check determinism of a second launch
+    plan.defect(X3, n, t, 1, d2, S)
+    plan2 = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    plan.defect(X3, n, t, 1, plan2, S)
+    torch.cuda.synchronize()
+    assert float(d2[:, 0].abs().max()) < 1e-14
+    assert torch.equal(d2, plan2)
+
+
+# ------------------------------------------------------------------------------------------------ direct
+@pytest.mark.parametrize("nstate", [6, 7])
+def test_direct_defect_vs_oracle_and_golden(gpu_ctx, oracle, nstate):
+    X, U, T = synth.direct_problem(30, seed=1, nstate=nstate)
+    X, U, t = X[:, :, 0], U[:, :, 0], T[:, 0]
+    U[:, 5] = 0.0    # zero-control node (prop_EP_deriv.jl:35-36)
+    d, e = lto.direct_defectCalc(X, U, t, 10, MU, DU, TU, 2000.0, ctx=gpu_ctx)
+    d_o, e_o = oracle.direct_defect(X, U, t, 10, MU, DU, TU, 2000.0)
+    assert d.shape == (nstate, 29) and e.shape == (29,)
+    assert np.abs(d - d_o).max() < 1e-12
+    assert np.abs(e - e_o).max() < 1e-3 * e_o.max() + 1e-18
+    for c in load("direct_numpy.json")["cases"]:
+        if c["nstate"] != nstate:
+            continue
+        Xg = np.array(c["X"]).T; Ug = np.array(c["U"]).T; tg = np.array(c["t"])
+        dg, eg = lto.direct_defectCalc(Xg, Ug, tg, c["nsteps"], MU, DU, TU, c["Isp"], ctx=gpu_ctx)
+        assert np.abs(dg - np.array(c["defect"]).T).max() < 1e-13
+        assert np.abs(eg - np.array(c["errors"])).max() < 1e-3 * np.abs(c["errors"]).max() + 1e-18
+
+
+@pytest.mark.parametrize("nstate", [6, 7])
+def test_direct_jacobian_vs_oracle(gpu_ctx, oracle, nstate):
+    """Variational-equation Jacobian == exact derivative of the discrete map (oracle duals) to 1e-11;
+    == the reference's forward differences (pert 1e-8, direct.jl:123-143) to FD noise; tf column ==
+    the reference's central difference (pert 1e-3, :503-516) to its truncation error."""
+    X, U, T = synth.direct_problem(24, seed=2, nstate=nstate)
+    X, U, t = X[:, :, 0], U[:, :, 0], T[:, 0]
+    U[:, 7] = 0.0       # zero-control node: Psi stays well defined; 7-state mdot uses the one-sided d|c|/dc
+    Jt, dtf, d, e = lto.direct_jacobian_blocks(X, U, t, 10, MU, DU, TU, 2000.0, ctx=gpu_ctx)
+    Jd, dh, dd = oracle.direct_jacobian_dual(X, U, t, 10, MU, DU, TU, 2000.0)
+    d_o, e_o = oracle.direct_defect(X, U, t, 10, MU, DU, TU, 2000.0)
+    assert Jt.shape == (nstate, 2 * (nstate + 3), 23)
+    assert np.abs(d - d_o).max() < 1e-12 and np.abs(e - e_o).max() < 1e-3 * e_o.max() + 1e-18
+    assert np.abs(Jt - Jd).max() < 1e-11 * max(1.0, np.abs(Jd).max())
+    Jfd = oracle.direct_jacobian_fd(X, U, t, d_o, 10, MU, DU, TU, 2000.0)
+    assert np.abs(Jt[:6] - Jfd[:6]).max() < 2e-6 * max(1.0, np.abs(Jfd).max())
+    hseg = np.diff(t)
+    dtf_exact = dh * (hseg / (t[-1] - t[0]))[None, :]
+    assert np.abs(dtf - dtf_exact).max() < 1e-9      # continuous vs discrete d/dh: RKF7(8) truncation
+    dtf_fd = oracle.direct_dtf_fd(X, U, t, 10, MU, DU, TU, 2000.0)
+    assert np.abs(dtf - dtf_fd).max() < 1e-6
+    # dense band scatter has the reference's shape and column order (direct.jl:146-162,:516)
+    J = lto.direct_scatter(Jt, dtf)
+    J_o = oracle.direct_scatter_dense(Jd, dtf_exact)
+    assert J.shape == (nstate * 23, 24 * (nstate + 3) + 1) == J_o.shape
+    assert np.abs(J - J_o).max() < 1e-9
+
+
+def test_direct_full_size_linearity(gpu_ctx):
+    """BASELINE configs[2] size (16 384 segments, 6-state, RKF7(8) nsteps = 10, on-device Jacobian blocks):
+    finite, small error estimates, and the Jacobian predicts the change of every defect under a perturbation
+    of all nodes (linearity, size-independent)."""
+    import torch
+    S = 16384
+    n = S + 1
+    X, U, T = synth.direct_problem(n, seed=3)
+    Xs = torch.from_numpy(synth.to_soa_nodes(X)).cuda(); Us = torch.from_numpy(synth.to_soa_nodes(U)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    plan = lto.DirectPlan(gpu_ctx, 6, n, 1, 10, MU, DU, TU, 2000.0)
+    d = torch.zeros(6, S, dtype=torch.float64, device="cuda"); e = torch.zeros(S, dtype=torch.float64, device="cuda")
+    d0 = torch.zeros_like(d)
+    plan.defect(Xs, n, Us, n, t, 1, d0, S, e)
+    Jac = torch.zeros(108, S, dtype=torch.float64, device="cuda"); dtf = torch.zeros(6, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(Xs, n, Us, n, t, 1, Jac, S, dtf, d, S, e)
+    torch.cuda.synchronize()
+    assert torch.isfinite(d).all() and torch.isfinite(Jac).all() and float(e.max()) < 1e-9
+    assert torch.equal(d, d0)                 # defect from the Jacobian kernel == defect kernel, bit for bit
+    delta = 1e-6
+    X2 = Xs.clone(); X2[1, :] += delta        # perturb y of every node
+    d2 = torch.zeros_like(d)
+    plan.defect(X2, n, Us, n, t, 1, d2, S, e)
+    torch.cuda.synchronize()
+    J = Jac.reshape(18, 6, S)                 # [col, row, s]
+    pred = (J[1] + J[6 + 1]) * delta          # d/dx_i[y] + d/dx_{i+1}[y]
+    assert float(((d2 - d) - pred).abs().max()) < 5e-10
+
+
+def test_pack_unpack_and_norms(gpu_ctx):
+    import torch
+    for ndim, count in ((12, 4097), (3, 1), (144, 333), (108, 64), (6, 255)):
+        a = torch.randn(count, ndim, dtype=torch.float64, device="cuda")   # node-contiguous == Julia [ndim x count]
+        soa = torch.zeros(ndim, count + 5, dtype=torch.float64, device="cuda")
+        lto.pack_soa(gpu_ctx, a, ndim, count, soa, count + 5)
+        torch.cuda.synchronize()
+        assert torch.equal(soa[:, :count], a.t())
+        b = torch.zeros_like(a)
+        lto.unpack_soa(gpu_ctx, soa, count + 5, ndim, count, b)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+    B, spt = 7, 300
+    d = torch.randn(12, B * spt, dtype=torch.float64, device="cuda")
+    ss = torch.zeros(B, dtype=torch.float64, device="cuda"); mx = torch.zeros(B, dtype=torch.float64, device="cuda")
+    lto.defect_norms(gpu_ctx, d, B * spt, 12, spt, B, ss, mx)
+    torch.cuda.synchronize()
+    dd = d.reshape(12, B, spt)
+    assert torch.allclose(ss, (dd ** 2).sum(dim=(0, 2)), rtol=1e-13)
+    assert torch.equal(mx, dd.abs().amax(dim=(0, 2)))
+    d[3, 2 * spt + 5] = float("nan")
+    lto.defect_norms(gpu_ctx, d, B * spt, 12, spt, B, ss, mx)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(mx[2])) and bool(torch.isfinite(mx[[0, 1, 3, 4, 5, 6]]).all())

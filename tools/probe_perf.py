@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Quick device-resident timing probe (development aid; bench.py is the contract benchmark)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import lowthrustopt_amd as lto
+from lowthrustopt_amd import synth
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ctx = lto.Context(0)
+    st = lto.current_stream_ptr()
+    print(torch.cuda.get_device_name(0))
+    prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    for S in (4096, 16384, 65536, 262144):
+        n = S + 1
+        XC, T = synth.indirect_problem(n)
+        X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+        defect = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+        for method, steps, name in ((lto.RK4, 64, "rk4x64"), (lto.RKF78_FIXED, 4, "rkf78x4"), (lto.DOP853_ADAPTIVE, 0, "dop853")):
+            plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(method, steps=steps))
+            ms = timeit(lambda: plan.defect(X, n, t, 1, defect, S, stream=st))
+            print("S=%7d %-8s defect        %9.3f ms  %10.3e seg/s" % (S, name, ms, S / ms * 1e3), flush=True)
+            if method == lto.RK4:
+                for cols in (1, 2, 3):
+                    plan.set_cols_per_lane(cols)
+                    ms = timeit(lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st), iters=10)
+                    print("S=%7d %-8s stm cols=%d    %9.3f ms  %10.3e seg/s  (%.2f TFLOP/s model)" % (
+                        S, name, cols, ms, S / ms * 1e3, S * 414e3 / ms / 1e9), flush=True)
+            elif S <= 65536:
+                ms = timeit(lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st), iters=5)
+                print("S=%7d %-8s stm           %9.3f ms  %10.3e seg/s" % (S, name, ms, S / ms * 1e3), flush=True)
+            plan.close()
+    # direct
+    for S in (16384, 131072):
+        n = S + 1
+        Xd, Ud, Td = synth.direct_problem(n)
+        X = torch.from_numpy(synth.to_soa_nodes(Xd)).cuda(); U = torch.from_numpy(synth.to_soa_nodes(Ud)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(Td[:, 0])).cuda()
+        defect = torch.zeros(6, S, dtype=torch.float64, device="cuda"); err = torch.zeros(S, dtype=torch.float64, device="cuda")
+        Jac = torch.zeros(108, S, dtype=torch.float64, device="cuda"); dtf = torch.zeros(6, S, dtype=torch.float64, device="cuda")
+        plan = lto.DirectPlan(ctx, 6, n, 1, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        ms = timeit(lambda: plan.defect(X, n, U, n, t, 1, defect, S, err, stream=st))
+        print("S=%7d direct defect           %9.3f ms  %10.3e seg/s" % (S, ms, S / ms * 1e3), flush=True)
+        ms = timeit(lambda: plan.jacobian(X, n, U, n, t, 1, Jac, S, dtf, defect, S, err, stream=st), iters=10)
+        print("S=%7d direct jacobian         %9.3f ms  %10.3e seg/s  (%.2f TFLOP/s model)" % (S, ms, S / ms * 1e3, S * 197e3 / ms / 1e9), flush=True)
+        plan.close()
+
+
+if __name__ == "__main__":
+    main()
