@@ -185,7 +185,7 @@ def main():
         desc = "C3: direct 6-dim, RKF7(8) nsteps=10 per half, on-device Jacobian blocks 6x18 + tf column + defect + errors"
         gather_rows = 6
 
-    gathered = torch.zeros(world, gather_rows, S, **f64) if world > 1 else None
+    gathered = torch.zeros(world * gather_rows, S, **f64) if world > 1 else None   # [rank][row][segment]
 
     def step():
         sweep()

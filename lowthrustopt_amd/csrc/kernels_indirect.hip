@@ -76,8 +76,7 @@ __device__ __forceinline__ void run_rkf78_adaptive(const Sys& sys, const double 
   }
 }
 
-// Adaptive DOP853 with the controller documented in oracle/lto_oracle.cpp (dop853): initial step by
-// Hairer's d0/d1/d2 rule, accept if err < 1, factor = min(10, 0.9 err^(-1/8)) (<= 1 after a rejection),
+// Adaptive DOP853 (DESIGN.md 'Integrators'): initial step by Hairer's d0/d1/d2 rule, accept if err < 1, factor = min(10, 0.9 err^(-1/8)) (<= 1 after a rejection),
 // rejection factor max(0.2, 0.9 err^(-1/8)).
 template <class Sys, int NERR>
 __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, const double rtol, const double atol,
