@@ -1,0 +1,159 @@
+# LowThrustOptHIP.jl -- Julia binding of liblto_hip.so (include/lto.h) for LowThrustOpt's shooting drivers.
+#
+# What it replaces: the bodies of the four closures nested in the reference drivers
+#   multiShoot_CRTBP_indirect:  defectCalc (src/multiShoot_CRTBP_indirect.jl:63-90), jacobianCalc (:93-146)
+#   multiShoot_CRTBP_direct:    defectCalc (src/multiShoot_CRTBP_direct.jl:66-109),  jacobianCalc (:111-166),
+#                               tf partial (:503-516)
+# The drivers' signatures, return tuples and inner array shapes are unchanged (INTEGRATION.md shows the patch).
+#
+# STATUS: there is no `julia` binary in the build image or on the GPU box, so this file has never been
+# executed.  It is kept deliberately thin: every ccall below has a line-for-line twin in
+# lowthrustopt_amd/_lib.py + hotpath.py (ctypes), and THAT twin is what the test-suite drives on the GPU.
+module LowThrustOptHIP
+
+using SparseArrays, LinearAlgebra
+
+export LtoContext, indirect_defectCalc, indirect_jacobianCalc, indirect_stm,
+       direct_defectCalc, direct_jacobianCalc, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
+
+const liblto = get(ENV, "LTO_HIP_LIB", joinpath(@__DIR__, "..", "lowthrustopt_amd", "liblto_hip.so"))
+
+const LTO_RK4 = Cint(0)
+const LTO_RKF78_FIXED = Cint(1)
+const LTO_RKF78_ADAPTIVE = Cint(2)
+const LTO_DOP853_ADAPTIVE = Cint(3)
+
+# isbits mirrors of the C structs (include/lto.h)
+struct LtoIntegrator
+    method::Cint
+    steps::Cint
+    rtol::Cdouble
+    atol::Cdouble
+    max_steps::Cint
+end
+# default = the reference's Vern8() setting: adaptive order-8 pair, reltol = abstol = 1e-13 (indirect.jl:79)
+LtoIntegrator() = LtoIntegrator(LTO_DOP853_ADAPTIVE, 0, 1e-13, 1e-13, 0)
+
+struct LtoParams          # the `params` tuple of indirect.jl:260, field for field
+    MU::Cdouble; DU::Cdouble; TU::Cdouble; thrustLimit::Cdouble
+    mass::Cdouble; time_direction::Cdouble; p::Cdouble; rho::Cdouble
+end
+LtoParams(t::Tuple) = LtoParams(map(Float64, t)...)
+
+struct LtoDirectParams
+    MU::Cdouble; DU::Cdouble; TU::Cdouble; Isp::Cdouble
+end
+
+mutable struct LtoContext
+    handle::Ptr{Cvoid}
+    function LtoContext(device::Integer = 0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:lto_create, liblto), Cint, (Ref{Ptr{Cvoid}}, Cint), h, device)
+        rc == 0 || error("lto_create failed with code $rc (no gfx950 device?)")
+        ctx = new(h[])
+        finalizer(c -> (c.handle == C_NULL || ccall((:lto_destroy, liblto), Cvoid, (Ptr{Cvoid},), c.handle); c.handle = C_NULL), ctx)
+        ctx
+    end
+end
+
+function check(ctx::LtoContext, rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:lto_last_error, liblto), Cstring, (Ptr{Cvoid},), ctx.handle))
+    # code 2 is the reference's own error("Invalid value of p!") (CRTBP_stateCostate_deriv.jl:52)
+    error(rc == 2 ? msg : "lto error $rc: $msg")
+end
+
+# ---------------------------------------------------------------------------------------------- indirect
+"defectCalc of multiShoot_CRTBP_indirect: returns (defect1[2nstate x (n_nodes-1)], errors[n_nodes-1])."
+function indirect_defectCalc(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params;
+                             integ::LtoIntegrator = LtoIntegrator())
+    ndim, n_nodes = size(XC_all)
+    defect1 = zeros(ndim, n_nodes - 1)
+    errors = zeros(n_nodes - 1)
+    prm = Ref(LtoParams(params))
+    rc = ccall((:lto_indirect_defect, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{LtoParams}, Cint, Ref{LtoIntegrator},
+                Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx.handle, ndim, n_nodes, 1, XC_all, t_TU, 1, prm, 1, Ref(integ), defect1, errors)
+    check(ctx, rc)
+    (defect1, errors)
+end
+
+"Compact Jacobian blocks Phi[2nstate x 2nstate x (n_nodes-1)] (= ForwardDiff.jacobian(f, x0) of indirect.jl:121) and the defect."
+function indirect_stm(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params;
+                      integ::LtoIntegrator = LtoIntegrator())
+    ndim, n_nodes = size(XC_all)
+    Phi = zeros(ndim, ndim, n_nodes - 1)
+    defect1 = zeros(ndim, n_nodes - 1)
+    prm = Ref(LtoParams(params))
+    rc = ccall((:lto_indirect_jacobian, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{LtoParams}, Cint, Ref{LtoIntegrator},
+                Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx.handle, ndim, n_nodes, 1, XC_all, t_TU, 1, prm, 1, Ref(integ), Phi, defect1)
+    check(ctx, rc)
+    (Phi, defect1)
+end
+
+"""jacobianCalc of multiShoot_CRTBP_indirect: Jac_full [2nstate(n_nodes-1) x 2nstate*n_nodes], row block i =
+[Phi_i | -I] at columns 2nstate(i-1)+(1:4nstate), with the columns of the two fixed end states zeroed
+(indirect.jl:123-142).  Returned sparse: the driver's least-squares step sparsifies it anyway (:181)."""
+function indirect_jacobianCalc(ctx::LtoContext, XC_all, t_TU, nstate, n_nodes, params; integ = LtoIntegrator())
+    (Phi, _) = indirect_stm(ctx, XC_all, t_TU, params; integ = integ)
+    nd = 2 * nstate
+    S = n_nodes - 1
+    I_idx = Int[]; J_idx = Int[]; V = Float64[]
+    for i = 1:S, c = 1:nd, r = 1:nd
+        push!(I_idx, (i - 1) * nd + r); push!(J_idx, (i - 1) * nd + c); push!(V, Phi[r, c, i])
+    end
+    for i = 1:S, r = 1:nd
+        push!(I_idx, (i - 1) * nd + r); push!(J_idx, i * nd + r); push!(V, -1.0)
+    end
+    Jac_full = sparse(I_idx, J_idx, V, nd * S, nd * n_nodes)
+    Jac_full[:, 1:nstate] .= 0
+    Jac_full[:, (nd * n_nodes - 2 * nstate + 1):(nd * n_nodes - nstate)] .= 0
+    dropzeros!(Jac_full)
+end
+
+# ---------------------------------------------------------------------------------------------- direct
+"defectCalc of multiShoot_CRTBP_direct: returns (defect1[nstate x (n_nodes-1)], errors[n_nodes-1])."
+function direct_defectCalc(ctx::LtoContext, X_all::Matrix{Float64}, u_all::Matrix{Float64}, t_TU::Vector{Float64},
+                           nstate, n_nodes, nsteps, Isp, MU, DU, TU)
+    defect1 = zeros(nstate, n_nodes - 1)
+    errors = zeros(n_nodes - 1)
+    prm = Ref(LtoDirectParams(MU, DU, TU, Isp))
+    rc = ccall((:lto_direct_defect, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ref{LtoDirectParams},
+                Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx.handle, nstate, n_nodes, 1, X_all, u_all, t_TU, 1, nsteps, prm, defect1, errors)
+    check(ctx, rc)
+    (defect1, errors)
+end
+
+"""jacobianCalc + tf partial of multiShoot_CRTBP_direct: Jac_full [nstate(n_nodes-1) x n_nodes(nstate+3)+1]
+(state columns node-major, then control columns, then tf: direct.jl:146-162, :516).  The blocks come from the
+variational equations integrated on the GPU, not from 18 perturbed re-propagations per segment."""
+function direct_jacobianCalc(ctx::LtoContext, X_all::Matrix{Float64}, u_all::Matrix{Float64}, t_TU::Vector{Float64},
+                             nstate, n_nodes, nsteps, Isp, MU, DU, TU)
+    nvar = 2 * (nstate + 3)
+    S = n_nodes - 1
+    Jac_temp = zeros(nstate, nvar, S)
+    ddefect_dt = zeros(nstate, S)
+    defect1 = zeros(nstate, S)
+    errors = zeros(S)
+    prm = Ref(LtoDirectParams(MU, DU, TU, Isp))
+    rc = ccall((:lto_direct_jacobian, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ref{LtoDirectParams},
+                Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx.handle, nstate, n_nodes, 1, X_all, u_all, t_TU, 1, nsteps, prm, Jac_temp, ddefect_dt, defect1, errors)
+    check(ctx, rc)
+    Jac_full = zeros(nstate * S, n_nodes * (nstate + 3) + 1)
+    for i = 1:S
+        rows = (i - 1) * nstate + 1 : i * nstate
+        Jac_full[rows, (i - 1) * nstate + 1 : (i + 1) * nstate] = Jac_temp[:, 1:2 * nstate, i]
+        Jac_full[rows, nstate * n_nodes + 3 * (i - 1) + 1 : nstate * n_nodes + 3 * (i - 1) + 6] = Jac_temp[:, 2 * nstate + 1 : end, i]
+    end
+    Jac_full[:, end] = ddefect_dt[:]
+    (Jac_full, defect1, errors)
+end
+
+end # module
