@@ -82,6 +82,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise LtoError(LTO_ENODEVICE, "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+        # PyTorch wheels bundle their own libamdhip64.so.7; the dynamic loader keeps whichever copy is loaded
+        # first.  If torch is going to share the process (bench.py, tests, torch.distributed) its runtime must
+        # come first, otherwise torch later finds "No HIP GPUs".  Without torch (Julia, C) the system ROCm is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported

@@ -174,7 +174,10 @@ def test_indirect_batch_homotopy_levels(gpu_ctx):
     assert Phi.shape == (12, 12, n - 1, B) and d.shape == (12, n - 1, B)
     for b in range(B):
         Phi1, d1 = lto.indirect_stm(XC[:, :, b], T[:, b], prms[b], integ, ctx=gpu_ctx)
-        assert np.array_equal(d[:, :, b], d1) and np.array_equal(Phi[:, :, :, b], Phi1)
+        # a mixed-p batch runs the runtime-dispatch kernel variant, singles the p-specialised ones: same
+        # arithmetic, different instruction schedule => agreement to round-off, not bit-for-bit
+        assert np.abs(d[:, :, b] - d1).max() < 1e-13
+        assert np.abs(Phi[:, :, :, b] - Phi1).max() < 1e-12 * np.abs(Phi1).max()
         assert np.abs(dd[:, :, b] - d1).max() < 1e-13
     # shared grid + shared params (the line-search batch: 20 trial points, indirect.jl:227-241)
     XC2 = np.repeat(XC[:, :, :1], 4, axis=2) * (1 + 1e-3 * np.arange(4))[None, None, :]
