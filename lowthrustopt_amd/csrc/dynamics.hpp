@@ -27,24 +27,43 @@ struct TrajParams {
   double MU;           // CRTBP mass ratio
 };
 
-// 1/sqrt(x) to ~1 ulp: v_rsq_f64 seed (~2^-23 relative) + two second-order Newton steps.
+// 1/sqrt(x) to ~1 ulp: v_rsq_f64 seed (relative error <~ 2^-26) + ONE third-order step
+//   y <- y (1 + e/2 + 3 e^2/8),  e = 1 - x y^2      (residual error ~ 5/16 e^3)
 // Arguments here are squared distances / squared norms of O(1e-6 .. 1e2): no range scaling needed.
 __device__ __forceinline__ double rsqrt_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double e = __builtin_fma(-x * y, y, 1.0);
-  y = __builtin_fma(0.5 * y, e, y);
-  e = __builtin_fma(-x * y, y, 1.0);
-  y = __builtin_fma(0.5 * y, e, y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-x * y, y, 1.0);
+  const double t = __builtin_fma(0.375, e, 0.5);
+  return __builtin_fma(y * e, t, y);
 }
-// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps.
+// 1/x to ~1 ulp: v_rcp_f64 seed + one third-order step  y <- y (1 + e + e^2), e = 1 - x y.
 __device__ __forceinline__ double rcp_nr(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-x, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  return y;
+  const double y = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, __builtin_fma(e, e, e), y);
+}
+// exp(z) for z <= 0 to ~1 ulp without the special-case handling of the general routine:
+// z = n ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial (remainder 4e-18), scaled by 2^n (underflows to 0).
+__device__ __forceinline__ double exp_neg(double z) {
+  z = fmax(z, -800.0);  // exp(-800) == 0 in binary64; keeps the reduction finite for rho -> 0
+  const double n = __builtin_rint(z * 1.4426950408889634);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, z);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = __builtin_fma(p, r, 1.0 / 479001600.0);
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)n);
 }
 
 // Coefficients one STM column needs at an RK stage of the 12-dim system:
@@ -68,7 +87,7 @@ __device__ __forceinline__ void control_law(const TrajParams& tp, double n, doub
   } else if (PM == PM_P1) {  // :41-43  umag = 1/2 (1 + tanh(g / (2 rho))) accelLimit, g = n - 1
     // 1/2 (1 + tanh x) = 1 / (1 + exp(-2x)): evaluated without cancellation or overflow for any rho.
     const double x = (n - 1.0) * tp.inv_2rho;
-    const double e = exp(-2.0 * fabs(x));
+    const double e = exp_neg(-2.0 * fabs(x));
     const double q = rcp_nr(1.0 + e);
     const double sig = (x >= 0.0) ? q : e * q;
     m = aL * sig;
@@ -158,6 +177,99 @@ __device__ __forceinline__ void rhs12(const double (&y)[12], const TrajParams& t
     vc.Hxz = __builtin_fma(st, lz0, ee * z * lx0) - qa * z;
     vc.Hyz = ee * __builtin_fma(yy, lz0, z * ly0) - qq * yy * z;
   }
+}
+
+// Fused base + ONE STM column (the COLS = 1 mapping used while the chip is not yet full): G and H are
+// applied through their dyadic structure  G = (1-cs) D - ... , H a = es a + (l.a)(e1 rho1 + e2 rho2) + (u1+u2) l - ...
+// instead of being built entry by entry, which saves ~40 fp64 instructions per RK stage per lane.
+//   y = (base[12], column[12]) -> k = (base_dot[12], column_dot[12])
+template <int PM>
+__device__ __forceinline__ void rhs12_fused1(const double (&y)[24], const TrajParams& tp, const double w2, double (&k)[24]) {
+  const double MU = tp.MU;
+  const double x = y[0], yy = y[1], z = y[2];
+  const double A = x + MU, B = A - 1.0;
+  const double yz2 = __builtin_fma(yy, yy, z * z);
+  const double d1 = __builtin_fma(A, A, yz2), d2 = __builtin_fma(B, B, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
+  const double cs = c1 + c2, omc = 1.0 - cs;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double ee = e1 + e2;
+  const double st = __builtin_fma(e1, A, e2 * B);
+  const double eey = ee * yy, eez = ee * z;
+
+  const double lx = y[9], ly = y[10], lz = y[11];
+  const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
+  const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
+  const double n = n2 * inv_n;
+  double m, ua, ub;
+  if (PM == PM_MIXED) {
+    if (tp.p == 1.0) control_law<PM_P1, true>(tp, n, inv_n, m, ua, ub);
+    else if (tp.p == 2.0) control_law<PM_P2, true>(tp, n, inv_n, m, ua, ub);
+    else if (tp.p == 0.0) control_law<PM_P0, true>(tp, n, inv_n, m, ua, ub);
+    else control_law<PM_PGEN, true>(tp, n, inv_n, m, ua, ub);
+  } else {
+    control_law<PM, true>(tp, n, inv_n, m, ua, ub);
+  }
+  const double lhx = lx * inv_n, lhy = ly * inv_n, lhz = lz * inv_n;
+
+  // s_b = rho_b . lambda_v ;  G lambda_v = ((1-cs) lx + tA, (1-cs) ly + es y, -cs lz + es z)
+  const double yzl = __builtin_fma(yy, ly, z * lz);
+  const double s1 = __builtin_fma(A, lx, yzl), s2 = __builtin_fma(B, lx, yzl);
+  const double t1 = e1 * s1, t2 = e2 * s2;
+  const double es = t1 + t2;
+  const double tA = __builtin_fma(t1, A, t2 * B);
+
+  k[0] = y[3]; k[1] = y[4]; k[2] = y[5];
+  k[3] = __builtin_fma(-c1, A, __builtin_fma(-c2, B, __builtin_fma(w2, y[4], x))) - m * lhx;
+  k[4] = __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)) - m * lhy;
+  k[5] = __builtin_fma(-cs, z, -m * lhz);
+  k[6] = -__builtin_fma(omc, lx, tA);
+  k[7] = -__builtin_fma(omc, ly, es * yy);
+  k[8] = -__builtin_fma(-cs, lz, es * z);
+  k[9] = __builtin_fma(w2, ly, -y[6]);
+  k[10] = __builtin_fma(-w2, lx, -y[7]);
+  k[11] = -y[8];
+
+  // ---- column c = (a, b, g, d)
+  const double ax = y[12], ay = y[13], az = y[14];
+  const double dx = y[21], dyv = y[22], dz = y[23];
+  // G a
+  const double yza = __builtin_fma(yy, ay, z * az);
+  const double r1a = __builtin_fma(A, ax, yza), r2a = __builtin_fma(B, ax, yza);
+  const double u1 = e1 * r1a, u2 = e2 * r2a;
+  const double us = u1 + u2;
+  const double uA = __builtin_fma(u1, A, u2 * B);
+  const double Gax = __builtin_fma(omc, ax, uA), Gay = __builtin_fma(omc, ay, us * yy), Gaz = __builtin_fma(-cs, az, us * z);
+  // G d
+  const double yzd = __builtin_fma(yy, dyv, z * dz);
+  const double r1d = __builtin_fma(A, dx, yzd), r2d = __builtin_fma(B, dx, yzd);
+  const double v1 = e1 * r1d, v2 = e2 * r2d;
+  const double vs = v1 + v2;
+  const double vA = __builtin_fma(v1, A, v2 * B);
+  const double Gdx = __builtin_fma(omc, dx, vA), Gdy = __builtin_fma(omc, dyv, vs * yy), Gdz = __builtin_fma(-cs, dz, vs * z);
+  // H a = es a + (l.a)(st, ee y, ee z) + us l - (wA, ws y, ws z),  w_b = 5 e_b i_b^2 s_b (rho_b . a)
+  const double la = __builtin_fma(lx, ax, __builtin_fma(ly, ay, lz * az));
+  const double w1 = (5.0 * i1s) * (t1 * r1a), w2b = (5.0 * i2s) * (t2 * r2a);
+  const double ws = w1 + w2b;
+  const double wA = __builtin_fma(w1, A, w2b * B);
+  const double Hax = __builtin_fma(es, ax, __builtin_fma(la, st, __builtin_fma(us, lx, -wA)));
+  const double Hay = __builtin_fma(es, ay, __builtin_fma(la, eey, __builtin_fma(us, ly, -ws * yy)));
+  const double Haz = __builtin_fma(es, az, __builtin_fma(la, eez, __builtin_fma(us, lz, -ws * z)));
+  // U d = -ua d + ub (lhat . d) lhat
+  const double ld = __builtin_fma(lhx, dx, __builtin_fma(lhy, dyv, lhz * dz));
+  const double tl = ub * ld;
+  k[12] = y[15]; k[13] = y[16]; k[14] = y[17];
+  k[15] = Gax + __builtin_fma(w2, y[16], __builtin_fma(-ua, dx, tl * lhx));
+  k[16] = Gay + __builtin_fma(-w2, y[15], __builtin_fma(-ua, dyv, tl * lhy));
+  k[17] = Gaz + __builtin_fma(-ua, dz, tl * lhz);
+  k[18] = -(Hax + Gdx);
+  k[19] = -(Hay + Gdy);
+  k[20] = -(Haz + Gdz);
+  k[21] = __builtin_fma(w2, dyv, -y[18]);
+  k[22] = __builtin_fma(-w2, dx, -y[19]);
+  k[23] = -y[20];
 }
 
 // One STM column c = (a, b, g, d) of the 12-dim system: cdot = F c.

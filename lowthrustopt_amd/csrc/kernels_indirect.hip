@@ -21,6 +21,10 @@ struct Sys12 {
   double w2;
   TrajParams tp;
   __device__ __forceinline__ void rhs(const double (&y)[DIM], double (&k)[DIM]) const {
+    if constexpr (COLS == 1) {
+      rhs12_fused1<PM>(y, tp, w2, k);
+      return;
+    }
     double yb[12], kb[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) yb[i] = y[i];
