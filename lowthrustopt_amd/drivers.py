@@ -1,0 +1,183 @@
+"""Host-side mirror of the reference's indirect shooting drivers, calling the HIP hot path.
+
+  multiShoot_CRTBP_indirect   src/multiShoot_CRTBP_indirect.jl:58-61, :254-345   (Newton loop, status flags)
+  optimizeTraj_OLS            :149-218   (least-squares step, adjoints-only mask, second-order correction)
+  lineSearch                  :221-246   (20 alphas; here ONE batched device launch instead of 20 sweeps -- SURVEY N2)
+  reduceFuel_indirect         src/HelperFunctions.jl:105-193   (rho continuation -- SURVEY N3)
+
+Same signatures, return tuples and status flags as the Julia functions (the reference is Julia; this mirror exists
+because no `julia` binary is available to run julia/LowThrustOptHIP.jl -- see INTEGRATION.md).  The propagation
+(defects, STM blocks) always runs on the GPU through the C ABI; only the small sparse least-squares solve is on the
+host, as in the reference (`-Jac_sparse \\ defect_vec`, :182).  The direct driver's JuMP/Ipopt QP
+(src/multiShoot_CRTBP_direct.jl:248-403) is out of scope; its hot-path closures are in hotpath.py.
+
+`ops` lets the CPU unit tests inject a different propagation back end; the product default is the HIP library.
+"""
+import numpy as np
+
+from . import hotpath
+
+
+class HipOps:
+    """Hot-path operators backed by liblto_hip.so (the product path)."""
+
+    def __init__(self, ctx=None, integ=None):
+        self.ctx = ctx or hotpath.default_context()
+        self.integ = integ or hotpath.integrator()     # adaptive order 8 @ 1e-13 = the reference's Vern8 setting
+
+    def defect(self, XC, t, params):
+        d, _ = hotpath.indirect_defectCalc(XC, t, params, self.integ, ctx=self.ctx)
+        return d
+
+    def stm(self, XC, t, params):
+        return hotpath.indirect_stm(XC, t, params, self.integ, ctx=self.ctx)
+
+    def defect_batch_sumsq(self, XC_batch, t, params):
+        """sum(defect.^2) per trial trajectory: one batched launch (+ on-device reduction when torch is present)."""
+        d, _ = hotpath.indirect_defectCalc(XC_batch, t, params, self.integ, ctx=self.ctx)
+        return np.sum(d * d, axis=(0, 1))
+
+
+def _solve_ls(J, rhs):
+    """x = -J \\ rhs (least squares).  The systems here are square or over-determined once the fixed-end-state
+    columns are dropped, so the solution is unique and independent of the factorisation used."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    if sp.issparse(J):
+        keep = np.flatnonzero(np.diff(J.tocsc().indptr) > 0)
+        Jk = J.tocsc()[:, keep]
+        x = np.zeros(J.shape[1])
+        if Jk.shape[0] == Jk.shape[1]:
+            try:
+                x[keep] = spl.spsolve(Jk, -rhs)
+                if np.all(np.isfinite(x)):
+                    return x
+            except Exception:
+                pass
+        sol = spl.lsmr(Jk, -rhs, atol=1e-15, btol=1e-15, conlim=1e14, maxiter=20 * Jk.shape[1])[0]
+        x[keep] = sol
+        return x
+    return np.linalg.lstsq(J, -rhs, rcond=None)[0]
+
+
+def optimizeTraj_OLS(XC_all, t_TU, defect, Phi, nstate, n_nodes, params, flag_adjointsOnly, ops):
+    """Least-squares Newton step with second-order correction (indirect.jl:149-218)."""
+    nd = 2 * nstate
+    defect_vec = defect.reshape(-1, order="F")
+    J = hotpath.indirect_scatter(Phi, sparse=True)
+    temp = np.ones(J.shape[1], dtype=bool)
+    if flag_adjointsOnly:                                   # :169-178: drop the state columns of nodes 1..n-1
+        for ind in range(n_nodes - 1):
+            temp[ind * nd: ind * nd + nstate] = False
+    Jm = J[:, np.flatnonzero(temp)]
+    upd = np.zeros(J.shape[1])
+    upd[temp] = _solve_ls(Jm, defect_vec)                   # :182
+    xc_update = upd.reshape(nd, n_nodes, order="F")
+    if np.abs(xc_update).max() < 1e-1:                      # :190  SOC: same Jacobian, defect at the trial point
+        d_soc = ops.defect(XC_all + xc_update, t_TU, params)
+        upd2 = np.zeros(J.shape[1])
+        upd2[temp] = _solve_ls(Jm, d_soc.reshape(-1, order="F"))
+        xc_update = xc_update + upd2.reshape(nd, n_nodes, order="F")
+    return xc_update
+
+
+def lineSearch(XC_all, xc_update, t_TU, params, ops):
+    """alpha in LinRange(0.1, 1, 20) minimising sum(defect.^2) (indirect.jl:221-246), all 20 trial trajectories in
+    one batched sweep."""
+    alpha_all = np.linspace(0.1, 1.0, 20)
+    trial = XC_all[:, :, None] + xc_update[:, :, None] * alpha_all[None, None, :]
+    er = ops.defect_batch_sumsq(np.asfortranarray(trial), t_TU, params)
+    return float(alpha_all[int(np.argmin(er))])             # first minimiser, as `alpha[er .== minimum(er)][1]`
+
+
+def multiShoot_CRTBP_indirect(XC_all, t_TU, MU, DU, TU, n_nodes, mass0, thrustLimit, plot_yn, flag_adjointsOnly,
+                              maxIter, p, rho, ops=None, verbose=True):
+    """Indirect multiple shooting with fixed end states (indirect.jl:58-61, :254-345).
+    Returns (XC_all, defect, status_flag): 0 converged, 1 maxIter reached, 2 NaN."""
+    ops = ops or HipOps()
+    XC_all = np.array(XC_all, dtype=np.float64, order="F")
+    t_TU = np.array(t_TU, dtype=np.float64)
+    nstate = XC_all.shape[0] // 2                            # :255
+    params = hotpath.make_params(MU, DU, TU, thrustLimit, mass0, 1.0, p, rho)   # :258-260
+    status_flag = 0
+    state_0 = XC_all[:nstate, 0].copy()
+    state_f = XC_all[:nstate, -1].copy()
+    defect = ops.defect(XC_all, t_TU, params)                # :274
+    iterCount = 0
+    er = 1.0
+    while er > 1e-10:                                        # :280
+        iterCount += 1
+        if iterCount > maxIter:
+            if verbose:
+                print("Reached max iteration count at %d iterations" % iterCount)
+            status_flag = 1
+            break
+        Phi, _ = ops.stm(XC_all, t_TU, params)               # jacobianCalc, :290
+        xc_update = optimizeTraj_OLS(XC_all, t_TU, defect, Phi, nstate, n_nodes, params, flag_adjointsOnly, ops)
+        alpha = 1.0
+        if iterCount > 3:                                    # :300
+            alpha = lineSearch(XC_all, xc_update, t_TU, params, ops)
+        XC_all = XC_all + xc_update * alpha
+        XC_all[:nstate, 0] = state_0                         # :324-325
+        XC_all[:nstate, -1] = state_f
+        defect = ops.defect(XC_all, t_TU, params)            # :328
+        er = float(np.max(np.abs(defect))) if np.all(np.isfinite(defect)) else float("nan")
+        if verbose:
+            print("Iter %d. Max defect = %.2e. alpha = %.3f." % (iterCount, er, alpha))
+        if not (er <= 1e3):                                  # :333-336 (also leaves the loop on NaN)
+            if verbose:
+                print("Not likely to converge. Aborting.")
+            iterCount += 100
+            if er != er:
+                break
+    if np.isnan(XC_all[0, 0]) or not np.all(np.isfinite(defect)):
+        status_flag = 2                                      # :339-341
+    return XC_all, defect, status_flag
+
+
+def reduceFuel_indirect(XC_all, t_TU, MU, DU, TU, n_nodes, mass, thrustLimit, rho_current, rho_target, ops=None,
+                        verbose=True, rng=None):
+    """rho continuation (HelperFunctions.jl:105-193): halve rho on success, back off on failure.
+    status_flag 3 = continuation exhausted (:161)."""
+    rng = rng or np.random.default_rng(0)
+    if rho_target > rho_current:
+        rho_target = rho_current
+    p = 1.0
+    rho_temp = rho_current
+    maxIter = 10
+
+    def run(X, rho):
+        return multiShoot_CRTBP_indirect(X, t_TU, MU, DU, TU, n_nodes, mass, thrustLimit, False, False, maxIter, p, rho,
+                                         ops=ops, verbose=verbose)
+
+    XC_new, defect, status = run(XC_all, rho_temp)
+    if status == 0 and rho_current == rho_target:
+        return XC_new, defect, status
+    while status != 0 and rho_temp < 1:                      # :133-143
+        rho_temp = min(rho_temp * 5, 1.0)
+        XC_new, defect, status = run(XC_all, rho_temp)
+    if rho_temp == 1 and status != 0:
+        return XC_new, defect, status
+    if status == 0:
+        XC_all = XC_new.copy()
+    count = 0
+    while rho_temp > rho_target or status != 0:              # :158-188
+        count += 1
+        if count > 100:
+            return XC_new, defect, 3
+        if status == 0:
+            XC_all = XC_new.copy()
+            rho_temp = max(rho_temp / 2, rho_target)
+        else:
+            rho_temp *= 3 * (1 + rng.random())
+        XC_new, defect, status = run(XC_all, rho_temp)
+    return XC_new, defect, status
+
+
+def homotopy_defect_sweep(XC_levels, t_TU, MU, DU, TU, mass, thrustLimit, rhos, ops=None):
+    """All continuation levels evaluated concurrently (BASELINE configs[3]): level l has its own node array
+    XC_levels[:, :, l] and smoothing rho_l; ONE launch returns max|defect| and sum(defect^2) per level."""
+    ops = ops or HipOps()
+    prms = [hotpath.make_params(MU, DU, TU, thrustLimit, mass, 1.0, 1.0, r) for r in rhos]
+    d, _ = hotpath.indirect_defectCalc(np.asfortranarray(XC_levels), t_TU, prms, ops.integ, ctx=ops.ctx)
+    return np.max(np.abs(d), axis=(0, 1)), np.sum(d * d, axis=(0, 1)), d

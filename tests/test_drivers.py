@@ -1,0 +1,123 @@
+"""Host drivers (lowthrustopt_amd/drivers.py) mirror multiShoot_CRTBP_indirect / reduceFuel_indirect.
+CPU: driver logic with an injected oracle back end.  GPU: the same problems through the HIP library."""
+import numpy as np
+import pytest
+
+import lowthrustopt_amd as lto
+from lowthrustopt_amd import drivers, synth
+from lowthrustopt_amd.constants import MU, DU, TU
+
+
+class OracleOps:
+    """Test-only propagation back end (the product's is drivers.HipOps)."""
+
+    def __init__(self, O, method=None):
+        self.O = O
+        self.method = O.DOP853_ADAPTIVE if method is None else method
+
+    def _prm(self, p):
+        return [p.MU, p.DU, p.TU, p.thrustLimit, p.mass, p.time_direction, p.p, p.rho]
+
+    def defect(self, XC, t, params):
+        d, _, rc = self.O.indirect_defect(XC, t, self._prm(params), self.method)
+        return d
+
+    def stm(self, XC, t, params):
+        Phi, d, rc = self.O.indirect_jacobian(XC, t, self._prm(params), self.method)
+        return Phi, d
+
+    def defect_batch_sumsq(self, XC_batch, t, params):
+        return np.array([np.sum(self.defect(XC_batch[:, :, b], t, params) ** 2) for b in range(XC_batch.shape[2])])
+
+
+def consistent_problem(O, n_nodes=8, p=2.0, rho=1.0, thrust=10.0, seed=0, pert=1e-3):
+    """Nodes sampled from ONE exact trajectory (zero defect), interior nodes then perturbed."""
+    rng = np.random.default_rng(seed)
+    H1 = synth.halo_orbits()[0]
+    y = np.concatenate([H1[:, 20], 0.05 * rng.standard_normal(6)])
+    prm = [MU, DU, TU, thrust, 1000.0, 1.0, p, rho]
+    t = np.arange(n_nodes) * 0.1
+    XC = np.zeros((12, n_nodes))
+    XC[:, 0] = y
+    for k in range(1, n_nodes):
+        y, rc, _, _ = O.flow_state_costate(y, prm, 0.1, O.DOP853_ADAPTIVE)
+        XC[:, k] = y
+    exact = XC.copy()
+    XC[:, 1:-1] += pert * rng.standard_normal((12, n_nodes - 2))
+    XC[6:, 0] += pert * rng.standard_normal(6)
+    XC[6:, -1] += pert * rng.standard_normal(6)
+    return XC, t, exact
+
+
+def test_driver_converges_with_injected_backend(oracle):
+    XC, t, exact = consistent_problem(oracle)
+    out, defect, status = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, 8, 1000.0, 10.0, False, False, 20, 2.0, 1.0,
+                                                            ops=OracleOps(oracle), verbose=False)
+    assert status == 0 and np.abs(defect).max() <= 1e-10
+    assert np.array_equal(out[:6, 0], XC[:6, 0]) and np.array_equal(out[:6, -1], XC[:6, -1])   # end states pinned
+    assert np.abs(out - exact).max() < 1e-6      # the fixed-endpoint problem has the sampled trajectory as solution
+
+
+def test_driver_status_flags(oracle):
+    XC, t, _ = consistent_problem(oracle, pert=1e-2)
+    out, defect, status = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, 8, 1000.0, 10.0, False, False, 1, 2.0, 1.0,
+                                                            ops=OracleOps(oracle), verbose=False)
+    assert status == 1                      # maxIter reached (indirect.jl:282-285)
+    XC[0, 3] = np.nan
+    out, defect, status = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, 8, 1000.0, 10.0, False, False, 5, 2.0, 1.0,
+                                                            ops=OracleOps(oracle), verbose=False)
+    assert status == 2                      # NaN (indirect.jl:339-341)
+
+
+def test_adjoints_only_mask_and_linesearch(oracle):
+    XC, t, exact = consistent_problem(oracle, pert=0.0)
+    rng = np.random.default_rng(5)
+    XC[6:, :] += 1e-3 * rng.standard_normal((6, 8))          # good states, poor adjoints
+    ops = OracleOps(oracle)
+    prm = lto.make_params(MU, DU, TU, 10.0, 1000.0, 1.0, 2.0, 1.0)
+    d0 = ops.defect(XC, t, prm)
+    Phi, _ = ops.stm(XC, t, prm)
+    upd = drivers.optimizeTraj_OLS(XC, t, d0, Phi, 6, 8, prm, True, ops)
+    assert np.all(upd[:6, :7] == 0.0)        # state columns of nodes 1..n-1 removed (indirect.jl:169-178)
+    assert np.abs(upd[6:, :]).max() > 0
+    alpha = drivers.lineSearch(XC, upd, t, prm, ops)
+    assert 0.1 <= alpha <= 1.0
+    d1 = ops.defect(XC + alpha * upd, t, prm)
+    assert np.sum(d1 ** 2) < np.sum(d0 ** 2)
+
+
+@pytest.mark.gpu
+def test_driver_on_gpu_matches_cpu_driver(gpu_ctx, oracle):
+    XC, t, exact = consistent_problem(oracle, n_nodes=12, seed=3)
+    ops = drivers.HipOps(gpu_ctx)
+    out, defect, status = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, 12, 1000.0, 10.0, False, False, 20, 2.0, 1.0,
+                                                            ops=ops, verbose=False)
+    assert status == 0 and np.abs(defect).max() <= 1e-10
+    out_c, defect_c, status_c = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, 12, 1000.0, 10.0, False, False, 20, 2.0,
+                                                                  1.0, ops=OracleOps(oracle), verbose=False)
+    assert status_c == 0 and np.abs(out - out_c).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_reduce_fuel_continuation_on_gpu(gpu_ctx, oracle):
+    """rho continuation 1 -> 0.25 on a p = 1 problem built from an exact trajectory at rho = 1."""
+    XC, t, exact = consistent_problem(oracle, n_nodes=10, p=1.0, rho=1.0, thrust=0.05, seed=4, pert=1e-5)
+    ops = drivers.HipOps(gpu_ctx)
+    out, defect, status = drivers.reduceFuel_indirect(XC, t, MU, DU, TU, 10, 1000.0, 0.05, 1.0, 0.25, ops=ops, verbose=False)
+    assert status == 0 and np.abs(defect).max() <= 1e-10
+    # the result satisfies the rho = 0.25 problem according to the oracle as well
+    d_o, _, rc = oracle.indirect_defect(out, t, [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 0.25], oracle.DOP853_ADAPTIVE)
+    assert np.abs(d_o).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_homotopy_levels_one_launch(gpu_ctx):
+    B = 16
+    XC, T = synth.indirect_problem(33, n_batch=B, seed=2)
+    rhos = synth.homotopy_rhos(B)
+    mx, ss, d = drivers.homotopy_defect_sweep(XC, T, MU, DU, TU, 1000.0, 0.05, rhos, ops=drivers.HipOps(gpu_ctx))
+    assert mx.shape == (B,) and ss.shape == (B,) and d.shape == (12, 32, B)
+    for b in (0, 7, 15):
+        d1, _ = lto.indirect_defectCalc(XC[:, :, b], T[:, b], lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, rhos[b]),
+                                        ctx=gpu_ctx)
+        assert np.abs(d[:, :, b] - d1).max() < 1e-13

@@ -62,5 +62,28 @@ def main():
         plan.close()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--host" not in sys.argv:
     main()
+
+
+def host_api_rate():
+    """PCIe-inclusive rate of the host-pointer ABI (what a Julia ccall sees): numpy in, numpy out."""
+    import time
+    ctx = lto.Context(0)
+    prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    for S in (29, 4096):
+        XC, T = synth.indirect_problem(S + 1)
+        XC, t = XC[:, :, 0], T[:, 0]
+        integ = lto.integrator(lto.RK4, steps=64)
+        for name, fn in (("stm", lambda: lto.indirect_stm(XC, t, prm, integ, ctx=ctx)),
+                         ("defect", lambda: lto.indirect_defectCalc(XC, t, prm, integ, ctx=ctx))):
+            fn(); fn()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            dt = (time.perf_counter() - t0) / 20
+            print("host-pointer ABI S=%5d rk4x64 %-6s %9.3f ms per call  %10.3e seg/s (PCIe + pack/unpack + plan inclusive)" % (S, name, dt * 1e3, S / dt), flush=True)
+
+
+if __name__ == "__main__" and "--host" in sys.argv:
+    host_api_rate()
