@@ -86,7 +86,11 @@ double lto_last_kernel_ms(lto_ctx* ctx);
 /* --------------------------------------------------------- host-pointer API (what Julia ccalls) */
 
 /* Replaces defectCalc of multiShoot_CRTBP_indirect (src/multiShoot_CRTBP_indirect.jl:63-90).
- *   XC      [ndim x n_nodes x n_batch]   ndim = 12 (state+costate; 14 reserved)
+ *   XC      [ndim x n_nodes x n_batch]   ndim = 12: the reference's state+costate system.
+ *                                        ndim = 14: (r, v, m, lambda_r, lambda_v, lambda_m), an EXTENSION with no
+ *                                        reference counterpart (BASELINE configs[1]; model after
+ *                                        GeneralCode/twoBody_stateCostate_mass_deriv.jl:11-78 in CRTBP units); the
+ *                                        `mass` field of lto_params then carries Isp [s] (mass is state[7]).
  *   t       [n_nodes x n_tgrids]         n_tgrids = 1 (shared grid) or n_batch
  *   prm     [n_prm]                      n_prm = 1 or n_batch
  *   defect  [ndim x (n_nodes-1) x n_batch]  = x(t_{i+1}; XC[:,i]) - XC[:,i+1]          (:82)

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblto_hip.so")
+LIB_PATH = os.environ.get("LTO_HIP_LIB") or os.path.join(_HERE, "liblto_hip.so")
 
 LTO_OK, LTO_EINVAL, LTO_ENULL, LTO_EUNSUPPORTED = 0, -1, -2, -3
 LTO_EHIP, LTO_EBADP, LTO_ENODEVICE = 1, 2, 3

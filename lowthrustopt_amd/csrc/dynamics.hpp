@@ -17,14 +17,16 @@ enum PMode : int { PM_P0 = 0, PM_P1 = 1, PM_P2 = 2, PM_PGEN = 3, PM_MIXED = 4 };
 
 // Per-trajectory constants, precomputed on the host in the reference's operation order.
 struct TrajParams {
-  double accel_limit;  // thrustLimit / mass / 1e3 * TU^2 / DU        (stateCostate_deriv.jl:33)
+  double accel_limit;  // thrustLimit / mass / 1e3 * TU^2 / DU        (stateCostate_deriv.jl:33); 12-dim only
   double inv_2rho;     // 1 / (2 rho)                                   (:43)
-  double al_over_rho;  // accel_limit / rho  (prefactor of d umag / d|lambda_v| for p = 1)
+  double inv_rho;      // 1 / rho   (d umag / d|lambda_v| for p = 1 is accelLimit/rho * e q^2)
   double p;            // control-law exponent
   double inv_p;        // 1 / p
   double inv_pm1;      // 1 / (p - 1)   (p > 1 only)
   double omega;        // time_direction
   double MU;           // CRTBP mass ratio
+  double cT;           // thrustLimit / 1e3 * TU^2 / DU: accelLimit = cT / m for the 14-dim (variable mass) system
+  double kappa_td;     // time_direction * 1e3 * DU / (TU * Isp * 9.81): mdot = -kappa_td * umag * m  (14-dim)
 };
 
 // 1/sqrt(x) to ~1 ulp: v_rsq_f64 seed (relative error <~ 2^-26) + ONE third-order step
@@ -74,16 +76,19 @@ struct VarCoef12 {
   double ua, ub, lx, ly, lz;
 };
 
-// Thrust magnitude m(n), n = |lambda_v|, and (if VAR) m' = dm/dn, for one control-law mode.
-// Returns through references; `inv_n` is 1/n (0 when n == 0, the reference's NaN guard :59-64).
+// Thrust magnitude umag(n), n = |lambda_v|, for accelLimit aL, and (if VAR) un = d umag / dn.
+//   m = umag, ua = umag / n, ub = ua - un  (so that  U d = -ua d + ub (lhat.d) lhat),
+//   tlim = true when umag is proportional to aL (every law except the unclamped p > 1 branch).
+// `inv_n` is 1/n (0 when n == 0, the reference's NaN guard :59-64).
 template <int PM, bool VAR>
-__device__ __forceinline__ void control_law(const TrajParams& tp, double n, double inv_n, double& m, double& ua,
-                                            double& ub) {
-  const double aL = tp.accel_limit;
+__device__ __forceinline__ void control_law(const TrajParams& tp, const double aL, double n, double inv_n, double& m,
+                                            double& ua, double& ub, double& un, bool& tlim) {
+  tlim = true;
+  un = 0.0;
   if (PM == PM_P0) {  // :36-39  umag = accelLimit
     m = aL;
     ua = aL * inv_n;
-    ub = ua;  // m' = 0
+    ub = ua;
   } else if (PM == PM_P1) {  // :41-43  umag = 1/2 (1 + tanh(g / (2 rho))) accelLimit, g = n - 1
     // 1/2 (1 + tanh x) = 1 / (1 + exp(-2x)): evaluated without cancellation or overflow for any rho.
     const double x = (n - 1.0) * tp.inv_2rho;
@@ -92,16 +97,29 @@ __device__ __forceinline__ void control_law(const TrajParams& tp, double n, doub
     const double sig = (x >= 0.0) ? q : e * q;
     m = aL * sig;
     ua = m * inv_n;
-    // m' = aL/(4 rho) sech^2 x = (aL / rho) e q^2
-    ub = VAR ? ua - tp.al_over_rho * (e * q) * q : 0.0;
+    if (VAR) un = (aL * tp.inv_rho) * (e * q) * q;   // aL/(4 rho) sech^2 x = (aL / rho) e q^2
+    ub = ua - un;
   } else if (PM == PM_P2) {  // :45-50 with p = 2: umag = n / 2, clamped at accelLimit
     const double mu = 0.5 * n;
     if (mu > aL) { m = aL; ua = aL * inv_n; ub = ua; }
-    else { m = mu; ua = 0.5; ub = 0.0; }  // u = -lambda_v / 2  =>  U = -I / 2 (also at n = 0)
+    else { m = mu; ua = 0.5; ub = 0.0; un = 0.5; tlim = false; }  // u = -lambda_v / 2 => U = -I / 2 (also at n = 0)
   } else {  // PM_PGEN :45-50  umag = (n / p)^(1 / (p - 1)), clamped
     const double mu = pow(tp.inv_p * n, tp.inv_pm1);
     if (mu > aL) { m = aL; ua = aL * inv_n; ub = ua; }
-    else { m = mu; ua = mu * inv_n; ub = VAR ? ua - ua * tp.inv_pm1 : 0.0; }  // m' = m / ((p-1) n)
+    else { m = mu; ua = mu * inv_n; un = ua * tp.inv_pm1; ub = ua - un; tlim = false; }  // un = umag / ((p-1) n)
+  }
+}
+
+template <int PM, bool VAR>
+__device__ __forceinline__ void control_dispatch(const TrajParams& tp, const double aL, double n, double inv_n, double& m,
+                                                 double& ua, double& ub, double& un, bool& tlim) {
+  if (PM == PM_MIXED) {
+    if (tp.p == 1.0) control_law<PM_P1, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+    else if (tp.p == 2.0) control_law<PM_P2, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+    else if (tp.p == 0.0) control_law<PM_P0, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+    else control_law<PM_PGEN, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+  } else {
+    control_law<PM, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
   }
 }
 
@@ -134,15 +152,9 @@ __device__ __forceinline__ void rhs12(const double (&y)[12], const TrajParams& t
   const double n2 = __builtin_fma(lx0, lx0, __builtin_fma(ly0, ly0, lz0 * lz0));
   const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
   const double n = n2 * inv_n;
-  double m, ua, ub;
-  if (PM == PM_MIXED) {
-    if (tp.p == 1.0) control_law<PM_P1, VAR>(tp, n, inv_n, m, ua, ub);
-    else if (tp.p == 2.0) control_law<PM_P2, VAR>(tp, n, inv_n, m, ua, ub);
-    else if (tp.p == 0.0) control_law<PM_P0, VAR>(tp, n, inv_n, m, ua, ub);
-    else control_law<PM_PGEN, VAR>(tp, n, inv_n, m, ua, ub);
-  } else {
-    control_law<PM, VAR>(tp, n, inv_n, m, ua, ub);
-  }
+  double m, ua, ub, un;
+  bool tlim;
+  control_dispatch<PM, VAR>(tp, tp.accel_limit, n, inv_n, m, ua, ub, un, tlim);
   const double lhx = lx0 * inv_n, lhy = ly0 * inv_n, lhz = lz0 * inv_n;
 
   dy[0] = y[3]; dy[1] = y[4]; dy[2] = y[5];                                   // :78
@@ -203,15 +215,9 @@ __device__ __forceinline__ void rhs12_fused1(const double (&y)[24], const TrajPa
   const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
   const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
   const double n = n2 * inv_n;
-  double m, ua, ub;
-  if (PM == PM_MIXED) {
-    if (tp.p == 1.0) control_law<PM_P1, true>(tp, n, inv_n, m, ua, ub);
-    else if (tp.p == 2.0) control_law<PM_P2, true>(tp, n, inv_n, m, ua, ub);
-    else if (tp.p == 0.0) control_law<PM_P0, true>(tp, n, inv_n, m, ua, ub);
-    else control_law<PM_PGEN, true>(tp, n, inv_n, m, ua, ub);
-  } else {
-    control_law<PM, true>(tp, n, inv_n, m, ua, ub);
-  }
+  double m, ua, ub, un;
+  bool tlim;
+  control_dispatch<PM, true>(tp, tp.accel_limit, n, inv_n, m, ua, ub, un, tlim);
   const double lhx = lx * inv_n, lhy = ly * inv_n, lhz = lz * inv_n;
 
   // s_b = rho_b . lambda_v ;  G lambda_v = ((1-cs) lx + tA, (1-cs) ly + es y, -cs lz + es z)
@@ -297,6 +303,123 @@ __device__ __forceinline__ void var_col12(const VarCoef12& vc, const double w2, 
   dc[9] = __builtin_fma(w2, dyv, -c[6]);
   dc[10] = __builtin_fma(-w2, dx, -c[7]);
   dc[11] = -c[8];
+}
+
+// ------------------------------------------------------------------------------ 14-dim extension
+// y = (r, v, m, lambda_r, lambda_v, lambda_m): CRTBP state+costate with mass flow and mass costate (BASELINE
+// configs[1]).  The reference has NO such RHS (its CRTBP system is 12-dim, constant mass); the model follows
+// GeneralCode/twoBody_stateCostate_mass_deriv.jl:11-78 re-expressed in CRTBP units, DESIGN.md "14-dim extension":
+//   aL = cT / m,  umag = law(|lambda_v|) (CRTBP form),  u = -umag lhat,  mdot = -kappa_td umag m,
+//   lambda_m_dot = -dH/dm = -umag n / m (thrust-limited laws)  or  kappa_td lambda_m umag (unclamped p > 1).
+struct VarCoef14 {
+  VarCoef12 c;              // G, H, U as in the 12-dim system
+  double umx, umy, umz;     // d u / d m = -um lhat,  um = d umag / d m
+  double mm, mn;            // d mdot / d m,  d mdot / d n   (n = |lambda_v|; d/d lambda_v = (.) lhat^T)
+  double Lm, Ln, Ll;        // d lambda_m_dot / d m, / d n, / d lambda_m
+};
+
+template <int PM, bool VAR>
+__device__ __forceinline__ void rhs14(const double (&y)[14], const TrajParams& tp, double (&dy)[14], VarCoef14& vc) {
+  const double MU = tp.MU;
+  const double x = y[0], yy = y[1], z = y[2], mass = y[6];
+  const double w2 = 2.0 * tp.omega;
+  const double a = x + MU, b = a - 1.0;
+  const double yz2 = __builtin_fma(yy, yy, z * z);
+  const double d1 = __builtin_fma(a, a, yz2), d2 = __builtin_fma(b, b, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
+  const double cs = c1 + c2;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double ee = e1 + e2;
+  const double sa = e1 * a, tb = e2 * b;
+  const double st = sa + tb;
+  const double Gxx = __builtin_fma(sa, a, __builtin_fma(tb, b, 1.0 - cs));
+  const double Gyy = __builtin_fma(ee * yy, yy, 1.0 - cs);
+  const double Gzz = __builtin_fma(ee * z, z, -cs);
+  const double Gxy = st * yy, Gxz = st * z, Gyz = ee * yy * z;
+
+  const double lx0 = y[10], ly0 = y[11], lz0 = y[12], lm = y[13];
+  const double n2 = __builtin_fma(lx0, lx0, __builtin_fma(ly0, ly0, lz0 * lz0));
+  const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
+  const double n = n2 * inv_n;
+  const double inv_m = rcp_nr(mass);
+  const double aL = tp.cT * inv_m;
+  double m, ua, ub, un;
+  bool tlim;
+  control_dispatch<PM, true>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+  const double lhx = lx0 * inv_n, lhy = ly0 * inv_n, lhz = lz0 * inv_n;
+  const double kt = tp.kappa_td;
+
+  dy[0] = y[3]; dy[1] = y[4]; dy[2] = y[5];
+  dy[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))) - m * lhx;
+  dy[4] = __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)) - m * lhy;
+  dy[5] = __builtin_fma(-cs, z, -m * lhz);
+  dy[6] = -kt * m * mass;
+  dy[7] = -__builtin_fma(Gxx, lx0, __builtin_fma(Gxy, ly0, Gxz * lz0));
+  dy[8] = -__builtin_fma(Gxy, lx0, __builtin_fma(Gyy, ly0, Gyz * lz0));
+  dy[9] = -__builtin_fma(Gxz, lx0, __builtin_fma(Gyz, ly0, Gzz * lz0));
+  dy[10] = __builtin_fma(w2, ly0, -y[7]);
+  dy[11] = __builtin_fma(-w2, lx0, -y[8]);
+  dy[12] = -y[9];
+  // tl = 1 for thrust-limited laws (umag ~ 1/m), 0 for the unclamped p > 1 law (umag independent of m); blended
+  // arithmetically so that no per-lane boolean stays live across the (register-starved) 13-stage integrators.
+  const double tl = tlim ? 1.0 : 0.0, ntl = 1.0 - tl;
+  const double mn_over_m = (m * n) * inv_m;
+  dy[13] = __builtin_fma(-tl, mn_over_m, ntl * (kt * lm * m));
+
+  if (VAR) {
+    VarCoef12& g = vc.c;
+    g.Gxx = Gxx; g.Gyy = Gyy; g.Gzz = Gzz; g.Gxy = Gxy; g.Gxz = Gxz; g.Gyz = Gyz;
+    g.ua = ua; g.ub = ub; g.lx = lhx; g.ly = lhy; g.lz = lhz;
+    const double s1 = __builtin_fma(a, lx0, __builtin_fma(yy, ly0, z * lz0));
+    const double s2 = __builtin_fma(b, lx0, __builtin_fma(yy, ly0, z * lz0));
+    const double q1 = 5.0 * e1 * i1s * s1, q2 = 5.0 * e2 * i2s * s2;
+    const double es = __builtin_fma(e1, s1, e2 * s2);
+    const double qq = q1 + q2;
+    const double qa = __builtin_fma(q1, a, q2 * b);
+    g.Hxx = es + 2.0 * st * lx0 - __builtin_fma(q1 * a, a, q2 * b * b);
+    g.Hyy = es + 2.0 * ee * yy * ly0 - qq * yy * yy;
+    g.Hzz = es + 2.0 * ee * z * lz0 - qq * z * z;
+    g.Hxy = __builtin_fma(st, ly0, ee * yy * lx0) - qa * yy;
+    g.Hxz = __builtin_fma(st, lz0, ee * z * lx0) - qa * z;
+    g.Hyz = ee * __builtin_fma(yy, lz0, z * ly0) - qq * yy * z;
+    // thrust-limited: um = d umag/dm = -umag/m and um m + umag = 0;  otherwise um = 0
+    const double um_neg = tl * (m * inv_m);                  // -um
+    vc.umx = um_neg * lhx; vc.umy = um_neg * lhy; vc.umz = um_neg * lhz;   // d u / d m = -um lhat
+    vc.mm = -kt * (ntl * m);                                 // d mdot / d m = -kt (um m + umag)
+    vc.mn = -kt * mass * un;                                 // d mdot / d n
+    vc.Lm = tl * (2.0 * mn_over_m * inv_m);
+    vc.Ln = __builtin_fma(-tl, __builtin_fma(un, n, m) * inv_m, ntl * (kt * lm * un));
+    vc.Ll = ntl * (kt * m);
+  }
+}
+
+// One STM column c = (a, b, mu, g, d, nu) of the 14-dim system.
+__device__ __forceinline__ void var_col14(const VarCoef14& v, const double w2, const double (&c)[14], double (&dc)[14]) {
+  const VarCoef12& vc = v.c;
+  const double ax = c[0], ay = c[1], az = c[2], mu = c[6];
+  const double dx = c[10], dyv = c[11], dz = c[12];
+  dc[0] = c[3]; dc[1] = c[4]; dc[2] = c[5];
+  const double ld = __builtin_fma(vc.lx, dx, __builtin_fma(vc.ly, dyv, vc.lz * dz));
+  const double tl = vc.ub * ld;
+  dc[3] = __builtin_fma(vc.Gxx, ax, __builtin_fma(vc.Gxy, ay, __builtin_fma(vc.Gxz, az,
+          __builtin_fma(w2, c[4], __builtin_fma(-vc.ua, dx, __builtin_fma(tl, vc.lx, v.umx * mu))))));
+  dc[4] = __builtin_fma(vc.Gxy, ax, __builtin_fma(vc.Gyy, ay, __builtin_fma(vc.Gyz, az,
+          __builtin_fma(-w2, c[3], __builtin_fma(-vc.ua, dyv, __builtin_fma(tl, vc.ly, v.umy * mu))))));
+  dc[5] = __builtin_fma(vc.Gxz, ax, __builtin_fma(vc.Gyz, ay, __builtin_fma(vc.Gzz, az,
+          __builtin_fma(-vc.ua, dz, __builtin_fma(tl, vc.lz, v.umz * mu)))));
+  dc[6] = __builtin_fma(v.mm, mu, v.mn * ld);
+  dc[7] = -__builtin_fma(vc.Hxx, ax, __builtin_fma(vc.Hxy, ay, __builtin_fma(vc.Hxz, az,
+           __builtin_fma(vc.Gxx, dx, __builtin_fma(vc.Gxy, dyv, vc.Gxz * dz)))));
+  dc[8] = -__builtin_fma(vc.Hxy, ax, __builtin_fma(vc.Hyy, ay, __builtin_fma(vc.Hyz, az,
+           __builtin_fma(vc.Gxy, dx, __builtin_fma(vc.Gyy, dyv, vc.Gyz * dz)))));
+  dc[9] = -__builtin_fma(vc.Hxz, ax, __builtin_fma(vc.Hyz, ay, __builtin_fma(vc.Hzz, az,
+           __builtin_fma(vc.Gxz, dx, __builtin_fma(vc.Gyz, dyv, vc.Gzz * dz)))));
+  dc[10] = __builtin_fma(w2, dyv, -c[7]);
+  dc[11] = __builtin_fma(-w2, dx, -c[8]);
+  dc[12] = -c[9];
+  dc[13] = __builtin_fma(v.Lm, mu, __builtin_fma(v.Ln, ld, v.Ll * c[13]));
 }
 
 // ------------------------------------------------------------------------------ A2 (direct path)

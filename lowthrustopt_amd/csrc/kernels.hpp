@@ -11,7 +11,7 @@ enum Method : int { M_RK4 = 0, M_RKF78_FIXED = 1, M_RKF78_ADAPTIVE = 2, M_DOP853
 // Device layout (include/lto.h, "device-resident API"): node j = b*n_nodes + k, segment
 // s = b*seg_per_traj + i, component-major with leading dimensions ld*.
 struct IndirectArgs {
-  const double* X; long ldx;       // [12][ldx] nodes
+  const double* X; long ldx;       // [ndim][ldx] nodes (ndim = 12 or 14)
   const double* t; int t_stride;   // t[b*t_stride + k]; t_stride = n_nodes (per-trajectory grids) or 0 (shared)
   const TrajParams* tp; int tp_stride;  // tp[b*tp_stride]; 1 or 0
   int n_nodes, seg_per_traj, S;
@@ -40,6 +40,8 @@ struct DirectArgs {
 hipError_t launch_indirect_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
 // cols_per_lane in {1,2,3}; 0 = choose from S.
 hipError_t launch_indirect_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
+hipError_t launch_indirect14_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
+hipError_t launch_indirect14_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
 

@@ -46,13 +46,12 @@ struct SysDirectVar {
 
 // Common per-lane setup: lane -> (segment, direction), initial half-arc state and DirectLane.
 template <int NS>
-__device__ __forceinline__ void direct_setup(const DirectArgs& a, int& s, int& dir, bool& active, double& hhalf,
+__device__ __forceinline__ void direct_setup(const DirectArgs& a, int& s, int& dir, double& hhalf,
                                              double& span_total, double (&x)[NS], DirectLane& L, double& nc) {
   const int gid = blockIdx.x * 64 + threadIdx.x;
   s = gid >> 1;
   dir = gid & 1;
-  active = s < a.S;
-  const int sc = active ? s : a.S - 1;  // inactive lanes shadow the last segment (keeps exchanges defined)
+  const int sc = (s < a.S) ? s : a.S - 1;  // inactive lanes shadow the last segment (keeps exchanges defined)
   const int traj = sc / a.seg_per_traj;
   const int i = sc - traj * a.seg_per_traj;
   const long node = (long)traj * a.n_nodes + i + dir;
@@ -76,10 +75,10 @@ __device__ __forceinline__ double xchg1(double v) { return __shfl_xor(v, 1); }
 // K3: defect + RKF7(8) error estimate.
 template <int NS>
 __global__ __launch_bounds__(64) void k_direct_defect(const DirectArgs a) {
-  int s, dir; bool active; double hhalf, span_total, nc;
+  int s, dir; double hhalf, span_total, nc;
   double x[NS];
   SysDirect<NS> sys;
-  direct_setup<NS>(a, s, dir, active, hhalf, span_total, x, sys.L, nc);
+  direct_setup<NS>(a, s, dir, hhalf, span_total, x, sys.L, nc);
   const double h = hhalf / (double)a.half_steps;
   double maxErr = 0.0;
   for (int k = 0; k < a.half_steps; ++k) {
@@ -90,6 +89,7 @@ __global__ __launch_bounds__(64) void k_direct_defect(const DirectArgs a) {
     for (int c = 0; c < NS; ++c) x[c] = xn[c];
   }
   if (dir) { x[3] = -x[3]; x[4] = -x[4]; x[5] = -x[5]; }     // direct.jl:98
+  const bool active = s < a.S;   // recomputed here: no per-lane boolean is kept live across the integrator
   double d[NS];
 #pragma unroll
   for (int c = 0; c < NS; ++c) d[c] = x[c] - xchg1(x[c]);    // fwd lane: state_for - stateF_back  (:101)
@@ -111,10 +111,10 @@ __global__ __launch_bounds__(64) void k_direct_defect(const DirectArgs a) {
 //   cols [2NS+3,2NS+6) d defect / d u_{i+1} = -R Psi_b
 template <int NS>
 __global__ __launch_bounds__(64) void k_direct_jacobian(const DirectArgs a) {
-  int s, dir; bool active; double hhalf, span_total, nc;
+  int s, dir; double hhalf, span_total, nc;
   double x[NS];
   SysDirectVar<NS> sys;
-  direct_setup<NS>(a, s, dir, active, hhalf, span_total, x, sys.L, nc);
+  direct_setup<NS>(a, s, dir, hhalf, span_total, x, sys.L, nc);
   const int j = blockIdx.y;
   const bool is_ctrl = j >= NS;
   const int jc = j - NS;
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64) void k_direct_jacobian(const DirectArgs a) {
     for (int c = 0; c < 2 * NS; ++c) y[c] = yn[c];
   }
 
+  const bool active = s < a.S;   // recomputed here: no per-lane boolean is kept live across the integrator
   // sensitivity column -> Jacobian block column
   if (active && a.Jac) {
     const int col = is_ctrl ? (2 * NS + 3 * dir + jc) : (NS * dir + j);

@@ -88,15 +88,18 @@ T* arena_take(lto_ctx* c, size_t count) {
 // Reference validity rule for p (stateCostate_deriv.jl:36-53): p == 0, p == 1 or p > 1.
 bool p_valid(double p) { return p == 0.0 || p == 1.0 || p > 1.0; }
 
-int make_traj_params(lto_ctx* c, const lto_params* prm, int n, TrajParams* out, int* pm_out) {
+int make_traj_params(lto_ctx* c, int ndim, const lto_params* prm, int n, TrajParams* out, int* pm_out) {
   int pm = -1;
   for (int i = 0; i < n; ++i) {
     const lto_params& q = prm[i];
     if (!p_valid(q.p)) return set_err(c, LTO_EBADP, "Invalid value of p!");
     TrajParams t;
-    t.accel_limit = q.thrustLimit / q.mass / 1e3 * (q.TU * q.TU) / q.DU;  // stateCostate_deriv.jl:33
+    // ndim = 12: `mass` is the constant spacecraft mass.  ndim = 14: mass is state[7] and the slot carries Isp.
+    t.accel_limit = (ndim == 12) ? q.thrustLimit / q.mass / 1e3 * (q.TU * q.TU) / q.DU : 0.0;  // stateCostate_deriv.jl:33
+    t.cT = q.thrustLimit / 1e3 * (q.TU * q.TU) / q.DU;
+    t.kappa_td = (ndim == 14) ? q.time_direction * 1e3 * q.DU / (q.TU * q.mass * 9.81) : 0.0;
     t.inv_2rho = 1.0 / (2.0 * q.rho);
-    t.al_over_rho = t.accel_limit / q.rho;
+    t.inv_rho = 1.0 / q.rho;
     t.p = q.p;
     t.inv_p = (q.p != 0.0) ? 1.0 / q.p : 0.0;
     t.inv_pm1 = (q.p > 1.0) ? 1.0 / (q.p - 1.0) : 0.0;
@@ -199,8 +202,7 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (!c || !out) return LTO_ENULL;
   *out = nullptr;
   if (!prm) return set_err(c, LTO_ENULL, "prm is NULL");
-  if (ndim == 14) return set_err(c, LTO_EUNSUPPORTED, "ndim = 14 (mass + mass costate) is not built yet");
-  if (ndim != 12) return set_err(c, LTO_EINVAL, "ndim must be 12");
+  if (ndim != 12 && ndim != 14) return set_err(c, LTO_EINVAL, "ndim must be 12 (or 14: mass + mass costate extension)");
   if (n_nodes < 2 || n_batch < 1) return set_err(c, LTO_EINVAL, "need n_nodes >= 2 and n_batch >= 1");
   if (n_prm != 1 && n_prm != n_batch) return set_err(c, LTO_EINVAL, "n_prm must be 1 or n_batch");
   if ((long)(n_nodes - 1) * n_batch > 0x7fffffffL) return set_err(c, LTO_EINVAL, "too many segments");
@@ -211,7 +213,7 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   TrajParams* h = (TrajParams*)std::malloc(sizeof(TrajParams) * (size_t)n_prm);
   if (!h) return set_err(c, LTO_EHIP, "host allocation failed");
   int pm = PM_MIXED;
-  rc = make_traj_params(c, prm, n_prm, h, &pm);
+  rc = make_traj_params(c, ndim, prm, n_prm, h, &pm);
   if (rc) { std::free(h); return rc; }
   lto_indirect_plan* p = new (std::nothrow) lto_indirect_plan();
   if (!p) { std::free(h); return set_err(c, LTO_EHIP, "host allocation failed"); }
@@ -284,7 +286,8 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  hipError_t e = launch_indirect_defect(p->pm, p->integ.method, a, st);
+  hipError_t e = (p->ndim == 12) ? launch_indirect_defect(p->pm, p->integ.method, a, st)
+                                 : launch_indirect14_defect(p->pm, p->integ.method, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_defect", e);
   return LTO_OK;
@@ -304,7 +307,8 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  hipError_t e = launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
+  hipError_t e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
+                                 : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
   return LTO_OK;

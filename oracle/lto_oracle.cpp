@@ -175,6 +175,68 @@ int rhs_state_costate(const T* y, const double* prm, T* dy) {
   return 0;
 }
 
+/* ------------------------------------------------------------------ 14-dim extension (NO reference output)
+ * CRTBP state + mass + costates + mass costate, y = (r, v, m, lambda_r, lambda_v, lambda_m), the ordering of the
+ * reference's two-body model GeneralCode/twoBody_stateCostate_mass_deriv.jl:17-20,59-76.  BASELINE configs[1]
+ * names a 14-dim CRTBP system that the reference does not contain (its CRTBP RHS is 12-dim, constant mass:
+ * src/CRTBP_stateCostate_deriv.jl:10).  Conventions chosen (DESIGN.md "14-dim extension"):
+ *   accelLimit uses the CURRENT mass (two-body model :26) in CRTBP units (stateCostate_deriv.jl:33);
+ *   control law and smoothing exactly as the CRTBP file (:36-53, tanh(g/(2 rho)));
+ *   mdot = -td * (thrust in N) / (Isp * 9.81) * TU, thrust[N] = umag*m*1e3*DU/TU^2   (prop_EP_deriv.jl:41-42 units);
+ *   lambda_m_dot = -dH/dm, H = lr.v + lv.(g + u) + lm*mdot; for every thrust-limited law this equals
+ *   (lambda_v . u)/m, the form of the two-body model (:76) without its km<->m factor 1e3.
+ * prm = (MU, DU, TU, thrustLimit, Isp, time_direction, p, rho): the `mass` slot of the tuple carries Isp. */
+template <class T>
+int rhs_state_costate_mass(const T* y, const double* prm, T* dy) {
+  const T MU = T(prm[0]);
+  const double DU = prm[1], TU = prm[2], thrustLimit = prm[3], Isp = prm[4];
+  const double td = prm[5], p = prm[6], rho = prm[7];
+  const T X1 = y[0], X2 = y[1], X3 = y[2], X4 = y[3], X5 = y[4], X6 = y[5], m = y[6];
+  const T L1 = y[7], L2 = y[8], L3 = y[9], L4 = y[10], L5 = y[11], L6 = y[12], Lm = y[13];
+  const T accelLimit = T(thrustLimit) / m / 1e3 * (T(TU) * T(TU)) / DU;
+  const T nlv = o_sqrt(L4 * L4 + L5 * L5 + L6 * L6);
+  T umag;
+  bool thrust_limited = true;
+  if (p == 0.0) {
+    umag = accelLimit;
+  } else if (p == 1.0) {
+    T g = nlv - 1.0;
+    umag = 0.5 * (1.0 + o_tanh(g / (2.0 * T(rho)))) * accelLimit;
+  } else if (p > 1.0) {
+    umag = o_powT(T(1.0) / T(p) * nlv, T(1.0) / (T(p) - 1.0));
+    if (umag > accelLimit) umag = accelLimit; else thrust_limited = false;
+  } else {
+    return 1;
+  }
+  T c1 = -umag * L4 / nlv, c2 = -umag * L5 / nlv, c3 = -umag * L6 / nlv;
+  if (o_isnan(c1)) { c1 = T(0.0); c2 = T(0.0); c3 = T(0.0); }
+  const double kappa = 1e3 * DU / (TU * Isp * 9.81);
+  const T d1 = (X1 + MU) * (X1 + MU) + X2 * X2 + X3 * X3;
+  const T d2 = (X1 + MU - 1.0) * (X1 + MU - 1.0) + X2 * X2 + X3 * X3;
+  const T r1_3 = o_pow(d1, 1.5), r2_3 = o_pow(d2, 1.5), r1_5 = o_pow(d1, 2.5), r2_5 = o_pow(d2, 2.5);
+  dy[0] = X4; dy[1] = X5; dy[2] = X6;
+  dy[3] = -(1.0 - MU) * (X1 + MU) / r1_3 - MU * (X1 - 1.0 + MU) / r2_3 + 2.0 * td * X5 + X1 + c1;
+  dy[4] = -(1.0 - MU) * X2 / r1_3 - MU * X2 / r2_3 - 2.0 * td * X4 + X2 + c2;
+  dy[5] = -(1.0 - MU) * X3 / r1_3 - MU * X3 / r2_3 + c3;
+  dy[6] = -td * kappa * umag * m;
+  /* lambda_r_dot = -G lambda_v with the tidal tensor G written out */
+  const T a = X1 + MU, b = X1 + MU - 1.0;
+  const T cs = (1.0 - MU) / r1_3 + MU / r2_3;
+  const T e1 = 3.0 * (1.0 - MU) / r1_5, e2 = 3.0 * MU / r2_5;
+  const T Gxx = 1.0 - cs + e1 * a * a + e2 * b * b, Gyy = 1.0 - cs + (e1 + e2) * X2 * X2, Gzz = (e1 + e2) * X3 * X3 - cs;
+  const T Gxy = (e1 * a + e2 * b) * X2, Gxz = (e1 * a + e2 * b) * X3, Gyz = (e1 + e2) * X2 * X3;
+  dy[7] = -(Gxx * L4 + Gxy * L5 + Gxz * L6);
+  dy[8] = -(Gxy * L4 + Gyy * L5 + Gyz * L6);
+  dy[9] = -(Gxz * L4 + Gyz * L5 + Gzz * L6);
+  dy[10] = 2.0 * L5 * td - L1;
+  dy[11] = -L2 - 2.0 * L4 * td;
+  dy[12] = -L3;
+  /* -dH/dm: thrust-limited laws have umag ~ 1/m (so d(mdot)/dm = 0); the unclamped p > 1 law does not depend on m */
+  if (thrust_limited) dy[13] = -umag * nlv / m;
+  else dy[13] = td * kappa * Lm * umag;
+  return 0;
+}
+
 /* ------------------------------------------------------------------ A2: given-thrust RHS
  * Follows src/CRTBP_prop_EP_deriv.jl:8-61.  n = 6 (mass literal 1000.0, :20) or 7 (mass = x[6]).
  * `control` is in Newtons and may carry sensitivities (T), so it is typed T. */
@@ -504,6 +566,39 @@ int lto_o_flow_stm_state_costate(double* y, const double* prm, double span, int 
   int rc = integrate<Dual<12>>(f, 12, Dual<12>(span), method, steps, rtol, atol, yd, nullptr, nacc, nrej);
   for (int r = 0; r < 12; ++r) { y[r] = yd[r].v; for (int c = 0; c < 12; ++c) Phi[c * 12 + r] = yd[r].d[c]; }
   return bad ? 1 : rc;
+}
+
+/* 14-dim extension: RHS, flow and flow+STM (dual numbers), same conventions as the 12-dim calls. */
+int lto_o_rhs_state_costate_mass(const double* y, const double* prm, double* dy) { return rhs_state_costate_mass<double>(y, prm, dy); }
+int lto_o_flow_state_costate_mass(double* y, const double* prm, double span, int method, int steps, double rtol, double atol) {
+  int bad = 0;
+  auto f = [&](const double* a, double* b) { bad |= rhs_state_costate_mass<double>(a, prm, b); };
+  int rc = integrate<double>(f, 14, span, method, steps, rtol, atol, y, nullptr, nullptr, nullptr);
+  return bad ? 1 : rc;
+}
+int lto_o_flow_stm_state_costate_mass(double* y, const double* prm, double span, int method, int steps, double rtol, double atol,
+                                      double* Phi) {
+  Dual<14> yd[14];
+  for (int i = 0; i < 14; ++i) { yd[i] = Dual<14>(y[i]); yd[i].d[i] = 1.0; }
+  int bad = 0;
+  auto f = [&](const Dual<14>* a, Dual<14>* b) { bad |= rhs_state_costate_mass<Dual<14>>(a, prm, b); };
+  int rc = integrate<Dual<14>>(f, 14, Dual<14>(span), method, steps, rtol, atol, yd, nullptr, nullptr, nullptr);
+  for (int r = 0; r < 14; ++r) { y[r] = yd[r].v; for (int c = 0; c < 14; ++c) Phi[c * 14 + r] = yd[r].d[c]; }
+  return bad ? 1 : rc;
+}
+/* sweep: XC [14 x n_nodes], Phi [14 x 14 x S] (or NULL), defect [14 x S] */
+int lto_o_indirect14(const double* XC, const double* t, int n_nodes, const double* prm, int method, int steps, double rtol,
+                     double atol, double* Phi, double* defect) {
+  int status = 0;
+  for (int i = 0; i < n_nodes - 1; ++i) {
+    double y[14];
+    std::memcpy(y, XC + 14 * i, sizeof y);
+    int rc = Phi ? lto_o_flow_stm_state_costate_mass(y, prm, t[i + 1] - t[i], method, steps, rtol, atol, Phi + 196 * i)
+                 : lto_o_flow_state_costate_mass(y, prm, t[i + 1] - t[i], method, steps, rtol, atol);
+    if (rc) status = rc;
+    for (int r = 0; r < 14; ++r) defect[14 * i + r] = y[r] - XC[14 * (i + 1) + r];
+  }
+  return status;
 }
 
 /* A7: indirect defectCalc, src/multiShoot_CRTBP_indirect.jl:63-90.

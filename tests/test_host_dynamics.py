@@ -1,0 +1,85 @@
+"""CPU: the product's device formulas (lowthrustopt_amd/csrc/dynamics.hpp) compiled for the host with a stub
+hip_runtime.h and checked against the oracle: RHS values, F * column against the dual-number / finite-difference
+Jacobian, explicit vs fused single-column path, 12- and 14-dim, every control-law mode."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from lowthrustopt_amd import synth
+from lowthrustopt_amd.constants import MU, DU, TU
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PM_P1, PM_P2, PM_MIXED = 1, 2, 4
+
+
+@pytest.fixture(scope="module")
+def chk(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("hostchk") / "libdynchk.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(HERE, "host_stub"),
+                           "-I", os.path.join(ROOT, "lowthrustopt_amd", "csrc"), "-o", out,
+                           os.path.join(HERE, "host_stub", "dynamics_check.cpp")])
+    return C.CDLL(out)
+
+
+def P(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def tp_vec(ndim, thr, mass_or_isp, td, p, rho):
+    """TrajParams exactly as lto_api.hip::make_traj_params fills it."""
+    aL = thr / mass_or_isp / 1e3 * (TU * TU) / DU if ndim == 12 else 0.0
+    cT = thr / 1e3 * (TU * TU) / DU
+    kt = td * 1e3 * DU / (TU * mass_or_isp * 9.81) if ndim == 14 else 0.0
+    return np.array([aL, 1 / (2 * rho), 1 / rho, p, (1 / p if p != 0 else 0.0), (1 / (p - 1) if p > 1 else 0.0), td, MU, cT, kt])
+
+
+CASES = [(1.0, 1.0, 0.05, 0.1, PM_P1), (1.0, 1e-2, 0.05, 1.0, PM_P1), (1.0, 1e-4, 10.0, 1.0, PM_P1), (2.0, 1.0, 10.0, 0.1, PM_P2),
+         (2.0, 1.0, 0.05, 1.0, PM_P2), (1.5, 1.0, 10.0, 0.3, PM_MIXED), (0.0, 1.0, 0.05, 0.1, PM_MIXED),
+         (1.0, 1.0, 0.05, 0.1, PM_MIXED), (2.0, 1.0, 10.0, 0.1, PM_MIXED), (1.2, 0.5, 0.001, 0.5, PM_MIXED)]
+
+
+@pytest.mark.parametrize("td", [1.0, -1.0])
+def test_device_formulas_12(chk, oracle, td):
+    assert chk.chk_sizeof_tp() == 80
+    rng = np.random.default_rng(0)
+    H1 = synth.halo_orbits()[0]
+    for p, rho, thr, lam, pm in CASES:
+        y = np.concatenate([H1[:, rng.integers(0, 99)], lam * rng.standard_normal(6)])
+        prm = [MU, DU, TU, thr, 1000.0, td, p, rho]
+        tp = tp_vec(12, thr, 1000.0, td, p, rho)
+        col = rng.standard_normal(12)
+        d = np.zeros(12); dc = np.zeros(12); df = np.zeros(12); dcf = np.zeros(12)
+        chk.chk_rhs12(P(y), P(tp), pm, P(d), P(col), P(dc), P(df), P(dcf))
+        ref = oracle.rhs_state_costate(y, prm)
+        J = oracle.rhs_state_costate_jac(y, prm)
+        sc = max(1.0, np.abs(ref).max())
+        assert np.abs(d - ref).max() < 5e-14 * sc and np.abs(df - ref).max() < 5e-14 * sc
+        Jc = J @ col
+        scj = max(1.0, np.abs(J).max() * np.abs(col).max())
+        assert np.abs(dc - Jc).max() < 1e-12 * scj and np.abs(dcf - Jc).max() < 1e-12 * scj
+
+
+def test_device_formulas_14(chk, oracle):
+    rng = np.random.default_rng(1)
+    H1 = synth.halo_orbits()[0]
+    for p, rho, thr, lam, pm in CASES:
+        y = np.concatenate([H1[:, rng.integers(0, 99)], [990.0], lam * rng.standard_normal(6), [0.3]])
+        prm = [MU, DU, TU, thr, 2000.0, 1.0, p, rho]
+        tp = tp_vec(14, thr, 2000.0, 1.0, p, rho)
+        col = rng.standard_normal(14)
+        d = np.zeros(14); dc = np.zeros(14)
+        chk.chk_rhs14(P(y), P(tp), pm, P(d), P(col), P(dc))
+        ref = oracle.rhs_state_costate_mass(y, prm)
+        assert np.abs(d - ref).max() < 5e-14 * max(1.0, np.abs(ref).max())
+        J = np.zeros((14, 14))
+        for c in range(14):          # central differences of the oracle RHS (FD noise ~1e-9 relative)
+            h = 1e-6 * max(1.0, abs(y[c]))
+            yp = y.copy(); yp[c] += h
+            ym = y.copy(); ym[c] -= h
+            J[:, c] = (oracle.rhs_state_costate_mass(yp, prm) - oracle.rhs_state_costate_mass(ym, prm)) / (yp[c] - ym[c])
+        Jc = J @ col
+        assert np.abs(dc - Jc).max() < 2e-8 * max(1.0, np.abs(J).max() * np.abs(col).max())
