@@ -146,7 +146,14 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* plan, void* stream, const doubl
  * plan, S ints each; NULL for fixed-step plans). */
 const int* lto_indirect_plan_steps_accepted(const lto_indirect_plan* plan);
 const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* plan);
-/* Tuning knob: STM columns integrated per lane (1, 2, 3, 4, 6 or 12); 0 = choose from S. */
+/* Tuning knobs for the STM sweep.  Kernel: AUTO picks the wave-specialised kernel (base wave + column waves per
+ * 16 segments, coefficients handed over through LDS) for latency-bound batches and for the 13-stage integrators,
+ * and the per-lane kernel (each lane re-integrates the base state with 1-3 columns) once the chip is full. */
+#define LTO_KERNEL_AUTO 0
+#define LTO_KERNEL_PER_LANE 1
+#define LTO_KERNEL_COOP 2
+int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
+/* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3); 0 = choose from S. */
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);
 
 int lto_direct_plan_create(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, int nsteps,

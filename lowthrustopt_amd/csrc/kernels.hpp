@@ -42,6 +42,8 @@ hipError_t launch_indirect_defect(int pm, int method, const IndirectArgs& a, hip
 hipError_t launch_indirect_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_indirect14_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_indirect14_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
+// wave-specialised STM kernel (kernels_indirect_coop.hip): base wave + column waves per 16 segments
+hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
 

@@ -39,6 +39,7 @@ struct lto_indirect_plan {
   int* d_nacc;
   int* d_nrej;
   int cols_per_lane;
+  int kernel;       // LTO_KERNEL_*
 };
 
 struct lto_direct_plan {
@@ -249,6 +250,14 @@ void lto_indirect_plan_destroy(lto_indirect_plan* p) {
 const int* lto_indirect_plan_steps_accepted(const lto_indirect_plan* p) { return p ? p->d_nacc : nullptr; }
 const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* p) { return p ? p->d_nrej : nullptr; }
 
+int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
+  if (!p) return LTO_ENULL;
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE or _COOP");
+  p->kernel = kernel;
+  return LTO_OK;
+}
+
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
   if (!p) return LTO_ENULL;
   if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2 or 3");
@@ -307,8 +316,16 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  hipError_t e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
-                                 : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
+  // Kernel choice (DESIGN.md "Kernels", measured on MI355X): RK4 -> per-lane kernels (4 096 segments: 131 us vs
+  // 150 us cooperative; the 4-stage state fits the registers and the per-stage barrier costs more than the
+  // redundant base work saves).  13-stage methods -> wave-specialised kernel (DOP853 @1e-13, 4 096 segments:
+  // 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms), whose 12/14-component lanes keep all slopes in registers.
+  int kern = p->kernel;
+  if (kern == LTO_KERNEL_AUTO) kern = (p->integ.method == LTO_RK4) ? LTO_KERNEL_PER_LANE : LTO_KERNEL_COOP;
+  hipError_t e;
+  if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
+  else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
+                           : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
   return LTO_OK;

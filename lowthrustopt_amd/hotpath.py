@@ -276,6 +276,11 @@ class IndirectPlan:
                                                    C.byref(integ), C.byref(h)))
         self.handle = h
 
+    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP = 0, 1, 2
+
+    def set_kernel(self, kernel):
+        self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
+
     def set_cols_per_lane(self, cols):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_cols_per_lane(self.handle, int(cols)))
 

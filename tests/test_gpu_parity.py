@@ -385,3 +385,48 @@ def test_pack_unpack_and_norms(gpu_ctx):
     lto.defect_norms(gpu_ctx, d, B * spt, 12, spt, B, ss, mx)
     torch.cuda.synchronize()
     assert bool(torch.isnan(mx[2])) and bool(torch.isfinite(mx[[0, 1, 3, 4, 5, 6]]).all())
+
+
+@pytest.mark.parametrize("ndim", [12, 14])
+@pytest.mark.parametrize("mname", list(METHODS))
+@pytest.mark.parametrize("kernel", ["per_lane", "coop"])
+def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, kernel):
+    """Both STM kernel families (per-lane: every lane re-integrates the base state; cooperative: base wave + column
+    waves exchanging the variational coefficients through LDS) against the oracle's dual-number STM, for every
+    integrator, ND = 12 and the 14-dim extension, ragged segment count (not a multiple of 16 or 64)."""
+    import torch
+    method, steps = METHODS[mname]
+    if ndim == 14 and method == lto.RKF78_ADAPTIVE and kernel == "per_lane":
+        pytest.skip("per-lane RKF78-adaptive STM is not instantiated for ND = 14")
+    n = 78
+    XC, T = synth.indirect_problem(n, seed=11)
+    XC, t = XC[:, :, 0], T[:, 0]
+    if ndim == 14:
+        X = np.zeros((14, n), order="F")
+        X[:6] = XC[:6]; X[6] = 1000.0 - 0.02 * np.arange(n); X[7:13] = XC[6:]; X[13] = 0.2
+        prm_l = [MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+    else:
+        X = XC
+        prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+    S = n - 1
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(method, steps=steps), ndim=ndim)
+    plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
+    Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(t)).cuda()
+    Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
+    d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+    torch.cuda.synchronize()
+    P = Phi.cpu().numpy().reshape(ndim, ndim, S).transpose(1, 0, 2)
+    dn = d.cpu().numpy()
+    if ndim == 12:
+        P_o, d_o, rc = oracle.indirect_jacobian(X, t, prm_l, method, steps)
+    else:
+        P_o, d_o, rc = oracle.indirect14(X, t, prm_l, method, steps)
+    assert rc == 0
+    adaptive = method in (lto.RKF78_ADAPTIVE, lto.DOP853_ADAPTIVE)
+    assert np.linalg.norm(dn - d_o) / np.linalg.norm(d_o + X[:, 1:]) < 1e-10
+    # fixed step: same discrete map -> round-off.  Adaptive: the cooperative DOP853 kernel uses the oracle's own
+    # error norm (values + all partials) and follows its step sequence; the others take their own steps.
+    tol = 1e-10 if not adaptive else (1e-9 if (kernel == "coop" and method == lto.DOP853_ADAPTIVE) else 1e-7)
+    assert np.abs(P - P_o).max() < tol * np.abs(P_o).max()

@@ -36,6 +36,10 @@ def main():
             plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(method, steps=steps))
             ms = timeit(lambda: plan.defect(X, n, t, 1, defect, S, stream=st))
             print("S=%7d %-8s defect        %9.3f ms  %10.3e seg/s" % (S, name, ms, S / ms * 1e3), flush=True)
+            plan.set_kernel(2)
+            ms = timeit(lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st), iters=5 if S > 20000 else 10)
+            print("S=%7d %-8s stm COOP      %9.3f ms  %10.3e seg/s" % (S, name, ms, S / ms * 1e3), flush=True)
+            plan.set_kernel(1)
             if method == lto.RK4:
                 for cols in (1, 2, 3):
                     plan.set_cols_per_lane(cols)
