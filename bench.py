@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c2_defect", "c3", "c4", "c5", "hbm"])
     ap.add_argument("--segments", type=int, default=0, help="segments per GPU (default: the workload's)")
     ap.add_argument("--cols", type=int, default=0, help="STM columns per lane (0 = auto)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-specialised (cooperative)")
+    ap.add_argument("--ndim", type=int, default=12, choices=[12, 14],
+                    help="12 = the reference's state+costate system (parity path); 14 = + mass and mass costate (extension)")
+    ap.add_argument("--method", default="", choices=["", "rk4", "rkf78", "dop853"], help="override the workload's integrator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -129,23 +133,37 @@ def main():
             prm = prm1
             steps = 1 if wl == "hbm" else 64
             integ = lto.integrator(lto.RK4, steps=steps)
+            if a.method == "rkf78":
+                integ = lto.integrator(lto.RKF78_FIXED, steps=4)
+            elif a.method == "dop853":
+                integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13)
             desc = {"c2": "C2: indirect 12-dim state+costate + 12x12 STM, RK4 x 64 steps, fp64, p=1 rho=1 thrust 0.05 N",
                     "c2_defect": "C2 (defect only): indirect 12-dim state+costate, RK4 x 64 steps",
                     "hbm": "HBM evidence point: indirect 12-dim + 12x12 STM, ONE RK4 step per segment"}[wl]
+        nd = a.ndim
+        if nd == 14:   # mass + mass costate extension: (r, v, m, lambda_r, lambda_v, lambda_m); params' mass slot = Isp
+            X14 = np.zeros((14, n, 1), order="F")
+            X14[:6] = XC[:6]; X14[6] = 1000.0; X14[7:13] = XC[6:]; X14[13] = 0.1
+            XC = X14
+            prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 2000.0, 1.0, 1.0, prm.rho)
         X = torch.from_numpy(synth.to_soa_nodes(XC)).to(dev)
         t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).to(dev)
-        plan = lto.IndirectPlan(ctx, n, 1, prm, integ)
+        plan = lto.IndirectPlan(ctx, n, 1, prm, integ, ndim=nd)
         if a.cols:
             plan.set_cols_per_lane(a.cols)
-        defect = torch.zeros(12, S, **f64)
-        Phi = torch.zeros(144, S, **f64)
+        if a.kernel:
+            plan.set_kernel(a.kernel)
+        defect = torch.zeros(nd, S, **f64)
+        Phi = torch.zeros(nd * nd, S, **f64)
         if wl in ("c2", "hbm"):
             def sweep():
                 plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)
         else:
             def sweep():
                 plan.defect(X, n, t, 1, defect, S, stream=st)
-        n_traj, gather_rows = 1, 12
+        n_traj, gather_rows = 1, nd
+        if nd == 14 or a.method:
+            desc += " [ndim=%d%s]" % (nd, (", integrator " + a.method) if a.method else "")
     elif wl == "c4":
         levels = 256 // max(world, 1) if not a.segments else max(1, a.segments // 1024)
         spt = 1024
@@ -232,7 +250,7 @@ def main():
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
                        "collective": "rccl all_gather(defect)" if world > 1 else "none", "integrator": "see workload"},
         }
-        if wl in WORK:
+        if wl in WORK and a.ndim == 12 and not a.method:
             flops, nbytes = WORK[wl]
             dur = kern_ms * 1e-3
             ach_tf = flops * S / dur / 1e12
@@ -252,7 +270,7 @@ def main():
                 "note": "register-resident fp64 ODE integration: bound by the FP64 vector pipe (no MFMA issued; MI355X "
                         "FP64 matrix peak equals the vector peak), not by HBM -- see DESIGN.md 'Roofline'",
             }
-        if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm"):
+        if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and a.ndim == 12 and not a.method:
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -5,11 +5,14 @@ cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/${1:-run}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > "$OUT/pytest_gpu.log"
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > "$OUT/pytest_gpu.log"
 cat "$OUT/pytest_gpu.log" | tail -8
 python bench.py 2>&1 | tail -3 > "$OUT/bench_c2.json"; cat "$OUT/bench_c2.json"
 python bench.py --workload hbm --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_hbm.json"; cat "$OUT/bench_hbm.json"
 python bench.py --workload c3 --cpu-seconds 5 2>&1 | tail -1 > "$OUT/bench_c3.json"; cat "$OUT/bench_c3.json"
+python bench.py --ndim 14 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_c2_ndim14.json"; cat "$OUT/bench_c2_ndim14.json"
+python bench.py --method dop853 --no-cpu-baseline --steps 50 2>&1 | tail -1 > "$OUT/bench_c2_dop853.json"; cat "$OUT/bench_c2_dop853.json"
+python bench.py --method rkf78 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_c2_rkf78x4.json"; cat "$OUT/bench_c2_rkf78x4.json"
 python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>&1 | tail -1 > "$OUT/bench_c4.json"; cat "$OUT/bench_c4.json"
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>&1 | tail -1 > "$OUT/bench_c5.json"; cat "$OUT/bench_c5.json"
 # kernel trace + stats of the contract command
