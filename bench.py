@@ -108,7 +108,9 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
     dist = None
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # LTO_BENCH_FORCE_COLLECTIVE=1 under torchrun exercises the RCCL path (init + all-gather) even at world size 1
+    force_coll = os.environ.get("LTO_BENCH_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ
+    if world > 1 or force_coll:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -203,17 +205,18 @@ def main():
         desc = "C3: direct 6-dim, RKF7(8) nsteps=10 per half, on-device Jacobian blocks 6x18 + tf column + defect + errors"
         gather_rows = 6
 
-    gathered = torch.zeros(world * gather_rows, S, **f64) if world > 1 else None   # [rank][row][segment]
+    use_coll = dist is not None
+    gathered = torch.zeros(world * gather_rows, S, **f64) if use_coll else None   # [rank][row][segment]
 
     def step():
         sweep()
-        if world > 1:
+        if use_coll:
             dist.all_gather_into_tensor(gathered, defect)   # RCCL over xGMI, same stream order
 
     for _ in range(a.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    if world > 1:
+    if use_coll:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -221,15 +224,16 @@ def main():
         ev[k][0].record()
         sweep()
         ev[k][1].record()
-        if world > 1:
+        if use_coll:
             dist.all_gather_into_tensor(gathered, defect)
-    if world > 1:
+    if use_coll:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
 
-    if world > 1:
+    if use_coll:
+        assert torch.equal(gathered[rank * gather_rows:(rank + 1) * gather_rows], defect), "all-gather slab mismatch"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -248,7 +252,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
-                       "collective": "rccl all_gather(defect)" if world > 1 else "none", "integrator": "see workload"},
+                       "collective": "rccl all_gather(defect)" if use_coll else "none", "integrator": "see workload"},
         }
         if wl in WORK and a.ndim == 12 and not a.method:
             flops, nbytes = WORK[wl]
@@ -273,7 +277,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and a.ndim == 12 and not a.method:
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_coll:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -109,6 +109,12 @@ int lto_indirect_jacobian(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, cons
                           int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ, double* Phi,
                           double* defect);
 
+/* Replaces densify (src/HelperFunctions.jl:51-101) for one trajectory: t_dense = LinRange(t[1], t[end], n_desired),
+ * every segment re-propagated from its node and sampled at the t_dense points inside [t_i, t_{i+1}), final propagated
+ * state appended.  XC_dense [ndim x n_desired], t_dense [n_desired]. */
+int lto_indirect_densify(lto_ctx* ctx, int ndim, int n_nodes, const double* XC, const double* t, const lto_params* prm,
+                         const lto_integrator* integ, int n_desired, double* XC_dense, double* t_dense);
+
 /* Replaces defectCalc of multiShoot_CRTBP_direct (src/multiShoot_CRTBP_direct.jl:66-109).
  *   X [nstate x n_nodes x n_batch] (nstate = 6 or 7), U [3 x n_nodes x n_batch] thrust in N,
  *   nsteps = points of the half-segment grid, i.e. nsteps-1 RKF7(8) steps per half (:84).
@@ -155,6 +161,12 @@ const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* plan);
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3); 0 = choose from S. */
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);
+
+/* Dense output (device): segment s is sampled at t_samples[first[s] .. first[s+1]) (sorted, inside the segment);
+ * Y[c*ldy + j] = x_c(t_samples[j]); final_state[c*n_batch + b] (or NULL) = x(t_n) of trajectory b. */
+int lto_indirect_dense_dev(lto_indirect_plan* plan, void* stream, const double* X, long ldx, const double* t,
+                           int n_tgrids, const int* first, const double* t_samples, double* Y, long ldy,
+                           double* final_state);
 
 int lto_direct_plan_create(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, int nsteps,
                            const lto_direct_params* prm, lto_direct_plan** out);

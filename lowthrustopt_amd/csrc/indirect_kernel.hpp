@@ -153,6 +153,83 @@ __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, co
   }
 }
 
+// Propagate y over `span` with the plan's integrator (shared by the sweep and the dense-output kernels).
+template <class Sys, int ND, int METHOD>
+__device__ __forceinline__ void advance(const Sys& sys, const double span, const IndirectArgs& a, double (&y)[Sys::DIM],
+                                        int& nacc, int& nrej, double& maxErr) {
+  constexpr int D = Sys::DIM;
+  if (METHOD == M_RK4) {
+    const double h = span / (double)a.steps;
+    for (int k = 0; k < a.steps; ++k) rk4_step(sys, h, y);
+    nacc += a.steps;
+  } else if (METHOD == M_RKF78_FIXED) {
+    const double h = span / (double)a.steps;
+    for (int k = 0; k < a.steps; ++k) {
+      double yn[D];
+      double delta;
+      if constexpr (D > 14) { double K[13][D]; delta = rkf78_step_mem<Sys, ND>(sys, h, y, K, yn); }
+      else delta = rkf78_step<Sys, ND>(sys, h, y, yn);
+      maxErr = fmax(maxErr, delta);
+#pragma unroll
+      for (int c = 0; c < D; ++c) y[c] = yn[c];
+    }
+    nacc += a.steps;
+  } else if (METHOD == M_RKF78_ADAPTIVE) {
+    int na = 0, nr = 0;
+    run_rkf78_adaptive<Sys, ND>(sys, span, a.rtol, a.max_steps, y, na, nr);
+    nacc += na; nrej += nr;
+  } else {
+    int na = 0, nr = 0;
+    run_dop853<Sys, D>(sys, span, a.rtol, a.atol, a.max_steps, y, na, nr);
+    nacc += na; nrej += nr;
+  }
+}
+
+// Dense output (replaces the per-segment re-propagation of densify, src/HelperFunctions.jl:51-101):
+// lane = segment; the segment's sample times are td[first[s] .. first[s+1]) (sorted, inside [t_i, t_{i+1})); the
+// lane integrates from sample to sample and stores the state at each one.  The reference evaluates Vern8's
+// interpolant at those times; stepping exactly onto them is at least as accurate.  If `final_state` is set the
+// last segment of each trajectory also stores x(t_n) (the `sol_forward[:,end]` column densify appends, :94-97).
+struct DenseArgs {
+  const int* first;        // [S+1] prefix offsets into td / columns of Y
+  const double* td;        // [n_samples] sample times
+  double* Y; long ldy;     // [ND][ldy]
+  double* final_state;     // [ND][n_batch] or null
+};
+
+template <int ND, int PM, int METHOD>
+__global__ __launch_bounds__(64) void k_indirect_dense(const IndirectArgs a, const DenseArgs d) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.S) return;
+  const int traj = s / a.seg_per_traj;
+  const int i = s - traj * a.seg_per_traj;
+  const long node = (long)traj * a.n_nodes + i;
+  const long tg = (long)traj * a.t_stride + i;
+  using Sys = SysIndirect<ND, PM, 0>;
+  Sys sys;
+  sys.tp = a.tp[(long)traj * a.tp_stride];
+  sys.w2 = 2.0 * sys.tp.omega;
+  double y[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + node];
+  double tcur = a.t[tg];
+  int nacc = 0, nrej = 0;
+  double maxErr = 0.0;
+  const int j0 = d.first[s], j1 = d.first[s + 1];
+  for (int j = j0; j < j1; ++j) {
+    const double ts = d.td[j];
+    if (ts > tcur) { advance<Sys, ND, METHOD>(sys, ts - tcur, a, y, nacc, nrej, maxErr); tcur = ts; }
+#pragma unroll
+    for (int c = 0; c < ND; ++c) d.Y[c * d.ldy + j] = y[c];
+  }
+  if (d.final_state && i == a.seg_per_traj - 1) {
+    const double te = a.t[tg + 1];
+    if (te > tcur) advance<Sys, ND, METHOD>(sys, te - tcur, a, y, nacc, nrej, maxErr);
+#pragma unroll
+    for (int c = 0; c < ND; ++c) d.final_state[c * (a.S / a.seg_per_traj) + traj] = y[c];
+  }
+}
+
 // COLS = 0: defect only (K1).  COLS >= 1: lane integrates base + COLS STM columns (K2); the
 // column group is blockIdx.y and the g = 0 lanes also emit the defect.
 template <int ND, int PM, int METHOD, int COLS>
@@ -182,27 +259,7 @@ __global__ __launch_bounds__(64) void k_indirect(const IndirectArgs a) {
 
   double maxErr = 0.0;
   int nacc = 0, nrej = 0;
-  if (METHOD == M_RK4) {
-    const double h = span / (double)a.steps;
-    for (int k = 0; k < a.steps; ++k) rk4_step(sys, h, y);
-    nacc = a.steps;
-  } else if (METHOD == M_RKF78_FIXED) {
-    const double h = span / (double)a.steps;
-    for (int k = 0; k < a.steps; ++k) {
-      double yn[D];
-      double delta;
-      if constexpr (D > 14) { double K[13][D]; delta = rkf78_step_mem<Sys, ND>(sys, h, y, K, yn); }
-      else delta = rkf78_step<Sys, ND>(sys, h, y, yn);
-      maxErr = fmax(maxErr, delta);
-#pragma unroll
-      for (int c = 0; c < D; ++c) y[c] = yn[c];
-    }
-    nacc = a.steps;
-  } else if (METHOD == M_RKF78_ADAPTIVE) {
-    run_rkf78_adaptive<Sys, ND>(sys, span, a.rtol, a.max_steps, y, nacc, nrej);
-  } else {
-    run_dop853<Sys, D>(sys, span, a.rtol, a.atol, a.max_steps, y, nacc, nrej);
-  }
+  advance<Sys, ND, METHOD>(sys, span, a, y, nacc, nrej, maxErr);
 
   if (COLS > 0) {
 #pragma unroll
@@ -225,6 +282,17 @@ template <int ND, int PM, int METHOD, int COLS>
 static hipError_t launch_one(const IndirectArgs& a, hipStream_t st) {
   dim3 grid((a.S + 63) / 64, COLS > 0 ? ND / COLS : 1);
   hipLaunchKernelGGL((k_indirect<ND, PM, METHOD, COLS>), grid, dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+template <int ND, int METHOD>
+static hipError_t launch_dense_pm(int pm, const IndirectArgs& a, const DenseArgs& d, hipStream_t st) {
+  dim3 grid((a.S + 63) / 64);
+  switch (pm) {
+    case PM_P1: hipLaunchKernelGGL((k_indirect_dense<ND, PM_P1, METHOD>), grid, dim3(64), 0, st, a, d); break;
+    case PM_P2: hipLaunchKernelGGL((k_indirect_dense<ND, PM_P2, METHOD>), grid, dim3(64), 0, st, a, d); break;
+    default: hipLaunchKernelGGL((k_indirect_dense<ND, PM_MIXED, METHOD>), grid, dim3(64), 0, st, a, d); break;
+  }
   return hipGetLastError();
 }
 

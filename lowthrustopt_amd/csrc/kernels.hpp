@@ -40,6 +40,8 @@ struct DirectArgs {
 hipError_t launch_indirect_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
 // cols_per_lane in {1,2,3}; 0 = choose from S.
 hipError_t launch_indirect_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
+struct DenseArgs;
+hipError_t launch_indirect_dense(int ndim, int pm, int method, const IndirectArgs& a, const DenseArgs& d, hipStream_t st);
 hipError_t launch_indirect14_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_indirect14_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
 // wave-specialised STM kernel (kernels_indirect_coop.hip): base wave + column waves per 16 segments

@@ -14,6 +14,16 @@
 #include "../../include/lto.h"
 #include "kernels.hpp"
 
+namespace lto {
+// mirrors indirect_kernel.hpp (kept out of kernels.hpp so that header stays kernel-agnostic)
+struct DenseArgs {
+  const int* first;
+  const double* td;
+  double* Y; long ldy;
+  double* final_state;
+};
+}  // namespace lto
+
 using namespace lto;
 
 struct lto_ctx {
@@ -26,6 +36,9 @@ struct lto_ctx {
   char* arena;
   size_t arena_bytes;
   size_t arena_top;
+  // small cache of device blocks for plan-owned buffers: the host-pointer API builds a plan per call, and a
+  // hipMalloc/hipFree pair costs more than a 29-segment sweep
+  struct { void* ptr; size_t bytes; } pool[8];
   char err[512];
 };
 
@@ -84,6 +97,32 @@ T* arena_take(lto_ctx* c, size_t count) {
   T* p = (T*)(c->arena + c->arena_top);
   c->arena_top += al256(count * sizeof(T));
   return p;
+}
+
+// ---- device block cache (see lto_ctx::pool)
+hipError_t pool_alloc(lto_ctx* c, void** out, size_t bytes) {
+  int best = -1;
+  for (int i = 0; i < 8; ++i)
+    if (c->pool[i].ptr && c->pool[i].bytes >= bytes && (best < 0 || c->pool[i].bytes < c->pool[best].bytes)) best = i;
+  if (best >= 0 && c->pool[best].bytes <= 4 * bytes + 4096) {
+    *out = c->pool[best].ptr;
+    c->pool[best].ptr = nullptr;
+    return hipSuccess;
+  }
+  return hipMalloc(out, bytes < 256 ? 256 : bytes);
+}
+void pool_free(lto_ctx* c, void* ptr, size_t bytes) {
+  if (!ptr) return;
+  if (bytes < 256) bytes = 256;
+  int slot = -1;
+  for (int i = 0; i < 8; ++i) if (!c->pool[i].ptr) { slot = i; break; }
+  if (slot < 0) {  // evict the smallest cached block
+    slot = 0;
+    for (int i = 1; i < 8; ++i) if (c->pool[i].bytes < c->pool[slot].bytes) slot = i;
+    (void)hipFree(c->pool[slot].ptr);
+  }
+  c->pool[slot].ptr = ptr;
+  c->pool[slot].bytes = bytes;
 }
 
 // Reference validity rule for p (stateCostate_deriv.jl:36-53): p == 0, p == 1 or p > 1.
@@ -172,6 +211,7 @@ void lto_destroy(lto_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->arena) (void)hipFree(c->arena);
+  for (int i = 0; i < 8; ++i) if (c->pool[i].ptr) (void)hipFree(c->pool[i].ptr);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -222,13 +262,13 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   p->ctx = c; p->ndim = ndim; p->n_nodes = n_nodes; p->n_batch = n_batch; p->S = (n_nodes - 1) * n_batch;
   p->pm = pm; p->n_prm = n_prm; p->integ = *integ;
   if (p->integ.max_steps <= 0) p->integ.max_steps = 100000;
-  hipError_t e = hipMalloc((void**)&p->d_tp, sizeof(TrajParams) * (size_t)n_prm);
+  hipError_t e = pool_alloc(c, (void**)&p->d_tp, sizeof(TrajParams) * (size_t)n_prm);
   if (e == hipSuccess) e = hipMemcpy(p->d_tp, h, sizeof(TrajParams) * (size_t)n_prm, hipMemcpyHostToDevice);
   std::free(h);
   const bool adaptive = integ->method == LTO_RKF78_ADAPTIVE || integ->method == LTO_DOP853_ADAPTIVE;
   if (e == hipSuccess && adaptive) {
-    e = hipMalloc((void**)&p->d_nacc, sizeof(int) * (size_t)p->S);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_nrej, sizeof(int) * (size_t)p->S);
+    e = pool_alloc(c, (void**)&p->d_nacc, sizeof(int) * (size_t)p->S);
+    if (e == hipSuccess) e = pool_alloc(c, (void**)&p->d_nrej, sizeof(int) * (size_t)p->S);
   }
   if (e != hipSuccess) {
     lto_indirect_plan_destroy(p);
@@ -241,9 +281,9 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
 void lto_indirect_plan_destroy(lto_indirect_plan* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
-  if (p->d_tp) (void)hipFree(p->d_tp);
-  if (p->d_nacc) (void)hipFree(p->d_nacc);
-  if (p->d_nrej) (void)hipFree(p->d_nrej);
+  pool_free(p->ctx, p->d_tp, sizeof(TrajParams) * (size_t)p->n_prm);
+  pool_free(p->ctx, p->d_nacc, sizeof(int) * (size_t)p->S);
+  pool_free(p->ctx, p->d_nrej, sizeof(int) * (size_t)p->S);
   delete p;
 }
 
@@ -328,6 +368,27 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
+  return LTO_OK;
+}
+
+/* ------------------------------------------------------------------------------ dense output */
+int lto_indirect_dense_dev(lto_indirect_plan* p, void* stream, const double* X, long ldx, const double* t, int n_tgrids,
+                           const int* first, const double* t_samples, double* Y, long ldy, double* final_state) {
+  if (!p) return LTO_ENULL;
+  lto_ctx* c = p->ctx;
+  IndirectArgs a;
+  int rc = fill_indirect_args(p, X, ldx, t, n_tgrids, &a);
+  if (rc) return rc;
+  if (!first || !t_samples || !Y) return set_err(c, LTO_ENULL, "first, t_samples or Y is NULL");
+  rc = bind_device(c);
+  if (rc) return rc;
+  DenseArgs d;
+  d.first = first; d.td = t_samples; d.Y = Y; d.ldy = ldy; d.final_state = final_state;
+  hipStream_t st = (hipStream_t)stream;
+  timing_begin(c, st);
+  hipError_t e = launch_indirect_dense(p->ndim, p->pm, p->integ.method, a, d, st);
+  timing_end(c, st);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_dense", e);
   return LTO_OK;
 }
 
@@ -530,6 +591,72 @@ int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const 
   } else {
     (void)hipStreamSynchronize(st);
   }
+  lto_indirect_plan_destroy(p);
+  return rc;
+}
+
+/* densify of src/HelperFunctions.jl:51-101 for one trajectory: t_dense = LinRange(t[1], t[end], n_desired); every
+ * segment is re-propagated and sampled at the t_dense points inside [t_i, t_{i+1}); the final propagated state is
+ * appended (:94-97).  XC_dense [ndim x n_desired], t_dense [n_desired]. */
+int lto_indirect_densify(lto_ctx* c, int ndim, int n_nodes, const double* XC, const double* t, const lto_params* prm,
+                         const lto_integrator* integ, int n_desired, double* XC_dense, double* t_dense) {
+  if (!c) return LTO_ENULL;
+  if (!XC || !t || !XC_dense || !t_dense) return set_err(c, LTO_ENULL, "XC, t, XC_dense or t_dense is NULL");
+  if (n_desired < 2) return set_err(c, LTO_EINVAL, "n_desired must be >= 2");
+  lto_indirect_plan* p = nullptr;
+  int rc = lto_indirect_plan_create(c, ndim, n_nodes, 1, prm, 1, integ, &p);
+  if (rc) return rc;
+  const int S = p->S;
+  int* h_first = (int*)std::malloc(sizeof(int) * (size_t)(S + 1));
+  if (!h_first) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "host allocation failed"); }
+  const double t0 = t[0], tn = t[n_nodes - 1];
+  for (int k = 0; k < n_desired; ++k) {
+    const double tau = (double)k / (double)(n_desired - 1);
+    t_dense[k] = (1.0 - tau) * t0 + tau * tn;
+  }
+  // samples of segment i: t_dense in [t_i, t_{i+1}); the last grid point (== t_n) is served by the final state
+  int j = 0;
+  for (int i = 0; i < S; ++i) {
+    h_first[i] = j;
+    while (j < n_desired - 1 && t_dense[j] < t[i + 1]) ++j;
+  }
+  h_first[S] = n_desired - 1;
+  const long J = n_nodes;
+  const size_t need = al256(sizeof(double) * ndim * J) * 2 + al256(sizeof(double) * n_nodes) + al256(sizeof(int) * (S + 1)) +
+                      al256(sizeof(double) * n_desired) * 2 + al256(sizeof(double) * ndim * n_desired) * 2 + 8192;
+  rc = arena_reserve(c, need);
+  if (rc) { std::free(h_first); lto_indirect_plan_destroy(p); return rc; }
+  c->arena_top = 0;
+  double* d_aos = arena_take<double>(c, (size_t)ndim * J);
+  double* d_X = arena_take<double>(c, (size_t)ndim * J);
+  double* d_t = arena_take<double>(c, (size_t)n_nodes);
+  int* d_first = arena_take<int>(c, (size_t)S + 1);
+  double* d_td = arena_take<double>(c, (size_t)n_desired);
+  double* d_Y = arena_take<double>(c, (size_t)ndim * n_desired);
+  double* d_Yaos = arena_take<double>(c, (size_t)ndim * n_desired);
+  hipStream_t st = c->stream;
+  hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * ndim * J, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_first, h_first, sizeof(int) * (S + 1), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_td, t_dense, sizeof(double) * n_desired, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
+  if (e != hipSuccess) { (void)hipStreamSynchronize(st); std::free(h_first); lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  // the final state lands in the last column of Y: final_state[c * n_batch + traj] with ld = n_desired, offset n_desired-1
+  // is not expressible through the [ND][n_batch] layout, so take it into the tail of d_Yaos and splice on the host side
+  double* d_final = d_Yaos;   // [ndim] (n_batch = 1); overwritten by the unpack afterwards, so copy it out first
+  rc = lto_indirect_dense_dev(p, st, d_X, J, d_t, 1, d_first, d_td, d_Y, n_desired, d_final);
+  if (rc == LTO_OK) {
+    // splice: Y[c][n_desired-1] = final[c]
+    for (int cc = 0; cc < ndim && e == hipSuccess; ++cc)
+      e = hipMemcpyAsync(d_Y + (size_t)cc * n_desired + (n_desired - 1), d_final + cc, sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = launch_unpack_soa(d_Y, n_desired, ndim, n_desired, d_Yaos, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(XC_dense, d_Yaos, sizeof(double) * ndim * n_desired, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  std::free(h_first);
   lto_indirect_plan_destroy(p);
   return rc;
 }

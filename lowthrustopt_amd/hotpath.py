@@ -185,6 +185,22 @@ def indirect_jacobianCalc(XC_all, t_TU, params, integ=None, ctx=None, sparse=Fal
     return indirect_scatter(Phi, sparse=sparse)
 
 
+def densify(XC_all, t_TU, params, n_desired, integ=None, ctx=None):
+    """densify (src/HelperFunctions.jl:51-101): (XC_dense[ndim x n_desired], t_dense[n_desired]); every segment is
+    re-propagated on the GPU and sampled at the uniformly spaced t_dense points that fall inside it."""
+    ctx = ctx or default_context()
+    integ = integ or integrator()
+    XC = _f64(XC_all)
+    t = _f64(t_TU)
+    ndim, n = XC.shape
+    prm, _ = _params_array(params)
+    XC_dense = np.zeros((ndim, int(n_desired)), order="F")
+    t_dense = np.zeros(int(n_desired))
+    ctx.check(ctx.lib.lto_indirect_densify(ctx.handle, ndim, n, _ptr(XC), _ptr(t), prm, C.byref(integ), int(n_desired),
+                                           _ptr(XC_dense), _ptr(t_dense)))
+    return XC_dense, t_dense
+
+
 def direct_defectCalc(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
     """defectCalc of multiShoot_CRTBP_direct (:66-109): returns (defect[nstate x (n-1)], errors[n-1])."""
     ctx = ctx or default_context()

@@ -430,3 +430,27 @@ def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, ke
     # error norm (values + all partials) and follows its step sequence; the others take their own steps.
     tol = 1e-10 if not adaptive else (1e-9 if (kernel == "coop" and method == lto.DOP853_ADAPTIVE) else 1e-7)
     assert np.abs(P - P_o).max() < tol * np.abs(P_o).max()
+
+
+@pytest.mark.parametrize("mname", ["dop853_adaptive", "rk4x64"])
+def test_densify_vs_oracle(gpu_ctx, oracle, mname):
+    """densify (src/HelperFunctions.jl:51-101): uniformly spaced dense output over the whole trajectory; every
+    sample equals the oracle's propagation from the owning segment's node to that time; last column = x(t_n)."""
+    method, steps = METHODS[mname]
+    n, n_desired = 13, 101
+    XC, T = synth.indirect_problem(n, seed=21, dt_range=(0.05, 0.25))
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 0.5]
+    XD, td = lto.densify(XC, t, lto.make_params(*prm_l), n_desired, lto.integrator(method, steps=steps), ctx=gpu_ctx)
+    assert XD.shape == (12, n_desired) and td.shape == (n_desired,)
+    assert td[0] == t[0] and td[-1] == t[-1] and np.allclose(np.diff(td), (t[-1] - t[0]) / (n_desired - 1), rtol=1e-12)
+    tol = 1e-10 if method == lto.RK4 else 1e-11
+    for j in range(n_desired - 1):
+        i = np.searchsorted(t, td[j], side="right") - 1
+        if td[j] == t[i]:
+            ref = XC[:, i]
+        else:
+            ref, rc, _, _ = oracle.flow_state_costate(XC[:, i], prm_l, td[j] - t[i], oracle.DOP853_ADAPTIVE)
+        assert np.abs(XD[:, j] - ref).max() < tol * max(1.0, np.abs(ref).max()), j
+    ref, rc, _, _ = oracle.flow_state_costate(XC[:, n - 2], prm_l, t[-1] - t[-2], oracle.DOP853_ADAPTIVE)
+    assert np.abs(XD[:, -1] - ref).max() < tol * max(1.0, np.abs(ref).max())
