@@ -158,11 +158,11 @@ def main():
         defect = torch.zeros(nd, S, **f64)
         Phi = torch.zeros(nd * nd, S, **f64)
         if wl in ("c2", "hbm"):
-            def sweep():
-                plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)
+            def sweep(dbuf):
+                plan.jacobian(X, n, t, 1, Phi, S, dbuf, S, stream=st)
         else:
-            def sweep():
-                plan.defect(X, n, t, 1, defect, S, stream=st)
+            def sweep(dbuf):
+                plan.defect(X, n, t, 1, dbuf, S, stream=st)
         n_traj, gather_rows = 1, nd
         if nd == 14 or a.method:
             desc += " [ndim=%d%s]" % (nd, (", integrator " + a.method) if a.method else "")
@@ -183,8 +183,8 @@ def main():
         defect = torch.zeros(12, S, **f64)
         Phi = torch.zeros(144, S, **f64)
 
-        def sweep():
-            plan.jacobian(X, n * levels, t, levels, Phi, S, defect, S, stream=st)
+        def sweep(dbuf):
+            plan.jacobian(X, n * levels, t, levels, Phi, S, dbuf, S, stream=st)
         desc = "C4: homotopy sweep, %d rho levels x 1024 segments per GPU, 12-dim + STM, RK4 x 64" % levels
         gather_rows = 12
     else:  # c3
@@ -200,40 +200,66 @@ def main():
         Jac = torch.zeros(108, S, **f64)
         dtf = torch.zeros(6, S, **f64)
 
-        def sweep():
-            plan.jacobian(X, n, U, n, t, 1, Jac, S, dtf, defect, S, errs, stream=st)
+        def sweep(dbuf):
+            plan.jacobian(X, n, U, n, t, 1, Jac, S, dtf, dbuf, S, errs, stream=st)
         desc = "C3: direct 6-dim, RKF7(8) nsteps=10 per half, on-device Jacobian blocks 6x18 + tf column + defect + errors"
         gather_rows = 6
 
     use_coll = dist is not None
-    gathered = torch.zeros(world * gather_rows, S, **f64) if use_coll else None   # [rank][row][segment]
+    # N > 1: the defect slab of step k is all-gathered (RCCL) on a side stream while step k+1 propagates: two defect /
+    # gather buffers alternate, events order producer -> collective -> buffer reuse.  All collectives complete before
+    # the closing barrier + synchronize, so every one of the K steps is fully inside the timed region.
+    dbufs = [defect, torch.zeros_like(defect)] if use_coll else [defect]
+    gathered = [torch.zeros(world * gather_rows, S, **f64) for _ in dbufs] if use_coll else None   # [rank][row][segment]
+    comm_stream = torch.cuda.Stream(device=dev) if use_coll else None
+    ev_done = [torch.cuda.Event() for _ in dbufs]      # collective on buffer b finished
+    ev_ready = [torch.cuda.Event() for _ in dbufs]     # sweep into buffer b finished
+    main = torch.cuda.current_stream()
 
-    def step():
-        sweep()
+    def step(k):
+        b = k % len(dbufs)
+        if use_coll and k >= len(dbufs):
+            main.wait_event(ev_done[b])                # buffer b is free again
+        sweep(dbufs[b])
         if use_coll:
-            dist.all_gather_into_tensor(gathered, defect)   # RCCL over xGMI, same stream order
+            ev_ready[b].record(main)
+            comm_stream.wait_event(ev_ready[b])
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(gathered[b], dbufs[b])   # RCCL over xGMI
+                ev_done[b].record(comm_stream)
 
-    for _ in range(a.warmup):
-        step()
+    for k in range(a.warmup):
+        step(k)
+    if use_coll:
+        comm_stream.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     if use_coll:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(a.steps):
+        b = k % len(dbufs)
+        if use_coll and (k >= len(dbufs) or a.warmup >= len(dbufs)):
+            main.wait_event(ev_done[b])
         ev[k][0].record()
-        sweep()
+        sweep(dbufs[b])
         ev[k][1].record()
         if use_coll:
-            dist.all_gather_into_tensor(gathered, defect)
+            ev_ready[b].record(main)
+            comm_stream.wait_event(ev_ready[b])
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(gathered[b], dbufs[b])
+                ev_done[b].record(comm_stream)
     if use_coll:
+        comm_stream.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
 
     if use_coll:
-        assert torch.equal(gathered[rank * gather_rows:(rank + 1) * gather_rows], defect), "all-gather slab mismatch"
+        for b in range(len(dbufs)):
+            assert torch.equal(gathered[b][rank * gather_rows:(rank + 1) * gather_rows], dbufs[b]), "all-gather slab mismatch"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -252,7 +278,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
-                       "collective": "rccl all_gather(defect)" if use_coll else "none", "integrator": "see workload"},
+                       "collective": "rccl all_gather(defect), overlapped with the next sweep on a side stream" if use_coll else "none", "integrator": "see workload"},
         }
         if wl in WORK and a.ndim == 12 and not a.method:
             flops, nbytes = WORK[wl]
