@@ -109,6 +109,14 @@ int lto_indirect_jacobian(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, cons
                           int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ, double* Phi,
                           double* defect);
 
+/* One whole Newton iteration of multiShoot_CRTBP_indirect with flag_adjointsOnly = false (indirect.jl:290-296):
+ * jacobianCalc (:93-146), the least-squares step of optimizeTraj_OLS (:181-182) and its second-order correction
+ * (:190-214, applied when norm(xc_update, Inf) < soc_threshold; the reference uses 1e-1).  Only XC and t are uploaded and
+ * xc_update [ndim x n_nodes x n_batch] and (optionally) the nominal defect are downloaded; Phi stays in HBM. */
+int lto_indirect_newton_step(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, const double* XC, const double* t,
+                             int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ,
+                             double soc_threshold, double* xc_update, double* defect);
+
 /* Replaces densify (src/HelperFunctions.jl:51-101) for one trajectory: t_dense = LinRange(t[1], t[end], n_desired),
  * every segment re-propagated from its node and sampled at the t_dense points inside [t_i, t_{i+1}), final propagated
  * state appended.  XC_dense [ndim x n_desired], t_dense [n_desired]. */
@@ -161,6 +169,15 @@ const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* plan);
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3); 0 = choose from S. */
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);
+
+/* Newton step of the indirect method solved on the device: delta = -Jac_full \ defect for the block-bidiagonal
+ * [Phi_i | -I] system with both end states fixed (src/multiShoot_CRTBP_indirect.jl:123-142, :181-182), by structured
+ * orthogonal cyclic reduction.  Phi != NULL factors and solves; Phi == NULL re-uses the stored factorisation for a new
+ * right-hand side (the second-order-correction re-solve, :190-214).  delta is SoA [12][ldx], node-indexed. */
+int lto_indirect_newton_solve_dev(lto_indirect_plan* plan, void* stream, const double* Phi, long ldp,
+                                  const double* defect, long ldd, double* delta, long ldx);
+/* y[i] = x[i] + alpha d[i], i < count (trial points X + alpha dX, update accumulation) */
+int lto_axpy_dev(lto_ctx* ctx, void* stream, const double* x, const double* d, double alpha, double* y, long count);
 
 /* Dense output (device): segment s is sampled at t_samples[first[s] .. first[s+1]) (sorted, inside the segment);
  * Y[c*ldy + j] = x_c(t_samples[j]); final_state[c*n_batch + b] (or NULL) = x(t_n) of trajectory b. */

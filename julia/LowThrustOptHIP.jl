@@ -13,7 +13,7 @@ module LowThrustOptHIP
 
 using SparseArrays, LinearAlgebra
 
-export LtoContext, indirect_defectCalc, indirect_jacobianCalc, indirect_stm,
+export LtoContext, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, densify,
        direct_defectCalc, direct_jacobianCalc, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
 
 const liblto = get(ENV, "LTO_HIP_LIB", joinpath(@__DIR__, "..", "lowthrustopt_amd", "liblto_hip.so"))
@@ -112,6 +112,36 @@ function indirect_jacobianCalc(ctx::LtoContext, XC_all, t_TU, nstate, n_nodes, p
     Jac_full[:, 1:nstate] .= 0
     Jac_full[:, (nd * n_nodes - 2 * nstate + 1):(nd * n_nodes - nstate)] .= 0
     dropzeros!(Jac_full)
+end
+
+"""One Newton iteration on the device (indirect.jl:290-296 with flag_adjointsOnly = false): jacobianCalc, the
+least-squares step of optimizeTraj_OLS and its second-order correction; returns (xc_update, defect)."""
+function indirect_newton_step(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params;
+                              integ::LtoIntegrator = LtoIntegrator(), soc_threshold::Float64 = 1e-1)
+    ndim, n_nodes = size(XC_all)
+    xc_update = zeros(ndim, n_nodes)
+    defect1 = zeros(ndim, n_nodes - 1)
+    rc = ccall((:lto_indirect_newton_step, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{LtoParams}, Cint, Ref{LtoIntegrator},
+                Cdouble, Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx.handle, ndim, n_nodes, 1, XC_all, t_TU, 1, Ref(LtoParams(params)), 1, Ref(integ), soc_threshold,
+               xc_update, defect1)
+    check(ctx, rc)
+    (xc_update, defect1)
+end
+
+"densify (src/HelperFunctions.jl:51-101): (XC_dense[ndim x n_desired], t_dense)."
+function densify(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params, n_desired::Integer;
+                 integ::LtoIntegrator = LtoIntegrator())
+    ndim, n_nodes = size(XC_all)
+    XC_dense = zeros(ndim, n_desired)
+    t_dense = zeros(n_desired)
+    rc = ccall((:lto_indirect_densify, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ref{LtoParams}, Ref{LtoIntegrator}, Cint, Ptr{Cdouble},
+                Ptr{Cdouble}),
+               ctx.handle, ndim, n_nodes, XC_all, t_TU, Ref(LtoParams(params)), Ref(integ), n_desired, XC_dense, t_dense)
+    check(ctx, rc)
+    (XC_dense, t_dense)
 end
 
 # ---------------------------------------------------------------------------------------------- direct

@@ -49,6 +49,12 @@ hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const Indirect
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
 
+// Newton step of the indirect method on the device (kernels_bvp.hip): structured orthogonal cyclic reduction.
+size_t bvp_workspace_doubles(int n_nodes, int n_batch);
+hipError_t launch_bvp_solve(const double* Phi, long ldp, const double* defect, long ldd, int n_nodes, int n_batch,
+                            double* workspace, double* delta, long ldx, hipStream_t st);
+hipError_t launch_axpy(const double* x, const double* d, double alpha, double* y, long count, hipStream_t st);
+
 hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st);
 hipError_t launch_unpack_soa(const double* soa, long ld, int ndim, long count, double* aos, hipStream_t st);
 hipError_t launch_defect_norms(const double* defect, long ldd, int ndim, int seg_per_traj, int n_batch, double* sumsq,

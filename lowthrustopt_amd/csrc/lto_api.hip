@@ -53,6 +53,8 @@ struct lto_indirect_plan {
   int* d_nrej;
   int cols_per_lane;
   int kernel;       // LTO_KERNEL_*
+  double* d_bvp;    // workspace of the device Newton solve (lazily allocated)
+  size_t bvp_bytes;
 };
 
 struct lto_direct_plan {
@@ -284,6 +286,7 @@ void lto_indirect_plan_destroy(lto_indirect_plan* p) {
   pool_free(p->ctx, p->d_tp, sizeof(TrajParams) * (size_t)p->n_prm);
   pool_free(p->ctx, p->d_nacc, sizeof(int) * (size_t)p->S);
   pool_free(p->ctx, p->d_nrej, sizeof(int) * (size_t)p->S);
+  pool_free(p->ctx, p->d_bvp, p->bvp_bytes);
   delete p;
 }
 
@@ -369,6 +372,115 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
   return LTO_OK;
+}
+
+/* ------------------------------------------------------------------------------ device Newton solve */
+int lto_indirect_newton_solve_dev(lto_indirect_plan* p, void* stream, const double* Phi, long ldp, const double* defect,
+                                  long ldd, double* delta, long ldx) {
+  if (!p) return LTO_ENULL;
+  lto_ctx* c = p->ctx;
+  if (p->ndim != 12) return set_err(c, LTO_EUNSUPPORTED, "device Newton solve is built for ndim = 12");
+  if (!defect || !delta) return set_err(c, LTO_ENULL, "defect or delta is NULL");
+  if (ldd < p->S || (Phi && ldp < p->S) || ldx < (long)p->n_nodes * p->n_batch) return set_err(c, LTO_EINVAL, "leading dimension too small");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  if (!p->d_bvp) {
+    if (!Phi) return set_err(c, LTO_EINVAL, "no factorisation yet: the first solve needs Phi");
+    p->bvp_bytes = sizeof(double) * bvp_workspace_doubles(p->n_nodes, p->n_batch);
+    hipError_t e = pool_alloc(c, (void**)&p->d_bvp, p->bvp_bytes);
+    if (e != hipSuccess) { p->d_bvp = nullptr; return set_err(c, LTO_EHIP, "newton workspace", e); }
+  }
+  hipError_t e = launch_bvp_solve(Phi, ldp, defect, ldd, p->n_nodes, p->n_batch, p->d_bvp, delta, ldx, (hipStream_t)stream);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_bvp_solve", e);
+  return LTO_OK;
+}
+
+int lto_axpy_dev(lto_ctx* c, void* stream, const double* x, const double* d, double alpha, double* y, long count) {
+  if (!c) return LTO_ENULL;
+  if (!x || !d || !y) return set_err(c, LTO_ENULL, "x, d or y is NULL");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  hipError_t e = launch_axpy(x, d, alpha, y, count, (hipStream_t)stream);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_axpy", e);
+  return LTO_OK;
+}
+
+/* One Newton iteration of multiShoot_CRTBP_indirect on the device (indirect.jl:290-296 with flag_adjointsOnly = false):
+ * jacobianCalc + the least-squares step of optimizeTraj_OLS (:181-182) + its second-order correction (:190-214).
+ * Only XC, t go up and xc_update, defect come down; Phi never leaves HBM. */
+int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, const double* XC, const double* t, int n_tgrids,
+                             const lto_params* prm, int n_prm, const lto_integrator* integ, double soc_threshold,
+                             double* xc_update, double* defect) {
+  if (!c) return LTO_ENULL;
+  if (!XC || !t || !xc_update) return set_err(c, LTO_ENULL, "XC, t or xc_update is NULL");
+  lto_indirect_plan* p = nullptr;
+  int rc = lto_indirect_plan_create(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);
+  if (rc) return rc;
+  if (ndim != 12) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EUNSUPPORTED, "device Newton step is built for ndim = 12"); }
+  if (n_tgrids != 1 && n_tgrids != n_batch) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
+  const long J = (long)n_nodes * n_batch, S = p->S;
+  const size_t need = al256(sizeof(double) * 12 * J) * 5 + al256(sizeof(double) * n_nodes * n_tgrids) +
+                      al256(sizeof(double) * 12 * S) * 3 + al256(sizeof(double) * 144 * S) + 16384;
+  rc = arena_reserve(c, need);
+  if (rc) { lto_indirect_plan_destroy(p); return rc; }
+  c->arena_top = 0;
+  double* d_aos = arena_take<double>(c, (size_t)12 * J);
+  double* d_X = arena_take<double>(c, (size_t)12 * J);
+  double* d_X2 = arena_take<double>(c, (size_t)12 * J);
+  double* d_del = arena_take<double>(c, (size_t)12 * J);
+  double* d_del2 = arena_take<double>(c, (size_t)12 * J);
+  double* d_t = arena_take<double>(c, (size_t)n_nodes * n_tgrids);
+  double* d_def = arena_take<double>(c, (size_t)12 * S);
+  double* d_def2 = arena_take<double>(c, (size_t)12 * S);
+  double* d_def_aos = arena_take<double>(c, (size_t)12 * S);
+  double* d_phi = arena_take<double>(c, (size_t)144 * S);
+  hipStream_t st = c->stream;
+  hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * 12 * J, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_pack_soa(d_aos, 12, J, d_X, J, st);
+  if (e != hipSuccess) { (void)hipStreamSynchronize(st); lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
+  if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, d_del, J);
+  double* h_del = nullptr;
+  if (rc == LTO_OK) {
+    h_del = (double*)std::malloc(sizeof(double) * 12 * (size_t)J);
+    if (!h_del) rc = set_err(c, LTO_EHIP, "host allocation failed");
+  }
+  if (rc == LTO_OK) {
+    e = hipMemcpyAsync(h_del, d_del, sizeof(double) * 12 * J, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "newton step", e);
+  }
+  if (rc == LTO_OK) {
+    double mx = 0.0;
+    bool finite = true;
+    for (long k = 0; k < 12 * J; ++k) { const double v = std::fabs(h_del[k]); if (!(v == v)) finite = false; if (v > mx) mx = v; }
+    if (finite && mx < soc_threshold) {   // :190  norm(xc_update, Inf) < 1e-1
+      e = launch_axpy(d_X, d_del, 1.0, d_X2, 12 * J, st);
+      if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "axpy", e);
+      if (rc == LTO_OK) rc = lto_indirect_defect_dev(p, st, d_X2, J, d_t, n_tgrids, d_def2, S, nullptr);
+      if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, nullptr, 0, d_def2, S, d_del2, J);
+      if (rc == LTO_OK) {
+        e = launch_axpy(d_del, d_del2, 1.0, d_del, 12 * J, st);
+        if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "axpy", e);
+      }
+    }
+  }
+  if (rc == LTO_OK) {
+    e = launch_unpack_soa(d_del, J, 12, J, d_aos, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(xc_update, d_aos, sizeof(double) * 12 * J, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && defect) {
+      e = launch_unpack_soa(d_def, S, 12, S, d_def_aos, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * 12 * S, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  std::free(h_del);
+  lto_indirect_plan_destroy(p);
+  return rc;
 }
 
 /* ------------------------------------------------------------------------------ dense output */

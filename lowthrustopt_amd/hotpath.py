@@ -185,6 +185,24 @@ def indirect_jacobianCalc(XC_all, t_TU, params, integ=None, ctx=None, sparse=Fal
     return indirect_scatter(Phi, sparse=sparse)
 
 
+def indirect_newton_step(XC_all, t_TU, params, integ=None, ctx=None, soc_threshold=1e-1):
+    """One Newton iteration on the device (jacobianCalc + least-squares step + second-order correction of
+    optimizeTraj_OLS, indirect.jl:290-296 with flag_adjointsOnly = false): returns (xc_update, defect)."""
+    ctx = ctx or default_context()
+    integ = integ or integrator()
+    XC = _f64(XC_all)
+    ndim, n, B, batched = _batch_dims(XC)
+    t, ntg = _tgrids(t_TU, n, B)
+    prm, nprm = _params_array(params)
+    upd = np.zeros((ndim, n, B), order="F")
+    defect = np.zeros((ndim, n - 1, B), order="F")
+    ctx.check(ctx.lib.lto_indirect_newton_step(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
+                                               float(soc_threshold), _ptr(upd), _ptr(defect)))
+    if not batched:
+        return upd[:, :, 0], defect[:, :, 0]
+    return upd, defect
+
+
 def densify(XC_all, t_TU, params, n_desired, integ=None, ctx=None):
     """densify (src/HelperFunctions.jl:51-101): (XC_dense[ndim x n_desired], t_dense[n_desired]); every segment is
     re-propagated on the GPU and sampled at the uniformly spaced t_dense points that fall inside it."""
@@ -307,6 +325,11 @@ class IndirectPlan:
     def jacobian(self, X, ldx, t, n_tgrids, Phi, ldp, defect=None, ldd=0, stream=None):
         self.ctx.check(self.ctx.lib.lto_indirect_jacobian_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(t),
                                                               int(n_tgrids), _dptr(Phi), int(ldp), _dptr(defect), int(ldd)))
+
+    def newton_solve(self, Phi, ldp, defect, ldd, delta, ldx, stream=None):
+        """delta = -J \\ defect on the device; Phi=None re-uses the stored factorisation (SOC re-solve)."""
+        self.ctx.check(self.ctx.lib.lto_indirect_newton_solve_dev(self.handle, stream, _dptr(Phi), int(ldp), _dptr(defect),
+                                                                  int(ldd), _dptr(delta), int(ldx)))
 
     def steps_accepted_ptr(self):
         return self.ctx.lib.lto_indirect_plan_steps_accepted(self.handle)

@@ -66,7 +66,7 @@ def main():
         plan.close()
 
 
-if __name__ == "__main__" and "--host" not in sys.argv:
+if __name__ == "__main__" and "--host" not in sys.argv and "--newton" not in sys.argv:
     main()
 
 
@@ -91,3 +91,25 @@ def host_api_rate():
 
 if __name__ == "__main__" and "--host" in sys.argv:
     host_api_rate()
+
+
+def newton_rate():
+    ctx = lto.Context(0)
+    st = lto.current_stream_ptr()
+    prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    for S in (29, 4096, 65536):
+        n = S + 1
+        XC, T = synth.indirect_problem(n)
+        X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+        d = torch.zeros(12, S, dtype=torch.float64, device="cuda"); Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+        delta = torch.zeros(12, n, dtype=torch.float64, device="cuda")
+        plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=64))
+        plan.jacobian(X, n, t, 1, Phi, S, d, S, stream=st)
+        ms = timeit(lambda: plan.newton_solve(Phi, S, d, S, delta, n, stream=st), iters=10)
+        ms2 = timeit(lambda: plan.newton_solve(None, 0, d, S, delta, n, stream=st), iters=10)
+        print("device Newton solve S=%6d: factor+solve %8.3f ms   re-solve (SOC) %8.3f ms" % (S, ms, ms2), flush=True)
+
+
+if __name__ == "__main__" and "--newton" in sys.argv:
+    newton_rate()
