@@ -72,6 +72,7 @@ SIGNATURES = {
     "lto_direct_plan_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LtoDirectParams),
                                          C.POINTER(_vp)]),
     "lto_direct_plan_destroy": (None, [_vp]),
+    "lto_direct_plan_set_kernel": (C.c_int, [_vp, C.c_int]),
     "lto_direct_defect_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp]),
     "lto_direct_jacobian_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp, _vp,
                                           C.c_long, _vp]),

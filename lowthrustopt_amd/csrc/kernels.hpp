@@ -48,6 +48,7 @@ hipError_t launch_indirect14_stm(int pm, int method, int cols_per_lane, const In
 hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
+hipError_t launch_direct_jacobian_coop(int nstate, const DirectArgs& a, hipStream_t st);
 
 // Newton step of the indirect method on the device (kernels_bvp.hip): structured orthogonal cyclic reduction.
 size_t bvp_workspace_doubles(int n_nodes, int n_batch);

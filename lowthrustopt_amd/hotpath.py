@@ -360,6 +360,9 @@ class DirectPlan:
                                                  C.byref(prm), C.byref(h)))
         self.handle = h
 
+    def set_kernel(self, kernel):
+        self.ctx.check(self.ctx.lib.lto_direct_plan_set_kernel(self.handle, int(kernel)))
+
     def defect(self, X, ldx, U, ldu, t, n_tgrids, defect, ldd, errors=None, stream=None):
         self.ctx.check(self.ctx.lib.lto_direct_defect_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(U), int(ldu),
                                                           _dptr(t), int(n_tgrids), _dptr(defect), int(ldd), _dptr(errors)))

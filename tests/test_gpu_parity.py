@@ -543,3 +543,34 @@ def test_newton_step_entry_point_converges(gpu_ctx, oracle):
         assert np.array_equal(XC[:6, 0], x0) and np.array_equal(XC[:6, -1], xf)
     assert np.abs(d).max() <= 1e-10 and it <= 5
     assert np.abs(XC - exact).max() < 1e-6
+
+
+@pytest.mark.parametrize("nstate", [6, 7])
+def test_direct_jacobian_kernel_variants_agree(gpu_ctx, oracle, nstate):
+    """Per-lane and wave-specialised direct Jacobian kernels: same blocks (round-off), both == oracle duals; ragged
+    segment count."""
+    import torch
+    n = 55
+    X, U, T = synth.direct_problem(n, seed=5, nstate=nstate)
+    U[:, 9, 0] = 0.0
+    S = n - 1
+    Xs = torch.from_numpy(synth.to_soa_nodes(X)).cuda(); Us = torch.from_numpy(synth.to_soa_nodes(U)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    plan = lto.DirectPlan(gpu_ctx, nstate, n, 1, 10, MU, DU, TU, 2000.0)
+    nvar = 2 * (nstate + 3)
+    out = {}
+    for kern in (1, 2):
+        plan.set_kernel(kern)
+        Jac = torch.zeros(nstate * nvar, S, dtype=torch.float64, device="cuda")
+        dtf = torch.zeros(nstate, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(nstate, S, dtype=torch.float64, device="cuda")
+        e = torch.zeros(S, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xs, n, Us, n, t, 1, Jac, S, dtf, d, S, e)
+        torch.cuda.synchronize()
+        out[kern] = [v.cpu().numpy() for v in (Jac, dtf, d, e)]
+    for a_, b_ in zip(out[1], out[2]):
+        assert np.abs(a_ - b_).max() < 1e-13 * max(1.0, np.abs(a_).max())
+    Jd, dh, dd = oracle.direct_jacobian_dual(X[:, :, 0], U[:, :, 0], T[:, 0], 10, MU, DU, TU, 2000.0)
+    Jg = out[2][0].reshape(nvar, nstate, S).transpose(1, 0, 2)
+    assert np.abs(Jg - Jd).max() < 1e-11 * max(1.0, np.abs(Jd).max())
+    assert np.abs(out[2][2] - dd).max() < 1e-12

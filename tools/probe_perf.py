@@ -61,8 +61,10 @@ def main():
         plan = lto.DirectPlan(ctx, 6, n, 1, 10, lto.MU, lto.DU, lto.TU, 2000.0)
         ms = timeit(lambda: plan.defect(X, n, U, n, t, 1, defect, S, err, stream=st))
         print("S=%7d direct defect           %9.3f ms  %10.3e seg/s" % (S, ms, S / ms * 1e3), flush=True)
-        ms = timeit(lambda: plan.jacobian(X, n, U, n, t, 1, Jac, S, dtf, defect, S, err, stream=st), iters=10)
-        print("S=%7d direct jacobian         %9.3f ms  %10.3e seg/s  (%.2f TFLOP/s model)" % (S, ms, S / ms * 1e3, S * 197e3 / ms / 1e9), flush=True)
+        for kern, kname in ((1, "per-lane"), (2, "coop")):
+            plan.set_kernel(kern)
+            ms = timeit(lambda: plan.jacobian(X, n, U, n, t, 1, Jac, S, dtf, defect, S, err, stream=st), iters=10)
+            print("S=%7d direct jacobian %-8s %9.3f ms  %10.3e seg/s  (%.2f TFLOP/s model)" % (S, kname, ms, S / ms * 1e3, S * 197e3 / ms / 1e9), flush=True)
         plan.close()
 
 
