@@ -29,6 +29,9 @@
 #include <vector>
 #include <algorithm>
 #include <quadmath.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "dop853_tableau.h"
 
@@ -601,6 +604,17 @@ int lto_o_indirect14(const double* XC, const double* t, int n_nodes, const doubl
   return status;
 }
 
+/* thread count for the OpenMP-annotated sweeps (CPU baseline only); returns the count in effect */
+int lto_o_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
 /* A7: indirect defectCalc, src/multiShoot_CRTBP_indirect.jl:63-90.
  * XC column-major [12 x n_nodes]; defect [12 x (n_nodes-1)]; errors[n_nodes-1] == 0 (:85).
  * method/steps/rtol/atol select the integrator (reference: adaptive order-8 pair @1e-13, :79). */
@@ -624,6 +638,9 @@ int lto_o_indirect_defect(const double* XC, const double* t, int n_nodes, const 
 int lto_o_indirect_jacobian(const double* XC, const double* t, int n_nodes, const double* prm, int method, int steps,
                             double rtol, double atol, double* Phi, double* defect) {
   int status = 0;
+  /* segments are independent (indirect.jl:116-124); the reference runs them serially -- the OpenMP pragma only
+   * serves the all-cores CPU baseline of bench.py (thread count set by lto_o_set_threads, default 1) */
+#pragma omp parallel for schedule(static) reduction(|:status)
   for (int i = 0; i < n_nodes - 1; ++i) {
     double y[12];
     std::memcpy(y, XC + 12 * i, sizeof y);
@@ -693,6 +710,7 @@ void lto_o_direct_jacobian_fd(const double* X, const double* U, const double* t,
                               int n_nodes, int nsteps, double MU, double DU, double TU, double Isp, double pert,
                               double* Jac_temp) {
   const int nvar = 2 * (nstate + 3);
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n_nodes - 1; ++i) {
     double XU[20];
     for (int r = 0; r < 2 * nstate; ++r) XU[r] = X[nstate * i + r];

@@ -34,7 +34,13 @@ def lib():
             build()
         _LIB = C.CDLL(path)
         _LIB.lto_o_flow_prop_ep.restype = C.c_double
+        _LIB.lto_o_set_threads(C.c_int(1))
     return _LIB
+
+
+def set_threads(n):
+    """OpenMP threads used by the annotated sweeps (all-cores CPU baseline); default is 1 = the reference's serial loop."""
+    return int(lib().lto_o_set_threads(C.c_int(int(n))))
 
 
 def _f(a):
