@@ -304,6 +304,16 @@ def main():
                 "note": "register-resident fp64 ODE integration: bound by the FP64 vector pipe (no MFMA issued; MI355X "
                         "FP64 matrix peak equals the vector peak), not by HBM -- see DESIGN.md 'Roofline'",
             }
+        if wl == "c5":
+            # wavefront-divergence / load-balance study: a wave runs until its slowest lane has finished
+            acc, rej = plan.step_counts(stream=st)
+            tot = (acc + rej).astype(np.float64)
+            pad = (-len(tot)) % 64
+            w = np.concatenate([tot, np.zeros(pad)]).reshape(-1, 64)
+            out["adaptive"] = {"steps_accepted_mean": float(acc.mean()), "steps_accepted_max": int(acc.max()),
+                               "steps_rejected_mean": float(rej.mean()), "steps_rejected_max": int(rej.max()),
+                               "wavefront_efficiency": float(tot.sum() / (w.max(axis=1).sum() * 64)),
+                               "note": "efficiency = lane-steps executed / (64 x slowest lane per wavefront)"}
         if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and a.ndim == 12 and not a.method:
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds)
             ncpu = os.cpu_count() or 1

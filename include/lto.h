@@ -160,6 +160,8 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* plan, void* stream, const doubl
  * plan, S ints each; NULL for fixed-step plans). */
 const int* lto_indirect_plan_steps_accepted(const lto_indirect_plan* plan);
 const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* plan);
+/* Copies the counters of the last adaptive sweep launched on `stream` to host arrays of S ints (either may be NULL). */
+int lto_indirect_plan_copy_steps(lto_indirect_plan* plan, void* stream, int* accepted, int* rejected);
 /* Tuning knobs for the STM sweep.  Kernel: AUTO picks the wave-specialised kernel (base wave + column waves per
  * 16 segments, coefficients handed over through LDS) for latency-bound batches and for the 13-stage integrators,
  * and the per-lane kernel (each lane re-integrates the base state with 1-3 columns) once the chip is full. */

@@ -294,6 +294,21 @@ void lto_indirect_plan_destroy(lto_indirect_plan* p) {
 const int* lto_indirect_plan_steps_accepted(const lto_indirect_plan* p) { return p ? p->d_nacc : nullptr; }
 const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* p) { return p ? p->d_nrej : nullptr; }
 
+int lto_indirect_plan_copy_steps(lto_indirect_plan* p, void* stream, int* accepted, int* rejected) {
+  if (!p) return LTO_ENULL;
+  lto_ctx* c = p->ctx;
+  if (!p->d_nacc || !p->d_nrej) return set_err(c, LTO_EINVAL, "fixed-step plan has no step counters");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipSuccess;
+  if (accepted) e = hipMemcpyAsync(accepted, p->d_nacc, sizeof(int) * (size_t)p->S, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && rejected) e = hipMemcpyAsync(rejected, p->d_nrej, sizeof(int) * (size_t)p->S, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "copy step counters", e);
+  return LTO_OK;
+}
+
 int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
   if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP)

@@ -331,6 +331,13 @@ class IndirectPlan:
         self.ctx.check(self.ctx.lib.lto_indirect_newton_solve_dev(self.handle, stream, _dptr(Phi), int(ldp), _dptr(defect),
                                                                   int(ldd), _dptr(delta), int(ldx)))
 
+    def step_counts(self, stream=None):
+        """(accepted[S], rejected[S]) of the last adaptive sweep (numpy int32)."""
+        acc = np.zeros(self.S, dtype=np.int32)
+        rej = np.zeros(self.S, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.lto_indirect_plan_copy_steps(self.handle, stream, _ptr(acc), _ptr(rej)))
+        return acc, rej
+
     def steps_accepted_ptr(self):
         return self.ctx.lib.lto_indirect_plan_steps_accepted(self.handle)
 

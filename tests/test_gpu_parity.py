@@ -574,3 +574,44 @@ def test_direct_jacobian_kernel_variants_agree(gpu_ctx, oracle, nstate):
     Jg = out[2][0].reshape(nvar, nstate, S).transpose(1, 0, 2)
     assert np.abs(Jg - Jd).max() < 1e-11 * max(1.0, np.abs(Jd).max())
     assert np.abs(out[2][2] - dd).max() < 1e-12
+
+
+def test_api_misuse_and_edge_sizes(gpu_ctx):
+    """Error behaviour of the C ABI: negative codes for misuse, nothing computed, message available."""
+    import ctypes as C
+    lib = gpu_ctx.lib
+    XC, T = synth.indirect_problem(5)
+    XC, t = np.asfortranarray(XC[:, :, 0]), T[:, 0].copy()
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    integ = lto.integrator(lto.RK4, steps=4)
+    d = np.zeros((12, 4), order="F")
+
+    def call(ndim=12, n_nodes=5, n_batch=1, xc=XC, tt=t, ntg=1, nprm=1, ig=integ, out=d):
+        arr = (lto.LtoParams * 1)(prm)
+        return lib.lto_indirect_defect(gpu_ctx.handle, ndim, n_nodes, n_batch, xc.ctypes.data_as(C.c_void_p) if xc is not None else None,
+                                       tt.ctypes.data_as(C.c_void_p), ntg, arr, nprm, C.byref(ig),
+                                       out.ctypes.data_as(C.c_void_p) if out is not None else None, None)
+    assert call() == 0
+    assert call(n_nodes=1) == -1                      # fewer than two nodes
+    assert call(n_batch=0) == -1
+    assert call(ndim=6) == -1
+    assert call(ntg=3) == -1                          # n_tgrids must be 1 or n_batch
+    assert call(nprm=2) == -1                         # n_prm must be 1 or n_batch
+    assert call(xc=None) == -2 and call(out=None) == -2
+    assert call(ig=lto.integrator(7, steps=4)) == -1  # unknown method
+    assert call(ig=lto.integrator(lto.DOP853_ADAPTIVE, rtol=0.0)) == -1
+    assert b"" != lib.lto_last_error(gpu_ctx.handle)
+    # zero-length segments (t_i == t_{i+1}): defect = x_i - x_{i+1}, identity STM, no NaN, for every integrator
+    t0 = np.zeros(5)
+    for method, steps in METHODS.values():
+        Phi, dd = lto.indirect_stm(XC, t0, prm, lto.integrator(method, steps=steps), ctx=gpu_ctx)
+        assert np.abs(dd - (XC[:, :-1] - XC[:, 1:])).max() < 1e-15
+        assert np.abs(Phi - np.eye(12)[:, :, None]).max() < 1e-15
+    # adaptive step counters are exposed
+    import torch
+    plan = lto.IndirectPlan(gpu_ctx, 5, 1, prm, lto.integrator(lto.DOP853_ADAPTIVE))
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda(); tt = torch.from_numpy(t).cuda()
+    dd = torch.zeros(12, 4, dtype=torch.float64, device="cuda")
+    plan.defect(X, 5, tt, 1, dd, 4)
+    acc, rej = plan.step_counts()
+    assert acc.shape == (4,) and np.all(acc >= 2) and np.all(acc < 100) and np.all(rej >= 0)
