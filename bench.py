@@ -125,7 +125,6 @@ def main():
     wl = a.workload
     prm1 = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
     f64 = dict(dtype=torch.float64, device=dev)
-    extra = {}
     if wl in ("c2", "c2_defect", "hbm", "c5"):
         S = a.segments or (65536 // max(world, 1) if wl == "c5" else 4096)
         n = S + 1
@@ -167,7 +166,7 @@ def main():
         else:
             def sweep(dbuf):
                 plan.defect(X, n, t, 1, dbuf, S, stream=st)
-        n_traj, gather_rows = 1, nd
+        gather_rows = nd
         if nd == 14 or a.method:
             desc += " [ndim=%d%s]" % (nd, (", integrator " + a.method) if a.method else "")
     elif wl == "c4":
@@ -316,6 +315,19 @@ def main():
                                "note": "efficiency = lane-steps executed / (64 x slowest lane per wavefront)"}
         if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and a.ndim == 12 and not a.method:
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds)
+            if wl == "c2":
+                # the metric's second half: defect L2 error of this very run against the oracle (checker), 256-segment sample
+                from oracle import oracle as O
+                ns = min(256, S)
+                prm_o = [lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+                Phi_o, d_o, rc = O.indirect_jacobian(XC[:, :ns + 1, 0], T[:ns + 1, 0], prm_o, O.RK4, 64)
+                d_g = defect[:, :ns].cpu().numpy()
+                P_g = Phi[:, :ns].cpu().numpy().reshape(12, 12, ns).transpose(1, 0, 2)
+                xn = np.linalg.norm(d_o + XC[:, 1:ns + 1, 0])
+                out["parity"] = {"defect_rel_l2": float(np.linalg.norm(d_g - d_o) / xn),
+                                 "stm_rel_max": float(np.abs(P_g - Phi_o).max() / np.abs(Phi_o).max()),
+                                 "sample_segments": ns, "oracle_rc": int(rc), "tolerance": 1e-10,
+                                 "against": "CPU oracle, same RK4 x 64 discrete map, dual-number STM"}
             ncpu = os.cpu_count() or 1
             if ncpu > 1:   # same restatement with the segment loop spread over every host core (reported, not the target)
                 out["cpu_baseline_all_cores"] = cpu_baseline("c3" if wl == "c3" else "c2", max(3.0, a.cpu_seconds / 3), threads=ncpu)

@@ -102,7 +102,7 @@ __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, co
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
     for (int i = 0; i < NERR; ++i) {
-      const double isc = 1.0 / __builtin_fma(rtol, fabs(y[i]), atol);
+      const double isc = rcp_nr(__builtin_fma(rtol, fabs(y[i]), atol));
       d0 = __builtin_fma(y[i] * isc, y[i] * isc, d0);
       d1 = __builtin_fma(K[0][i] * isc, K[0][i] * isc, d1);
     }
@@ -115,7 +115,7 @@ __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, co
     double d2 = 0.0;
 #pragma unroll
     for (int i = 0; i < NERR; ++i) {
-      const double isc = 1.0 / __builtin_fma(rtol, fabs(y[i]), atol);
+      const double isc = rcp_nr(__builtin_fma(rtol, fabs(y[i]), atol));
       const double df = (K[1][i] - K[0][i]) * isc;
       d2 = __builtin_fma(df, df, d2);
     }
@@ -190,13 +190,6 @@ __device__ __forceinline__ void advance(const Sys& sys, const double span, const
 // lane integrates from sample to sample and stores the state at each one.  The reference evaluates Vern8's
 // interpolant at those times; stepping exactly onto them is at least as accurate.  If `final_state` is set the
 // last segment of each trajectory also stores x(t_n) (the `sol_forward[:,end]` column densify appends, :94-97).
-struct DenseArgs {
-  const int* first;        // [S+1] prefix offsets into td / columns of Y
-  const double* td;        // [n_samples] sample times
-  double* Y; long ldy;     // [ND][ldy]
-  double* final_state;     // [ND][n_batch] or null
-};
-
 template <int ND, int PM, int METHOD>
 __global__ __launch_bounds__(64) void k_indirect_dense(const IndirectArgs a, const DenseArgs d) {
   const int s = blockIdx.x * 64 + threadIdx.x;

@@ -40,7 +40,13 @@ struct DirectArgs {
 hipError_t launch_indirect_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
 // cols_per_lane in {1,2,3}; 0 = choose from S.
 hipError_t launch_indirect_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
-struct DenseArgs;
+// dense output: segment s is sampled at td[first[s] .. first[s+1]); Y is SoA [ndim][ldy]
+struct DenseArgs {
+  const int* first;        // [S+1] prefix offsets into td / columns of Y
+  const double* td;        // [n_samples] sample times
+  double* Y; long ldy;     // [ND][ldy]
+  double* final_state;     // [ND][n_batch] or null: x(t_n) of every trajectory
+};
 hipError_t launch_indirect_dense(int ndim, int pm, int method, const IndirectArgs& a, const DenseArgs& d, hipStream_t st);
 hipError_t launch_indirect14_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_indirect14_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);

@@ -28,8 +28,6 @@ namespace lto {
 constexpr int COOP_SEG = 16;  // segments per workgroup
 
 struct TabRK4c {
-  static constexpr int NS = 4;
-  static constexpr bool FSAL = false;
   static constexpr double A[4][4] = {{0}, {0.5}, {0, 0.5}, {0, 0, 1.0}};
   static constexpr double B[4] = {1. / 6, 1. / 3, 1. / 3, 1. / 6};
 };
@@ -46,10 +44,9 @@ template <int METHOD> __device__ __forceinline__ constexpr double tabB(int k) {
 }
 template <int METHOD> struct TabN { static constexpr int NS = METHOD == M_RK4 ? 4 : (METHOD == M_DOP853_ADAPTIVE ? 12 : 13); };
 
-struct CoopCtrl {
-  double h;      // step the NEXT trial uses
-  int accept;    // last trial accepted
-  int done;      // segment finished (t reached span, or max_steps exhausted)
+struct CoopCtrl {   // ode78 decision of the base lane, broadcast through LDS
+  double h;        // step the NEXT trial uses
+  int accept;      // last trial accepted
 };
 
 template <int ND, int PM, int METHOD>
@@ -174,7 +171,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
       // of row r (a dual number's partials share the scale of its value), published by the base lane.
       if (is_base) {
 #pragma unroll
-        for (int c = 0; c < ND; ++c) s_scale[c][seg] = 1.0 / __builtin_fma(rtol, fabs(y[c]), atol);
+        for (int c = 0; c < ND; ++c) s_scale[c][seg] = rcp_nr(__builtin_fma(rtol, fabs(y[c]), atol));
       }
       slope(y, K[0], buf); buf ^= 1;
       double isc0[ND];
@@ -245,7 +242,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
       if (DOP) {
         if (is_base) {
 #pragma unroll
-          for (int c = 0; c < ND; ++c) s_scale[c][seg] = 1.0 / __builtin_fma(rtol, fmax(fabs(y[c]), fabs(yn[c])), atol);
+          for (int c = 0; c < ND; ++c) s_scale[c][seg] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[c]), fabs(yn[c])), atol));
         }
         slope(yn, K[12], buf); buf ^= 1;
         double e5 = 0.0, e3 = 0.0;

@@ -14,16 +14,6 @@
 #include "../../include/lto.h"
 #include "kernels.hpp"
 
-namespace lto {
-// mirrors indirect_kernel.hpp (kept out of kernels.hpp so that header stays kernel-agnostic)
-struct DenseArgs {
-  const int* first;
-  const double* td;
-  double* Y; long ldy;
-  double* final_state;
-};
-}  // namespace lto
-
 using namespace lto;
 
 struct lto_ctx {

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dop853_tableau.h"
+#include "dynamics.hpp"  // rcp_nr
 
 namespace lto {
 
@@ -137,7 +138,7 @@ __device__ __forceinline__ double dop853_try(const Sys& sys, const double h, con
       if (DP8_E5[k] != 0.0) a5 = __builtin_fma(DP8_E5[k], K[k][i], a5);
       if (DP8_E3[k] != 0.0) a3 = __builtin_fma(DP8_E3[k], K[k][i], a3);
     }
-    const double inv_sc = 1.0 / __builtin_fma(rtol, fmax(fabs(y[i]), fabs(ynew[i])), atol);
+    const double inv_sc = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[i]), fabs(ynew[i])), atol));
     a5 *= inv_sc; a3 *= inv_sc;
     e5 = __builtin_fma(a5, a5, e5);
     e3 = __builtin_fma(a3, a3, e3);
@@ -265,7 +266,7 @@ __device__ __forceinline__ double dop853_try_mem(const Sys& sys, const TabMem& T
   double e5 = 0.0, e3 = 0.0;
 #pragma unroll
   for (int i = 0; i < NERR; ++i) {
-    const double inv_sc = 1.0 / __builtin_fma(rtol, fmax(fabs(y[i]), fabs(ynew[i])), atol);
+    const double inv_sc = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[i]), fabs(ynew[i])), atol));
     const double v5 = a5[i] * inv_sc, v3 = a3[i] * inv_sc;
     e5 = __builtin_fma(v5, v5, e5);
     e3 = __builtin_fma(v3, v3, e3);
