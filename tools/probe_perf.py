@@ -68,7 +68,7 @@ def main():
         plan.close()
 
 
-if __name__ == "__main__" and "--host" not in sys.argv and "--newton" not in sys.argv:
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--host", "--newton", "--small")):
     main()
 
 
@@ -115,3 +115,34 @@ def newton_rate():
 
 if __name__ == "__main__" and "--newton" in sys.argv:
     newton_rate()
+
+
+def small_sweeps():
+    """Time per sweep at the demo size (29 segments) and at 4 096, device-resident."""
+    ctx = lto.Context(0)
+    st = lto.current_stream_ptr()
+    prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    for S in (29, 4096):
+        n = S + 1
+        XC, T = synth.indirect_problem(n)
+        X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+        d = torch.zeros(12, S, dtype=torch.float64, device="cuda"); Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+        for method, steps, name in ((lto.RK4, 64, "rk4x64"), (lto.RKF78_FIXED, 4, "rkf78x4"), (lto.DOP853_ADAPTIVE, 0, "dop853@1e-13")):
+            plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(method, steps=steps))
+            a = timeit(lambda: plan.defect(X, n, t, 1, d, S, stream=st), iters=50) * 1e3
+            b = timeit(lambda: plan.jacobian(X, n, t, 1, Phi, S, d, S, stream=st), iters=50) * 1e3
+            print("S=%5d %-13s defect sweep %7.1f us   STM sweep %7.1f us" % (S, name, a, b), flush=True)
+        Xd, Ud, Td = synth.direct_problem(n)
+        Xs = torch.from_numpy(synth.to_soa_nodes(Xd)).cuda(); Us = torch.from_numpy(synth.to_soa_nodes(Ud)).cuda()
+        td = torch.from_numpy(np.ascontiguousarray(Td[:, 0])).cuda()
+        dd = torch.zeros(6, S, dtype=torch.float64, device="cuda"); e = torch.zeros(S, dtype=torch.float64, device="cuda")
+        J = torch.zeros(108, S, dtype=torch.float64, device="cuda"); dtf = torch.zeros(6, S, dtype=torch.float64, device="cuda")
+        dp = lto.DirectPlan(ctx, 6, n, 1, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        a = timeit(lambda: dp.defect(Xs, n, Us, n, td, 1, dd, S, e, stream=st), iters=50) * 1e3
+        b = timeit(lambda: dp.jacobian(Xs, n, Us, n, td, 1, J, S, dtf, dd, S, e, stream=st), iters=50) * 1e3
+        print("S=%5d direct rkf78 n=10 defect sweep %7.1f us   Jacobian sweep %7.1f us" % (S, a, b), flush=True)
+
+
+if __name__ == "__main__" and "--small" in sys.argv:
+    small_sweeps()
