@@ -109,13 +109,14 @@ int lto_indirect_jacobian(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, cons
                           int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ, double* Phi,
                           double* defect);
 
-/* One whole Newton iteration of multiShoot_CRTBP_indirect with flag_adjointsOnly = false (indirect.jl:290-296):
- * jacobianCalc (:93-146), the least-squares step of optimizeTraj_OLS (:181-182) and its second-order correction
- * (:190-214, applied when norm(xc_update, Inf) < soc_threshold; the reference uses 1e-1).  Only XC and t are uploaded and
- * xc_update [ndim x n_nodes x n_batch] and (optionally) the nominal defect are downloaded; Phi stays in HBM. */
+/* One whole Newton iteration of multiShoot_CRTBP_indirect (indirect.jl:290-296): jacobianCalc (:93-146), the
+ * least-squares step of optimizeTraj_OLS (:149-218) incl. the flag_adjointsOnly column mask (:169-178) and the
+ * second-order correction (:190-214, applied when norm(xc_update, Inf) < soc_threshold; the reference uses 1e-1).
+ * Only XC and t are uploaded and xc_update [ndim x n_nodes x n_batch] and (optionally) the nominal defect are
+ * downloaded; Phi stays in HBM. */
 int lto_indirect_newton_step(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, const double* XC, const double* t,
                              int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ,
-                             double soc_threshold, double* xc_update, double* defect);
+                             int flag_adjointsOnly, double soc_threshold, double* xc_update, double* defect);
 
 /* Replaces densify (src/HelperFunctions.jl:51-101) for one trajectory: t_dense = LinRange(t[1], t[end], n_desired),
  * every segment re-propagated from its node and sampled at the t_dense points inside [t_i, t_{i+1}), final propagated
@@ -174,10 +175,13 @@ int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);
 
 /* Newton step of the indirect method solved on the device: delta = -Jac_full \ defect for the block-bidiagonal
  * [Phi_i | -I] system with both end states fixed (src/multiShoot_CRTBP_indirect.jl:123-142, :181-182), by structured
- * orthogonal cyclic reduction.  Phi != NULL factors and solves; Phi == NULL re-uses the stored factorisation for a new
- * right-hand side (the second-order-correction re-solve, :190-214).  delta is SoA [12][ldx], node-indexed. */
+ * orthogonal cyclic reduction.  adjoints_only = 0: the square system of the regular iterations.  adjoints_only = 1:
+ * the state columns of every node are masked out (:169-178) and the over-determined system is solved in the
+ * least-squares sense, as `\` does.  Phi != NULL factors and solves; Phi == NULL re-uses the stored factorisation
+ * of the same variant for a new right-hand side (the second-order-correction re-solve, :190-214).
+ * delta is SoA [12][ldx], node-indexed. */
 int lto_indirect_newton_solve_dev(lto_indirect_plan* plan, void* stream, const double* Phi, long ldp,
-                                  const double* defect, long ldd, double* delta, long ldx);
+                                  const double* defect, long ldd, int adjoints_only, double* delta, long ldx);
 /* y[i] = x[i] + alpha d[i], i < count (trial points X + alpha dX, update accumulation) */
 int lto_axpy_dev(lto_ctx* ctx, void* stream, const double* x, const double* d, double alpha, double* y, long count);
 

@@ -114,18 +114,19 @@ function indirect_jacobianCalc(ctx::LtoContext, XC_all, t_TU, nstate, n_nodes, p
     dropzeros!(Jac_full)
 end
 
-"""One Newton iteration on the device (indirect.jl:290-296 with flag_adjointsOnly = false): jacobianCalc, the
-least-squares step of optimizeTraj_OLS and its second-order correction; returns (xc_update, defect)."""
+"""One Newton iteration on the device (indirect.jl:290-296): jacobianCalc, the least-squares step of
+optimizeTraj_OLS (incl. the flag_adjointsOnly column mask) and its second-order correction; returns (xc_update, defect)."""
 function indirect_newton_step(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params;
-                              integ::LtoIntegrator = LtoIntegrator(), soc_threshold::Float64 = 1e-1)
+                              integ::LtoIntegrator = LtoIntegrator(), flag_adjointsOnly::Bool = false,
+                              soc_threshold::Float64 = 1e-1)
     ndim, n_nodes = size(XC_all)
     xc_update = zeros(ndim, n_nodes)
     defect1 = zeros(ndim, n_nodes - 1)
     rc = ccall((:lto_indirect_newton_step, liblto), Cint,
                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{LtoParams}, Cint, Ref{LtoIntegrator},
-                Cdouble, Ptr{Cdouble}, Ptr{Cdouble}),
-               ctx.handle, ndim, n_nodes, 1, XC_all, t_TU, 1, Ref(LtoParams(params)), 1, Ref(integ), soc_threshold,
-               xc_update, defect1)
+                Cint, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx.handle, ndim, n_nodes, 1, XC_all, t_TU, 1, Ref(LtoParams(params)), 1, Ref(integ),
+               flag_adjointsOnly ? 1 : 0, soc_threshold, xc_update, defect1)
     check(ctx, rc)
     (xc_update, defect1)
 end

@@ -50,7 +50,7 @@ SIGNATURES = {
     "lto_indirect_jacobian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
                                         C.POINTER(LtoIntegrator), _vp, _vp]),
     "lto_indirect_newton_step": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
-                                           C.POINTER(LtoIntegrator), C.c_double, _vp, _vp]),
+                                           C.POINTER(LtoIntegrator), C.c_int, C.c_double, _vp, _vp]),
     "lto_indirect_densify": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.POINTER(LtoParams), C.POINTER(LtoIntegrator), C.c_int,
                                        _vp, _vp]),
     "lto_direct_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
@@ -62,7 +62,7 @@ SIGNATURES = {
     "lto_indirect_plan_destroy": (None, [_vp]),
     "lto_indirect_defect_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp]),
     "lto_indirect_jacobian_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp, C.c_long]),
-    "lto_indirect_newton_solve_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, C.c_long]),
+    "lto_indirect_newton_solve_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, C.c_int, _vp, C.c_long]),
     "lto_axpy_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, _vp, C.c_long]),
     "lto_indirect_dense_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),
     "lto_indirect_plan_steps_accepted": (_vp, [_vp]),

@@ -59,7 +59,7 @@ hipError_t launch_direct_jacobian_coop(int nstate, const DirectArgs& a, hipStrea
 // Newton step of the indirect method on the device (kernels_bvp.hip): structured orthogonal cyclic reduction.
 size_t bvp_workspace_doubles(int n_nodes, int n_batch);
 hipError_t launch_bvp_solve(const double* Phi, long ldp, const double* defect, long ldd, int n_nodes, int n_batch,
-                            double* workspace, double* delta, long ldx, hipStream_t st);
+                            int adjoints_only, double* workspace, double* delta, long ldx, hipStream_t st);
 hipError_t launch_axpy(const double* x, const double* d, double alpha, double* y, long count, hipStream_t st);
 
 hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st);

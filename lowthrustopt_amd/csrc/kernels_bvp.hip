@@ -18,83 +18,101 @@
 
 namespace lto {
 
-// per block row: A (144, column-major), B (144), r (12)
-constexpr int ROW_DOUBLES = 300;
-// per eliminated node: R (144, upper triangle used), Ca (144), Cb (144), g (12), V (24 x 12 reflectors), tau (12)
-constexpr int REC_R = 0, REC_CA = 144, REC_CB = 288, REC_G = 432, REC_V = 444, REC_TAU = 732, REC_DOUBLES = 744;
+// Two variants (template parameter NU = free unknowns per node):
+//   NU = 12  the square system of the regular iterations (all 12 components of the interior nodes free, the two end
+//            states fixed): 24 x 36 stacks, 12 reflections eliminate the shared unknown, the other 12 rows ARE the new
+//            block row.
+//   NU = 6   flag_adjointsOnly (indirect.jl:169-178): only the costates are free, A_i = Phi_i[:, 7:12], B_i = -I[:, 7:12];
+//            the system is over-determined (12(n-1) equations, 6n unknowns) and is solved in the least-squares sense,
+//            as `\` does: the 24 x 18 stack is triangularised completely (18 reflections); rows 0-5 define the shared
+//            unknown, rows 6-17 are the new (upper-trapezoidal) block row, rows 18-23 carry only residual and drop out.
+template <int NU> struct BvpDims {
+  static constexpr int NK = (NU == 12) ? 12 : 18;            // Householder reflections per pair
+  static constexpr int NCOLS = 3 * NU + 1;                   // mid | left | right | rhs
+  static constexpr int ROW = 24 * NU + 12;                   // A (12 x NU), B (12 x NU), r (12)
+  static constexpr int REC_R = 0, REC_CA = NU * NU, REC_CB = 2 * NU * NU, REC_G = 3 * NU * NU;
+  static constexpr int REC_V = 3 * NU * NU + NU, REC_TAU = REC_V + 24 * NK, REC = REC_TAU + NK;
+};
 
 struct BvpArgs {
   int n_nodes, n_batch, S_traj;       // S_traj = n_nodes - 1
-  double* rows0; double* rows1;       // ping-pong block rows  [n_batch][S_traj][ROW_DOUBLES]
-  double* rec;                        // [n_batch][n_nodes][REC_DOUBLES]  (entries 1 .. n_nodes-2 used)
+  double* rows0; double* rows1;       // ping-pong block rows  [n_batch][S_traj][ROW]
+  double* rec;                        // [n_batch][n_nodes][REC]  (entries 1 .. n_nodes-2 used)
   double* delta; long ldx;            // SoA [12][ldx], node j = b*n_nodes + k
 };
 
 // level-0 rows from the STM sweep's outputs
+template <int NU>
 __global__ __launch_bounds__(256) void k_bvp_init(const double* __restrict__ Phi, long ldp, const double* __restrict__ defect,
                                                   long ldd, BvpArgs a) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over S_total * 300
+  using D = BvpDims<NU>;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long S_total = (long)a.S_traj * a.n_batch;
-  if (idx >= S_total * ROW_DOUBLES) return;
-  const long s = idx / ROW_DOUBLES;
-  const int e = (int)(idx - s * ROW_DOUBLES);
+  if (idx >= S_total * D::ROW) return;
+  const long s = idx / D::ROW;
+  const int e = (int)(idx - s * D::ROW);
   const int i = (int)(s % a.S_traj);
   double v;
-  if (e < 144) {                       // A = Phi_i, fixed initial state: columns 0..5 of the first block zeroed
-    const int c = e / 12;
-    v = (i == 0 && c < 6) ? 0.0 : Phi[(long)e * ldp + s];
-  } else if (e < 288) {                // B = -I, fixed final state: columns 0..5 of the last block zeroed
-    const int c = (e - 144) / 12, r = (e - 144) % 12;
-    v = (r == c && !(i == a.S_traj - 1 && c < 6)) ? -1.0 : 0.0;
+  if (e < 12 * NU) {                   // A: columns of Phi_i that belong to free unknowns
+    const int c = e / 12, r = e % 12;
+    const int pc = (NU == 12) ? c : 6 + c;
+    v = (NU == 12 && i == 0 && c < 6) ? 0.0 : Phi[(long)(pc * 12 + r) * ldp + s];   // fixed initial state (:141)
+  } else if (e < 24 * NU) {            // B = -I restricted to the free unknowns
+    const int c = (e - 12 * NU) / 12, r = (e - 12 * NU) % 12;
+    const int pc = (NU == 12) ? c : 6 + c;
+    v = (r == pc && !(NU == 12 && i == a.S_traj - 1 && c < 6)) ? -1.0 : 0.0;       // fixed final state (:142)
   } else {
-    v = -defect[(long)(e - 288) * ldd + s];
+    v = -defect[(long)(e - 24 * NU) * ldd + s];
   }
   a.rows0[idx] = v;
 }
 
-// right-hand side only (re-solve with the stored factorisation)
+template <int NU>
 __global__ __launch_bounds__(256) void k_bvp_init_rhs(const double* __restrict__ defect, long ldd, BvpArgs a) {
+  using D = BvpDims<NU>;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over S_total * 12
   const long S_total = (long)a.S_traj * a.n_batch;
   if (idx >= S_total * 12) return;
   const long s = idx / 12;
   const int c = (int)(idx - s * 12);
-  a.rows0[s * ROW_DOUBLES + 288 + c] = -defect[(long)c * ldd + s];
+  a.rows0[s * D::ROW + 24 * NU + c] = -defect[(long)c * ldd + s];
 }
 
-// One wavefront per pair.  grid = (pairs + carry, n_batch), block = 64.
+// One wavefront per pair.  grid = (pairs + carry, n_batch), block = 64.  Lane c < NCOLS holds column c of the stack.
+template <int NU>
 __global__ __launch_bounds__(64) void k_bvp_reduce(BvpArgs a, int level, int M, const double* __restrict__ cur, double* __restrict__ nxt) {
+  using D = BvpDims<NU>;
   const int j = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
   const int npairs = M / 2;
-  const double* rows = cur + (long)b * a.S_traj * ROW_DOUBLES;
-  double* out = nxt + (long)b * a.S_traj * ROW_DOUBLES;
+  const double* rows = cur + (long)b * a.S_traj * D::ROW;
+  double* out = nxt + (long)b * a.S_traj * D::ROW;
   if (j >= npairs) {                   // odd row carried to the next level unchanged
-    const double* src = rows + (long)(M - 1) * ROW_DOUBLES;
-    double* dst = out + (long)npairs * ROW_DOUBLES;
-    for (int e = c; e < ROW_DOUBLES; e += 64) dst[e] = src[e];
+    const double* src = rows + (long)(M - 1) * D::ROW;
+    double* dst = out + (long)npairs * D::ROW;
+    for (int e = c; e < D::ROW; e += 64) dst[e] = src[e];
     return;
   }
-  const double* top = rows + (long)(2 * j) * ROW_DOUBLES;
-  const double* bot = top + ROW_DOUBLES;
+  const double* top = rows + (long)(2 * j) * D::ROW;
+  const double* bot = top + D::ROW;
   double col[24];
 #pragma unroll
   for (int r = 0; r < 24; ++r) col[r] = 0.0;
-  if (c < 12) {
+  if (c < NU) {                        // shared unknown: [B_top; A_bot]
 #pragma unroll
-    for (int r = 0; r < 12; ++r) { col[r] = top[144 + c * 12 + r]; col[12 + r] = bot[c * 12 + r]; }
-  } else if (c < 24) {
+    for (int r = 0; r < 12; ++r) { col[r] = top[12 * NU + c * 12 + r]; col[12 + r] = bot[c * 12 + r]; }
+  } else if (c < 2 * NU) {             // left unknown: [A_top; 0]
 #pragma unroll
-    for (int r = 0; r < 12; ++r) col[r] = top[(c - 12) * 12 + r];
-  } else if (c < 36) {
+    for (int r = 0; r < 12; ++r) col[r] = top[(c - NU) * 12 + r];
+  } else if (c < 3 * NU) {             // right unknown: [0; B_bot]
 #pragma unroll
-    for (int r = 0; r < 12; ++r) col[12 + r] = bot[144 + (c - 24) * 12 + r];
-  } else if (c == 36) {
+    for (int r = 0; r < 12; ++r) col[12 + r] = bot[12 * NU + (c - 2 * NU) * 12 + r];
+  } else if (c == 3 * NU) {
 #pragma unroll
-    for (int r = 0; r < 12; ++r) { col[r] = top[288 + r]; col[12 + r] = bot[288 + r]; }
+    for (int r = 0; r < 12; ++r) { col[r] = top[24 * NU + r]; col[12 + r] = bot[24 * NU + r]; }
   }
   double tau_mine = 0.0;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) {
+  for (int k = 0; k < D::NK; ++k) {
     // reflector from column k (computed in every lane, only lane k's is used)
     double xn2 = 0.0;
 #pragma unroll
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(64) void k_bvp_reduce(BvpArgs a, int level, int M, 
     double v[24];
 #pragma unroll
     for (int r = k + 1; r < 24; ++r) v[r] = __shfl(col[r], k);
-    if (c > k && c <= 36) {
+    if (c > k && c < D::NCOLS) {
       double w = col[k];
 #pragma unroll
       for (int r = k + 1; r < 24; ++r) w = __builtin_fma(v[r], col[r], w);
@@ -128,67 +146,86 @@ __global__ __launch_bounds__(64) void k_bvp_reduce(BvpArgs a, int level, int M, 
     }
   }
   const int mid = (2 * j + 1) << level;
-  double* rec = a.rec + ((long)b * a.n_nodes + mid) * REC_DOUBLES;
-  double* nr = out + (long)j * ROW_DOUBLES;
-  if (c < 12) {
+  double* rec = a.rec + ((long)b * a.n_nodes + mid) * D::REC;
+  double* nr = out + (long)j * D::ROW;
+  // reflectors: lane k < NK holds v_k below the diagonal
+  if (c < D::NK) {
 #pragma unroll
-    for (int r = 0; r < 12; ++r) rec[REC_R + c * 12 + r] = (r <= c) ? col[r] : 0.0;
+    for (int r = 0; r < 24; ++r) rec[D::REC_V + c * 24 + r] = (r > c) ? col[r] : (r == c ? 1.0 : 0.0);
+    rec[D::REC_TAU + c] = tau_mine;
+  }
+  // rows 0 .. NU-1: the eliminated unknown; rows NU .. NU+11: the new block row (entries below the diagonal of a
+  // triangularised column are reflector storage, i.e. structural zeros of the matrix)
+  if (c < NU) {
 #pragma unroll
-    for (int r = 0; r < 24; ++r) rec[REC_V + c * 24 + r] = (r > c) ? col[r] : (r == c ? 1.0 : 0.0);
-    rec[REC_TAU + c] = tau_mine;
-  } else if (c < 24) {
+    for (int r = 0; r < NU; ++r) rec[D::REC_R + c * NU + r] = (r <= c) ? col[r] : 0.0;
+  } else if (c < 2 * NU) {
 #pragma unroll
-    for (int r = 0; r < 12; ++r) { rec[REC_CA + (c - 12) * 12 + r] = col[r]; nr[(c - 12) * 12 + r] = col[12 + r]; }
-  } else if (c < 36) {
+    for (int r = 0; r < NU; ++r) rec[D::REC_CA + (c - NU) * NU + r] = col[r];
 #pragma unroll
-    for (int r = 0; r < 12; ++r) { rec[REC_CB + (c - 24) * 12 + r] = col[r]; nr[144 + (c - 24) * 12 + r] = col[12 + r]; }
-  } else if (c == 36) {
+    for (int r = 0; r < 12; ++r) nr[(c - NU) * 12 + r] = (c < D::NK && NU + r > c) ? 0.0 : col[NU + r];
+  } else if (c < 3 * NU) {
 #pragma unroll
-    for (int r = 0; r < 12; ++r) { rec[REC_G + r] = col[r]; nr[288 + r] = col[12 + r]; }
+    for (int r = 0; r < NU; ++r) rec[D::REC_CB + (c - 2 * NU) * NU + r] = col[r];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) nr[12 * NU + (c - 2 * NU) * 12 + r] = (c < D::NK && NU + r > c) ? 0.0 : col[NU + r];
+  } else if (c == 3 * NU) {
+#pragma unroll
+    for (int r = 0; r < NU; ++r) rec[D::REC_G + r] = col[r];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) nr[24 * NU + r] = col[NU + r];
   }
 }
 
 // Re-apply the stored reflectors to a new right-hand side.  One lane per pair (+ carry).
+template <int NU>
 __global__ __launch_bounds__(64) void k_bvp_reduce_rhs(BvpArgs a, int level, int M, const double* __restrict__ cur, double* __restrict__ nxt) {
+  using D = BvpDims<NU>;
   const int j = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
   const int npairs = M / 2;
-  const double* rows = cur + (long)b * a.S_traj * ROW_DOUBLES;
-  double* out = nxt + (long)b * a.S_traj * ROW_DOUBLES;
+  const double* rows = cur + (long)b * a.S_traj * D::ROW;
+  double* out = nxt + (long)b * a.S_traj * D::ROW;
   if (j == npairs && (M & 1)) {
-    for (int r = 0; r < 12; ++r) out[(long)npairs * ROW_DOUBLES + 288 + r] = rows[(long)(M - 1) * ROW_DOUBLES + 288 + r];
+    for (int r = 0; r < 12; ++r) out[(long)npairs * D::ROW + 24 * NU + r] = rows[(long)(M - 1) * D::ROW + 24 * NU + r];
     return;
   }
   if (j >= npairs) return;
   double x[24];
 #pragma unroll
-  for (int r = 0; r < 12; ++r) { x[r] = rows[(long)(2 * j) * ROW_DOUBLES + 288 + r]; x[12 + r] = rows[(long)(2 * j + 1) * ROW_DOUBLES + 288 + r]; }
+  for (int r = 0; r < 12; ++r) { x[r] = rows[(long)(2 * j) * D::ROW + 24 * NU + r]; x[12 + r] = rows[(long)(2 * j + 1) * D::ROW + 24 * NU + r]; }
   const int mid = (2 * j + 1) << level;
-  double* rec = a.rec + ((long)b * a.n_nodes + mid) * REC_DOUBLES;
+  double* rec = a.rec + ((long)b * a.n_nodes + mid) * D::REC;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const double* v = rec + REC_V + k * 24;
+  for (int k = 0; k < D::NK; ++k) {
+    const double* v = rec + D::REC_V + k * 24;
     double w = x[k];
 #pragma unroll
     for (int r = k + 1; r < 24; ++r) w = __builtin_fma(v[r], x[r], w);
-    w *= rec[REC_TAU + k];
+    w *= rec[D::REC_TAU + k];
     x[k] -= w;
 #pragma unroll
     for (int r = k + 1; r < 24; ++r) x[r] = __builtin_fma(-w, v[r], x[r]);
   }
 #pragma unroll
-  for (int r = 0; r < 12; ++r) { rec[REC_G + r] = x[r]; out[(long)j * ROW_DOUBLES + 288 + r] = x[12 + r]; }
+  for (int r = 0; r < NU; ++r) rec[D::REC_G + r] = x[r];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) out[(long)j * D::ROW + 24 * NU + r] = x[NU + r];
 }
 
-// Last level: one row  A d_first + B d_last = r  with d_first[0:6] = d_last[0:6] = 0  ->  12 x 12 system for the
-// two end-node costate updates (Gaussian elimination with partial pivoting).  One lane per trajectory.
+// Last level: one row  A d_first + B d_last = r.  NU = 12: the end states are fixed, 12 x 12 system for the two
+// end-node costate updates.  NU = 6: 12 x 12 system for the costates of the first and last node.  Gaussian elimination
+// with partial pivoting, one lane per trajectory.
+template <int NU>
 __global__ __launch_bounds__(64) void k_bvp_final(BvpArgs a, const double* __restrict__ cur) {
+  using D = BvpDims<NU>;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= a.n_batch) return;
-  const double* row = cur + (long)b * a.S_traj * ROW_DOUBLES;
+  const double* row = cur + (long)b * a.S_traj * D::ROW;
   double Mx[12][13];
+  const int off = (NU == 12) ? 6 : 0;          // free columns of each block
   for (int r = 0; r < 12; ++r) {
-    for (int c = 0; c < 6; ++c) { Mx[r][c] = row[(6 + c) * 12 + r]; Mx[r][6 + c] = row[144 + (6 + c) * 12 + r]; }
-    Mx[r][12] = row[288 + r];
+    for (int c = 0; c < 6; ++c) { Mx[r][c] = row[(off + c) * 12 + r]; Mx[r][6 + c] = row[12 * NU + (off + c) * 12 + r]; }
+    Mx[r][12] = row[24 * NU + r];
   }
   for (int k = 0; k < 12; ++k) {
     int piv = k;
@@ -217,33 +254,40 @@ __global__ __launch_bounds__(64) void k_bvp_final(BvpArgs a, const double* __res
 }
 
 // Back-substitution at one level: d_mid = R^{-1} (g - Ca d_left - Cb d_right).  One lane per pair.
+template <int NU>
 __global__ __launch_bounds__(64) void k_bvp_backsub(BvpArgs a, int level, int M) {
+  using D = BvpDims<NU>;
   const int j = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
   if (j >= M / 2) return;
   const int mid = (2 * j + 1) << level, left = (2 * j) << level;
   int right = (2 * j + 2) << level;
   if (right > a.n_nodes - 1) right = a.n_nodes - 1;
-  const double* rec = a.rec + ((long)b * a.n_nodes + mid) * REC_DOUBLES;
+  const double* rec = a.rec + ((long)b * a.n_nodes + mid) * D::REC;
   const long nb = (long)b * a.n_nodes;
-  double dl[12], dr[12], x[12];
+  constexpr int off = 12 - NU;                 // NU = 6: unknowns are components 6..11 (the costates)
+  double dl[NU], dr[NU], x[NU];
 #pragma unroll
-  for (int c = 0; c < 12; ++c) { dl[c] = a.delta[(long)c * a.ldx + nb + left]; dr[c] = a.delta[(long)c * a.ldx + nb + right]; }
+  for (int c = 0; c < NU; ++c) { dl[c] = a.delta[(long)(off + c) * a.ldx + nb + left]; dr[c] = a.delta[(long)(off + c) * a.ldx + nb + right]; }
 #pragma unroll
-  for (int r = 0; r < 12; ++r) {
-    double s = rec[REC_G + r];
+  for (int r = 0; r < NU; ++r) {
+    double s = rec[D::REC_G + r];
 #pragma unroll
-    for (int c = 0; c < 12; ++c) s -= rec[REC_CA + c * 12 + r] * dl[c] + rec[REC_CB + c * 12 + r] * dr[c];
+    for (int c = 0; c < NU; ++c) s -= rec[D::REC_CA + c * NU + r] * dl[c] + rec[D::REC_CB + c * NU + r] * dr[c];
     x[r] = s;
   }
 #pragma unroll
-  for (int k = 11; k >= 0; --k) {
+  for (int k = NU - 1; k >= 0; --k) {
     double s = x[k];
 #pragma unroll
-    for (int c = k + 1; c < 12; ++c) s -= rec[REC_R + c * 12 + k] * x[c];
-    x[k] = s / rec[REC_R + k * 12 + k];
+    for (int c = k + 1; c < NU; ++c) s -= rec[D::REC_R + c * NU + k] * x[c];
+    x[k] = s / rec[D::REC_R + k * NU + k];
   }
 #pragma unroll
-  for (int c = 0; c < 12; ++c) a.delta[(long)c * a.ldx + nb + mid] = x[c];
+  for (int c = 0; c < NU; ++c) a.delta[(long)(off + c) * a.ldx + nb + mid] = x[c];
+  if (NU == 6) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a.delta[(long)c * a.ldx + nb + mid] = 0.0;   // states are not updated
+  }
 }
 
 // y = x + alpha * d  (elementwise over an SoA [rows][ld] block): trial points, SOC accumulation
@@ -254,24 +298,26 @@ __global__ __launch_bounds__(256) void k_axpy(const double* __restrict__ x, cons
 }
 
 size_t bvp_workspace_doubles(int n_nodes, int n_batch) {
-  return (size_t)2 * (n_nodes - 1) * n_batch * ROW_DOUBLES + (size_t)n_nodes * n_batch * REC_DOUBLES;
+  // sized for the larger (NU = 12) variant; the adjoints-only variant uses a prefix of the same workspace
+  return (size_t)2 * (n_nodes - 1) * n_batch * BvpDims<12>::ROW + (size_t)n_nodes * n_batch * BvpDims<12>::REC;
 }
 
-// Factor (if Phi != null) or re-apply to a new rhs (Phi == null), then solve: delta[12][ldx] (SoA, node-indexed).
-hipError_t launch_bvp_solve(const double* Phi, long ldp, const double* defect, long ldd, int n_nodes, int n_batch,
-                            double* workspace, double* delta, long ldx, hipStream_t st) {
+template <int NU>
+static hipError_t bvp_solve_impl(const double* Phi, long ldp, const double* defect, long ldd, int n_nodes, int n_batch,
+                                 double* workspace, double* delta, long ldx, hipStream_t st) {
+  using D = BvpDims<NU>;
   BvpArgs a;
   a.n_nodes = n_nodes; a.n_batch = n_batch; a.S_traj = n_nodes - 1;
-  const size_t rows_sz = (size_t)a.S_traj * n_batch * ROW_DOUBLES;
+  const size_t rows_sz = (size_t)a.S_traj * n_batch * D::ROW;
   a.rows0 = workspace; a.rows1 = workspace + rows_sz; a.rec = workspace + 2 * rows_sz;
   a.delta = delta; a.ldx = ldx;
   const long S_total = (long)a.S_traj * n_batch;
   if (Phi) {
-    const long cnt = S_total * ROW_DOUBLES;
-    hipLaunchKernelGGL(k_bvp_init, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, Phi, ldp, defect, ldd, a);
+    const long cnt = S_total * D::ROW;
+    hipLaunchKernelGGL((k_bvp_init<NU>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, Phi, ldp, defect, ldd, a);
   } else {
     const long cnt = S_total * 12;
-    hipLaunchKernelGGL(k_bvp_init_rhs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, defect, ldd, a);
+    hipLaunchKernelGGL((k_bvp_init_rhs<NU>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, defect, ldd, a);
   }
   double* cur = a.rows0;
   double* nxt = a.rows1;
@@ -280,18 +326,25 @@ hipError_t launch_bvp_solve(const double* Phi, long ldp, const double* defect, l
   while (M > 1) {
     Ms[level] = M;
     const int npairs = M / 2, carry = M & 1;
-    if (Phi) hipLaunchKernelGGL(k_bvp_reduce, dim3(npairs + carry, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
-    else hipLaunchKernelGGL(k_bvp_reduce_rhs, dim3((npairs + carry + 63) / 64, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
+    if (Phi) hipLaunchKernelGGL((k_bvp_reduce<NU>), dim3(npairs + carry, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
+    else hipLaunchKernelGGL((k_bvp_reduce_rhs<NU>), dim3((npairs + carry + 63) / 64, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
     double* t = cur; cur = nxt; nxt = t;
     M = npairs + carry;
     ++level;
   }
-  hipLaunchKernelGGL(k_bvp_final, dim3((n_batch + 63) / 64), dim3(64), 0, st, a, cur);
+  hipLaunchKernelGGL((k_bvp_final<NU>), dim3((n_batch + 63) / 64), dim3(64), 0, st, a, cur);
   for (int l = level - 1; l >= 0; --l) {
     const int npairs = Ms[l] / 2;
-    hipLaunchKernelGGL(k_bvp_backsub, dim3((npairs + 63) / 64, n_batch), dim3(64), 0, st, a, l, Ms[l]);
+    hipLaunchKernelGGL((k_bvp_backsub<NU>), dim3((npairs + 63) / 64, n_batch), dim3(64), 0, st, a, l, Ms[l]);
   }
   return hipGetLastError();
+}
+
+// Factor (if Phi != null) or re-apply to a new rhs (Phi == null), then solve: delta[12][ldx] (SoA, node-indexed).
+hipError_t launch_bvp_solve(const double* Phi, long ldp, const double* defect, long ldd, int n_nodes, int n_batch,
+                            int adjoints_only, double* workspace, double* delta, long ldx, hipStream_t st) {
+  return adjoints_only ? bvp_solve_impl<6>(Phi, ldp, defect, ldd, n_nodes, n_batch, workspace, delta, ldx, st)
+                       : bvp_solve_impl<12>(Phi, ldp, defect, ldd, n_nodes, n_batch, workspace, delta, ldx, st);
 }
 
 hipError_t launch_axpy(const double* x, const double* d, double alpha, double* y, long count, hipStream_t st) {

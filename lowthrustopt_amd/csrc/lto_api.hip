@@ -45,6 +45,7 @@ struct lto_indirect_plan {
   int kernel;       // LTO_KERNEL_*
   double* d_bvp;    // workspace of the device Newton solve (lazily allocated)
   size_t bvp_bytes;
+  int bvp_variant;  // -1 none, 0 square system, 1 adjoints-only least squares: what the stored factorisation is
 };
 
 struct lto_direct_plan {
@@ -253,7 +254,7 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (!p) { std::free(h); return set_err(c, LTO_EHIP, "host allocation failed"); }
   std::memset(p, 0, sizeof *p);
   p->ctx = c; p->ndim = ndim; p->n_nodes = n_nodes; p->n_batch = n_batch; p->S = (n_nodes - 1) * n_batch;
-  p->pm = pm; p->n_prm = n_prm; p->integ = *integ;
+  p->pm = pm; p->n_prm = n_prm; p->integ = *integ; p->bvp_variant = -1;
   if (p->integ.max_steps <= 0) p->integ.max_steps = 100000;
   hipError_t e = pool_alloc(c, (void**)&p->d_tp, sizeof(TrajParams) * (size_t)n_prm);
   if (e == hipSuccess) e = hipMemcpy(p->d_tp, h, sizeof(TrajParams) * (size_t)n_prm, hipMemcpyHostToDevice);
@@ -382,7 +383,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
 
 /* ------------------------------------------------------------------------------ device Newton solve */
 int lto_indirect_newton_solve_dev(lto_indirect_plan* p, void* stream, const double* Phi, long ldp, const double* defect,
-                                  long ldd, double* delta, long ldx) {
+                                  long ldd, int adjoints_only, double* delta, long ldx) {
   if (!p) return LTO_ENULL;
   lto_ctx* c = p->ctx;
   if (p->ndim != 12) return set_err(c, LTO_EUNSUPPORTED, "device Newton solve is built for ndim = 12");
@@ -396,8 +397,11 @@ int lto_indirect_newton_solve_dev(lto_indirect_plan* p, void* stream, const doub
     hipError_t e = pool_alloc(c, (void**)&p->d_bvp, p->bvp_bytes);
     if (e != hipSuccess) { p->d_bvp = nullptr; return set_err(c, LTO_EHIP, "newton workspace", e); }
   }
-  hipError_t e = launch_bvp_solve(Phi, ldp, defect, ldd, p->n_nodes, p->n_batch, p->d_bvp, delta, ldx, (hipStream_t)stream);
+  const int variant = adjoints_only ? 1 : 0;
+  if (!Phi && p->bvp_variant != variant) return set_err(c, LTO_EINVAL, "re-solve requested for a variant that was not factored");
+  hipError_t e = launch_bvp_solve(Phi, ldp, defect, ldd, p->n_nodes, p->n_batch, variant, p->d_bvp, delta, ldx, (hipStream_t)stream);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_bvp_solve", e);
+  if (Phi) p->bvp_variant = variant;
   return LTO_OK;
 }
 
@@ -411,12 +415,12 @@ int lto_axpy_dev(lto_ctx* c, void* stream, const double* x, const double* d, dou
   return LTO_OK;
 }
 
-/* One Newton iteration of multiShoot_CRTBP_indirect on the device (indirect.jl:290-296 with flag_adjointsOnly = false):
+/* One Newton iteration of multiShoot_CRTBP_indirect on the device (indirect.jl:290-296; both settings of flag_adjointsOnly):
  * jacobianCalc + the least-squares step of optimizeTraj_OLS (:181-182) + its second-order correction (:190-214).
  * Only XC, t go up and xc_update, defect come down; Phi never leaves HBM. */
 int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, const double* XC, const double* t, int n_tgrids,
-                             const lto_params* prm, int n_prm, const lto_integrator* integ, double soc_threshold,
-                             double* xc_update, double* defect) {
+                             const lto_params* prm, int n_prm, const lto_integrator* integ, int flag_adjointsOnly,
+                             double soc_threshold, double* xc_update, double* defect) {
   if (!c) return LTO_ENULL;
   if (!XC || !t || !xc_update) return set_err(c, LTO_ENULL, "XC, t or xc_update is NULL");
   lto_indirect_plan* p = nullptr;
@@ -446,7 +450,7 @@ int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (e == hipSuccess) e = launch_pack_soa(d_aos, 12, J, d_X, J, st);
   if (e != hipSuccess) { (void)hipStreamSynchronize(st); lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
   rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
-  if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, d_del, J);
+  if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, flag_adjointsOnly, d_del, J);
   double* h_del = nullptr;
   if (rc == LTO_OK) {
     h_del = (double*)std::malloc(sizeof(double) * 12 * (size_t)J);
@@ -465,7 +469,7 @@ int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
       e = launch_axpy(d_X, d_del, 1.0, d_X2, 12 * J, st);
       if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "axpy", e);
       if (rc == LTO_OK) rc = lto_indirect_defect_dev(p, st, d_X2, J, d_t, n_tgrids, d_def2, S, nullptr);
-      if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, nullptr, 0, d_def2, S, d_del2, J);
+      if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, nullptr, 0, d_def2, S, flag_adjointsOnly, d_del2, J);
       if (rc == LTO_OK) {
         e = launch_axpy(d_del, d_del2, 1.0, d_del, 12 * J, st);
         if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "axpy", e);

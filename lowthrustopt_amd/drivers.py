@@ -32,10 +32,10 @@ class HipOps:
     def stm(self, XC, t, params):
         return hotpath.indirect_stm(XC, t, params, self.integ, ctx=self.ctx)
 
-    def newton_step(self, XC, t, params):
-        """jacobianCalc + least-squares step + second-order correction in one device-resident call
-        (indirect.jl:290-296, flag_adjointsOnly = false): Phi never leaves HBM."""
-        upd, _ = hotpath.indirect_newton_step(XC, t, params, self.integ, ctx=self.ctx)
+    def newton_step(self, XC, t, params, flag_adjointsOnly=False):
+        """jacobianCalc + least-squares step (incl. the adjoints-only mask) + second-order correction in one
+        device-resident call (indirect.jl:290-296): Phi never leaves HBM."""
+        upd, _ = hotpath.indirect_newton_step(XC, t, params, self.integ, ctx=self.ctx, flag_adjointsOnly=flag_adjointsOnly)
         return upd
 
     def defect_batch_sumsq(self, XC_batch, t, params):
@@ -118,8 +118,8 @@ def multiShoot_CRTBP_indirect(XC_all, t_TU, MU, DU, TU, n_nodes, mass0, thrustLi
                 print("Reached max iteration count at %d iterations" % iterCount)
             status_flag = 1
             break
-        if not flag_adjointsOnly and hasattr(ops, "newton_step") and getattr(ops, "device_newton", True):
-            xc_update = ops.newton_step(XC_all, t_TU, params)    # :290-296 on the device (block-bidiagonal solve + SOC)
+        if hasattr(ops, "newton_step") and getattr(ops, "device_newton", True):
+            xc_update = ops.newton_step(XC_all, t_TU, params, flag_adjointsOnly)   # :290-296 on the device
         else:
             Phi, _ = ops.stm(XC_all, t_TU, params)               # jacobianCalc, :290
             xc_update = optimizeTraj_OLS(XC_all, t_TU, defect, Phi, nstate, n_nodes, params, flag_adjointsOnly, ops)

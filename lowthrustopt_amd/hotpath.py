@@ -185,9 +185,9 @@ def indirect_jacobianCalc(XC_all, t_TU, params, integ=None, ctx=None, sparse=Fal
     return indirect_scatter(Phi, sparse=sparse)
 
 
-def indirect_newton_step(XC_all, t_TU, params, integ=None, ctx=None, soc_threshold=1e-1):
-    """One Newton iteration on the device (jacobianCalc + least-squares step + second-order correction of
-    optimizeTraj_OLS, indirect.jl:290-296 with flag_adjointsOnly = false): returns (xc_update, defect)."""
+def indirect_newton_step(XC_all, t_TU, params, integ=None, ctx=None, soc_threshold=1e-1, flag_adjointsOnly=False):
+    """One Newton iteration on the device (jacobianCalc + least-squares step of optimizeTraj_OLS incl. the
+    adjoints-only column mask + second-order correction, indirect.jl:290-296): returns (xc_update, defect)."""
     ctx = ctx or default_context()
     integ = integ or integrator()
     XC = _f64(XC_all)
@@ -197,7 +197,7 @@ def indirect_newton_step(XC_all, t_TU, params, integ=None, ctx=None, soc_thresho
     upd = np.zeros((ndim, n, B), order="F")
     defect = np.zeros((ndim, n - 1, B), order="F")
     ctx.check(ctx.lib.lto_indirect_newton_step(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
-                                               float(soc_threshold), _ptr(upd), _ptr(defect)))
+                                               1 if flag_adjointsOnly else 0, float(soc_threshold), _ptr(upd), _ptr(defect)))
     if not batched:
         return upd[:, :, 0], defect[:, :, 0]
     return upd, defect
@@ -326,10 +326,10 @@ class IndirectPlan:
         self.ctx.check(self.ctx.lib.lto_indirect_jacobian_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(t),
                                                               int(n_tgrids), _dptr(Phi), int(ldp), _dptr(defect), int(ldd)))
 
-    def newton_solve(self, Phi, ldp, defect, ldd, delta, ldx, stream=None):
+    def newton_solve(self, Phi, ldp, defect, ldd, delta, ldx, stream=None, adjoints_only=False):
         """delta = -J \\ defect on the device; Phi=None re-uses the stored factorisation (SOC re-solve)."""
         self.ctx.check(self.ctx.lib.lto_indirect_newton_solve_dev(self.handle, stream, _dptr(Phi), int(ldp), _dptr(defect),
-                                                                  int(ldd), _dptr(delta), int(ldx)))
+                                                                  int(ldd), 1 if adjoints_only else 0, _dptr(delta), int(ldx)))
 
     def step_counts(self, stream=None):
         """(accepted[S], rejected[S]) of the last adaptive sweep (numpy int32)."""

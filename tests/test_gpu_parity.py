@@ -491,6 +491,8 @@ def test_device_newton_solve_vs_dense(gpu_ctx, oracle, n_nodes, n_batch):
     d2 = d * 0.5 + 0.01
     delta2 = torch.zeros_like(delta)
     plan.newton_solve(None, 0, d2, S, delta2, J)
+    with pytest.raises(lto.LtoError):                 # a re-solve of the other variant was never factored
+        plan.newton_solve(None, 0, d2, S, delta2, J, adjoints_only=True)
     torch.cuda.synchronize()
     d2n = d2.cpu().numpy().reshape(12, n_batch, n_nodes - 1).transpose(0, 2, 1)
     de2 = delta2.cpu().numpy().reshape(12, n_batch, n_nodes).transpose(0, 2, 1)
@@ -615,3 +617,43 @@ def test_api_misuse_and_edge_sizes(gpu_ctx):
     plan.defect(X, 5, tt, 1, dd, 4)
     acc, rej = plan.step_counts()
     assert acc.shape == (4,) and np.all(acc >= 2) and np.all(acc < 100) and np.all(rej >= 0)
+
+
+@pytest.mark.parametrize("n_nodes,n_batch", [(2, 1), (3, 1), (30, 1), (31, 2), (200, 3)])
+def test_device_adjoints_only_least_squares_vs_dense(gpu_ctx, n_nodes, n_batch):
+    """flag_adjointsOnly (indirect.jl:169-178): state columns masked, over-determined system solved in the
+    least-squares sense on the device == numpy lstsq on the masked dense Jacobian."""
+    import torch
+    XC, T = synth.indirect_problem(n_nodes, n_batch=n_batch, seed=41, dt_range=(0.05, 0.2))
+    prm = lto.make_params(MU, DU, TU, 10.0, 1000.0, 1.0, 2.0, 1.0)
+    S = (n_nodes - 1) * n_batch
+    J = n_nodes * n_batch
+    plan = lto.IndirectPlan(gpu_ctx, n_nodes, n_batch, prm, lto.integrator(lto.RKF78_FIXED, steps=6))
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+    d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    delta = torch.full((12, J), float("nan"), dtype=torch.float64, device="cuda")
+    plan.jacobian(X, J, t, n_batch, Phi, S, d, S)
+    plan.newton_solve(Phi, S, d, S, delta, J, adjoints_only=True)
+    d2 = d * 0.3 - 0.02
+    delta2 = torch.zeros_like(delta)
+    plan.newton_solve(None, 0, d2, S, delta2, J, adjoints_only=True)
+    torch.cuda.synchronize()
+    Pn = Phi.cpu().numpy().reshape(12, 12, n_batch, n_nodes - 1).transpose(1, 0, 3, 2)
+    for dev_d, dev_delta in ((d, delta), (d2, delta2)):
+        dn = dev_d.cpu().numpy().reshape(12, n_batch, n_nodes - 1).transpose(0, 2, 1)
+        de = dev_delta.cpu().numpy().reshape(12, n_batch, n_nodes).transpose(0, 2, 1)
+        assert np.all(np.isfinite(de))
+        for b in range(n_batch):
+            Jd = lto.indirect_scatter(np.asfortranarray(Pn[:, :, :, b]))
+            keep = np.ones(12 * n_nodes, dtype=bool)
+            for k in range(n_nodes - 1):
+                keep[12 * k:12 * k + 6] = False           # indirect.jl:172-175
+            keep[12 * (n_nodes - 1):12 * (n_nodes - 1) + 6] = False   # zero columns of the fixed final state
+            rhs = -dn[:, :, b].reshape(-1, order="F")
+            ref = np.zeros(12 * n_nodes)
+            ref[keep] = np.linalg.lstsq(Jd[:, keep], rhs, rcond=None)[0]
+            ref = ref.reshape(12, n_nodes, order="F")
+            assert np.all(de[:6, :, b] == 0.0)            # states untouched
+            assert np.abs(de[:, :, b] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
