@@ -78,11 +78,12 @@ __global__ __launch_bounds__(256) void k_bvp_init_rhs(const double* __restrict__
   a.rows0[s * D::ROW + 24 * NU + c] = -defect[(long)c * ldd + s];
 }
 
-// One wavefront per pair.  grid = (pairs + carry, n_batch), block = 64.  Lane c < NCOLS holds column c of the stack.
+// One wavefront per pair (j = pair index or the carry slot, b = trajectory, c = lane).  Lane c < NCOLS holds column c
+// of the stack.
 template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_reduce(BvpArgs a, int level, int M, const double* __restrict__ cur, double* __restrict__ nxt) {
+__device__ __forceinline__ void bvp_reduce_pair(const BvpArgs& a, int level, int M, const double* cur, double* nxt, const int j,
+                                                const int b, const int c) {
   using D = BvpDims<NU>;
-  const int j = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
   const int npairs = M / 2;
   const double* rows = cur + (long)b * a.S_traj * D::ROW;
   double* out = nxt + (long)b * a.S_traj * D::ROW;
@@ -177,11 +178,16 @@ __global__ __launch_bounds__(64) void k_bvp_reduce(BvpArgs a, int level, int M, 
   }
 }
 
+template <int NU>
+__global__ __launch_bounds__(64) void k_bvp_reduce(BvpArgs a, int level, int M, const double* __restrict__ cur, double* __restrict__ nxt) {
+  bvp_reduce_pair<NU>(a, level, M, cur, nxt, blockIdx.x, blockIdx.y, threadIdx.x);
+}
+
 // Re-apply the stored reflectors to a new right-hand side.  One lane per pair (+ carry).
 template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_reduce_rhs(BvpArgs a, int level, int M, const double* __restrict__ cur, double* __restrict__ nxt) {
+__device__ __forceinline__ void bvp_reduce_rhs_pair(const BvpArgs& a, int level, int M, const double* cur, double* nxt, const int j,
+                                                    const int b) {
   using D = BvpDims<NU>;
-  const int j = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
   const int npairs = M / 2;
   const double* rows = cur + (long)b * a.S_traj * D::ROW;
   double* out = nxt + (long)b * a.S_traj * D::ROW;
@@ -212,52 +218,72 @@ __global__ __launch_bounds__(64) void k_bvp_reduce_rhs(BvpArgs a, int level, int
   for (int r = 0; r < 12; ++r) out[(long)j * D::ROW + 24 * NU + r] = x[NU + r];
 }
 
+template <int NU>
+__global__ __launch_bounds__(64) void k_bvp_reduce_rhs(BvpArgs a, int level, int M, const double* __restrict__ cur, double* __restrict__ nxt) {
+  bvp_reduce_rhs_pair<NU>(a, level, M, cur, nxt, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
+}
+
 // Last level: one row  A d_first + B d_last = r.  NU = 12: the end states are fixed, 12 x 12 system for the two
 // end-node costate updates.  NU = 6: 12 x 12 system for the costates of the first and last node.  Gaussian elimination
 // with partial pivoting, one lane per trajectory.
 template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_final(BvpArgs a, const double* __restrict__ cur) {
+__device__ __forceinline__ void bvp_final_one(const BvpArgs& a, const double* cur, const int b, const int lane) {
+  // One wavefront per trajectory: lane r < 12 holds row r of the augmented 12 x 13 system in registers; pivot search,
+  // row swap and elimination go through cross-lane shuffles (no scratch arrays).
   using D = BvpDims<NU>;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.n_batch) return;
   const double* row = cur + (long)b * a.S_traj * D::ROW;
-  double Mx[12][13];
-  const int off = (NU == 12) ? 6 : 0;          // free columns of each block
-  for (int r = 0; r < 12; ++r) {
-    for (int c = 0; c < 6; ++c) { Mx[r][c] = row[(off + c) * 12 + r]; Mx[r][6 + c] = row[12 * NU + (off + c) * 12 + r]; }
-    Mx[r][12] = row[24 * NU + r];
-  }
+  const int r = lane < 12 ? lane : 11;
+  constexpr int off = (NU == 12) ? 6 : 0;      // free columns of each block
+  double m[13];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { m[c] = row[(off + c) * 12 + r]; m[6 + c] = row[12 * NU + (off + c) * 12 + r]; }
+  m[12] = row[24 * NU + r];
+#pragma unroll
   for (int k = 0; k < 12; ++k) {
-    int piv = k;
-    double best = fabs(Mx[k][k]);
-    for (int r = k + 1; r < 12; ++r) if (fabs(Mx[r][k]) > best) { best = fabs(Mx[r][k]); piv = r; }
-    if (piv != k) for (int c = k; c < 13; ++c) { const double t = Mx[k][c]; Mx[k][c] = Mx[piv][c]; Mx[piv][c] = t; }
-    const double inv = 1.0 / Mx[k][k];
-    for (int r = k + 1; r < 12; ++r) {
-      const double f = Mx[r][k] * inv;
-      for (int c = k + 1; c < 13; ++c) Mx[r][c] -= f * Mx[k][c];
+    // partial pivoting: row with the largest |m[.][k]| among rows >= k (ties -> lowest row)
+    double best = (lane >= k && lane < 12) ? fabs(m[k]) : -1.0;
+    int piv = lane;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o);
+      const int op = __shfl_xor(piv, o);
+      if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
     }
+    piv = __shfl(piv, 0);                       // lanes 0..15 agree after the butterfly
+    // swap rows k and piv
+    const int src = (lane == k) ? piv : (lane == piv ? k : lane);
+#pragma unroll
+    for (int c = 0; c < 13; ++c) m[c] = __shfl(m[c], src);
+    const double pk = __shfl(m[k], k);
+    const double f = (lane > k && lane < 12) ? m[k] / pk : 0.0;
+#pragma unroll
+    for (int c = k + 1; c < 13; ++c) m[c] = __builtin_fma(-f, __shfl(m[c], k), m[c]);
   }
+  // back substitution: x[k] = (m[k][12] - sum_{c>k} m[k][c] x[c]) / m[k][k], broadcast as it is formed
   double x[12];
+#pragma unroll
   for (int k = 11; k >= 0; --k) {
-    double s = Mx[k][12];
-    for (int c = k + 1; c < 12; ++c) s -= Mx[k][c] * x[c];
-    x[k] = s / Mx[k][k];
+    double sacc = m[12];
+#pragma unroll
+    for (int c = k + 1; c < 12; ++c) sacc = __builtin_fma(-m[c], x[c], sacc);
+    x[k] = __shfl(sacc / m[k], k);
   }
-  const long n0 = (long)b * a.n_nodes, n1 = n0 + a.n_nodes - 1;
-  for (int c = 0; c < 6; ++c) {
-    a.delta[(long)c * a.ldx + n0] = 0.0;
-    a.delta[(long)c * a.ldx + n1] = 0.0;
-    a.delta[(long)(6 + c) * a.ldx + n0] = x[c];
-    a.delta[(long)(6 + c) * a.ldx + n1] = x[6 + c];
+  if (lane == 0) {
+    const long n0 = (long)b * a.n_nodes, n1 = n0 + a.n_nodes - 1;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      a.delta[(long)c * a.ldx + n0] = 0.0;
+      a.delta[(long)c * a.ldx + n1] = 0.0;
+      a.delta[(long)(6 + c) * a.ldx + n0] = x[c];
+      a.delta[(long)(6 + c) * a.ldx + n1] = x[6 + c];
+    }
   }
 }
 
 // Back-substitution at one level: d_mid = R^{-1} (g - Ca d_left - Cb d_right).  One lane per pair.
 template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_backsub(BvpArgs a, int level, int M) {
+__device__ __forceinline__ void bvp_backsub_pair(const BvpArgs& a, int level, int M, const int j, const int b) {
   using D = BvpDims<NU>;
-  const int j = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
   if (j >= M / 2) return;
   const int mid = (2 * j + 1) << level, left = (2 * j) << level;
   int right = (2 * j + 2) << level;
@@ -287,6 +313,40 @@ __global__ __launch_bounds__(64) void k_bvp_backsub(BvpArgs a, int level, int M)
   if (NU == 6) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) a.delta[(long)c * a.ldx + nb + mid] = 0.0;   // states are not updated
+  }
+}
+
+template <int NU>
+__global__ __launch_bounds__(64) void k_bvp_backsub(BvpArgs a, int level, int M) {
+  bvp_backsub_pair<NU>(a, level, M, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
+}
+
+// Tail of the reduction in ONE launch: once a level has at most 16 block rows (8 pairs = 8 wavefronts, 2 per SIMD: the full register budget) the
+// remaining levels, the final 12 x 12 solve and the matching back-substitution levels run inside one 512-thread
+// workgroup per trajectory, separated by __syncthreads() (block-scope ordering of the global-memory block rows).
+// A 30-node problem (the reference demo) is then init + this kernel instead of 12 dependent tiny launches.
+constexpr int BVP_TAIL_MAX = 16;
+
+template <int NU>
+__global__ __launch_bounds__(512) void k_bvp_tail(BvpArgs a, int level0, int M0, double* cur, double* nxt, int factor) {
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int M = M0, level = level0;
+  int Ms[8];
+  while (M > 1) {
+    Ms[level - level0] = M;
+    const int npairs = M / 2, carry = M & 1;
+    if (factor) { if (wave < npairs + carry) bvp_reduce_pair<NU>(a, level, M, cur, nxt, wave, b, lane); }
+    else if (tid < npairs + carry) bvp_reduce_rhs_pair<NU>(a, level, M, cur, nxt, tid, b);
+    __syncthreads();
+    double* t = cur; cur = nxt; nxt = t;
+    M = npairs + carry;
+    ++level;
+  }
+  if (wave == 0) bvp_final_one<NU>(a, cur, b, lane);
+  __syncthreads();
+  for (int l = level - 1; l >= level0; --l) {
+    bvp_backsub_pair<NU>(a, l, Ms[l - level0], tid, b);
+    __syncthreads();
   }
 }
 
@@ -323,7 +383,7 @@ static hipError_t bvp_solve_impl(const double* Phi, long ldp, const double* defe
   double* nxt = a.rows1;
   int M = a.S_traj, level = 0;
   int Ms[40];
-  while (M > 1) {
+  while (M > BVP_TAIL_MAX) {
     Ms[level] = M;
     const int npairs = M / 2, carry = M & 1;
     if (Phi) hipLaunchKernelGGL((k_bvp_reduce<NU>), dim3(npairs + carry, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
@@ -332,7 +392,8 @@ static hipError_t bvp_solve_impl(const double* Phi, long ldp, const double* defe
     M = npairs + carry;
     ++level;
   }
-  hipLaunchKernelGGL((k_bvp_final<NU>), dim3((n_batch + 63) / 64), dim3(64), 0, st, a, cur);
+  // remaining levels (M <= 32), final solve and their back-substitution in one launch per trajectory
+  hipLaunchKernelGGL((k_bvp_tail<NU>), dim3(n_batch), dim3(512), 0, st, a, level, M, cur, nxt, Phi ? 1 : 0);
   for (int l = level - 1; l >= 0; --l) {
     const int npairs = Ms[l] / 2;
     hipLaunchKernelGGL((k_bvp_backsub<NU>), dim3((npairs + 63) / 64, n_batch), dim3(64), 0, st, a, l, Ms[l]);
