@@ -13,7 +13,11 @@
 namespace lto {
 
 // Control-law modes of CRTBP_stateCostate_deriv! (stateCostate_deriv.jl:36-53).
-enum PMode : int { PM_P0 = 0, PM_P1 = 1, PM_P2 = 2, PM_PGEN = 3, PM_MIXED = 4 };
+enum PMode : int { PM_P0 = 0, PM_P1 = 1, PM_P2 = 2, PM_PGEN = 3, PM_NCLASS = 4 };
+// Control-law class of an exponent p (valid p only: 0, 1 or > 1).  Every kernel is compiled for ONE class, so the law
+// is straight-line code; a batch that mixes classes is swept by one launch per class present, each launch skipping the
+// other classes' trajectories (IndirectArgs::class_filter).
+__host__ __device__ inline int p_class(double p) { return (p == 1.0) ? PM_P1 : (p == 2.0) ? PM_P2 : (p == 0.0) ? PM_P0 : PM_PGEN; }
 
 // Per-trajectory constants, precomputed on the host in the reference's operation order.
 struct TrajParams {
@@ -113,14 +117,8 @@ __device__ __forceinline__ void control_law(const TrajParams& tp, const double a
 template <int PM, bool VAR>
 __device__ __forceinline__ void control_dispatch(const TrajParams& tp, const double aL, double n, double inv_n, double& m,
                                                  double& ua, double& ub, double& un, bool& tlim) {
-  if (PM == PM_MIXED) {
-    if (tp.p == 1.0) control_law<PM_P1, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
-    else if (tp.p == 2.0) control_law<PM_P2, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
-    else if (tp.p == 0.0) control_law<PM_P0, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
-    else control_law<PM_PGEN, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
-  } else {
-    control_law<PM, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
-  }
+  static_assert(PM >= PM_P0 && PM < PM_NCLASS, "kernels are compiled per control-law class");
+  control_law<PM, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
 }
 
 // A1: ydot for y = (r, v, lambda_r, lambda_v); optionally the column coefficients.

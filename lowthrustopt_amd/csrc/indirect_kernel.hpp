@@ -81,6 +81,11 @@ __device__ __forceinline__ void run_rkf78_adaptive(const Sys& sys, const double 
       ++nacc;
     } else {
       ++nrej;
+      if (delta != delta) {                   // NaN step: poison the result instead of returning a partial one
+#pragma unroll
+        for (int i = 0; i < D; ++i) y[i] = delta;
+        t = span;                             // (fmin below would drop the NaN and keep stepping)
+      }
     }
     if (delta == 0.0) delta = 1e-16;
     h = fmin(hmax, 0.8 * h * sqrt(sqrt(sqrt(tau / delta))));
@@ -149,6 +154,11 @@ __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, co
       h_abs = h * fmax(0.2, 0.9 * pow_m8th(err));
       rejected = 1.0;
       ++nrej;
+      if (err != err) {                       // a NaN never recovers: poison and stop instead of max_steps retries
+#pragma unroll
+        for (int i = 0; i < D; ++i) y[i] = err;
+        t = span;
+      }
     }
   }
 }
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(64) void k_indirect_dense(const IndirectArgs a, con
   using Sys = SysIndirect<ND, PM, 0>;
   Sys sys;
   sys.tp = a.tp[(long)traj * a.tp_stride];
+  if (a.class_filter && p_class(sys.tp.p) != PM) return;
   sys.w2 = 2.0 * sys.tp.omega;
   double y[ND];
 #pragma unroll
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(64) void k_indirect(const IndirectArgs a) {
   constexpr int D = Sys::DIM;
   Sys sys;
   sys.tp = a.tp[(long)traj * a.tp_stride];
+  if (a.class_filter && p_class(sys.tp.p) != PM) return;   // mixed-class batch: another launch owns this trajectory
   sys.w2 = 2.0 * sys.tp.omega;
 
   double y[D];
@@ -278,24 +290,31 @@ static hipError_t launch_one(const IndirectArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// `pm` = bit mask of the control-law classes present in the batch.  One launch per class; with more than one class
+// each launch filters its own trajectories (class_filter), so no kernel ever branches on p.
+
 template <int ND, int METHOD>
-static hipError_t launch_dense_pm(int pm, const IndirectArgs& a, const DenseArgs& d, hipStream_t st) {
-  dim3 grid((a.S + 63) / 64);
-  switch (pm) {
-    case PM_P1: hipLaunchKernelGGL((k_indirect_dense<ND, PM_P1, METHOD>), grid, dim3(64), 0, st, a, d); break;
-    case PM_P2: hipLaunchKernelGGL((k_indirect_dense<ND, PM_P2, METHOD>), grid, dim3(64), 0, st, a, d); break;
-    default: hipLaunchKernelGGL((k_indirect_dense<ND, PM_MIXED, METHOD>), grid, dim3(64), 0, st, a, d); break;
-  }
+static hipError_t launch_dense_pm(int pm, const IndirectArgs& a0, const DenseArgs& d, hipStream_t st) {
+  dim3 grid((a0.S + 63) / 64);
+  IndirectArgs a = a0;
+  a.class_filter = single_class(pm) ? 0 : 1;
+  if (pm & (1 << PM_P0)) hipLaunchKernelGGL((k_indirect_dense<ND, PM_P0, METHOD>), grid, dim3(64), 0, st, a, d);
+  if (pm & (1 << PM_P1)) hipLaunchKernelGGL((k_indirect_dense<ND, PM_P1, METHOD>), grid, dim3(64), 0, st, a, d);
+  if (pm & (1 << PM_P2)) hipLaunchKernelGGL((k_indirect_dense<ND, PM_P2, METHOD>), grid, dim3(64), 0, st, a, d);
+  if (pm & (1 << PM_PGEN)) hipLaunchKernelGGL((k_indirect_dense<ND, PM_PGEN, METHOD>), grid, dim3(64), 0, st, a, d);
   return hipGetLastError();
 }
 
 template <int ND, int METHOD, int COLS>
-static hipError_t launch_pm(int pm, const IndirectArgs& a, hipStream_t st) {
-  switch (pm) {
-    case PM_P1: return launch_one<ND, PM_P1, METHOD, COLS>(a, st);
-    case PM_P2: return launch_one<ND, PM_P2, METHOD, COLS>(a, st);
-    default: return launch_one<ND, PM_MIXED, METHOD, COLS>(a, st);  // p = 0, general p > 1, mixed batches
-  }
+static hipError_t launch_pm(int pm, const IndirectArgs& a0, hipStream_t st) {
+  IndirectArgs a = a0;
+  a.class_filter = single_class(pm) ? 0 : 1;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_one<ND, PM_P0, METHOD, COLS>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_one<ND, PM_P1, METHOD, COLS>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_one<ND, PM_P2, METHOD, COLS>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_one<ND, PM_PGEN, METHOD, COLS>(a, st);
+  return e;
 }
 
 }  // namespace lto

@@ -21,6 +21,7 @@ struct IndirectArgs {
   double* errors;                  // [S] or null
   double* Phi; long ldp;           // [144][ldp] (col*12+row) or null
   int* nacc; int* nrej;            // [S] adaptive step counters or null
+  int class_filter;                // set by the launchers: 1 = this launch handles only trajectories of the kernel's p-class
 };
 
 struct DirectArgs {
@@ -36,7 +37,9 @@ struct DirectArgs {
   double* dtf;                     // [nstate][ldd] or null
 };
 
-// Launchers return hipSuccess or the launch error.  `pm` is a PMode, `method` a Method.
+static inline bool single_class(int pm) { return (pm & (pm - 1)) == 0; }   // pm: bit mask of p-classes
+
+// Launchers return hipSuccess or the launch error.  `pm` is a bit mask of the PMode classes present in the batch (bit c = class c), `method` a Method.
 hipError_t launch_indirect_defect(int pm, int method, const IndirectArgs& a, hipStream_t st);
 // cols_per_lane in {1,2,3}; 0 = choose from S.
 hipError_t launch_indirect_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);

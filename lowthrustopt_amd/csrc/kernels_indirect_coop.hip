@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
   const int role = is_base ? ND : col;                         // row of s_part
   const int s_raw = blockIdx.x * COOP_SEG + seg;
   const int s = s_raw < a.S ? s_raw : a.S - 1;                 // shadow lanes repeat the last segment
-  const bool writer = (s_raw < a.S) && (rho <= ND);
+  const bool in_range = (s_raw < a.S) && (rho <= ND);
 
   const int traj = s / a.seg_per_traj;
   const int i = s - traj * a.seg_per_traj;
@@ -84,6 +84,10 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
   const double span = a.t[tg + 1] - a.t[tg];
   const TrajParams tp = a.tp[(long)traj * a.tp_stride];
   const double w2 = 2.0 * tp.omega;
+  // mixed-class batch: segments of another control-law class are owned by that class's launch; here they idle
+  // through the barriers (never stored, never hold the adaptive loop open)
+  const bool mine = !a.class_filter || p_class(tp.p) == PM;
+  if (!__syncthreads_or(mine)) return;         // workgroup-uniform
 
   // state of this lane: base state (base wave) or one STM column (column waves)
   double y[ND], K[NSL][ND];
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
           if (tabB<METHOD>(k) != 0.0) acc = __builtin_fma(tabB<METHOD>(k), K[k][c], acc);
         y[c] = __builtin_fma(h, acc, y[c]);
       }
-      if (METHOD == M_RKF78_FIXED && is_base) {
+      if constexpr (METHOD == M_RKF78_FIXED) if (is_base) {
 #pragma unroll
         for (int c = 0; c < ND; ++c)
           maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
     const double rtol = a.rtol, atol = a.atol;
     double h_abs = 0.0, t = 0.0;
     double rejected = 0.0;
-    int done = !(span > 0.0);
+    int done = !(span > 0.0) || !mine;
     if (DOP) {
       // Hairer initial step over all ND + ND^2 components.  Row r of every column is scaled with the BASE value
       // of row r (a dual number's partials share the scale of its value), published by the base lane.
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
           if (tabB<METHOD>(k) != 0.0) acc = __builtin_fma(tabB<METHOD>(k), K[k][c], acc);
         yn[c] = __builtin_fma(h, acc, y[c]);
       }
-      double accept;
+      double accept, bad = 0.0;
       if (DOP) {
         if (is_base) {
 #pragma unroll
@@ -273,30 +277,40 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
         } else {
           h_abs = h * fmax(0.2, 0.9 / sqrt(sqrt(sqrt(err))));
           accept = 0.0;
+          if (err != err) bad = err;           // a NaN never recovers: poison the segment and stop (below)
         }
         __syncthreads();                       // s_part is rewritten by the next trial
       } else {
         // ode78: error and |x|_inf over the BASE state only (ode.jl:492-497): the base lane decides, LDS broadcasts
         if (is_base) {
-          double delta = 0.0, nx = 0.0;
+          double delta = 0.0, nx = 0.0, gsum = 0.0;
 #pragma unroll
           for (int c = 0; c < ND; ++c) {
-            delta = fmax(delta, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
+            const double g = (K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0));
+            delta = fmax(delta, fabs(g));
             nx = fmax(nx, fabs(y[c]));
+            gsum += g + y[c];
           }
+          if (gsum != gsum) delta = gsum;     // fmax drops NaNs; the reference's maximum() propagates them
           const double tau = rtol * fmax(nx, 1.0);
           const int acc_i = delta <= tau;
           if (delta == 0.0) delta = 1e-16;
-          s_ctrl[seg].h = fmin(hmax, 0.8 * h * sqrt(sqrt(sqrt(tau / delta))));
+          const double hn = 0.8 * h * sqrt(sqrt(sqrt(tau / delta)));
+          s_ctrl[seg].h = (hn != hn) ? hn : fmin(hmax, hn);   // keep a NaN visible (fmin would drop it)
           s_ctrl[seg].accept = acc_i;
         }
         __syncthreads();
         h_abs = s_ctrl[seg].h;
         accept = s_ctrl[seg].accept ? 1.0 : 0.0;
+        if (h_abs != h_abs) bad = h_abs;
         __syncthreads();
       }
       if (!done) {
-        if (accept != 0.0) {
+        if (bad != 0.0) {                      // NaN in the step: NaN results (status_flag 2 upstream), no max_steps stall
+#pragma unroll
+          for (int c = 0; c < ND; ++c) y[c] = bad;
+          t = span;
+        } else if (accept != 0.0) {
           t = (DOP && last != 0.0) ? span : t + h;
 #pragma unroll
           for (int c = 0; c < ND; ++c) y[c] = yn[c];
@@ -318,6 +332,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
     }
   }
 
+  const bool writer = in_range && mine;
   if (writer) {
     if (is_base) {
       if (a.defect) {
@@ -342,12 +357,15 @@ static hipError_t launch_coop_one(const IndirectArgs& a, hipStream_t st) {
 }
 
 template <int ND, int METHOD>
-static hipError_t launch_coop_pm(int pm, const IndirectArgs& a, hipStream_t st) {
-  switch (pm) {
-    case PM_P1: return launch_coop_one<ND, PM_P1, METHOD>(a, st);
-    case PM_P2: return launch_coop_one<ND, PM_P2, METHOD>(a, st);
-    default: return launch_coop_one<ND, PM_MIXED, METHOD>(a, st);
-  }
+static hipError_t launch_coop_pm(int pm, const IndirectArgs& a0, hipStream_t st) {
+  IndirectArgs a = a0;
+  a.class_filter = single_class(pm) ? 0 : 1;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_coop_one<ND, PM_P0, METHOD>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_coop_one<ND, PM_P1, METHOD>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_coop_one<ND, PM_P2, METHOD>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_coop_one<ND, PM_PGEN, METHOD>(a, st);
+  return e;
 }
 
 hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const IndirectArgs& a, hipStream_t st) {

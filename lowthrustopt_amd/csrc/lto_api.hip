@@ -35,7 +35,7 @@ struct lto_ctx {
 struct lto_indirect_plan {
   lto_ctx* ctx;
   int ndim, n_nodes, n_batch, S;
-  int pm;           // PMode
+  int pm;           // bit mask of the PMode classes present in the batch
   int n_prm;        // 1 or n_batch
   lto_integrator integ;
   TrajParams* d_tp;
@@ -123,7 +123,7 @@ void pool_free(lto_ctx* c, void* ptr, size_t bytes) {
 bool p_valid(double p) { return p == 0.0 || p == 1.0 || p > 1.0; }
 
 int make_traj_params(lto_ctx* c, int ndim, const lto_params* prm, int n, TrajParams* out, int* pm_out) {
-  int pm = -1;
+  int pm = 0;
   for (int i = 0; i < n; ++i) {
     const lto_params& q = prm[i];
     if (!p_valid(q.p)) return set_err(c, LTO_EBADP, "Invalid value of p!");
@@ -140,10 +140,9 @@ int make_traj_params(lto_ctx* c, int ndim, const lto_params* prm, int n, TrajPar
     t.omega = q.time_direction;
     t.MU = q.MU;
     out[i] = t;
-    const int m = (q.p == 1.0) ? PM_P1 : (q.p == 2.0) ? PM_P2 : PM_MIXED;
-    pm = (pm < 0 || pm == m) ? m : PM_MIXED;
+    pm |= 1 << p_class(q.p);
   }
-  *pm_out = pm < 0 ? PM_MIXED : pm;
+  *pm_out = pm;                                  // bit mask of the control-law classes present
   return LTO_OK;
 }
 
@@ -247,7 +246,7 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (rc) return rc;
   TrajParams* h = (TrajParams*)std::malloc(sizeof(TrajParams) * (size_t)n_prm);
   if (!h) return set_err(c, LTO_EHIP, "host allocation failed");
-  int pm = PM_MIXED;
+  int pm = 0;
   rc = make_traj_params(c, ndim, prm, n_prm, h, &pm);
   if (rc) { std::free(h); return rc; }
   lto_indirect_plan* p = new (std::nothrow) lto_indirect_plan();

@@ -81,7 +81,7 @@ __device__ __forceinline__ double rkf78_step(const Sys& sys, const double h, con
     }
     sys.rhs(yt, K[s]);
   }
-  double delta = 0.0;
+  double delta = 0.0, gsum = 0.0;              // fmax drops NaNs; gsum keeps them (the reference's maximum() propagates)
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     double a = 0.0;
@@ -92,9 +92,10 @@ __device__ __forceinline__ double rkf78_step(const Sys& sys, const double h, con
     if (i < NERR) {
       const double g = (K[0][i] + K[10][i] - K[11][i] - K[12][i]) * (h * (41.0 / 840.0));
       delta = fmax(delta, fabs(g));
+      gsum += g;
     }
   }
-  return delta;
+  return (gsum != gsum) ? gsum : delta;
 }
 
 // ------------------------------------------------------------------------------------ DOP853
@@ -235,13 +236,14 @@ __device__ __forceinline__ double rkf78_step_mem(const Sys& sys, const double h,
   sys.rhs(y, K[0]);
   stages_mem<Sys>(sys, kTabRKF78, 13, h, y, K);
   combine_mem<Sys>(kTabRKF78, 13, h, y, K, ynew);
-  double delta = 0.0;
+  double delta = 0.0, gsum = 0.0;
 #pragma unroll
   for (int i = 0; i < NERR; ++i) {
     const double g = (K[0][i] + K[10][i] - K[11][i] - K[12][i]) * (h * (41.0 / 840.0));
     delta = fmax(delta, fabs(g));
+    gsum += g;
   }
-  return delta;
+  return (gsum != gsum) ? gsum : delta;
 }
 
 // DOP853 trial step, memory-resident slopes; same contract as dop853_try (K[0] = f(y) on entry, K[12] = f(ynew) on exit).

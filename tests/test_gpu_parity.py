@@ -122,16 +122,18 @@ def test_indirect_stm_adaptive_vs_oracle(gpu_ctx, oracle, mname, pcase):
     assert np.abs(Phi - Phi_o).max() < (1e-5 if tol_d > 1e-10 else 1e-7) * np.abs(Phi_o).max()
 
 
+@pytest.mark.parametrize("pp", [1.0, 2.0, 1.5, 0.0])
 @pytest.mark.parametrize("cols", [1, 2, 3])
-def test_indirect_stm_cols_per_lane_agree(gpu_ctx, cols):
-    """All column-group mappings (1, 2, 3 STM columns per lane) produce the same Phi to round-off."""
+def test_indirect_stm_cols_per_lane_agree(gpu_ctx, cols, pp):
+    """All column-group mappings (1, 2, 3 STM columns per lane) produce the same Phi to round-off, for every
+    control-law class."""
     import torch
     n = 200
     XC, T = synth.indirect_problem(n, seed=4)
     X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
     t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
     S = n - 1
-    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, pp, 1.0)
     plan = lto.IndirectPlan(gpu_ctx, n, 1, prm, lto.integrator(lto.RK4, steps=32))
     out = {}
     for c in (1, cols):
@@ -183,8 +185,8 @@ def test_indirect_batch_homotopy_levels(gpu_ctx):
     assert Phi.shape == (12, 12, n - 1, B) and d.shape == (12, n - 1, B)
     for b in range(B):
         Phi1, d1 = lto.indirect_stm(XC[:, :, b], T[:, b], prms[b], integ, ctx=gpu_ctx)
-        # a mixed-p batch runs the runtime-dispatch kernel variant, singles the p-specialised ones: same
-        # arithmetic, different instruction schedule => agreement to round-off, not bit-for-bit
+        # a batch that mixes control-law classes is swept by one launch per class with the same p-specialised kernels
+        # the singles use (each launch filters its own trajectories)
         assert np.abs(d[:, :, b] - d1).max() < 1e-13
         assert np.abs(Phi[:, :, :, b] - Phi1).max() < 1e-12 * np.abs(Phi1).max()
         assert np.abs(dd[:, :, b] - d1).max() < 1e-13
@@ -194,6 +196,53 @@ def test_indirect_batch_homotopy_levels(gpu_ctx):
     for b in range(4):
         d1, _ = lto.indirect_defectCalc(XC2[:, :, b], T[:, 0], prms[0], integ, ctx=gpu_ctx)
         assert np.array_equal(d2[:, :, b], d1)
+
+
+@pytest.mark.parametrize("ndim", [12, 14])
+@pytest.mark.parametrize("mname", list(METHODS))
+@pytest.mark.parametrize("kernel", ["per_lane", "coop"])
+def test_indirect_mixed_control_law_classes(gpu_ctx, ndim, mname, kernel):
+    """A batch whose trajectories use all four control-law classes (p = 0, 1, 2, general p > 1; indirect.jl params
+    tuple, stateCostate_deriv.jl:36-53) with segments of different classes inside one wavefront / workgroup: defect,
+    STM and step counts equal those of single-trajectory sweeps, for every integrator and both STM kernel families."""
+    import torch
+    method, steps = METHODS[mname]
+    if ndim == 14 and method == lto.RKF78_ADAPTIVE and kernel == "per_lane":
+        pytest.skip("per-lane RKF78-adaptive STM is not instantiated for ND = 14")
+    ps = [1.0, 0.0, 2.0, 1.5, 1.0, 2.0, 3.0]
+    B, n = len(ps), 8                                          # 7 segments per trajectory: classes interleave in a wave
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=31, dt_range=(0.05, 0.3))
+    if ndim == 14:
+        X = np.zeros((14, n, B), order="F")
+        X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+        slot = 2000.0
+    else:
+        X, slot = XC, 1000.0
+    prms = [lto.make_params(MU, DU, TU, 0.05 * (1 + b % 3), slot, 1.0, ps[b], 0.5 ** b) for b in range(B)]
+    integ = lto.integrator(method, steps=steps)
+    S = n - 1
+
+    def run(Xh, Th, pr, nb):
+        plan = lto.IndirectPlan(gpu_ctx, n, nb, pr, integ, ndim=ndim)
+        plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
+        Xd = torch.from_numpy(synth.to_soa_nodes(Xh)).cuda()
+        td = torch.from_numpy(np.ascontiguousarray(Th.T.reshape(-1) if Th.ndim == 2 else Th)).cuda()
+        J = S * nb
+        Phi = torch.zeros(ndim * ndim, J, dtype=torch.float64, device="cuda")
+        d = torch.zeros(ndim, J, dtype=torch.float64, device="cuda")
+        d0 = torch.full((ndim, J), 7.0, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n * nb, td, nb, Phi, J, d, J)
+        plan.defect(Xd, n * nb, td, nb, d0, J)
+        torch.cuda.synchronize()
+        return Phi.cpu().numpy(), d.cpu().numpy(), d0.cpu().numpy()
+
+    Phi, d, d0 = run(X, T, prms, B)
+    assert np.all(np.isfinite(Phi)) and np.all(np.isfinite(d)) and np.all(np.isfinite(d0))
+    for b in range(B):
+        Phi1, d1, d01 = run(X[:, :, b], T[:, b], prms[b], 1)
+        sl = slice(b * S, (b + 1) * S)
+        assert np.array_equal(Phi[:, sl], Phi1), "STM, trajectory %d (p = %g)" % (b, ps[b])
+        assert np.array_equal(d[:, sl], d1) and np.array_equal(d0[:, sl], d01)
 
 
 def test_indirect_backward_time_direction(gpu_ctx, oracle):
@@ -282,6 +331,128 @@ def test_indirect_full_size_properties(gpu_ctx, oracle):
     torch.cuda.synchronize()
     assert float(d2[:, 0].abs().max()) < 1e-14
     assert torch.equal(d2, plan2)
+
+
+@pytest.mark.parametrize("ndim", [12, 14])
+@pytest.mark.parametrize("mname", ["rkf78_adaptive", "dop853_adaptive"])
+@pytest.mark.parametrize("kernel", ["per_lane", "coop"])
+def test_indirect_adaptive_nan_is_poison_not_a_stall(gpu_ctx, ndim, mname, kernel):
+    """A NaN node under an adaptive integrator: the segment leaving it and the one arriving at it come back NaN
+    (status_flag = 2 path, indirect.jl:339-341), every other segment is untouched, and the sweep does not spin
+    through max_steps rejected trials (the reference's solver aborts on NaN; here the step loop exits at once)."""
+    import time
+    import torch
+    method, steps = METHODS[mname]
+    if ndim == 14 and method == lto.RKF78_ADAPTIVE and kernel == "per_lane":
+        pytest.skip("per-lane RKF78-adaptive STM is not instantiated for ND = 14")
+    n = 40
+    XC, T = synth.indirect_problem(n, seed=21)
+    XC, t = XC[:, :, 0], T[:, 0]
+    if ndim == 14:
+        X = np.zeros((14, n), order="F")
+        X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+        prm_l = [MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+    else:
+        X = XC.copy()
+        prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+    S = n - 1
+    bad = 17
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(method, steps=steps, max_steps=100000),
+                            ndim=ndim)
+    plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
+    td = torch.from_numpy(np.ascontiguousarray(t)).cuda()
+
+    def sweep(Xh):
+        Xd = torch.from_numpy(synth.to_soa_nodes(Xh)).cuda()
+        Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        d0 = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+        plan.defect(Xd, n, td, 1, d0, S)
+        torch.cuda.synchronize()
+        return Phi.cpu().numpy(), d.cpu().numpy(), d0.cpu().numpy(), time.perf_counter() - t0
+
+    Phi_ok, d_ok, d0_ok, _ = sweep(X)
+    Xn = X.copy()
+    Xn[1, bad] = np.nan
+    Phi_n, d_n, d0_n, dt = sweep(Xn)
+    assert dt < 0.25, "NaN segment stalled the sweep for %.3f s" % dt
+    for dd, ref in ((d_n, d_ok), (d0_n, d0_ok)):
+        assert np.all(np.isnan(dd[:, bad])) and np.isnan(dd[1, bad - 1])
+        keep = np.ones(S, bool); keep[[bad - 1, bad]] = False
+        assert np.array_equal(dd[:, keep], ref[:, keep])
+    assert np.all(np.isnan(Phi_n[:, bad]))
+    keep = np.ones(S, bool); keep[bad] = False
+    assert np.array_equal(Phi_n[:, keep], Phi_ok[:, keep])
+
+
+def test_indirect_homotopy_full_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[3] size (64 trajectories x 64 rho-levels x 64 segments = 262 144 segments, RK4 x 64, defect
+    only): the batched launch equals per-level launches bit for bit on a sample of levels, matches the oracle on a
+    sample of segments, and levels that share nodes but differ in rho give different defects (the per-level parameter
+    tuple is really used)."""
+    import torch
+    n, B = 65, 4096
+    XC1, T = synth.indirect_problem(n, n_batch=64, seed=5)
+    XC = np.asfortranarray(np.repeat(XC1, 64, axis=2))            # trajectory-major: batch b = traj*64 + level
+    rhos = np.geomspace(1.0, 1e-4, 64)
+    prm_list = [[MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, float(rhos[b % 64])] for b in range(B)]
+    prms = [lto.make_params(*q) for q in prm_list]
+    integ = lto.integrator(lto.RK4, steps=64)
+    tb = np.asfortranarray(np.repeat(T, 64, axis=1))
+    d, _ = lto.indirect_defectCalc(XC, tb, prms, integ, ctx=gpu_ctx)
+    assert d.shape == (12, n - 1, B) and np.all(np.isfinite(d))
+    for b in (0, 63, 64 * 17 + 31, B - 1):
+        d1, _ = lto.indirect_defectCalc(XC[:, :, b], tb[:, b], prms[b], integ, ctx=gpu_ctx)
+        assert np.abs(d1 - d[:, :, b]).max() < 1e-12 * max(1.0, np.abs(d1).max())
+        for i in (0, 31, 63):
+            y, rc, _, _ = oracle.flow_state_costate(XC[:, i, b], prm_list[b], tb[i + 1, b] - tb[i, b], oracle.RK4, 64)
+            assert rc == 0
+            assert np.linalg.norm(d[:, i, b] - (y - XC[:, i + 1, b])) < 1e-10 * np.linalg.norm(y)
+    assert np.abs(d[:, :, 0] - d[:, :, 63]).max() > 1e-6           # rho = 1 vs rho = 1e-4 on the same nodes
+
+
+def test_indirect_adaptive_full_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[4] size (65 536 segments, adaptive order 8 @ 1e-13, + STM): every Phi symplectic, a sample of
+    segments equals the oracle, step counts are positive and bounded, and the cooperative and per-lane kernels agree
+    to the integrator tolerance."""
+    import torch
+    S = 65536
+    n = S + 1
+    XC, T = synth.indirect_problem(n, seed=3, dt_range=(0.02, 0.4))
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator())
+    out = {}
+    for kern in (plan.KERNEL_COOP, plan.KERNEL_PER_LANE):
+        plan.set_kernel(kern)
+        Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(X, n, t, 1, Phi, S, d, S)
+        torch.cuda.synchronize()
+        acc, rej = plan.step_counts()
+        assert acc.min() >= 1 and acc.max() <= 200 and rej.min() >= 0 and rej.max() <= 200
+        out[kern] = (Phi, d)
+    Phi, d = out[plan.KERNEL_COOP]
+    Phi2, d2 = out[plan.KERNEL_PER_LANE]
+    assert float((d - d2).abs().max()) < 1e-9
+    assert float((Phi - Phi2).abs().max() / Phi.abs().max()) < 1e-7
+    P = Phi.reshape(12, 12, S).permute(1, 0, 2)                  # [row, col, s]
+    Om = torch.zeros(12, 12, dtype=torch.float64, device="cuda")
+    Om[:6, 6:] = torch.eye(6, dtype=torch.float64); Om[6:, :6] = -torch.eye(6, dtype=torch.float64)
+    PtOP = torch.einsum("ris,rq,qjs->ijs", P, Om, P)
+    scale = torch.clamp(P.abs().amax(dim=(0, 1)) ** 2, min=1.0)
+    assert float(((PtOP - Om[:, :, None]).abs().amax(dim=(0, 1)) / scale).max()) < 1e-9
+    Pn = P.cpu().numpy(); dn = d.cpu().numpy()
+    for i in range(0, S, 4096):
+        y, Phi_o, rc, _, _ = oracle.flow_stm_state_costate(XC[:, i, 0], prm_l, T[i + 1, 0] - T[i, 0],
+                                                           oracle.DOP853_ADAPTIVE, 0)
+        assert rc == 0
+        assert np.abs(Pn[:, :, i] - Phi_o).max() < 1e-9 * np.abs(Phi_o).max()
+        assert np.linalg.norm(dn[:, i] - (y - XC[:, i + 1, 0])) < 1e-10 * np.linalg.norm(y)
 
 
 # ------------------------------------------------------------------------------------------------ direct
@@ -387,11 +558,13 @@ def test_pack_unpack_and_norms(gpu_ctx):
     assert bool(torch.isnan(mx[2])) and bool(torch.isfinite(mx[[0, 1, 3, 4, 5, 6]]).all())
 
 
+@pytest.mark.parametrize("pcase", ["p1_rho1", "p2_clamped", "p1.5", "p0"])
 @pytest.mark.parametrize("ndim", [12, 14])
 @pytest.mark.parametrize("mname", list(METHODS))
 @pytest.mark.parametrize("kernel", ["per_lane", "coop"])
-def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, kernel):
-    """Both STM kernel families (per-lane: every lane re-integrates the base state; cooperative: base wave + column
+def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, kernel, pcase):
+    """Every instantiated STM kernel (family x integrator x dimension x control-law class) against the oracle.
+    Both STM kernel families (per-lane: every lane re-integrates the base state; cooperative: base wave + column
     waves exchanging the variational coefficients through LDS) against the oracle's dual-number STM, for every
     integrator, ND = 12 and the 14-dim extension, ragged segment count (not a multiple of 16 or 64)."""
     import torch
@@ -399,15 +572,16 @@ def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, ke
     if ndim == 14 and method == lto.RKF78_ADAPTIVE and kernel == "per_lane":
         pytest.skip("per-lane RKF78-adaptive STM is not instantiated for ND = 14")
     n = 78
-    XC, T = synth.indirect_problem(n, seed=11)
+    pp, rho, thr, lam = P_CASES[pcase]
+    XC, T = synth.indirect_problem(n, seed=11, lam_sigma=lam)
     XC, t = XC[:, :, 0], T[:, 0]
     if ndim == 14:
         X = np.zeros((14, n), order="F")
         X[:6] = XC[:6]; X[6] = 1000.0 - 0.02 * np.arange(n); X[7:13] = XC[6:]; X[13] = 0.2
-        prm_l = [MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+        prm_l = [MU, DU, TU, thr, 2000.0, 1.0, pp, rho]
     else:
         X = XC
-        prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+        prm_l = [MU, DU, TU, thr, 1000.0, 1.0, pp, rho]
     S = n - 1
     plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(method, steps=steps), ndim=ndim)
     plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
