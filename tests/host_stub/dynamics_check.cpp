@@ -12,7 +12,8 @@ void chk_rhs14(const double* y, const double* tpv, int pm, double* dy, const dou
   VarCoef14 vc;
   if (pm == PM_P1) rhs14<PM_P1, true>(yy, tp, d, vc);
   else if (pm == PM_P2) rhs14<PM_P2, true>(yy, tp, d, vc);
-  else rhs14<PM_MIXED, true>(yy, tp, d, vc);
+  else if (pm == PM_P0) rhs14<PM_P0, true>(yy, tp, d, vc);
+  else rhs14<PM_PGEN, true>(yy, tp, d, vc);
   var_col14(vc, 2.0 * tp.omega, c, dc);
   for (int i = 0; i < 14; ++i) { dy[i] = d[i]; dcol[i] = dc[i]; }
 }
@@ -23,14 +24,16 @@ void chk_rhs12(const double* y, const double* tpv, int pm, double* dy, const dou
   VarCoef12 vc;
   if (pm == PM_P1) rhs12<PM_P1, true>(yy, tp, d, vc);
   else if (pm == PM_P2) rhs12<PM_P2, true>(yy, tp, d, vc);
-  else rhs12<PM_MIXED, true>(yy, tp, d, vc);
+  else if (pm == PM_P0) rhs12<PM_P0, true>(yy, tp, d, vc);
+  else rhs12<PM_PGEN, true>(yy, tp, d, vc);
   var_col12(vc, 2.0 * tp.omega, c, dc);
   for (int i = 0; i < 12; ++i) { dy[i] = d[i]; dcol[i] = dc[i]; }
   double y24[24], k24[24];
   for (int i = 0; i < 12; ++i) { y24[i] = y[i]; y24[12 + i] = col[i]; }
   if (pm == PM_P1) rhs12_fused1<PM_P1>(y24, tp, 2.0 * tp.omega, k24);
   else if (pm == PM_P2) rhs12_fused1<PM_P2>(y24, tp, 2.0 * tp.omega, k24);
-  else rhs12_fused1<PM_MIXED>(y24, tp, 2.0 * tp.omega, k24);
+  else if (pm == PM_P0) rhs12_fused1<PM_P0>(y24, tp, 2.0 * tp.omega, k24);
+  else rhs12_fused1<PM_PGEN>(y24, tp, 2.0 * tp.omega, k24);
   for (int i = 0; i < 12; ++i) { dy_f[i] = k24[i]; dcol_f[i] = k24[12 + i]; }
 }
 int chk_sizeof_tp() { return (int)sizeof(TrajParams); }

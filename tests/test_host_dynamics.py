@@ -13,7 +13,7 @@ from lowthrustopt_amd.constants import MU, DU, TU
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-PM_P1, PM_P2, PM_MIXED = 1, 2, 4
+PM_P0, PM_P1, PM_P2, PM_PGEN = 0, 1, 2, 3     # dynamics.hpp PMode: one compiled control law per class
 
 
 @pytest.fixture(scope="module")
@@ -38,8 +38,8 @@ def tp_vec(ndim, thr, mass_or_isp, td, p, rho):
 
 
 CASES = [(1.0, 1.0, 0.05, 0.1, PM_P1), (1.0, 1e-2, 0.05, 1.0, PM_P1), (1.0, 1e-4, 10.0, 1.0, PM_P1), (2.0, 1.0, 10.0, 0.1, PM_P2),
-         (2.0, 1.0, 0.05, 1.0, PM_P2), (1.5, 1.0, 10.0, 0.3, PM_MIXED), (0.0, 1.0, 0.05, 0.1, PM_MIXED),
-         (1.0, 1.0, 0.05, 0.1, PM_MIXED), (2.0, 1.0, 10.0, 0.1, PM_MIXED), (1.2, 0.5, 0.001, 0.5, PM_MIXED)]
+         (2.0, 1.0, 0.05, 1.0, PM_P2), (1.5, 1.0, 10.0, 0.3, PM_PGEN), (0.0, 1.0, 0.05, 0.1, PM_P0),
+         (0.0, 1.0, 10.0, 1.0, PM_P0), (3.0, 1.0, 10.0, 0.1, PM_PGEN), (1.2, 0.5, 0.001, 0.5, PM_PGEN)]
 
 
 @pytest.mark.parametrize("td", [1.0, -1.0])
