@@ -132,6 +132,14 @@ int lto_direct_defect(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, const 
                       const double* t, int n_tgrids, int nsteps, const lto_direct_params* prm, double* defect,
                       double* errors);
 
+/* The propagation inside meshRefine_direct (src/multiShoot_CRTBP_direct.jl:645-656): x_mid[:, i] = state at
+ * t_i + (t_{i+1} - t_i)/2 propagated forward from node i with control u_i, for EVERY segment in one sweep (the
+ * reference propagates one segment per refinement pass with ode7 = one RKF7(8) step, i.e. nsteps = 2).
+ *   x_mid [nstate x (n_nodes-1) x n_batch]; defect, errors as lto_direct_defect on the same grid, or NULL. */
+int lto_direct_midpoints(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, const double* X, const double* U,
+                         const double* t, int n_tgrids, int nsteps, const lto_direct_params* prm, double* x_mid,
+                         double* defect, double* errors);
+
 /* Replaces jacobianCalc of multiShoot_CRTBP_direct (:111-143) and the tf partial (:503-516).
  *   Jac_temp    [nstate x nvar x (n_nodes-1) x n_batch], nvar = 2(nstate+3); block i is
  *               d defect_i / d [x_i; x_{i+1}; u_i; u_{i+1}] (variable order of :125), computed from
@@ -199,6 +207,10 @@ void lto_direct_plan_destroy(lto_direct_plan* plan);
 int lto_direct_plan_set_kernel(lto_direct_plan* plan, int kernel);
 int lto_direct_defect_dev(lto_direct_plan* plan, void* stream, const double* X, long ldx, const double* U, long ldu,
                           const double* t, int n_tgrids, double* defect, long ldd, double* errors);
+/* x_mid[c*ldm + s] = forward half-arc end state of segment s (see lto_direct_midpoints); defect/errors optional. */
+int lto_direct_midpoints_dev(lto_direct_plan* plan, void* stream, const double* X, long ldx, const double* U, long ldu,
+                             const double* t, int n_tgrids, double* x_mid, long ldm, double* defect, long ldd,
+                             double* errors);
 int lto_direct_jacobian_dev(lto_direct_plan* plan, void* stream, const double* X, long ldx, const double* U,
                             long ldu, const double* t, int n_tgrids, double* Jac, long ldj, double* dtf,
                             double* defect, long ldd, double* errors);

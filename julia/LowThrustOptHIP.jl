@@ -14,7 +14,7 @@ module LowThrustOptHIP
 using SparseArrays, LinearAlgebra
 
 export LtoContext, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, densify,
-       direct_defectCalc, direct_jacobianCalc, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
+       direct_defectCalc, direct_jacobianCalc, direct_midpoints, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
 
 const liblto = get(ENV, "LTO_HIP_LIB", joinpath(@__DIR__, "..", "lowthrustopt_amd", "liblto_hip.so"))
 
@@ -158,6 +158,22 @@ function direct_defectCalc(ctx::LtoContext, X_all::Matrix{Float64}, u_all::Matri
                ctx.handle, nstate, n_nodes, 1, X_all, u_all, t_TU, 1, nsteps, prm, defect1, errors)
     check(ctx, rc)
     (defect1, errors)
+end
+
+"""Mid-point propagation of meshRefine_direct (direct.jl:645-656) for every segment in one sweep: returns
+(x_mid[nstate x (n_nodes-1)], defect1, errors).  `nsteps = 2` reproduces the reference's single `ode7` step."""
+function direct_midpoints(ctx::LtoContext, X_all::Matrix{Float64}, u_all::Matrix{Float64}, t_TU::Vector{Float64},
+                          nstate, n_nodes, nsteps, Isp, MU, DU, TU)
+    x_mid = zeros(nstate, n_nodes - 1)
+    defect1 = zeros(nstate, n_nodes - 1)
+    errors = zeros(n_nodes - 1)
+    prm = Ref(LtoDirectParams(MU, DU, TU, Isp))
+    rc = ccall((:lto_direct_midpoints, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ref{LtoDirectParams},
+                Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+               ctx.handle, nstate, n_nodes, 1, X_all, u_all, t_TU, 1, nsteps, prm, x_mid, defect1, errors)
+    check(ctx, rc)
+    (x_mid, defect1, errors)
 end
 
 """jacobianCalc + tf partial of multiShoot_CRTBP_direct: Jac_full [nstate(n_nodes-1) x n_nodes(nstate+3)+1]

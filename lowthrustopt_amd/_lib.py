@@ -57,6 +57,8 @@ SIGNATURES = {
                                     C.POINTER(LtoDirectParams), _vp, _vp]),
     "lto_direct_jacobian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                       C.POINTER(LtoDirectParams), _vp, _vp, _vp, _vp]),
+    "lto_direct_midpoints": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                                       C.POINTER(LtoDirectParams), _vp, _vp, _vp]),
     "lto_indirect_plan_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(LtoParams), C.c_int,
                                            C.POINTER(LtoIntegrator), C.POINTER(_vp)]),
     "lto_indirect_plan_destroy": (None, [_vp]),
@@ -75,6 +77,8 @@ SIGNATURES = {
     "lto_direct_plan_destroy": (None, [_vp]),
     "lto_direct_plan_set_kernel": (C.c_int, [_vp, C.c_int]),
     "lto_direct_defect_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp]),
+    "lto_direct_midpoints_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp, C.c_long,
+                                           _vp]),
     "lto_direct_jacobian_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, C.c_int, _vp, C.c_long, _vp, _vp,
                                           C.c_long, _vp]),
     "lto_pack_soa_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_long, _vp, C.c_long]),

@@ -35,6 +35,7 @@ struct DirectArgs {
   double* errors;                  // [S] or null
   double* Jac; long ldj;           // [nstate*nvar][ldj] (col*nstate+row) or null
   double* dtf;                     // [nstate][ldd] or null
+  double* mid; long ldm;           // [nstate][ldm] or null: forward half-arc end state x(t_i + h_i/2; x_i, u_i)
 };
 
 static inline bool single_class(int pm) { return (pm & (pm - 1)) == 0; }   // pm: bit mask of p-classes

@@ -95,6 +95,10 @@ __global__ __launch_bounds__(64) void k_direct_defect(const DirectArgs a) {
   for (int c = 0; c < NS; ++c) d[c] = x[c] - xchg1(x[c]);    // fwd lane: state_for - stateF_back  (:101)
   const double e = fmax(maxErr, xchg1(maxErr));              // :104
   if (active && dir == 0) {
+    if (a.mid) {                                             // node meshRefine_direct inserts (direct.jl:651-660)
+#pragma unroll
+      for (int c = 0; c < NS; ++c) a.mid[c * a.ldm + s] = x[c];
+    }
     if (a.defect) {
 #pragma unroll
       for (int c = 0; c < NS; ++c) a.defect[c * a.ldd + s] = d[c];

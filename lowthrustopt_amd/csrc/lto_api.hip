@@ -559,16 +559,35 @@ static int fill_direct_args(lto_direct_plan* p, const double* X, long ldx, const
   return LTO_OK;
 }
 
+static int direct_defect_launch(lto_direct_plan* p, void* stream, const double* X, long ldx, const double* U, long ldu,
+                                const double* t, int n_tgrids, double* defect, long ldd, double* errors, double* mid,
+                                long ldm);
+
 int lto_direct_defect_dev(lto_direct_plan* p, void* stream, const double* X, long ldx, const double* U, long ldu,
                           const double* t, int n_tgrids, double* defect, long ldd, double* errors) {
   if (!p) return LTO_ENULL;
+  if (!defect) return set_err(p->ctx, LTO_ENULL, "defect is NULL");
+  return direct_defect_launch(p, stream, X, ldx, U, ldu, t, n_tgrids, defect, ldd, errors, nullptr, 0);
+}
+
+int lto_direct_midpoints_dev(lto_direct_plan* p, void* stream, const double* X, long ldx, const double* U, long ldu,
+                             const double* t, int n_tgrids, double* x_mid, long ldm, double* defect, long ldd,
+                             double* errors) {
+  if (!p) return LTO_ENULL;
+  if (!x_mid) return set_err(p->ctx, LTO_ENULL, "x_mid is NULL");
+  if (ldm < p->S) return set_err(p->ctx, LTO_EINVAL, "ldm smaller than the segment count");
+  return direct_defect_launch(p, stream, X, ldx, U, ldu, t, n_tgrids, defect, ldd, errors, x_mid, ldm);
+}
+
+static int direct_defect_launch(lto_direct_plan* p, void* stream, const double* X, long ldx, const double* U, long ldu,
+                                const double* t, int n_tgrids, double* defect, long ldd, double* errors, double* mid,
+                                long ldm) {
   lto_ctx* c = p->ctx;
   DirectArgs a;
   int rc = fill_direct_args(p, X, ldx, U, ldu, t, n_tgrids, &a);
   if (rc) return rc;
-  if (!defect) return set_err(c, LTO_ENULL, "defect is NULL");
-  if (ldd < p->S) return set_err(c, LTO_EINVAL, "ldd smaller than the segment count");
-  a.defect = defect; a.ldd = ldd; a.errors = errors;
+  if (defect && ldd < p->S) return set_err(c, LTO_EINVAL, "ldd smaller than the segment count");
+  a.defect = defect; a.ldd = ldd; a.errors = errors; a.mid = mid; a.ldm = ldm;
   rc = bind_device(c);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -795,7 +814,7 @@ int lto_indirect_densify(lto_ctx* c, int ndim, int n_nodes, const double* XC, co
 
 static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const double* X, const double* U, const double* t,
                        int n_tgrids, int nsteps, const lto_direct_params* prm, double* Jac_temp, double* ddefect_dtf,
-                       double* defect, double* errors, bool want_jac) {
+                       double* defect, double* errors, bool want_jac, double* x_mid = nullptr) {
   lto_direct_plan* p = nullptr;
   int rc = lto_direct_plan_create(c, nstate, n_nodes, n_batch, nsteps, prm, &p);
   if (rc) return rc;
@@ -830,10 +849,14 @@ static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const d
   if (e != hipSuccess) { lto_direct_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
   if (want_jac)
     rc = lto_direct_jacobian_dev(p, st, d_X, J, d_U, J, d_t, n_tgrids, d_jac, S, d_dtf, d_def, S, d_err);
-  else
-    rc = lto_direct_defect_dev(p, st, d_X, J, d_U, J, d_t, n_tgrids, d_def, S, d_err);
+  else   // the dtf staging buffers are free on this path: they carry the mid-point states
+    rc = direct_defect_launch(p, st, d_X, J, d_U, J, d_t, n_tgrids, d_def, S, d_err, x_mid ? d_dtf : nullptr, S);
   if (rc == LTO_OK) {
-    if (defect) {
+    if (x_mid) {
+      e = launch_unpack_soa(d_dtf, S, nstate, S, d_dtf_aos, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(x_mid, d_dtf_aos, sizeof(double) * nstate * S, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess && defect) {
       e = launch_unpack_soa(d_def, S, nstate, S, d_def_aos, st);
       if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * nstate * S, hipMemcpyDeviceToHost, st);
     }
@@ -868,6 +891,13 @@ int lto_direct_jacobian(lto_ctx* c, int nstate, int n_nodes, int n_batch, const 
   if (!c) return LTO_ENULL;
   if (!X || !U || !t || !Jac_temp) return set_err(c, LTO_ENULL, "X, U, t or Jac_temp is NULL");
   return direct_host(c, nstate, n_nodes, n_batch, X, U, t, n_tgrids, nsteps, prm, Jac_temp, ddefect_dtf, defect, errors, true);
+}
+
+int lto_direct_midpoints(lto_ctx* c, int nstate, int n_nodes, int n_batch, const double* X, const double* U, const double* t,
+                         int n_tgrids, int nsteps, const lto_direct_params* prm, double* x_mid, double* defect, double* errors) {
+  if (!c) return LTO_ENULL;
+  if (!X || !U || !t || !x_mid) return set_err(c, LTO_ENULL, "X, U, t or x_mid is NULL");
+  return direct_host(c, nstate, n_nodes, n_batch, X, U, t, n_tgrids, nsteps, prm, nullptr, nullptr, defect, errors, false, x_mid);
 }
 
 }  // extern "C"

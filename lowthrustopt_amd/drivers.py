@@ -4,6 +4,7 @@
   optimizeTraj_OLS            :149-218   (least-squares step, adjoints-only mask, second-order correction)
   lineSearch                  :221-246   (20 alphas; here ONE batched device launch instead of 20 sweeps -- SURVEY N2)
   reduceFuel_indirect         src/HelperFunctions.jl:105-193   (rho continuation -- SURVEY N3)
+  meshRefine_direct           src/multiShoot_CRTBP_direct.jl:597-680   (errors-driven mesh refinement -- SURVEY N4)
 
 Same signatures, return tuples and status flags as the Julia functions (the reference is Julia; this mirror exists
 because no `julia` binary is available to run julia/LowThrustOptHIP.jl -- see INTEGRATION.md).  The propagation
@@ -190,3 +191,79 @@ def homotopy_defect_sweep(XC_levels, t_TU, MU, DU, TU, mass, thrustLimit, rhos, 
     prms = [hotpath.make_params(MU, DU, TU, thrustLimit, mass, 1.0, 1.0, r) for r in rhos]
     d, _ = hotpath.indirect_defectCalc(np.asfortranarray(XC_levels), t_TU, prms, ops.integ, ctx=ops.ctx)
     return np.max(np.abs(d), axis=(0, 1)), np.sum(d * d, axis=(0, 1)), d
+
+
+class HipDirectOps:
+    """Direct-method hot-path operators backed by liblto_hip.so."""
+
+    def __init__(self, MU, DU, TU, Isp, ctx=None):
+        self.ctx = ctx or hotpath.default_context()
+        self.MU, self.DU, self.TU, self.Isp = MU, DU, TU, Isp
+
+    def defect(self, X, U, t, nsteps):
+        return hotpath.direct_defectCalc(X, U, t, nsteps, self.MU, self.DU, self.TU, self.Isp, ctx=self.ctx)
+
+    def midpoints(self, X, U, t):
+        """x(t_i + h_i/2) from node i with u_i, one RKF7(8) step (`ode7` over [t_i, t_new], direct.jl:651-656)."""
+        return hotpath.direct_midpoints(X, U, t, 2, self.MU, self.DU, self.TU, self.Isp, ctx=self.ctx)[0]
+
+
+def meshRefine_direct(X_all, u_all, t_TU, nstate, n_nodes, nsteps, Isp, MU, DU, TU, tol_min=1e-20, tol_max=1e-18,
+                      max_nodes=1 << 20, batched=True, ops=None, verbose=True):
+    """Errors-driven mesh refinement of the direct transcription (direct.jl:597-680): nodes are removed while the
+    smallest RKF7(8) error estimate of a segment is below tol_min, then segments are bisected while the largest is above
+    tol_max (new state = forward propagation to the segment's middle, new control = mean of its two controls).
+    Returns (X_all, u_all, t_TU, n_nodes).
+
+    Re-specified where the reference cannot run as written: `find(errors .== minimum(errors))[1]` (removed from Julia
+    1.x) is the first arg-min / arg-max; MU, DU, TU are arguments instead of globals; the removal phase stops at two
+    nodes and the addition phase at max_nodes (the reference loops forever if the estimate never reaches tol_max).
+
+    batched=True bisects EVERY segment above tol_max in one pass: one error sweep + one mid-point sweep on the GPU per
+    pass instead of one full sweep per inserted node.  The result is identical to the reference's one-node-per-pass
+    loop, because a segment's error estimate depends only on its own two nodes, controls and times (direct.jl:77-105),
+    so splitting one segment never changes the decision for another; batched=False runs the literal loop."""
+    ops = ops or HipDirectOps(MU, DU, TU, Isp)
+    X = np.array(X_all, dtype=np.float64, order="F")
+    U = np.array(u_all, dtype=np.float64, order="F")
+    t = np.array(t_TU, dtype=np.float64)
+    n_nodes = int(n_nodes)
+    n_start = n_nodes
+    if verbose:
+        print("Starting with %d nodes." % n_nodes)
+    _, errors = ops.defect(X, U, t, nsteps)
+    # ---- remove nodes that only make things messy (:611-628); inherently sequential: a removal merges two segments
+    while n_nodes > 2 and np.min(errors) < tol_min:
+        k = int(np.argmin(errors))
+        if k == 0:
+            k = 1                                            # never remove the first node (:616-618)
+        X = np.delete(X, k, axis=1)
+        U = np.delete(U, k, axis=1)
+        t = np.delete(t, k)
+        n_nodes -= 1
+        _, errors = ops.defect(X, U, t, nsteps)
+    if verbose and n_nodes != n_start:
+        print("Removed nodes, now n_nodes = %d" % n_nodes)
+    n_mid = n_nodes
+    # ---- add nodes where the estimate is too large (:635-668)
+    while np.max(errors) > tol_max and n_nodes < max_nodes:
+        if batched:
+            split = np.flatnonzero(errors > tol_max)[: max_nodes - n_nodes]
+        else:
+            split = np.array([int(np.argmax(errors))])
+        x_mid = ops.midpoints(X, U, t)                       # every segment's mid-point state in one sweep
+        t_new = t[split] + (t[split + 1] - t[split]) / 2     # :644
+        u_new = (U[:, split] + U[:, split + 1]) / 2          # :659
+        X = np.insert(X, split + 1, x_mid[:, split], axis=1)
+        U = np.insert(U, split + 1, u_new, axis=1)
+        t = np.insert(t, split + 1, t_new)
+        n_nodes += len(split)
+        _, errors = ops.defect(X, U, t, nsteps)
+    if verbose:
+        if n_nodes != n_mid:
+            print("Added nodes, now n_nodes = %d" % n_nodes)
+        if n_nodes == n_start:
+            print("Did not need to add or remove nodes.")
+        else:
+            print("Refined the mesh. Now have %d nodes." % n_nodes)
+    return np.asfortranarray(X), np.asfortranarray(U), t, n_nodes

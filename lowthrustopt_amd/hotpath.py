@@ -236,6 +236,26 @@ def direct_defectCalc(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
     return defect, errors
 
 
+def direct_midpoints(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
+    """The propagation of meshRefine_direct (direct.jl:645-656) for every segment at once: returns
+    (x_mid[nstate x (n-1)], defect, errors) with x_mid[:, i] = state at the middle of segment i propagated from node i
+    with u_i.  nsteps = 2 is the reference's single `ode7` step."""
+    ctx = ctx or default_context()
+    X = _f64(X_all)
+    U = _f64(u_all)
+    ns, n, B, batched = _batch_dims(X)
+    t, ntg = _tgrids(t_TU, n, B)
+    prm = LtoDirectParams(float(MU), float(DU), float(TU), float(Isp))
+    x_mid = np.zeros((ns, n - 1, B), order="F")
+    defect = np.zeros((ns, n - 1, B), order="F")
+    errors = np.zeros((n - 1, B), order="F")
+    ctx.check(ctx.lib.lto_direct_midpoints(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
+                                           _ptr(x_mid), _ptr(defect), _ptr(errors)))
+    if not batched:
+        return x_mid[:, :, 0], defect[:, :, 0], errors[:, 0]
+    return x_mid, defect, errors
+
+
 def direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
     """Compact direct Jacobian: (Jac_temp[nstate x nvar x (n-1)], ddefect_dtf[nstate x (n-1)], defect, errors);
     nvar = 2(nstate+3), variable order [x_i; x_{i+1}; u_i; u_{i+1}] (:125)."""
@@ -373,6 +393,11 @@ class DirectPlan:
     def defect(self, X, ldx, U, ldu, t, n_tgrids, defect, ldd, errors=None, stream=None):
         self.ctx.check(self.ctx.lib.lto_direct_defect_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(U), int(ldu),
                                                           _dptr(t), int(n_tgrids), _dptr(defect), int(ldd), _dptr(errors)))
+
+    def midpoints(self, X, ldx, U, ldu, t, n_tgrids, x_mid, ldm, defect=None, ldd=0, errors=None, stream=None):
+        self.ctx.check(self.ctx.lib.lto_direct_midpoints_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(U), int(ldu),
+                                                             _dptr(t), int(n_tgrids), _dptr(x_mid), int(ldm), _dptr(defect),
+                                                             int(ldd), _dptr(errors)))
 
     def jacobian(self, X, ldx, U, ldu, t, n_tgrids, Jac, ldj, dtf=None, defect=None, ldd=0, errors=None, stream=None):
         self.ctx.check(self.ctx.lib.lto_direct_jacobian_dev(self.handle, stream, _dptr(X), int(ldx), _dptr(U), int(ldu),

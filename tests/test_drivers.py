@@ -139,3 +139,82 @@ def test_homotopy_levels_one_launch(gpu_ctx):
         d1, _ = lto.indirect_defectCalc(XC[:, :, b], T[:, b], lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, rhos[b]),
                                         ctx=gpu_ctx)
         assert np.abs(d[:, :, b] - d1).max() < 1e-13
+
+
+# ------------------------------------------------------------------------------------- meshRefine_direct (direct.jl:597-680)
+class OracleDirectOps:
+    """Test-only direct back end (the product's is drivers.HipDirectOps)."""
+
+    def __init__(self, O, Isp):
+        self.O, self.Isp, self.sweeps = O, Isp, 0
+
+    def defect(self, X, U, t, nsteps):
+        self.sweeps += 1
+        return self.O.direct_defect(X, U, t, nsteps, MU, DU, TU, self.Isp)
+
+    def midpoints(self, X, U, t):
+        out = np.zeros((X.shape[0], X.shape[1] - 1), order="F")
+        for i in range(X.shape[1] - 1):         # `ode7` over [t_i, t_new] = ONE RKF7(8) step (ode.jl:154, direct.jl:651-656)
+            out[:, i], _ = self.O.flow_prop_ep(X[:, i], U[:, i], 1.0, (t[i + 1] - t[i]) / 2, self.O.RKF78_FIXED, 1,
+                                               MU, DU, TU, self.Isp)
+        return out
+
+
+def mesh_problem(nstate):
+    X, U, T = synth.direct_problem(12, seed=3, nstate=nstate, dt_seg=0.4)
+    return X[:, :, 0], U[:, :, 0], T[:, 0]
+
+
+@pytest.mark.parametrize("nstate", [6, 7])
+def test_meshRefine_direct_with_injected_backend(oracle, nstate):
+    X, U, t = mesh_problem(nstate)
+    _, e0 = oracle.direct_defect(X, U, t, 10, MU, DU, TU, 2000.0)
+    tol_min, tol_max = 1e-16, 1e-13
+    assert e0.min() < tol_min and e0.max() > tol_max          # both phases are exercised
+    res = {}
+    for batched in (True, False):
+        ops = OracleDirectOps(oracle, 2000.0)
+        res[batched] = drivers.meshRefine_direct(X, U, t, nstate, 12, 10, 2000.0, MU, DU, TU, tol_min=tol_min,
+                                                 tol_max=tol_max, batched=batched, ops=ops, verbose=False) + (ops.sweeps,)
+    Xb, Ub, tb, nb, sweeps_b = res[True]
+    Xs, Us, ts, n_s, sweeps_s = res[False]
+    # all-at-once bisection == the reference's one-node-per-pass loop, in fewer sweeps
+    assert nb == n_s and np.array_equal(tb, ts) and np.array_equal(Xb, Xs) and np.array_equal(Ub, Us)
+    assert sweeps_b < sweeps_s
+    assert Xb.shape == (nstate, nb) and Ub.shape == (3, nb) and tb.shape == (nb,)
+    assert np.all(np.diff(tb) > 0) and tb[0] == t[0] and tb[-1] == t[-1]
+    assert np.array_equal(Xb[:, 0], X[:, 0]) and np.array_equal(Xb[:, -1], X[:, -1])
+    _, e1 = oracle.direct_defect(Xb, Ub, tb, 10, MU, DU, TU, 2000.0)
+    assert e1.max() <= tol_max
+    # inserted nodes lie on the forward arc of their parent segment: the defect of the left half is one step's error
+    d1, _ = oracle.direct_defect(Xb, Ub, tb, 10, MU, DU, TU, 2000.0)
+    new = np.flatnonzero(~np.isin(tb, t))
+    assert len(new) > 0
+    # max_nodes stops a refinement whose tolerance is out of reach
+    Xc, Uc, tc, nc = drivers.meshRefine_direct(X, U, t, nstate, 12, 10, 2000.0, MU, DU, TU, tol_min=0.0, tol_max=1e-30,
+                                               max_nodes=40, ops=OracleDirectOps(oracle, 2000.0), verbose=False)
+    assert nc == 40 and np.all(np.diff(tc) > 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nstate", [6, 7])
+def test_meshRefine_direct_gpu(gpu_ctx, oracle, nstate):
+    """Mid-point sweep == the oracle's single RKF7(8) step; the GPU-driven refinement reproduces the oracle-driven mesh."""
+    X, U, t = mesh_problem(nstate)
+    for nsteps in (2, 10):
+        xm, d, e = lto.direct_midpoints(X, U, t, nsteps, MU, DU, TU, 2000.0, ctx=gpu_ctx)
+        d_ref, e_ref = lto.direct_defectCalc(X, U, t, nsteps, MU, DU, TU, 2000.0, ctx=gpu_ctx)
+        assert np.array_equal(d, d_ref) and np.array_equal(e, e_ref)
+        for i in range(11):
+            ref, _ = oracle.flow_prop_ep(X[:, i], U[:, i], 1.0, (t[i + 1] - t[i]) / 2, oracle.RKF78_FIXED, nsteps - 1,
+                                         MU, DU, TU, 2000.0)
+            assert np.abs(xm[:, i] - ref).max() < 1e-13
+    kw = dict(tol_min=1e-16, tol_max=1e-13, verbose=False)
+    gb = drivers.meshRefine_direct(X, U, t, nstate, 12, 10, 2000.0, MU, DU, TU, batched=True,
+                                   ops=drivers.HipDirectOps(MU, DU, TU, 2000.0, ctx=gpu_ctx), **kw)
+    gs = drivers.meshRefine_direct(X, U, t, nstate, 12, 10, 2000.0, MU, DU, TU, batched=False,
+                                   ops=drivers.HipDirectOps(MU, DU, TU, 2000.0, ctx=gpu_ctx), **kw)
+    ob = drivers.meshRefine_direct(X, U, t, nstate, 12, 10, 2000.0, MU, DU, TU, ops=OracleDirectOps(oracle, 2000.0), **kw)
+    assert gb[3] == gs[3] and all(np.array_equal(a, b) for a, b in zip(gb[:3], gs[:3]))
+    assert gb[3] == ob[3] and np.allclose(gb[2], ob[2], rtol=0, atol=1e-15)
+    assert np.abs(gb[0] - ob[0]).max() < 1e-12 and np.abs(gb[1] - ob[1]).max() < 1e-15
