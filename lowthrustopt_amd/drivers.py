@@ -5,6 +5,7 @@
   lineSearch                  :221-246   (20 alphas; here ONE batched device launch instead of 20 sweeps -- SURVEY N2)
   reduceFuel_indirect         src/HelperFunctions.jl:105-193   (rho continuation -- SURVEY N3)
   meshRefine_direct           src/multiShoot_CRTBP_direct.jl:597-680   (errors-driven mesh refinement -- SURVEY N4)
+  lineSearch_direct           src/multiShoot_CRTBP_direct.jl:405-430   (10 alphas in ONE batched launch -- SURVEY N2)
 
 Same signatures, return tuples and status flags as the Julia functions (the reference is Julia; this mirror exists
 because no `julia` binary is available to run julia/LowThrustOptHIP.jl -- see INTEGRATION.md).  The propagation
@@ -206,6 +207,24 @@ class HipDirectOps:
     def midpoints(self, X, U, t):
         """x(t_i + h_i/2) from node i with u_i, one RKF7(8) step (`ode7` over [t_i, t_new], direct.jl:651-656)."""
         return hotpath.direct_midpoints(X, U, t, 2, self.MU, self.DU, self.TU, self.Isp, ctx=self.ctx)[0]
+
+    def defect_batch_sumsq(self, X_batch, U_batch, t, nsteps):
+        """sum(defect.^2) of every trial trajectory X_batch[:, :, b], U_batch[:, :, b]: one batched launch."""
+        d, _ = hotpath.direct_defectCalc(X_batch, U_batch, t, nsteps, self.MU, self.DU, self.TU, self.Isp, ctx=self.ctx)
+        return np.sum(d * d, axis=(0, 1))
+
+
+def lineSearch_direct(X_all, x_update, u_all, u_update, t_TU, nstate, n_nodes, nsteps, Isp, MU, DU, TU, ops=None):
+    """alpha in LinRange(0.1, 1, 10) minimising sum(defect.^2) of the direct transcription (direct.jl:405-430); the ten
+    trial trajectories are one batched sweep instead of ten."""
+    ops = ops or HipDirectOps(MU, DU, TU, Isp)
+    alpha_all = np.linspace(0.1, 1.0, 10)
+    X_all = np.asarray(X_all, dtype=np.float64); x_update = np.asarray(x_update, dtype=np.float64)
+    u_all = np.asarray(u_all, dtype=np.float64); u_update = np.asarray(u_update, dtype=np.float64)
+    Xt = X_all[:, :, None] + x_update[:, :, None] * alpha_all[None, None, :]
+    Ut = u_all[:, :, None] + u_update[:, :, None] * alpha_all[None, None, :]
+    er = ops.defect_batch_sumsq(np.asfortranarray(Xt), np.asfortranarray(Ut), t_TU, nsteps)
+    return float(alpha_all[int(np.argmin(er))])             # first minimiser, as `alpha[1]` (:428-429)
 
 
 def meshRefine_direct(X_all, u_all, t_TU, nstate, n_nodes, nsteps, Isp, MU, DU, TU, tol_min=1e-20, tol_max=1e-18,

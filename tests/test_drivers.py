@@ -152,6 +152,9 @@ class OracleDirectOps:
         self.sweeps += 1
         return self.O.direct_defect(X, U, t, nsteps, MU, DU, TU, self.Isp)
 
+    def defect_batch_sumsq(self, Xb, Ub, t, nsteps):
+        return np.array([np.sum(self.defect(Xb[:, :, b], Ub[:, :, b], t, nsteps)[0] ** 2) for b in range(Xb.shape[2])])
+
     def midpoints(self, X, U, t):
         out = np.zeros((X.shape[0], X.shape[1] - 1), order="F")
         for i in range(X.shape[1] - 1):         # `ode7` over [t_i, t_new] = ONE RKF7(8) step (ode.jl:154, direct.jl:651-656)
@@ -218,3 +221,33 @@ def test_meshRefine_direct_gpu(gpu_ctx, oracle, nstate):
     assert gb[3] == gs[3] and all(np.array_equal(a, b) for a, b in zip(gb[:3], gs[:3]))
     assert gb[3] == ob[3] and np.allclose(gb[2], ob[2], rtol=0, atol=1e-15)
     assert np.abs(gb[0] - ob[0]).max() < 1e-12 and np.abs(gb[1] - ob[1]).max() < 1e-15
+
+
+def _direct_linesearch_case(nstate):
+    X, U, T = synth.direct_problem(16, seed=8, nstate=nstate)
+    X, U, t = X[:, :, 0], U[:, :, 0], T[:, 0]
+    rng = np.random.default_rng(4)
+    dx = 1e-3 * rng.standard_normal(X.shape); du = 1e-3 * rng.standard_normal(U.shape)
+    return X + dx, -dx / 0.6, U + du, -du / 0.6, t
+
+
+@pytest.mark.parametrize("nstate", [6, 7])
+def test_lineSearch_direct_with_injected_backend(oracle, nstate):
+    X, xu, U, uu, t = _direct_linesearch_case(nstate)
+    a = drivers.lineSearch_direct(X, xu, U, uu, t, nstate, 16, 10, 2000.0, MU, DU, TU, ops=OracleDirectOps(oracle, 2000.0))
+    er = [np.sum(oracle.direct_defect(X + xu * al, U + uu * al, t, 10, MU, DU, TU, 2000.0)[0] ** 2)
+          for al in np.linspace(0.1, 1.0, 10)]
+    assert a == np.linspace(0.1, 1.0, 10)[int(np.argmin(er))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nstate", [6, 7])
+def test_lineSearch_direct_gpu(gpu_ctx, oracle, nstate):
+    X, xu, U, uu, t = _direct_linesearch_case(nstate)
+    ops = drivers.HipDirectOps(MU, DU, TU, 2000.0, ctx=gpu_ctx)
+    a = drivers.lineSearch_direct(X, xu, U, uu, t, nstate, 16, 10, 2000.0, MU, DU, TU, ops=ops)
+    al = np.linspace(0.1, 1.0, 10)
+    Xt = np.asfortranarray(X[:, :, None] + xu[:, :, None] * al); Ut = np.asfortranarray(U[:, :, None] + uu[:, :, None] * al)
+    er_gpu = ops.defect_batch_sumsq(Xt, Ut, t, 10)
+    er_o = OracleDirectOps(oracle, 2000.0).defect_batch_sumsq(Xt, Ut, t, 10)
+    assert np.allclose(er_gpu, er_o, rtol=1e-9, atol=1e-24) and a == al[int(np.argmin(er_o))]
