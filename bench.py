@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2_defect", "c3", "c4", "c5", "hbm"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2_defect", "c3", "c4", "c5", "c5_stm", "hbm"])
+    ap.add_argument("--no-rebalance", action="store_true",
+                    help="c5: keep the natural segment order (default: lanes ordered by the warm-up sweep's step counts)")
     ap.add_argument("--segments", type=int, default=0, help="segments per GPU (default: the workload's)")
     ap.add_argument("--cols", type=int, default=0, help="STM columns per lane (0 = auto)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-specialised (cooperative)")
@@ -125,14 +127,16 @@ def main():
     wl = a.workload
     prm1 = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
     f64 = dict(dtype=torch.float64, device=dev)
-    if wl in ("c2", "c2_defect", "hbm", "c5"):
-        S = a.segments or (65536 // max(world, 1) if wl == "c5" else 4096)
+    c5 = wl in ("c5", "c5_stm")
+    if wl in ("c2", "c2_defect", "hbm") or c5:
+        S = a.segments or (65536 // max(world, 1) if c5 else 4096)
         n = S + 1
-        if wl == "c5":
+        if c5:
             XC, T = synth.indirect_problem(n, seed=1 + rank, dt_range=(0.05, 0.5))
             prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1e-3)
             integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13)
-            desc = "C5: indirect 12-dim defect, adaptive DOP853 rtol=atol=1e-13, dt_seg~U[0.05,0.5], rho=1e-3"
+            desc = "C5: indirect 12-dim defect%s, adaptive DOP853 rtol=atol=1e-13, dt_seg~U[0.05,0.5], rho=1e-3" % (
+                " + 12x12 STM" if wl == "c5_stm" else "")
         else:
             XC, T = synth.indirect_problem(n, seed=rank)
             prm = prm1
@@ -160,7 +164,7 @@ def main():
             plan.set_kernel(a.kernel)
         defect = torch.zeros(nd, S, **f64)
         Phi = torch.zeros(nd * nd, S, **f64)
-        if wl in ("c2", "hbm"):
+        if wl in ("c2", "hbm", "c5_stm"):
             def sweep(dbuf):
                 plan.jacobian(X, n, t, 1, Phi, S, dbuf, S, stream=st)
         else:
@@ -233,6 +237,10 @@ def main():
 
     for k in range(a.warmup):
         step(k)
+    rebalanced = False
+    if c5 and a.warmup > 0 and not a.no_rebalance:
+        plan.rebalance(stream=st)                      # lanes ordered by the warm-up sweep's step counts (on device)
+        rebalanced = True
     if use_coll:
         comm_stream.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -303,16 +311,24 @@ def main():
                 "note": "register-resident fp64 ODE integration: bound by the FP64 vector pipe (no MFMA issued; MI355X "
                         "FP64 matrix peak equals the vector peak), not by HBM -- see DESIGN.md 'Roofline'",
             }
-        if wl == "c5":
+        if c5:
             # wavefront-divergence / load-balance study: a wave runs until its slowest lane has finished
             acc, rej = plan.step_counts(stream=st)
             tot = (acc + rej).astype(np.float64)
-            pad = (-len(tot)) % 64
-            w = np.concatenate([tot, np.zeros(pad)]).reshape(-1, 64)
+            grp = 16 if wl == "c5_stm" else 64          # cooperative STM kernel: 16 segments share a workgroup's step loop
+            pad = (-len(tot)) % grp
+
+            def eff(v):
+                w = np.concatenate([v, np.zeros(pad)]).reshape(-1, grp)
+                return float(v.sum() / (w.max(axis=1).sum() * grp))
             out["adaptive"] = {"steps_accepted_mean": float(acc.mean()), "steps_accepted_max": int(acc.max()),
                                "steps_rejected_mean": float(rej.mean()), "steps_rejected_max": int(rej.max()),
-                               "wavefront_efficiency": float(tot.sum() / (w.max(axis=1).sum() * 64)),
-                               "note": "efficiency = lane-steps executed / (64 x slowest lane per wavefront)"}
+                               "wavefront_efficiency_natural_order": eff(tot),
+                               "wavefront_efficiency": eff(np.sort(tot)[::-1]) if rebalanced else eff(tot),
+                               "rebalanced": rebalanced,
+                               "group": grp,
+                               "note": "efficiency = segment-steps executed / (group x slowest segment per wavefront / workgroup); rebalanced = "
+                                       "lto_indirect_plan_rebalance ordered the lanes by the warm-up sweep's step counts"}
         if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and a.ndim == 12 and not a.method:
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds)
             if wl == "c2":

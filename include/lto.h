@@ -171,6 +171,15 @@ const int* lto_indirect_plan_steps_accepted(const lto_indirect_plan* plan);
 const int* lto_indirect_plan_steps_rejected(const lto_indirect_plan* plan);
 /* Copies the counters of the last adaptive sweep launched on `stream` to host arrays of S ints (either may be NULL). */
 int lto_indirect_plan_copy_steps(lto_indirect_plan* plan, void* stream, int* accepted, int* rejected);
+/* Load balancing of adaptive sweeps.  Segments that need many steps (long or sharply switching arcs) hold their
+ * whole wavefront / workgroup until they finish.  lto_indirect_plan_rebalance orders the lanes of all SUBSEQUENT sweeps
+ * of this plan by the step counts of the LAST sweep, heaviest first, so that neighbouring lanes do similar work
+ * (counting sort on the device, asynchronous on `stream`).  Results do not change: every segment still takes its own
+ * step sequence and is stored at its own index.  Call it again when the trajectory has moved enough to change the
+ * step counts; lto_indirect_plan_reset_order returns to the natural order.  Fixed-step plans: LTO_EINVAL. */
+int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
+int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
+
 /* Tuning knobs for the STM sweep.  Kernel: AUTO picks the wave-specialised kernel (base wave + column waves per
  * 16 segments, coefficients handed over through LDS) for latency-bound batches and for the 13-stage integrators,
  * and the per-lane kernel (each lane re-integrates the base state with 1-3 columns) once the chip is full. */

@@ -238,8 +238,9 @@ __global__ __launch_bounds__(64) void k_indirect_dense(const IndirectArgs a, con
 // column group is blockIdx.y and the g = 0 lanes also emit the defect.
 template <int ND, int PM, int METHOD, int COLS>
 __global__ __launch_bounds__(64) void k_indirect(const IndirectArgs a) {
-  const int s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= a.S) return;
+  const int sl = blockIdx.x * 64 + threadIdx.x;
+  if (sl >= a.S) return;
+  const int s = a.order ? a.order[sl] : sl;    // balanced order: neighbouring lanes take similar numbers of steps
   const int g = blockIdx.y;
   const int traj = s / a.seg_per_traj;
   const int i = s - traj * a.seg_per_traj;

@@ -21,6 +21,7 @@ struct IndirectArgs {
   double* errors;                  // [S] or null
   double* Phi; long ldp;           // [144][ldp] (col*12+row) or null
   int* nacc; int* nrej;            // [S] adaptive step counters or null
+  const int* order;                // [S] or null: lane -> segment map of adaptive sweeps (lto_indirect_plan_rebalance)
   int class_filter;                // set by the launchers: 1 = this launch handles only trajectories of the kernel's p-class
 };
 
@@ -68,6 +69,8 @@ hipError_t launch_axpy(const double* x, const double* d, double alpha, double* y
 
 hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st);
 hipError_t launch_unpack_soa(const double* soa, long ld, int ndim, long count, double* aos, hipStream_t st);
+constexpr int LTO_ORDER_BINS = 1024;   // int workspace launch_segment_order needs
+hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bins, int* order, hipStream_t st);
 hipError_t launch_defect_norms(const double* defect, long ldd, int ndim, int seg_per_traj, int n_batch, double* sumsq,
                                double* maxabs, hipStream_t st);
 

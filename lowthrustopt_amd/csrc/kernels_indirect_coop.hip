@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
   const int col = is_base ? 0 : rho;
   const int role = is_base ? ND : col;                         // row of s_part
   const int s_raw = blockIdx.x * COOP_SEG + seg;
-  const int s = s_raw < a.S ? s_raw : a.S - 1;                 // shadow lanes repeat the last segment
+  const int s_lin = s_raw < a.S ? s_raw : a.S - 1;             // shadow lanes repeat the last segment
+  const int s = a.order ? a.order[s_lin] : s_lin;              // balanced order (lto_indirect_plan_rebalance)
   const bool in_range = (s_raw < a.S) && (rho <= ND);
 
   const int traj = s / a.seg_per_traj;

@@ -92,6 +92,61 @@ __global__ __launch_bounds__(256) void k_defect_norms(const double* __restrict__
   }
 }
 
+// ---- load balancing of adaptive sweeps: segment order by the step counts of the previous sweep, heaviest first.
+// Counting sort on key = min(accepted + rejected, ORDER_BINS - 1): histogram, descending exclusive scan, scatter.
+// The order inside a bin is whatever the atomics produce; nothing depends on it (each segment's result is its own).
+constexpr int ORDER_BINS = 1024;
+
+__device__ __forceinline__ int order_key(const int* nacc, const int* nrej, int s) {
+  const int k = nacc[s] + nrej[s];
+  return k < 0 ? 0 : (k >= ORDER_BINS ? ORDER_BINS - 1 : k);
+}
+
+__global__ __launch_bounds__(256) void k_order_hist(const int* nacc, const int* nrej, int S, int* bins) {
+  __shared__ int h[ORDER_BINS];
+  for (int i = threadIdx.x; i < ORDER_BINS; i += 256) h[i] = 0;
+  __syncthreads();
+  for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) atomicAdd(&h[order_key(nacc, nrej, s)], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < ORDER_BINS; i += 256)
+    if (h[i]) atomicAdd(&bins[i], h[i]);
+}
+
+// bins[k] <- number of segments with a key > k (start offset of bin k in descending order); one workgroup.
+__global__ __launch_bounds__(ORDER_BINS) void k_order_scan(int* bins) {
+  __shared__ int a[ORDER_BINS];
+  const int i = threadIdx.x;                    // position i holds key ORDER_BINS-1-i
+  const int mine = bins[ORDER_BINS - 1 - i];
+  a[i] = mine;
+  __syncthreads();
+  for (int off = 1; off < ORDER_BINS; off <<= 1) {
+    const int v = (i >= off) ? a[i - off] : 0;
+    __syncthreads();
+    a[i] += v;
+    __syncthreads();
+  }
+  bins[ORDER_BINS - 1 - i] = a[i] - mine;
+}
+
+__global__ __launch_bounds__(256) void k_order_scatter(const int* nacc, const int* nrej, int S, int* cursor, int* order) {
+  for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) {
+    const int pos = atomicAdd(&cursor[order_key(nacc, nrej, s)], 1);
+    if (pos >= 0 && pos < S) order[pos] = s;    // always true for a consistent histogram; keeps a stale one harmless
+  }
+}
+
+hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bins, int* order, hipStream_t st) {
+  if (S <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(bins, 0, sizeof(int) * ORDER_BINS, st);
+  if (e != hipSuccess) return e;
+  int blocks = (S + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_order_hist, dim3(blocks), dim3(256), 0, st, nacc, nrej, S, bins);
+  hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_BINS), 0, st, bins);
+  hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(256), 0, st, nacc, nrej, S, bins, order);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st) {
   if (count <= 0) return hipSuccess;
   if (ndim < 1 || ndim > MAXDIM) return hipErrorInvalidValue;

@@ -29,6 +29,12 @@ struct lto_ctx {
   // small cache of device blocks for plan-owned buffers: the host-pointer API builds a plan per call, and a
   // hipMalloc/hipFree pair costs more than a 29-segment sweep
   struct { void* ptr; size_t bytes; } pool[8];
+  // lane order of the last large adaptive sweep made through the host-pointer API (which builds a plan per call):
+  // consecutive Newton iterations sweep the same problem, so the previous call's step counts balance this one.
+  // A stale order is still a valid permutation -- it can only cost speed, never correctness.
+  int* order_cache;      // [order_S + LTO_ORDER_BINS]
+  long order_S;
+  int order_ndim;
   char err[512];
 };
 
@@ -41,6 +47,9 @@ struct lto_indirect_plan {
   TrajParams* d_tp;
   int* d_nacc;
   int* d_nrej;
+  int* d_order;     // [S] lane -> segment map of adaptive sweeps + LTO_ORDER_BINS ints of sort workspace (lazily allocated)
+  int use_order;
+  int order_borrowed;  // d_order belongs to the context's cache
   int cols_per_lane;
   int kernel;       // LTO_KERNEL_*
   double* d_bvp;    // workspace of the device Newton solve (lazily allocated)
@@ -204,6 +213,7 @@ void lto_destroy(lto_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->arena) (void)hipFree(c->arena);
+  if (c->order_cache) (void)hipFree(c->order_cache);
   for (int i = 0; i < 8; ++i) if (c->pool[i].ptr) (void)hipFree(c->pool[i].ptr);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
@@ -262,6 +272,8 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (e == hipSuccess && adaptive) {
     e = pool_alloc(c, (void**)&p->d_nacc, sizeof(int) * (size_t)p->S);
     if (e == hipSuccess) e = pool_alloc(c, (void**)&p->d_nrej, sizeof(int) * (size_t)p->S);
+    if (e == hipSuccess) e = hipMemset(p->d_nacc, 0, sizeof(int) * (size_t)p->S);
+    if (e == hipSuccess) e = hipMemset(p->d_nrej, 0, sizeof(int) * (size_t)p->S);
   }
   if (e != hipSuccess) {
     lto_indirect_plan_destroy(p);
@@ -277,6 +289,7 @@ void lto_indirect_plan_destroy(lto_indirect_plan* p) {
   pool_free(p->ctx, p->d_tp, sizeof(TrajParams) * (size_t)p->n_prm);
   pool_free(p->ctx, p->d_nacc, sizeof(int) * (size_t)p->S);
   pool_free(p->ctx, p->d_nrej, sizeof(int) * (size_t)p->S);
+  if (!p->order_borrowed) pool_free(p->ctx, p->d_order, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS));
   pool_free(p->ctx, p->d_bvp, p->bvp_bytes);
   delete p;
 }
@@ -296,6 +309,28 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* p, void* stream, int* accept
   if (e == hipSuccess && rejected) e = hipMemcpyAsync(rejected, p->d_nrej, sizeof(int) * (size_t)p->S, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "copy step counters", e);
+  return LTO_OK;
+}
+
+int lto_indirect_plan_rebalance(lto_indirect_plan* p, void* stream) {
+  if (!p) return LTO_ENULL;
+  lto_ctx* c = p->ctx;
+  if (!p->d_nacc || !p->d_nrej) return set_err(c, LTO_EINVAL, "fixed-step plan: every segment takes the same number of steps");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  if (!p->d_order) {
+    hipError_t e = pool_alloc(c, (void**)&p->d_order, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS));
+    if (e != hipSuccess) return set_err(c, LTO_EHIP, "order allocation", e);
+  }
+  hipError_t e = launch_segment_order(p->d_nacc, p->d_nrej, p->S, p->d_order + p->S, p->d_order, (hipStream_t)stream);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_segment_order", e);
+  p->use_order = 1;
+  return LTO_OK;
+}
+
+int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
+  if (!p) return LTO_ENULL;
+  p->use_order = 0;
   return LTO_OK;
 }
 
@@ -327,6 +362,7 @@ static int fill_indirect_args(lto_indirect_plan* p, const double* X, long ldx, c
   a->n_nodes = p->n_nodes; a->seg_per_traj = p->n_nodes - 1; a->S = p->S;
   a->steps = p->integ.steps; a->rtol = p->integ.rtol; a->atol = p->integ.atol; a->max_steps = p->integ.max_steps;
   a->nacc = p->d_nacc; a->nrej = p->d_nrej;
+  a->order = p->use_order ? p->d_order : nullptr;
   return LTO_OK;
 }
 
@@ -414,6 +450,37 @@ int lto_axpy_dev(lto_ctx* c, void* stream, const double* x, const double* d, dou
   return LTO_OK;
 }
 
+/* Host-pointer API: adopt / refresh the context's cached lane order (see lto_ctx::order_cache).  Below these sizes
+ * one round of wavefronts / workgroups covers the chip and the order cannot matter. */
+static const long kOrderMinStm = 8192, kOrderMinDefect = 131072;
+
+static bool host_order_wanted(const lto_indirect_plan* p, bool stm) {
+  return p->d_nacc && p->S >= (stm ? kOrderMinStm : kOrderMinDefect);
+}
+
+static void host_order_adopt(lto_ctx* c, lto_indirect_plan* p, bool stm) {
+  if (!host_order_wanted(p, stm) || !c->order_cache || c->order_S != p->S || c->order_ndim != p->ndim) return;
+  p->d_order = c->order_cache; p->order_borrowed = 1; p->use_order = 1;
+}
+
+static void host_order_refresh(lto_ctx* c, lto_indirect_plan* p, bool stm, hipStream_t st) {
+  if (!host_order_wanted(p, stm)) return;
+  if (!c->order_cache || c->order_S != p->S) {
+    if (p->use_order) return;                      // (cannot happen: adoption requires a matching cache)
+    if (c->order_cache) { (void)hipStreamSynchronize(st); (void)hipFree(c->order_cache); c->order_cache = nullptr; }
+    if (hipMalloc((void**)&c->order_cache, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS)) != hipSuccess) {
+      c->order_cache = nullptr; (void)hipGetLastError();
+      return;                                      // balancing is an optimisation: carry on without it
+    }
+    c->order_S = p->S;
+  }
+  c->order_ndim = p->ndim;
+  if (launch_segment_order(p->d_nacc, p->d_nrej, p->S, c->order_cache + p->S, c->order_cache, st) != hipSuccess) {
+    (void)hipGetLastError();
+    c->order_S = 0;                                // never adopt a half-written order
+  }
+}
+
 /* One Newton iteration of multiShoot_CRTBP_indirect on the device (indirect.jl:290-296; both settings of flag_adjointsOnly):
  * jacobianCalc + the least-squares step of optimizeTraj_OLS (:181-182) + its second-order correction (:190-214).
  * Only XC, t go up and xc_update, defect come down; Phi never leaves HBM. */
@@ -448,7 +515,9 @@ int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_aos, 12, J, d_X, J, st);
   if (e != hipSuccess) { (void)hipStreamSynchronize(st); lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  host_order_adopt(c, p, true);
   rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
+  if (rc == LTO_OK) host_order_refresh(c, p, true, st);
   if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, flag_adjointsOnly, d_del, J);
   double* h_del = nullptr;
   if (rc == LTO_OK) {
@@ -688,7 +757,9 @@ int lto_indirect_defect(lto_ctx* c, int ndim, int n_nodes, int n_batch, const do
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
   if (e != hipSuccess) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  host_order_adopt(c, p, false);
   rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, errors ? d_err : nullptr);
+  if (rc == LTO_OK) host_order_refresh(c, p, false, st);
   if (rc == LTO_OK) {
     e = launch_unpack_soa(d_def, S, ndim, S, d_def_aos, st);
     if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * ndim * S, hipMemcpyDeviceToHost, st);
@@ -729,7 +800,9 @@ int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const 
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
   if (e != hipSuccess) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  host_order_adopt(c, p, true);
   rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
+  if (rc == LTO_OK) host_order_refresh(c, p, true, st);
   if (rc == LTO_OK) {
     e = launch_unpack_soa(d_phi, S, nn, S, d_phi_aos, st);
     if (e == hipSuccess) e = hipMemcpyAsync(Phi, d_phi_aos, sizeof(double) * nn * S, hipMemcpyDeviceToHost, st);

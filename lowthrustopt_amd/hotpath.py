@@ -351,6 +351,13 @@ class IndirectPlan:
         self.ctx.check(self.ctx.lib.lto_indirect_newton_solve_dev(self.handle, stream, _dptr(Phi), int(ldp), _dptr(defect),
                                                                   int(ldd), 1 if adjoints_only else 0, _dptr(delta), int(ldx)))
 
+    def rebalance(self, stream=None):
+        """Order the lanes of subsequent adaptive sweeps by the last sweep's step counts (heaviest first)."""
+        self.ctx.check(self.ctx.lib.lto_indirect_plan_rebalance(self.handle, stream))
+
+    def reset_order(self):
+        self.ctx.check(self.ctx.lib.lto_indirect_plan_reset_order(self.handle))
+
     def step_counts(self, stream=None):
         """(accepted[S], rejected[S]) of the last adaptive sweep (numpy int32)."""
         acc = np.zeros(self.S, dtype=np.int32)

@@ -455,6 +455,80 @@ def test_indirect_adaptive_full_size_properties(gpu_ctx, oracle):
         assert np.linalg.norm(dn[:, i] - (y - XC[:, i + 1, 0])) < 1e-10 * np.linalg.norm(y)
 
 
+@pytest.mark.parametrize("ndim", [12, 14])
+@pytest.mark.parametrize("kernel", ["per_lane", "coop"])
+def test_indirect_rebalance_changes_order_not_results(gpu_ctx, ndim, kernel):
+    """lto_indirect_plan_rebalance: lanes ordered by the previous sweep's step counts (heaviest first).  Defect, STM and
+    step counters are bit-identical to the natural order; a second rebalance and reset_order are consistent; a
+    fixed-step plan refuses."""
+    import torch
+    n, B = 301, 3                                              # 900 segments, ragged vs 16 and 64
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=41, dt_range=(0.02, 0.5))
+    if ndim == 14:
+        X = np.zeros((14, n, B), order="F")
+        X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+        slot = 2000.0
+    else:
+        X, slot = XC, 1000.0
+    prms = [lto.make_params(MU, DU, TU, 0.05, slot, 1.0, 1.0 if b != 1 else 2.0, 10.0 ** -b) for b in range(B)]
+    plan = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator(), ndim=ndim)
+    plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
+    Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    S = (n - 1) * B
+
+    def sweep():
+        Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        d0 = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n * B, td, B, Phi, S, d, S)
+        cj = plan.step_counts()
+        plan.defect(Xd, n * B, td, B, d0, S)
+        cd = plan.step_counts()
+        torch.cuda.synchronize()
+        return Phi.cpu().numpy(), d.cpu().numpy(), d0.cpu().numpy(), cj, cd
+
+    ref = sweep()
+    assert ref[4][0].max() > 2 * ref[4][0].min()               # the step counts really differ across segments
+    for _ in range(2):
+        plan.rebalance()
+        out = sweep()
+        for a, b in zip(out[:3], ref[:3]):
+            assert np.array_equal(a, b)
+        for a, b in zip(out[3] + out[4], ref[3] + ref[4]):
+            assert np.array_equal(a, b)
+    plan.reset_order()
+    out = sweep()
+    assert all(np.array_equal(a, b) for a, b in zip(out[:3], ref[:3]))
+    fixed = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator(lto.RK4, steps=4), ndim=ndim)
+    with pytest.raises(lto.LtoError) as ei:
+        fixed.rebalance()
+    assert ei.value.code == -1
+
+
+def test_host_api_reuses_step_order_between_calls(gpu_ctx):
+    """The host-pointer API builds a plan per call; for large adaptive sweeps the context remembers the lane order
+    derived from the previous call's step counts (consecutive Newton iterations sweep the same problem).  Results are
+    independent of that cache: first call (natural order), second call (cached order), a differently sized call in
+    between, and the whole Newton step agree bit for bit."""
+    n = 8300
+    XC, T = synth.indirect_problem(n, seed=51, dt_range=(0.02, 0.4))
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1e-2)
+    integ = lto.integrator()
+    Phi1, d1 = lto.indirect_stm(XC, t, prm, integ, ctx=gpu_ctx)
+    Phi2, d2 = lto.indirect_stm(XC, t, prm, integ, ctx=gpu_ctx)
+    assert np.array_equal(Phi1, Phi2) and np.array_equal(d1, d2)
+    lto.indirect_stm(XC[:, :8250], t[:8250], prm, integ, ctx=gpu_ctx)        # re-sizes the cache
+    Phi3, d3 = lto.indirect_stm(XC * (1 + 1e-9), t, prm, integ, ctx=gpu_ctx)  # stale order, new data
+    Phi4, d4 = lto.indirect_stm(XC * (1 + 1e-9), t, prm, integ, ctx=gpu_ctx)
+    assert np.array_equal(Phi3, Phi4) and np.array_equal(d3, d4)
+    u1, dd1 = lto.indirect_newton_step(XC, t, prm, integ, ctx=gpu_ctx)
+    u2, dd2 = lto.indirect_newton_step(XC, t, prm, integ, ctx=gpu_ctx)
+    assert np.array_equal(dd1, d1) and np.array_equal(dd2, d1)
+    assert np.array_equal(u1, u2)
+
+
 # ------------------------------------------------------------------------------------------------ direct
 @pytest.mark.parametrize("nstate", [6, 7])
 def test_direct_defect_vs_oracle_and_golden(gpu_ctx, oracle, nstate):
