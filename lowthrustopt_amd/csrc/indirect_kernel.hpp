@@ -69,7 +69,7 @@ __device__ __forceinline__ void run_rkf78_adaptive(const Sys& sys, const double 
     double yn[D];
     double delta;
     if constexpr (D > 14) { double K[13][D]; delta = rkf78_step_mem<Sys, NERR>(sys, h, y, K, yn); }
-    else delta = rkf78_step<Sys, NERR>(sys, h, y, yn);
+    else delta = rkf78_step<Sys, NERR, true>(sys, h, y, yn);
     double nx = 0.0;
 #pragma unroll
     for (int i = 0; i < NERR; ++i) nx = fmax(nx, fabs(y[i]));

@@ -61,7 +61,8 @@ struct TabRKF78 {
 
 // One RKF7(8) step.  ynew = y + h sum_k chi_k f_k (local extrapolation, ode.jl:937);
 // returns delta = || h 41/840 sum_k psi_k f_k ||_inf over the first NERR components (ode.jl:940-943).
-template <class Sys, int NERR>
+// NANPROP (adaptive callers): a NaN component makes delta NaN, as the reference's maximum() does; fmax alone drops it.
+template <class Sys, int NERR, bool NANPROP = false>
 __device__ __forceinline__ double rkf78_step(const Sys& sys, const double h, const double (&y)[Sys::DIM],
                                              double (&ynew)[Sys::DIM]) {
   constexpr int D = Sys::DIM;
@@ -92,10 +93,10 @@ __device__ __forceinline__ double rkf78_step(const Sys& sys, const double h, con
     if (i < NERR) {
       const double g = (K[0][i] + K[10][i] - K[11][i] - K[12][i]) * (h * (41.0 / 840.0));
       delta = fmax(delta, fabs(g));
-      gsum += g;
+      if (NANPROP) gsum += g;
     }
   }
-  return (gsum != gsum) ? gsum : delta;
+  return (NANPROP && gsum != gsum) ? gsum : delta;
 }
 
 // ------------------------------------------------------------------------------------ DOP853

@@ -15,6 +15,7 @@ python bench.py --method dop853 --no-cpu-baseline --steps 50 2>&1 | tail -1 > "$
 python bench.py --method rkf78 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_c2_rkf78x4.json"; cat "$OUT/bench_c2_rkf78x4.json"
 python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>&1 | tail -1 > "$OUT/bench_c4.json"; cat "$OUT/bench_c4.json"
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>&1 | tail -1 > "$OUT/bench_c5.json"; cat "$OUT/bench_c5.json"
+python bench.py --workload c5_stm --no-cpu-baseline --steps 10 --warmup 2 2>&1 | tail -1 > "$OUT/bench_c5_stm.json"; cat "$OUT/bench_c5_stm.json"
 # kernel trace + stats of the contract command
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2" -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2.log" 2>&1
 # PMC passes, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
