@@ -6,6 +6,8 @@
   reduceFuel_indirect         src/HelperFunctions.jl:105-193   (rho continuation -- SURVEY N3)
   meshRefine_direct           src/multiShoot_CRTBP_direct.jl:597-680   (errors-driven mesh refinement -- SURVEY N4)
   lineSearch_direct           src/multiShoot_CRTBP_direct.jl:405-430   (10 alphas in ONE batched launch -- SURVEY N2)
+  controlLaw_cart             src/multiShoot_CRTBP_indirect.jl:389-440 (costates -> thrust vectors in N: the u_all format
+                                                                        of the direct transcription; host post-processing)
 
 Same signatures, return tuples and status flags as the Julia functions (the reference is Julia; this mirror exists
 because no `julia` binary is available to run julia/LowThrustOptHIP.jl -- see INTEGRATION.md).  The propagation
@@ -286,3 +288,26 @@ def meshRefine_direct(X_all, u_all, t_TU, nstate, n_nodes, nsteps, Isp, MU, DU, 
         else:
             print("Refined the mesh. Now have %d nodes." % n_nodes)
     return np.asfortranarray(X), np.asfortranarray(U), t, n_nodes
+
+
+def controlLaw_cart(lambda_v, thrustLimit, p, rho, mass, DU=None, TU=None):
+    """Thrust vector(s) in N from the velocity costate(s) (indirect.jl:389-440): lambda_v [3] or [3 x n] ->
+    control of the same shape.  Same law as the propagated dynamics (stateCostate_deriv.jl:33-64); like the reference,
+    a zero primer vector yields NaN (0/0 in `lambda_v ./ norm(lambda_v)`, :439) and an invalid p raises."""
+    from .constants import DU as _DU, TU as _TU
+    DU = _DU if DU is None else DU
+    TU = _TU if TU is None else TU
+    lam = np.asarray(lambda_v, dtype=np.float64)
+    n = np.sqrt(np.sum(lam * lam, axis=0))
+    accelLimit = thrustLimit / mass / 1e3 * TU ** 2 / DU            # N -> DU/TU^2 (:412)
+    if p == 0:
+        umag = np.full_like(n, accelLimit)
+    elif p == 1:
+        umag = 0.5 * (1.0 + np.tanh((n - 1.0) / (2.0 * rho))) * accelLimit
+    elif p > 1:
+        umag = np.minimum((n / p) ** (1.0 / (p - 1.0)), accelLimit)
+    else:
+        raise ValueError("Invalid value of p!")
+    umag = np.where(np.isnan(umag), 0.0, umag)                      # :431-433
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return -umag * lam / n * mass * DU * 1e3 / TU ** 2          # DU/TU^2 -> N (:439)

@@ -251,3 +251,25 @@ def test_lineSearch_direct_gpu(gpu_ctx, oracle, nstate):
     er_gpu = ops.defect_batch_sumsq(Xt, Ut, t, 10)
     er_o = OracleDirectOps(oracle, 2000.0).defect_batch_sumsq(Xt, Ut, t, 10)
     assert np.allclose(er_gpu, er_o, rtol=1e-9, atol=1e-24) and a == al[int(np.argmin(er_o))]
+
+
+def test_controlLaw_cart_matches_the_propagated_dynamics(oracle):
+    """controlLaw_cart (indirect.jl:389-440) in N == the control acceleration inside the RHS (thrust acceleration =
+    v_dot minus the ballistic v_dot), for every law; NaN for a zero primer vector; invalid p raises."""
+    rng = np.random.default_rng(2)
+    H1 = synth.halo_orbits()[0]
+    for p, rho, thr in ((1.0, 1.0, 0.05), (1.0, 1e-3, 0.05), (2.0, 1.0, 10.0), (2.0, 1.0, 0.05), (1.5, 1.0, 10.0), (0.0, 1.0, 0.05)):
+        lam = rng.standard_normal((3, 7)) * (1.0 if p == 1.0 else 0.3)
+        u = drivers.controlLaw_cart(lam, thr, p, rho, 1000.0)
+        assert u.shape == (3, 7)
+        for k in range(7):
+            y = np.concatenate([H1[:, 10 + k], rng.standard_normal(3), lam[:, k]])
+            dy = oracle.rhs_state_costate(y, [MU, DU, TU, thr, 1000.0, 1.0, p, rho])
+            y0 = y.copy(); y0[9:] = 0.0                                   # lambda_v = 0 -> control zeroed (:59-64)
+            dy0 = oracle.rhs_state_costate(y0, [MU, DU, TU, thr, 1000.0, 1.0, p, rho])
+            acc = (dy[3:6] - dy0[3:6]) * 1000.0 * DU * 1e3 / TU ** 2       # DU/TU^2 -> N
+            assert np.abs(u[:, k] - acc).max() < 1e-9 * max(1.0, np.abs(acc).max())
+        assert np.allclose(drivers.controlLaw_cart(lam[:, 0], thr, p, rho, 1000.0), u[:, 0], rtol=0, atol=0)
+    assert np.all(np.isnan(drivers.controlLaw_cart(np.zeros(3), 0.05, 1.0, 1.0, 1000.0)))
+    with pytest.raises(ValueError):
+        drivers.controlLaw_cart(np.ones(3), 0.05, 0.5, 1.0, 1000.0)
