@@ -176,7 +176,8 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* plan, void* stream, int* acc
  * of this plan by the step counts of the LAST sweep, heaviest first, so that neighbouring lanes do similar work
  * (counting sort on the device, asynchronous on `stream`).  Results do not change: every segment still takes its own
  * step sequence and is stored at its own index.  Call it again when the trajectory has moved enough to change the
- * step counts; lto_indirect_plan_reset_order returns to the natural order.  Fixed-step plans: LTO_EINVAL. */
+ * step counts; lto_indirect_plan_reset_order returns to the natural order.  Fixed-step plans, and plans that have not
+ * swept yet: LTO_EINVAL. */
 int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
 int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 

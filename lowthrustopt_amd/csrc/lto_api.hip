@@ -50,6 +50,7 @@ struct lto_indirect_plan {
   int* d_order;     // [S] lane -> segment map of adaptive sweeps + LTO_ORDER_BINS ints of sort workspace (lazily allocated)
   int use_order;
   int order_borrowed;  // d_order belongs to the context's cache
+  int swept;           // an adaptive sweep has filled the step counters
   int cols_per_lane;
   int kernel;       // LTO_KERNEL_*
   double* d_bvp;    // workspace of the device Newton solve (lazily allocated)
@@ -272,8 +273,6 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (e == hipSuccess && adaptive) {
     e = pool_alloc(c, (void**)&p->d_nacc, sizeof(int) * (size_t)p->S);
     if (e == hipSuccess) e = pool_alloc(c, (void**)&p->d_nrej, sizeof(int) * (size_t)p->S);
-    if (e == hipSuccess) e = hipMemset(p->d_nacc, 0, sizeof(int) * (size_t)p->S);
-    if (e == hipSuccess) e = hipMemset(p->d_nrej, 0, sizeof(int) * (size_t)p->S);
   }
   if (e != hipSuccess) {
     lto_indirect_plan_destroy(p);
@@ -316,6 +315,7 @@ int lto_indirect_plan_rebalance(lto_indirect_plan* p, void* stream) {
   if (!p) return LTO_ENULL;
   lto_ctx* c = p->ctx;
   if (!p->d_nacc || !p->d_nrej) return set_err(c, LTO_EINVAL, "fixed-step plan: every segment takes the same number of steps");
+  if (!p->swept) return set_err(c, LTO_EINVAL, "no sweep has run on this plan yet: there are no step counts to balance by");
   int rc = bind_device(c);
   if (rc) return rc;
   if (!p->d_order) {
@@ -363,6 +363,7 @@ static int fill_indirect_args(lto_indirect_plan* p, const double* X, long ldx, c
   a->steps = p->integ.steps; a->rtol = p->integ.rtol; a->atol = p->integ.atol; a->max_steps = p->integ.max_steps;
   a->nacc = p->d_nacc; a->nrej = p->d_nrej;
   a->order = p->use_order ? p->d_order : nullptr;
+  p->swept = 1;                                    // every caller launches a sweep right after a successful fill
   return LTO_OK;
 }
 
@@ -384,6 +385,7 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
                                  : launch_indirect14_defect(p->pm, p->integ.method, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_defect", e);
+  p->swept = 1;
   return LTO_OK;
 }
 
@@ -413,6 +415,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
+  p->swept = 1;
   return LTO_OK;
 }
 
@@ -579,6 +582,7 @@ int lto_indirect_dense_dev(lto_indirect_plan* p, void* stream, const double* X, 
   hipError_t e = launch_indirect_dense(p->ndim, p->pm, p->integ.method, a, d, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_dense", e);
+  p->swept = 1;
   return LTO_OK;
 }
 

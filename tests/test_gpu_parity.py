@@ -501,9 +501,11 @@ def test_indirect_rebalance_changes_order_not_results(gpu_ctx, ndim, kernel):
     out = sweep()
     assert all(np.array_equal(a, b) for a, b in zip(out[:3], ref[:3]))
     fixed = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator(lto.RK4, steps=4), ndim=ndim)
-    with pytest.raises(lto.LtoError) as ei:
-        fixed.rebalance()
-    assert ei.value.code == -1
+    fresh = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator(), ndim=ndim)      # no sweep yet: nothing to sort by
+    for bad in (fixed, fresh):
+        with pytest.raises(lto.LtoError) as ei:
+            bad.rebalance()
+        assert ei.value.code == -1
 
 
 def test_host_api_reuses_step_order_between_calls(gpu_ctx):
