@@ -235,6 +235,33 @@ int lto_unpack_soa_dev(lto_ctx* ctx, void* stream, const double* soa, long ld, i
 int lto_defect_norms_dev(lto_ctx* ctx, void* stream, const double* defect, long ldd, int ndim, int seg_per_traj,
                          int n_batch, double* sumsq, double* maxabs);
 
+/* ------------------------------------------------- several GPUs behind one host process
+ * For a single-process host (the Julia drivers) that owns more than one GPU.  A group holds one context per entry of
+ * device_ids (ids may repeat).  Each call is split into contiguous shards -- whole trajectories when n_batch > 1,
+ * otherwise segment blocks of the one trajectory with a one-node halo (segment i reads nodes i and i+1 only:
+ * multiShoot_CRTBP_indirect.jl:71-86, multiShoot_CRTBP_direct.jl:77-105) -- and every shard runs the single-device entry
+ * point of the same name on its own host thread.  Arguments, layouts, results and error codes are those of
+ * lto_indirect_defect / lto_indirect_jacobian / lto_direct_defect / lto_direct_jacobian; each shard writes its own
+ * contiguous slab of the caller's column-major outputs, so there is no collective.  (Multi-process hosts shard the
+ * same way with one lto_ctx per process: bench.py, lowthrustopt_amd/sharding.py.) */
+typedef struct lto_group lto_group;
+int lto_group_create(int n_devices, const int* device_ids, lto_group** out);
+void lto_group_destroy(lto_group* group);
+const char* lto_group_last_error(const lto_group* group);
+int lto_group_size(const lto_group* group);
+int lto_group_indirect_defect(lto_group* group, int ndim, int n_nodes, int n_batch, const double* XC, const double* t,
+                              int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ, double* defect,
+                              double* errors);
+int lto_group_indirect_jacobian(lto_group* group, int ndim, int n_nodes, int n_batch, const double* XC, const double* t,
+                                int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ, double* Phi,
+                                double* defect);
+int lto_group_direct_defect(lto_group* group, int nstate, int n_nodes, int n_batch, const double* X, const double* U,
+                            const double* t, int n_tgrids, int nsteps, const lto_direct_params* prm, double* defect,
+                            double* errors);
+int lto_group_direct_jacobian(lto_group* group, int nstate, int n_nodes, int n_batch, const double* X, const double* U,
+                              const double* t, int n_tgrids, int nsteps, const lto_direct_params* prm, double* Jac_temp,
+                              double* ddefect_dtf, double* defect, double* errors);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,9 +11,9 @@
 # lowthrustopt_amd/_lib.py + hotpath.py (ctypes), and THAT twin is what the test-suite drives on the GPU.
 module LowThrustOptHIP
 
-using SparseArrays, LinearAlgebra
+using SparseArrays, LinearAlgebra, Libdl
 
-export LtoContext, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, densify,
+export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, densify,
        direct_defectCalc, direct_jacobianCalc, direct_midpoints, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
 
 const liblto = get(ENV, "LTO_HIP_LIB", joinpath(@__DIR__, "..", "lowthrustopt_amd", "liblto_hip.so"))
@@ -56,22 +56,47 @@ mutable struct LtoContext
     end
 end
 
-function check(ctx::LtoContext, rc::Cint)
+"""Several GPUs behind this one Julia process (lto_group_*, include/lto.h): `LtoGroup([0, 1, 2, 3])`.  Accepted wherever
+the four sweep closures take an `LtoContext`; each sweep is split into contiguous shards (segment blocks with a
+one-node halo, or whole trajectories of a batch), one host thread and one device context per entry."""
+mutable struct LtoGroup
+    handle::Ptr{Cvoid}
+    function LtoGroup(devices::Vector{<:Integer})
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        ids = Cint.(devices)
+        rc = ccall((:lto_group_create, liblto), Cint, (Cint, Ptr{Cint}, Ref{Ptr{Cvoid}}), length(ids), ids, h)
+        rc == 0 || error("lto_group_create failed with code $rc")
+        g = new(h[])
+        finalizer(c -> (c.handle == C_NULL || ccall((:lto_group_destroy, liblto), Cvoid, (Ptr{Cvoid},), c.handle); c.handle = C_NULL), g)
+        g
+    end
+end
+
+const LtoHandle = Union{LtoContext, LtoGroup}
+const _libhandle = Ref{Ptr{Cvoid}}(C_NULL)
+libhandle() = (_libhandle[] == C_NULL && (_libhandle[] = Libdl.dlopen(liblto)); _libhandle[])
+# entry point of a sweep: lto_<name> for one context, lto_group_<name> for a group (identical argument lists)
+entry(::LtoContext, name::Symbol) = Libdl.dlsym(libhandle(), Symbol("lto_", name))
+entry(::LtoGroup, name::Symbol) = Libdl.dlsym(libhandle(), Symbol("lto_group_", name))
+last_error(ctx::LtoContext) = unsafe_string(ccall((:lto_last_error, liblto), Cstring, (Ptr{Cvoid},), ctx.handle))
+last_error(g::LtoGroup) = unsafe_string(ccall((:lto_group_last_error, liblto), Cstring, (Ptr{Cvoid},), g.handle))
+
+function check(ctx::LtoHandle, rc::Cint)
     rc == 0 && return
-    msg = unsafe_string(ccall((:lto_last_error, liblto), Cstring, (Ptr{Cvoid},), ctx.handle))
+    msg = last_error(ctx)
     # code 2 is the reference's own error("Invalid value of p!") (CRTBP_stateCostate_deriv.jl:52)
     error(rc == 2 ? msg : "lto error $rc: $msg")
 end
 
 # ---------------------------------------------------------------------------------------------- indirect
 "defectCalc of multiShoot_CRTBP_indirect: returns (defect1[2nstate x (n_nodes-1)], errors[n_nodes-1])."
-function indirect_defectCalc(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params;
+function indirect_defectCalc(ctx::LtoHandle, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params;
                              integ::LtoIntegrator = LtoIntegrator())
     ndim, n_nodes = size(XC_all)
     defect1 = zeros(ndim, n_nodes - 1)
     errors = zeros(n_nodes - 1)
     prm = Ref(LtoParams(params))
-    rc = ccall((:lto_indirect_defect, liblto), Cint,
+    rc = ccall(entry(ctx, :indirect_defect), Cint,
                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{LtoParams}, Cint, Ref{LtoIntegrator},
                 Ptr{Cdouble}, Ptr{Cdouble}),
                ctx.handle, ndim, n_nodes, 1, XC_all, t_TU, 1, prm, 1, Ref(integ), defect1, errors)
@@ -80,13 +105,13 @@ function indirect_defectCalc(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vec
 end
 
 "Compact Jacobian blocks Phi[2nstate x 2nstate x (n_nodes-1)] (= ForwardDiff.jacobian(f, x0) of indirect.jl:121) and the defect."
-function indirect_stm(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params;
+function indirect_stm(ctx::LtoHandle, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params;
                       integ::LtoIntegrator = LtoIntegrator())
     ndim, n_nodes = size(XC_all)
     Phi = zeros(ndim, ndim, n_nodes - 1)
     defect1 = zeros(ndim, n_nodes - 1)
     prm = Ref(LtoParams(params))
-    rc = ccall((:lto_indirect_jacobian, liblto), Cint,
+    rc = ccall(entry(ctx, :indirect_jacobian), Cint,
                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{LtoParams}, Cint, Ref{LtoIntegrator},
                 Ptr{Cdouble}, Ptr{Cdouble}),
                ctx.handle, ndim, n_nodes, 1, XC_all, t_TU, 1, prm, 1, Ref(integ), Phi, defect1)
@@ -97,7 +122,7 @@ end
 """jacobianCalc of multiShoot_CRTBP_indirect: Jac_full [2nstate(n_nodes-1) x 2nstate*n_nodes], row block i =
 [Phi_i | -I] at columns 2nstate(i-1)+(1:4nstate), with the columns of the two fixed end states zeroed
 (indirect.jl:123-142).  Returned sparse: the driver's least-squares step sparsifies it anyway (:181)."""
-function indirect_jacobianCalc(ctx::LtoContext, XC_all, t_TU, nstate, n_nodes, params; integ = LtoIntegrator())
+function indirect_jacobianCalc(ctx::LtoHandle, XC_all, t_TU, nstate, n_nodes, params; integ = LtoIntegrator())
     (Phi, _) = indirect_stm(ctx, XC_all, t_TU, params; integ = integ)
     nd = 2 * nstate
     S = n_nodes - 1
@@ -147,12 +172,12 @@ end
 
 # ---------------------------------------------------------------------------------------------- direct
 "defectCalc of multiShoot_CRTBP_direct: returns (defect1[nstate x (n_nodes-1)], errors[n_nodes-1])."
-function direct_defectCalc(ctx::LtoContext, X_all::Matrix{Float64}, u_all::Matrix{Float64}, t_TU::Vector{Float64},
+function direct_defectCalc(ctx::LtoHandle, X_all::Matrix{Float64}, u_all::Matrix{Float64}, t_TU::Vector{Float64},
                            nstate, n_nodes, nsteps, Isp, MU, DU, TU)
     defect1 = zeros(nstate, n_nodes - 1)
     errors = zeros(n_nodes - 1)
     prm = Ref(LtoDirectParams(MU, DU, TU, Isp))
-    rc = ccall((:lto_direct_defect, liblto), Cint,
+    rc = ccall(entry(ctx, :direct_defect), Cint,
                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ref{LtoDirectParams},
                 Ptr{Cdouble}, Ptr{Cdouble}),
                ctx.handle, nstate, n_nodes, 1, X_all, u_all, t_TU, 1, nsteps, prm, defect1, errors)
@@ -179,7 +204,7 @@ end
 """jacobianCalc + tf partial of multiShoot_CRTBP_direct: Jac_full [nstate(n_nodes-1) x n_nodes(nstate+3)+1]
 (state columns node-major, then control columns, then tf: direct.jl:146-162, :516).  The blocks come from the
 variational equations integrated on the GPU, not from 18 perturbed re-propagations per segment."""
-function direct_jacobianCalc(ctx::LtoContext, X_all::Matrix{Float64}, u_all::Matrix{Float64}, t_TU::Vector{Float64},
+function direct_jacobianCalc(ctx::LtoHandle, X_all::Matrix{Float64}, u_all::Matrix{Float64}, t_TU::Vector{Float64},
                              nstate, n_nodes, nsteps, Isp, MU, DU, TU)
     nvar = 2 * (nstate + 3)
     S = n_nodes - 1
@@ -188,7 +213,7 @@ function direct_jacobianCalc(ctx::LtoContext, X_all::Matrix{Float64}, u_all::Mat
     defect1 = zeros(nstate, S)
     errors = zeros(S)
     prm = Ref(LtoDirectParams(MU, DU, TU, Isp))
-    rc = ccall((:lto_direct_jacobian, liblto), Cint,
+    rc = ccall(entry(ctx, :direct_jacobian), Cint,
                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ref{LtoDirectParams},
                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
                ctx.handle, nstate, n_nodes, 1, X_all, u_all, t_TU, 1, nsteps, prm, Jac_temp, ddefect_dt, defect1, errors)

@@ -59,6 +59,18 @@ SIGNATURES = {
                                       C.POINTER(LtoDirectParams), _vp, _vp, _vp, _vp]),
     "lto_direct_midpoints": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
                                        C.POINTER(LtoDirectParams), _vp, _vp, _vp]),
+    "lto_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "lto_group_destroy": (None, [_vp]),
+    "lto_group_last_error": (C.c_char_p, [_vp]),
+    "lto_group_size": (C.c_int, [_vp]),
+    "lto_group_indirect_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
+                                            C.POINTER(LtoIntegrator), _vp, _vp]),
+    "lto_group_indirect_jacobian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
+                                              C.POINTER(LtoIntegrator), _vp, _vp]),
+    "lto_group_direct_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                                          C.POINTER(LtoDirectParams), _vp, _vp]),
+    "lto_group_direct_jacobian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                                            C.POINTER(LtoDirectParams), _vp, _vp, _vp, _vp]),
     "lto_indirect_plan_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(LtoParams), C.c_int,
                                            C.POINTER(LtoIntegrator), C.POINTER(_vp)]),
     "lto_indirect_plan_destroy": (None, [_vp]),

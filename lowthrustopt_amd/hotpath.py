@@ -76,11 +76,57 @@ class Context:
             msg = self.lib.lto_last_error(self.handle)
             raise LtoError(rc, msg.decode() if msg else "")
 
+    def fn(self, name):
+        """Entry point lto_<name> of this handle type (a Group substitutes lto_group_<name>)."""
+        return getattr(self.lib, "lto_" + name)
+
     def set_timing(self, on):
         self.check(self.lib.lto_set_timing(self.handle, 1 if on else 0))
 
     def last_kernel_ms(self):
         return float(self.lib.lto_last_kernel_ms(self.handle))
+
+
+class Group:
+    """Several GPUs behind this one process (lto_group_*): pass as `ctx=` to indirect_defectCalc, indirect_stm,
+    direct_defectCalc and direct_jacobian_blocks (and the functions built on them).  The sweep is split into
+    contiguous shards, one host thread and one context per entry of `devices` (ids may repeat)."""
+
+    SWEEPS = ("indirect_defect", "indirect_jacobian", "direct_defect", "direct_jacobian")
+
+    def __init__(self, devices):
+        self.lib = _lib.load_library()
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self.lib.lto_group_create(len(devices), ids, C.byref(h))
+        if rc != 0:
+            raise LtoError(rc, "lto_group_create failed")
+        self.handle = h
+        self.devices = [int(d) for d in devices]
+
+    def fn(self, name):
+        if name not in self.SWEEPS:
+            raise LtoError(-3, "lto_%s has no group form: use a Context" % name)
+        return getattr(self.lib, "lto_group_" + name)
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.lto_group_last_error(self.handle)
+            raise LtoError(rc, msg.decode() if msg else "")
+
+    def __len__(self):
+        return int(self.lib.lto_group_size(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lto_group_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _DEFAULT_CTX = {}
@@ -127,7 +173,7 @@ def indirect_defectCalc(XC_all, t_TU, params, integ=None, ctx=None):
     prm, nprm = _params_array(params)
     defect = np.zeros((ndim, n - 1, B), order="F")
     errors = np.zeros((n - 1, B), order="F")
-    ctx.check(ctx.lib.lto_indirect_defect(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
+    ctx.check(ctx.fn("indirect_defect")(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
                                           _ptr(defect), _ptr(errors)))
     if not batched:
         return defect[:, :, 0], errors[:, 0]
@@ -145,7 +191,7 @@ def indirect_stm(XC_all, t_TU, params, integ=None, ctx=None):
     prm, nprm = _params_array(params)
     Phi = np.zeros((ndim, ndim, n - 1, B), order="F")
     defect = np.zeros((ndim, n - 1, B), order="F")
-    ctx.check(ctx.lib.lto_indirect_jacobian(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
+    ctx.check(ctx.fn("indirect_jacobian")(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
                                             _ptr(Phi), _ptr(defect)))
     if not batched:
         return Phi[:, :, :, 0], defect[:, :, 0]
@@ -196,7 +242,7 @@ def indirect_newton_step(XC_all, t_TU, params, integ=None, ctx=None, soc_thresho
     prm, nprm = _params_array(params)
     upd = np.zeros((ndim, n, B), order="F")
     defect = np.zeros((ndim, n - 1, B), order="F")
-    ctx.check(ctx.lib.lto_indirect_newton_step(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
+    ctx.check(ctx.fn("indirect_newton_step")(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
                                                1 if flag_adjointsOnly else 0, float(soc_threshold), _ptr(upd), _ptr(defect)))
     if not batched:
         return upd[:, :, 0], defect[:, :, 0]
@@ -214,7 +260,7 @@ def densify(XC_all, t_TU, params, n_desired, integ=None, ctx=None):
     prm, _ = _params_array(params)
     XC_dense = np.zeros((ndim, int(n_desired)), order="F")
     t_dense = np.zeros(int(n_desired))
-    ctx.check(ctx.lib.lto_indirect_densify(ctx.handle, ndim, n, _ptr(XC), _ptr(t), prm, C.byref(integ), int(n_desired),
+    ctx.check(ctx.fn("indirect_densify")(ctx.handle, ndim, n, _ptr(XC), _ptr(t), prm, C.byref(integ), int(n_desired),
                                            _ptr(XC_dense), _ptr(t_dense)))
     return XC_dense, t_dense
 
@@ -229,7 +275,7 @@ def direct_defectCalc(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
     prm = LtoDirectParams(float(MU), float(DU), float(TU), float(Isp))
     defect = np.zeros((ns, n - 1, B), order="F")
     errors = np.zeros((n - 1, B), order="F")
-    ctx.check(ctx.lib.lto_direct_defect(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
+    ctx.check(ctx.fn("direct_defect")(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
                                         _ptr(defect), _ptr(errors)))
     if not batched:
         return defect[:, :, 0], errors[:, 0]
@@ -249,7 +295,7 @@ def direct_midpoints(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
     x_mid = np.zeros((ns, n - 1, B), order="F")
     defect = np.zeros((ns, n - 1, B), order="F")
     errors = np.zeros((n - 1, B), order="F")
-    ctx.check(ctx.lib.lto_direct_midpoints(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
+    ctx.check(ctx.fn("direct_midpoints")(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
                                            _ptr(x_mid), _ptr(defect), _ptr(errors)))
     if not batched:
         return x_mid[:, :, 0], defect[:, :, 0], errors[:, 0]
@@ -270,7 +316,7 @@ def direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None
     dtf = np.zeros((ns, n - 1, B), order="F")
     defect = np.zeros((ns, n - 1, B), order="F")
     errors = np.zeros((n - 1, B), order="F")
-    ctx.check(ctx.lib.lto_direct_jacobian(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
+    ctx.check(ctx.fn("direct_jacobian")(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
                                           _ptr(Jt), _ptr(dtf), _ptr(defect), _ptr(errors)))
     if not batched:
         return Jt[:, :, :, 0], dtf[:, :, 0], defect[:, :, 0], errors[:, 0]
