@@ -39,9 +39,12 @@ def stacked_guess(n_nodes=30, tof_days=20.0, tau1=0.75):
     return X, t
 
 
-def main(seed=0, verbose=True, rho_target=1e-2):
-    ctx = lto.Context(0)
-    ops = drivers.HipOps(ctx)                      # adaptive order-8 pair @1e-13 (the reference's setting)
+def main(seed=0, verbose=True, rho_target=1e-2, python_loop=False):
+    ctx = lto.default_context(0)
+    # default: every multiShoot_CRTBP_indirect call is ONE library call (lto_indirect_solve: Newton loop, line search
+    # and end-state pinning on the device); --python-loop drives the same device operators from the Python mirror of
+    # the reference loop.  Integrator: adaptive order-8 pair @1e-13 (the reference's setting).
+    ops = drivers.HipOps(ctx) if python_loop else None
     n = 30
     X, t = stacked_guess(n)
     rng = np.random.default_rng(seed)
@@ -69,9 +72,9 @@ def main(seed=0, verbose=True, rho_target=1e-2):
                 thr = 0.5 * (1 + np.tanh((lam - 1) / (2 * rho_target))) * 0.05
                 print("thrust profile: on %.0f %% of the flight, max %.3f N" % (100 * np.mean(thr > 0.025), thr.max()))
     print("wall time %.2f s" % (time.perf_counter() - t0))
-    ctx.close()
     return res
 
 
 if __name__ == "__main__":
-    main(rho_target=float(sys.argv[1]) if len(sys.argv) > 1 else 1e-2, verbose="-q" not in sys.argv)
+    args = [a for a in sys.argv[1:] if not a.startswith("-")]
+    main(rho_target=float(args[0]) if args else 1e-2, verbose="-q" not in sys.argv, python_loop="--python-loop" in sys.argv)

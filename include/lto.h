@@ -118,6 +118,18 @@ int lto_indirect_newton_step(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, c
                              int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ,
                              int flag_adjointsOnly, double soc_threshold, double* xc_update, double* defect);
 
+/* The whole Newton loop of multiShoot_CRTBP_indirect (src/multiShoot_CRTBP_indirect.jl:254-345) in one call, trajectory
+ * resident in HBM: while max|defect| > 1e-10 { jacobianCalc; optimizeTraj_OLS incl. adjoints-only mask and second-order
+ * correction (:149-218); after iteration 3 the 20-point lineSearch (:221-246) as ONE batched sweep; XC += alpha *
+ * xc_update; end states re-pinned (:324-325); defectCalc }.  Only scalars cross PCIe inside the loop.
+ *   XC_in, XC_out [12 x n_nodes] (may alias), defect [12 x (n_nodes-1)] or NULL,
+ *   *status_flag: 0 converged, 1 maxIter reached (also after "Not likely to converge", :333-336), 2 NaN (:339-341),
+ *   *iterations (or NULL): the reference's iterCount on exit,
+ *   history (or NULL): [2 x maxIter] column k = (max|defect|, alpha) after iteration k+1 -- the progress line of :332. */
+int lto_indirect_solve(lto_ctx* ctx, int ndim, int n_nodes, const double* XC_in, const double* t, const lto_params* prm,
+                       const lto_integrator* integ, int flag_adjointsOnly, int maxIter, double* XC_out, double* defect,
+                       int* status_flag, int* iterations, double* history);
+
 /* Replaces densify (src/HelperFunctions.jl:51-101) for one trajectory: t_dense = LinRange(t[1], t[end], n_desired),
  * every segment re-propagated from its node and sampled at the t_dense points inside [t_i, t_{i+1}), final propagated
  * state appended.  XC_dense [ndim x n_desired], t_dense [n_desired]. */

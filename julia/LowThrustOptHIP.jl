@@ -13,7 +13,7 @@ module LowThrustOptHIP
 
 using SparseArrays, LinearAlgebra, Libdl
 
-export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, densify,
+export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, indirect_solve, densify,
        direct_defectCalc, direct_jacobianCalc, direct_midpoints, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
 
 const liblto = get(ENV, "LTO_HIP_LIB", joinpath(@__DIR__, "..", "lowthrustopt_amd", "liblto_hip.so"))
@@ -168,6 +168,34 @@ function densify(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}
                ctx.handle, ndim, n_nodes, XC_all, t_TU, Ref(LtoParams(params)), Ref(integ), n_desired, XC_dense, t_dense)
     check(ctx, rc)
     (XC_dense, t_dense)
+end
+
+"""The whole Newton loop of multiShoot_CRTBP_indirect (indirect.jl:254-345) in one library call, trajectory resident on
+the GPU: returns (XC_all, defect, status_flag) exactly as the reference driver does, so
+`multiShoot_CRTBP_indirect(XC_all, t_TU, MU, DU, TU, n_nodes, mass0, thrustLimit, plot_yn, flag_adjointsOnly, maxIter, p, rho)`
+can forward to `indirect_solve(LTO, XC_all, t_TU, (MU, DU, TU, thrustLimit, mass0, 1.0, p, rho), flag_adjointsOnly, maxIter)`
+when `plot_yn` is false."""
+function indirect_solve(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{Float64}, params, flag_adjointsOnly::Bool,
+                        maxIter::Integer; integ::LtoIntegrator = LtoIntegrator(), verbose::Bool = true)
+    ndim, n_nodes = size(XC_all)
+    XC_new = zeros(ndim, n_nodes)
+    defect1 = zeros(ndim, n_nodes - 1)
+    history = fill(NaN, 2, max(maxIter, 1))
+    status = Ref{Cint}(0); iters = Ref{Cint}(0)
+    rc = ccall((:lto_indirect_solve, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ref{LtoParams}, Ref{LtoIntegrator}, Cint, Cint,
+                Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ptr{Cdouble}),
+               ctx.handle, ndim, n_nodes, XC_all, t_TU, Ref(LtoParams(params)), Ref(integ), flag_adjointsOnly ? 1 : 0, maxIter,
+               XC_new, defect1, status, iters, history)
+    check(ctx, rc)
+    if verbose
+        for k = 1:size(history, 2)
+            isnan(history[2, k]) && break
+            println("Iter $k. Max defect = $(history[1, k]). α = $(history[2, k]).")
+        end
+        status[] == 1 && println("Reached max iteration count at $(iters[]) iterations")
+    end
+    (XC_new, defect1, Int(status[]))
 end
 
 # ---------------------------------------------------------------------------------------------- direct

@@ -147,6 +147,42 @@ hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bi
   return hipGetLastError();
 }
 
+// ---- driver-loop helpers (lto_indirect_solve): line-search trial points and end-state pinning, SoA in / SoA out
+// Xt[c][b*n + k] = X[c][k] + alphas[b] d[c][k]    (the trial trajectories of lineSearch, indirect.jl:227-233)
+__global__ __launch_bounds__(256) void k_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb,
+                                                      const double* alphas, double* Xt, long ldt) {
+  const long total = (long)ndim * nb * n;
+  for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += gridDim.x * 256L) {
+    const int k = (int)(q % n);
+    const int b = (int)((q / n) % nb);
+    const int c = (int)(q / ((long)n * nb));
+    Xt[c * ldt + (long)b * n + k] = __builtin_fma(alphas[b], d[c * ld + k], X[c * ld + k]);
+  }
+}
+
+// save (dir = 0) or restore (dir = 1) the first `nrow` rows of node 0 and node n-1 (indirect.jl:270-271, :324-325)
+__global__ void k_end_states(double* X, long ld, int n, int nrow, double* saved, int dir) {
+  const int r = threadIdx.x;
+  if (r >= 2 * nrow) return;
+  const long idx = (long)(r % nrow) * ld + (r < nrow ? 0 : n - 1);
+  if (dir) X[idx] = saved[r]; else saved[r] = X[idx];
+}
+
+hipError_t launch_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, const double* alphas, double* Xt,
+                               long ldt, hipStream_t st) {
+  const long total = (long)ndim * nb * n;
+  if (total <= 0) return hipSuccess;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_trial_points, dim3((unsigned)blocks), dim3(256), 0, st, X, d, ld, ndim, n, nb, alphas, Xt, ldt);
+  return hipGetLastError();
+}
+
+hipError_t launch_end_states(double* X, long ld, int n, int nrow, double* saved, int restore, hipStream_t st) {
+  hipLaunchKernelGGL(k_end_states, dim3(1), dim3(64), 0, st, X, ld, n, nrow, saved, restore);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st) {
   if (count <= 0) return hipSuccess;
   if (ndim < 1 || ndim > MAXDIM) return hipErrorInvalidValue;

@@ -564,6 +564,127 @@ int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   return rc;
 }
 
+/* Whole Newton loop of multiShoot_CRTBP_indirect (src/multiShoot_CRTBP_indirect.jl:254-345) with the trajectory
+ * resident in HBM: per iteration one STM sweep, the structured least-squares step (+ second-order correction), the
+ * 20-point line search as ONE batched sweep after iteration 3, end-state pinning and the defect check.  Only scalars
+ * cross PCIe inside the loop (max|xc_update|, 20 sums of squares, max|defect|). */
+int lto_indirect_solve(lto_ctx* c, int ndim, int n_nodes, const double* XC_in, const double* t, const lto_params* prm,
+                       const lto_integrator* integ, int flag_adjointsOnly, int maxIter, double* XC_out, double* defect,
+                       int* status_flag, int* iterations, double* history) {
+  if (!c) return LTO_ENULL;
+  if (!XC_in || !t || !prm || !integ || !XC_out || !status_flag) return set_err(c, LTO_ENULL, "XC_in, t, prm, integ, XC_out or status_flag is NULL");
+  if (ndim != 12) return set_err(c, LTO_EUNSUPPORTED, "the device Newton loop is built for ndim = 12");
+  if (maxIter < 0) return set_err(c, LTO_EINVAL, "maxIter must be >= 0");
+  constexpr int NA = 20;                                   // LinRange(0.1, 1, 20), :227
+  lto_indirect_plan* p = nullptr;
+  lto_indirect_plan* pl = nullptr;                         // the NA line-search trial trajectories as one batch
+  int rc = lto_indirect_plan_create(c, 12, n_nodes, 1, prm, 1, integ, &p);
+  if (rc) return rc;
+  rc = lto_indirect_plan_create(c, 12, n_nodes, NA, prm, 1, integ, &pl);
+  if (rc) { lto_indirect_plan_destroy(p); return rc; }
+  const long J = n_nodes, S = n_nodes - 1;
+  const size_t need = al256(sizeof(double) * 12 * J) * 5 + al256(sizeof(double) * 12 * J * NA) + al256(sizeof(double) * n_nodes) +
+                      al256(sizeof(double) * 12 * S) * 3 + al256(sizeof(double) * 12 * S * NA) + al256(sizeof(double) * 144 * S) + 65536;
+  rc = arena_reserve(c, need);
+  if (rc) { lto_indirect_plan_destroy(pl); lto_indirect_plan_destroy(p); return rc; }
+  c->arena_top = 0;
+  double* d_aos = arena_take<double>(c, (size_t)12 * J);
+  double* d_X = arena_take<double>(c, (size_t)12 * J);
+  double* d_X2 = arena_take<double>(c, (size_t)12 * J);
+  double* d_del = arena_take<double>(c, (size_t)12 * J);
+  double* d_del2 = arena_take<double>(c, (size_t)12 * J);
+  double* d_Xt = arena_take<double>(c, (size_t)12 * J * NA);
+  double* d_t = arena_take<double>(c, (size_t)n_nodes);
+  double* d_def = arena_take<double>(c, (size_t)12 * S);
+  double* d_def2 = arena_take<double>(c, (size_t)12 * S);
+  double* d_def_aos = arena_take<double>(c, (size_t)12 * S);
+  double* d_deft = arena_take<double>(c, (size_t)12 * S * NA);
+  double* d_phi = arena_take<double>(c, (size_t)144 * S);
+  double* d_small = arena_take<double>(c, 64);             // [0..11] saved end states, [16..35] alphas, [40..59] sums, [60] max
+  hipStream_t st = c->stream;
+  double alphas[NA], h_ss[NA], h_mx = 0.0;
+  for (int b = 0; b < NA; ++b) alphas[b] = 0.1 + (1.0 - 0.1) / (NA - 1) * b;
+  alphas[NA - 1] = 1.0;
+
+  hipError_t e = hipMemcpyAsync(d_aos, XC_in, sizeof(double) * 12 * J, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_small + 16, alphas, sizeof alphas, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_pack_soa(d_aos, 12, J, d_X, J, st);
+  if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, 6, d_small, 0, st);          // state_0, state_f  (:270-271)
+  if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage in", e);
+
+  // max |v| of an SoA block [rows][ld] with `count` valid columns -> host (NaN if any entry is NaN)
+  auto max_abs = [&](const double* v, long ld, int rows, long count, double* out) -> int {
+    hipError_t q = launch_defect_norms(v, ld, rows, (int)count, 1, nullptr, d_small + 60, st);
+    if (q == hipSuccess) q = hipMemcpyAsync(out, d_small + 60, sizeof(double), hipMemcpyDeviceToHost, st);
+    if (q == hipSuccess) q = hipStreamSynchronize(st);
+    return q == hipSuccess ? LTO_OK : set_err(c, LTO_EHIP, "norm", q);
+  };
+
+  int iter = 0, status = 0;
+  double er = 1.0;                                         // :279
+  if (rc == LTO_OK) rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, 1, d_def, S, nullptr);       // :274
+  while (rc == LTO_OK && er > 1e-10) {                     // :280
+    ++iter;
+    if (iter > maxIter) { status = 1; break; }             // :282-286
+    rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, 1, d_phi, S, d_def, S);                     // :290
+    if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, flag_adjointsOnly, d_del, J);   // :182
+    if (rc == LTO_OK) rc = max_abs(d_del, J, 12, J, &h_mx);
+    if (rc != LTO_OK) break;
+    if (h_mx == h_mx && h_mx < 1e-1) {                     // second-order correction, :190-214
+      e = launch_axpy(d_X, d_del, 1.0, d_X2, 12 * J, st);
+      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "axpy", e); break; }
+      rc = lto_indirect_defect_dev(p, st, d_X2, J, d_t, 1, d_def2, S, nullptr);
+      if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, nullptr, 0, d_def2, S, flag_adjointsOnly, d_del2, J);
+      if (rc != LTO_OK) break;
+      e = launch_axpy(d_del, d_del2, 1.0, d_del, 12 * J, st);
+      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "axpy", e); break; }
+    }
+    double alpha = 1.0;
+    if (iter > 3) {                                        // :300-302: 20 trial trajectories, one sweep
+      e = launch_trial_points(d_X, d_del, J, 12, n_nodes, NA, d_small + 16, d_Xt, J * NA, st);
+      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "trial points", e); break; }
+      rc = lto_indirect_defect_dev(pl, st, d_Xt, J * NA, d_t, 1, d_deft, S * NA, nullptr);
+      if (rc != LTO_OK) break;
+      e = launch_defect_norms(d_deft, S * NA, 12, (int)S, NA, d_small + 40, nullptr, st);          // sum(defect.^2), :240
+      if (e == hipSuccess) e = hipMemcpyAsync(h_ss, d_small + 40, sizeof h_ss, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "line search", e); break; }
+      int best = 0;                                        // alpha[er .== minimum(er)][1]: first minimiser (:244-245)
+      for (int b = 1; b < NA; ++b) if (h_ss[b] < h_ss[best]) best = b;
+      alpha = alphas[best];
+    }
+    e = launch_axpy(d_X, d_del, alpha, d_X, 12 * J, st);                                            // :304
+    if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, 6, d_small, 1, st);                // :324-325
+    if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "update", e); break; }
+    rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, 1, d_def, S, nullptr);                        // :328
+    if (rc == LTO_OK) rc = max_abs(d_def, S, 12, S, &er);                                          // :331
+    if (rc != LTO_OK) break;
+    if (history && iter <= maxIter) { history[2 * (iter - 1)] = er; history[2 * (iter - 1) + 1] = alpha; }
+    if (er > 1e3) iter += 100;                             // "Not likely to converge. Aborting." (:333-336)
+  }
+  if (rc == LTO_OK) {
+    e = launch_unpack_soa(d_X, J, 12, J, d_aos, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(XC_out, d_aos, sizeof(double) * 12 * J, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && defect) {
+      e = launch_unpack_soa(d_def, S, 12, S, d_def_aos, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * 12 * S, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = max_abs(d_def, S, 12, S, &h_mx) == LTO_OK ? hipSuccess : hipErrorUnknown;
+    if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
+    // :339-341 flags a NaN trajectory; a NaN defect leaves the loop the same way (NaN > 1e-10 is false), so both
+    // report status 2 here, as drivers.multiShoot_CRTBP_indirect does
+    if (rc == LTO_OK && (XC_out[0] != XC_out[0] || h_mx != h_mx)) status = 2;
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  *status_flag = status;
+  if (iterations) *iterations = iter;
+  lto_indirect_plan_destroy(pl);
+  lto_indirect_plan_destroy(p);
+  return rc;
+}
+
 /* ------------------------------------------------------------------------------ dense output */
 int lto_indirect_dense_dev(lto_indirect_plan* p, void* stream, const double* X, long ldx, const double* t, int n_tgrids,
                            const int* first, const double* t_samples, double* Y, long ldy, double* final_state) {

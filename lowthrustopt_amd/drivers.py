@@ -104,6 +104,19 @@ def multiShoot_CRTBP_indirect(XC_all, t_TU, MU, DU, TU, n_nodes, mass0, thrustLi
                               maxIter, p, rho, ops=None, verbose=True):
     """Indirect multiple shooting with fixed end states (indirect.jl:58-61, :254-345).
     Returns (XC_all, defect, status_flag): 0 converged, 1 maxIter reached, 2 NaN."""
+    if ops is None and np.asarray(XC_all).shape[0] == 12:
+        # product default: the whole loop below is one library call with the trajectory resident on the device
+        # (lto_indirect_solve); the Python loop remains for injected back ends and for the 14-dim extension
+        params = hotpath.make_params(MU, DU, TU, thrustLimit, mass0, 1.0, p, rho)
+        XC_out, defect, status_flag, iterCount, hist = hotpath.indirect_solve(XC_all, t_TU, params, None, flag_adjointsOnly, maxIter)
+        if verbose:
+            for k, (er, alpha) in enumerate(hist):
+                print("Iter %d. Max defect = %.2e. alpha = %.3f." % (k + 1, er, alpha))
+                if not (er <= 1e3):
+                    print("Not likely to converge. Aborting.")
+            if status_flag == 1:
+                print("Reached max iteration count at %d iterations" % iterCount)
+        return XC_out, defect, status_flag
     ops = ops or HipOps()
     XC_all = np.array(XC_all, dtype=np.float64, order="F")
     t_TU = np.array(t_TU, dtype=np.float64)

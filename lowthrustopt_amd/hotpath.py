@@ -249,6 +249,26 @@ def indirect_newton_step(XC_all, t_TU, params, integ=None, ctx=None, soc_thresho
     return upd, defect
 
 
+def indirect_solve(XC_all, t_TU, params, integ=None, flag_adjointsOnly=False, maxIter=10, ctx=None):
+    """The Newton loop of multiShoot_CRTBP_indirect (indirect.jl:254-345) as ONE library call, trajectory resident on
+    the device: returns (XC_all, defect, status_flag, iterCount, history[k] = (max|defect|, alpha) of iteration k+1)."""
+    ctx = ctx or default_context()
+    integ = integ or integrator()
+    XC = _f64(XC_all)
+    ndim, n = XC.shape
+    t = np.ascontiguousarray(t_TU, dtype=np.float64)
+    prm, _ = _params_array(params)
+    XC_out = np.zeros((ndim, n), order="F")
+    defect = np.zeros((ndim, n - 1), order="F")
+    hist = np.full((2, max(int(maxIter), 1)), np.nan, order="F")
+    status = C.c_int(0)
+    iters = C.c_int(0)
+    ctx.check(ctx.fn("indirect_solve")(ctx.handle, ndim, n, _ptr(XC), _ptr(t), prm, C.byref(integ), 1 if flag_adjointsOnly else 0,
+                                       int(maxIter), _ptr(XC_out), _ptr(defect), C.byref(status), C.byref(iters), _ptr(hist)))
+    done = int(np.count_nonzero(~np.isnan(hist[1])))          # alpha is written for every completed iteration
+    return XC_out, defect, status.value, iters.value, hist[:, :done].T.copy()
+
+
 def densify(XC_all, t_TU, params, n_desired, integ=None, ctx=None):
     """densify (src/HelperFunctions.jl:51-101): (XC_dense[ndim x n_desired], t_dense[n_desired]); every segment is
     re-propagated on the GPU and sampled at the uniformly spaced t_dense points that fall inside it."""

@@ -273,3 +273,46 @@ def test_controlLaw_cart_matches_the_propagated_dynamics(oracle):
     assert np.all(np.isnan(drivers.controlLaw_cart(np.zeros(3), 0.05, 1.0, 1.0, 1000.0)))
     with pytest.raises(ValueError):
         drivers.controlLaw_cart(np.ones(3), 0.05, 0.5, 1.0, 1000.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adjoints_only", [False, True])
+def test_device_newton_loop_equals_python_loop(gpu_ctx, oracle, adjoints_only):
+    """lto_indirect_solve (whole multiShoot_CRTBP_indirect loop in one call, trajectory resident on the device) against
+    the Python mirror of the reference loop driving the same device operators: same status, same iteration history,
+    same converged trajectory; maxIter and NaN paths report the reference's status flags."""
+    XC, t, exact = consistent_problem(oracle, n_nodes=20, pert=1e-3, seed=5)
+    prm = lto.make_params(MU, DU, TU, 10.0, 1000.0, 1.0, 2.0, 1.0)
+    XC_d, def_d, st_d, it_d, hist = lto.indirect_solve(XC, t, prm, None, adjoints_only, 25, ctx=gpu_ctx)
+    XC_p, def_p, st_p = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, 20, 1000.0, 10.0, False, adjoints_only, 25, 2.0, 1.0,
+                                                          ops=drivers.HipOps(gpu_ctx), verbose=False)
+    assert st_d == st_p
+    assert np.array_equal(XC_d[:6, 0], XC[:6, 0]) and np.array_equal(XC_d[:6, -1], XC[:6, -1])
+    if st_d == 0:
+        assert np.abs(def_d).max() <= 1e-10 and hist.shape == (it_d, 2) and hist[-1, 0] <= 1e-10
+        assert np.abs(XC_d - XC_p).max() < 1e-8
+        if not adjoints_only:
+            assert np.abs(XC_d - exact).max() < 1e-6
+    assert len(hist) >= 1 and np.all(hist[:3, 1] == 1.0)     # no line search before iteration 4 (indirect.jl:300)
+    # a step that blows the defect up past 1e3 aborts the way the reference does: iterCount += 100 -> status 1 (:333-336)
+    XCb, _, _ = consistent_problem(oracle, n_nodes=20, pert=3e-3, seed=5)
+    _, _, stb, itb, hb = lto.indirect_solve(XCb, t, prm, None, False, 25, ctx=gpu_ctx)
+    _, _, stb_p = drivers.multiShoot_CRTBP_indirect(XCb, t, MU, DU, TU, 20, 1000.0, 10.0, False, False, 25, 2.0, 1.0,
+                                                    ops=drivers.HipOps(gpu_ctx), verbose=False)
+    assert stb == stb_p
+    if hb[-1, 0] > 1e3:
+        assert stb == 1 and itb > 100
+    # the driver's default path is the device loop
+    XC_q, def_q, st_q = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, 20, 1000.0, 10.0, False, adjoints_only, 25, 2.0, 1.0,
+                                                          verbose=False)
+    assert st_q == st_d and np.array_equal(XC_q, XC_d) and np.array_equal(def_q, def_d)
+    # maxIter reached -> status 1 with iterCount = maxIter + 1 (indirect.jl:282-286)
+    _, _, st1, it1, h1 = lto.indirect_solve(XC, t, prm, None, adjoints_only, 1, ctx=gpu_ctx)
+    assert st1 == 1 and it1 == 2 and h1.shape == (1, 2)
+    # NaN in the trajectory -> status 2 (indirect.jl:339-341)
+    XCn = XC.copy(); XCn[0, 0] = np.nan
+    _, dn, st2, _, _ = lto.indirect_solve(XCn, t, prm, None, adjoints_only, 5, ctx=gpu_ctx)
+    assert st2 == 2 and np.isnan(dn).any()
+    with pytest.raises(lto.LtoError) as ei:
+        lto.indirect_solve(XC, t, lto.make_params(MU, DU, TU, 10.0, 1000.0, 1.0, 0.5, 1.0), None, False, 5, ctx=gpu_ctx)
+    assert ei.value.code == 2
