@@ -68,7 +68,7 @@ def main():
         plan.close()
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--host", "--newton", "--small")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--host", "--newton", "--small", "--solve")):
     main()
 
 
@@ -146,3 +146,30 @@ def small_sweeps():
 
 if __name__ == "__main__" and "--small" in sys.argv:
     small_sweeps()
+
+
+if __name__ == "__main__" and "--solve" in sys.argv:
+    # whole Newton loop in one call (lto_indirect_solve) vs the Python mirror of the loop on the same device operators
+    from lowthrustopt_amd import drivers
+    from lowthrustopt_amd.constants import MU, DU, TU
+    ctx = lto.default_context(0)
+    for n in (30, 300, 3000):
+        XC, T = synth.indirect_problem(n, seed=3, dt_seg=0.05, lam_sigma=0.05)
+        XC, t = XC[:, :, 0], T[:, 0]
+        prm = lto.make_params(MU, DU, TU, 10.0, 1000.0, 1.0, 2.0, 1.0)
+        # make the guess consistent first so that the timed solves converge in a few iterations from a small perturbation
+        X0, d0, st0, it0, h0 = lto.indirect_solve(XC, t, prm, None, False, 50, ctx=ctx)
+        rng = np.random.default_rng(0)
+        Xp = X0.copy(); Xp[:, 1:-1] += 1e-4 * rng.standard_normal((12, n - 2))
+        for name, fn in (("lto_indirect_solve", lambda: lto.indirect_solve(Xp, t, prm, None, False, 20, ctx=ctx)),
+                         ("python loop", lambda: drivers.multiShoot_CRTBP_indirect(Xp, t, MU, DU, TU, n, 1000.0, 10.0, False, False, 20,
+                                                                                   2.0, 1.0, ops=drivers.HipOps(ctx), verbose=False))):
+            out = fn()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                out = fn()
+            dt = (time.perf_counter() - t0) / 10
+            its = out[3] if len(out) > 3 else -1
+            print("n_nodes=%5d %-20s status %d  %s iterations  %.3f ms per solve%s (base guess: status %d after %d)" % (
+                n, name, out[2], its if its >= 0 else "?", dt * 1e3, ("  = %.0f us per Newton iteration" % (dt * 1e6 / its)) if its > 0 else "", st0, it0),
+                flush=True)
