@@ -5,13 +5,16 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU (RCCL).
 Rank 0 prints ONE JSON line.
 
-Workload (default `c2`, BASELINE.json configs[1]): indirect method, 12-dim state+costate PLUS the 12x12 STM
-(the metric's "state+costate+STM" unit), 4 096 shooting segments per GPU, fixed-step RK4, 64 steps per
-segment, fp64, p = 1, rho = 1, thrust 0.05 N -- i.e. one `jacobianCalc` sweep (which also emits the defect) of
-src/multiShoot_CRTBP_indirect.jl:93-146 per step.  Inputs are synthetic halo->halo stacked trajectories
-(lowthrustopt_amd/synth.py) resident in HBM (struct-of-arrays) before the timed region starts.
+Workload (default `c2`, BASELINE.json configs[1] "Indirect 14-dim state+costate, 4 096 segments, fixed-step RK4
+fp64"): indirect method, 14-dim state + mass + costates PLUS the 14x14 STM (the metric's "state+costate+STM" unit),
+4 096 shooting segments per GPU, RK4 with 64 steps per segment, fp64, p = 1, rho = 1, thrust 0.05 N -- i.e. one
+`jacobianCalc` sweep (which also emits the defect) of src/multiShoot_CRTBP_indirect.jl:93-146 per step.  Inputs are
+synthetic halo->halo stacked trajectories (lowthrustopt_amd/synth.py) resident in HBM (struct-of-arrays) before the
+timed region starts.  The reference's own CRTBP system is 12-dim (constant mass): the same sweep on that
+system -- the one reference parity is claimed for -- is timed in the same run and reported as `reference_system_12dim`
+(`--ndim 12` makes it the main line).
 N > 1: weak scaling -- every rank sweeps its own 4 096 segments, then one RCCL all-gather of the per-rank
-defect slabs (12 x 4096 doubles = 393 KB per rank) gives every rank the full defect vector.
+defect slabs (ndim x 4096 doubles) gives every rank the full defect vector.
 
 Other workloads (`--workload c3|c4|c5|hbm`) are measurement aids for DESIGN.md, not the contract line.
 """
@@ -31,13 +34,26 @@ PEAK_FP64_TFLOPS = 78.6   # MI355X vector (= matrix) FP64 peak
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 # Algorithmic work per unit (DESIGN.md "Roofline"): flops = steps*(stages*F_rhs + C_tab*dim)
+# F_rhs (model flops: + - x / sqrt tanh = 1, FMA = 2): 12-dim 95, + 12x12 variational 1070; 14-dim 110,
+# + 14x14 variational 1490 = 116 base + 86 coefficient build + 14 columns x 92 (counted on dynamics.hpp).
 WORK = {
-    # name: (flops per segment, algorithmic bytes per segment)
-    "c2": (64 * (4 * 1070 + 14 * 156), 1456),       # 12-dim + 12x12 STM, RK4 x 64
-    "c2_defect": (64 * (4 * 95 + 14 * 12), 304),
-    "c3": (18 * (13 * 232 + 132 * 60), 1080 + 48),   # direct 6-dim + Phi + Psi, RKF7(8) 9 steps x 2 halves
-    "hbm": (1 * (4 * 1070 + 14 * 156), 1456),        # 1 RK4 step + full STM output: the HBM evidence point
+    # (name, ndim): (flops per segment, algorithmic bytes per segment)
+    ("c2", 12): (64 * (4 * 1070 + 14 * 156), 1456),       # 12-dim + 12x12 STM, RK4 x 64
+    ("c2", 14): (64 * (4 * 1490 + 14 * 210), 1920),       # 14-dim + 14x14 STM, RK4 x 64  (BASELINE configs[1])
+    ("c2_defect", 12): (64 * (4 * 95 + 14 * 12), 304),
+    ("c2_defect", 14): (64 * (4 * 110 + 14 * 14), 352),
+    ("c3", 12): (18 * (13 * 232 + 132 * 60), 1080 + 48),  # direct 6-dim + Phi + Psi, RKF7(8) 9 steps x 2 halves
+    ("hbm", 12): (1 * (4 * 1070 + 14 * 156), 1456),       # 1 RK4 step + full STM output: the HBM evidence point
+    ("hbm", 14): (1 * (4 * 1490 + 14 * 210), 1920),
 }
+
+
+def to14(XC):
+    """(r, v, lambda_r, lambda_v) -> (r, v, m, lambda_r, lambda_v, lambda_m) with m = 1000 kg, lambda_m = 0.1; the
+    params' mass slot carries Isp for the 14-dim system (include/lto.h)."""
+    X = np.zeros((14,) + XC.shape[1:], order="F")
+    X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.1
+    return X
 
 
 def parse():
@@ -51,15 +67,16 @@ def parse():
     ap.add_argument("--segments", type=int, default=0, help="segments per GPU (default: the workload's)")
     ap.add_argument("--cols", type=int, default=0, help="STM columns per lane (0 = auto)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-specialised (cooperative)")
-    ap.add_argument("--ndim", type=int, default=12, choices=[12, 14],
-                    help="12 = the reference's state+costate system (parity path); 14 = + mass and mass costate (extension)")
+    ap.add_argument("--ndim", type=int, default=0, choices=[0, 12, 14],
+                    help="14 = state + mass + costates (BASELINE configs[1]; default of c2 / c2_defect / hbm); 12 = the "
+                         "reference's own constant-mass system (parity path; default of the other workloads)")
     ap.add_argument("--method", default="", choices=["", "rk4", "rkf78", "dop853"], help="override the workload's integrator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def cpu_baseline(workload, seconds, threads=1):
+def cpu_baseline(workload, seconds, threads=1, ndim=12):
     """Oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload.  threads = 1 is
     the reference's own execution model (serial loop over segments); threads > 1 parallelises that loop with OpenMP."""
     from oracle import oracle as O
@@ -80,11 +97,17 @@ def cpu_baseline(workload, seconds, threads=1):
     else:
         XC, T = synth.indirect_problem(nseg + 1, seed=0)
         XC, t = XC[:, :, 0], T[:, 0]
+        if ndim == 14:
+            XC = to14(XC)
+            prm14 = [lto.MU, lto.DU, lto.TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
 
-        def run():
-            O.indirect_jacobian(XC, t, prm, O.RK4, 64)
+            def run():
+                O.indirect14(XC, t, prm14, O.RK4, 64)
+        else:
+            def run():
+                O.indirect_jacobian(XC, t, prm, O.RK4, 64)
         per_call = nseg
-        what = "indirect 12-dim + 12x12 STM by dual numbers through RK4 x 64 (same discrete map as the GPU run)"
+        what = "indirect %d-dim + %dx%d STM by dual numbers through RK4 x 64 (same discrete map as the GPU run)" % (ndim, ndim, ndim)
     O.lib()
     used = O.set_threads(threads)
     run()
@@ -99,6 +122,82 @@ def cpu_baseline(workload, seconds, threads=1):
     O.set_threads(1)
     return {"value": per_call * calls / el, "unit": "segment-integrations/s", "cores": used, "kind": "port",
             "sample": "%d segments x %d sweeps in %.1f s; %s; host has %d cores" % (per_call, calls, el, what, os.cpu_count() or 0)}
+
+
+def roofline(wl, ndim, S, kern_ms):
+    flops, nbytes = WORK[(wl, ndim)]
+    dur = kern_ms * 1e-3
+    ach_tf = flops * S / dur / 1e12
+    ach_gb = nbytes * S / dur / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_%s%s.json" % (wl, "" if ndim == 14 or wl == "c3" else "_ndim12"))
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {
+        "bound": "fp64_valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+        "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
+        "kernel_ms": kern_ms, "flops_per_segment": flops, "bytes_per_segment": nbytes,
+        "hbm": {"achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBS},
+        "note": "register-resident fp64 ODE integration: bound by the FP64 vector pipe (no MFMA issued; MI355X "
+                "FP64 matrix peak equals the vector peak), not by HBM -- see DESIGN.md 'Roofline'",
+    }
+
+
+def parity_vs_oracle(ndim, XC, T, defect, Phi, S):
+    """Defect / STM of the benchmark's own last sweep against the oracle (checker) on a 256-segment sample."""
+    from oracle import oracle as O
+    import lowthrustopt_amd as lto
+    ns = min(256, S)
+    if ndim == 14:
+        prm_o = [lto.MU, lto.DU, lto.TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+        Phi_o, d_o, rc = O.indirect14(XC[:, :ns + 1, 0], T[:ns + 1, 0], prm_o, O.RK4, 64)
+        against = ("CPU oracle of the same 14-dim model, same RK4 x 64 discrete map, dual-number STM (build extension: the "
+                   "reference has no 14-dim CRTBP system, so this is implementation parity, not reference parity)")
+    else:
+        prm_o = [lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+        Phi_o, d_o, rc = O.indirect_jacobian(XC[:, :ns + 1, 0], T[:ns + 1, 0], prm_o, O.RK4, 64)
+        against = "CPU oracle, same RK4 x 64 discrete map, dual-number STM"
+    d_g = defect[:, :ns].cpu().numpy()
+    P_g = Phi[:, :ns].cpu().numpy().reshape(ndim, ndim, ns).transpose(1, 0, 2)
+    xn = np.linalg.norm(d_o + XC[:, 1:ns + 1, 0])
+    return {"defect_rel_l2": float(np.linalg.norm(d_g - d_o) / xn),
+            "stm_rel_max": float(np.abs(P_g - Phi_o).max() / np.abs(Phi_o).max()),
+            "sample_segments": ns, "oracle_rc": int(rc), "tolerance": 1e-10, "against": against}
+
+
+def leg_12dim(lto, synth, ctx, st, torch, a, with_oracle):
+    """C2 on the reference's own 12-dim system: same segments, integrator, step count and timing method."""
+    S = 4096
+    n = S + 1
+    XC, T = synth.indirect_problem(n, seed=0)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=64))
+    defect = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+    for _ in range(a.warmup):
+        plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()
+        plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
+           "workload": "C2 on the reference's CRTBP_stateCostate_deriv! system: 12-dim state+costate + 12x12 STM, 4 096 "
+                       "segments, RK4 x 64, fp64", "roofline": roofline("c2", 12, S, kern_ms)}
+    if with_oracle:
+        out["parity"] = parity_vs_oracle(12, XC, T, defect, Phi, S)
+    plan.close()
+    return out
 
 
 def main():
@@ -125,6 +224,8 @@ def main():
     st = lto.current_stream_ptr()
 
     wl = a.workload
+    if a.ndim == 0:
+        a.ndim = 14 if wl in ("c2", "c2_defect", "hbm") else 12
     prm1 = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
     f64 = dict(dtype=torch.float64, device=dev)
     c5 = wl in ("c5", "c5_stm")
@@ -146,14 +247,13 @@ def main():
                 integ = lto.integrator(lto.RKF78_FIXED, steps=4)
             elif a.method == "dop853":
                 integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13)
-            desc = {"c2": "C2: indirect 12-dim state+costate + 12x12 STM, RK4 x 64 steps, fp64, p=1 rho=1 thrust 0.05 N",
-                    "c2_defect": "C2 (defect only): indirect 12-dim state+costate, RK4 x 64 steps",
-                    "hbm": "HBM evidence point: indirect 12-dim + 12x12 STM, ONE RK4 step per segment"}[wl]
+            dd = (a.ndim, a.ndim, a.ndim)
+            desc = {"c2": "C2: indirect %d-dim state+costate + %dx%d STM, RK4 x 64 steps, fp64, p=1 rho=1 thrust 0.05 N" % dd,
+                    "c2_defect": "C2 (defect only): indirect %d-dim state+costate, RK4 x 64 steps" % a.ndim,
+                    "hbm": "HBM evidence point: indirect %d-dim + %dx%d STM, ONE RK4 step per segment" % dd}[wl]
         nd = a.ndim
-        if nd == 14:   # mass + mass costate extension: (r, v, m, lambda_r, lambda_v, lambda_m); params' mass slot = Isp
-            X14 = np.zeros((14, n, 1), order="F")
-            X14[:6] = XC[:6]; X14[6] = 1000.0; X14[7:13] = XC[6:]; X14[13] = 0.1
-            XC = X14
+        if nd == 14:   # mass + mass costate: (r, v, m, lambda_r, lambda_v, lambda_m); params' mass slot = Isp
+            XC = to14(XC)
             prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 2000.0, 1.0, 1.0, prm.rho)
         X = torch.from_numpy(synth.to_soa_nodes(XC)).to(dev)
         t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).to(dev)
@@ -171,8 +271,8 @@ def main():
             def sweep(dbuf):
                 plan.defect(X, n, t, 1, dbuf, S, stream=st)
         gather_rows = nd
-        if nd == 14 or a.method:
-            desc += " [ndim=%d%s]" % (nd, (", integrator " + a.method) if a.method else "")
+        if a.method:
+            desc += " [integrator %s]" % a.method
     elif wl == "c4":
         levels = 256 // max(world, 1) if not a.segments else max(1, a.segments // 1024)
         spt = 1024
@@ -291,26 +391,8 @@ def main():
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
                        "collective": "rccl all_gather(defect), overlapped with the next sweep on a side stream" if use_coll else "none", "integrator": "see workload"},
         }
-        if wl in WORK and a.ndim == 12 and not a.method:
-            flops, nbytes = WORK[wl]
-            dur = kern_ms * 1e-3
-            ach_tf = flops * S / dur / 1e12
-            ach_gb = nbytes * S / dur / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % wl)
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {
-                "bound": "fp64_valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
-                "kernel_ms": kern_ms, "flops_per_segment": flops, "bytes_per_segment": nbytes,
-                "hbm": {"achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBS},
-                "note": "register-resident fp64 ODE integration: bound by the FP64 vector pipe (no MFMA issued; MI355X "
-                        "FP64 matrix peak equals the vector peak), not by HBM -- see DESIGN.md 'Roofline'",
-            }
+        if (wl, a.ndim) in WORK and not a.method:
+            out["roofline"] = roofline(wl, a.ndim, S, kern_ms)
         if c5:
             # wavefront-divergence / load-balance study: a wave runs until its slowest lane has finished
             acc, rej = plan.step_counts(stream=st)
@@ -329,24 +411,18 @@ def main():
                                "group": grp,
                                "note": "efficiency = segment-steps executed / (group x slowest segment per wavefront / workgroup); rebalanced = "
                                        "lto_indirect_plan_rebalance ordered the lanes by the warm-up sweep's step counts"}
-        if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and a.ndim == 12 and not a.method:
-            out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds)
+        if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and not a.method:
+            out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds, ndim=a.ndim)
             if wl == "c2":
                 # the metric's second half: defect L2 error of this very run against the oracle (checker), 256-segment sample
-                from oracle import oracle as O
-                ns = min(256, S)
-                prm_o = [lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
-                Phi_o, d_o, rc = O.indirect_jacobian(XC[:, :ns + 1, 0], T[:ns + 1, 0], prm_o, O.RK4, 64)
-                d_g = defect[:, :ns].cpu().numpy()
-                P_g = Phi[:, :ns].cpu().numpy().reshape(12, 12, ns).transpose(1, 0, 2)
-                xn = np.linalg.norm(d_o + XC[:, 1:ns + 1, 0])
-                out["parity"] = {"defect_rel_l2": float(np.linalg.norm(d_g - d_o) / xn),
-                                 "stm_rel_max": float(np.abs(P_g - Phi_o).max() / np.abs(Phi_o).max()),
-                                 "sample_segments": ns, "oracle_rc": int(rc), "tolerance": 1e-10,
-                                 "against": "CPU oracle, same RK4 x 64 discrete map, dual-number STM"}
+                out["parity"] = parity_vs_oracle(a.ndim, XC, T, defect, Phi, S)
             ncpu = os.cpu_count() or 1
             if ncpu > 1:   # same restatement with the segment loop spread over every host core (reported, not the target)
-                out["cpu_baseline_all_cores"] = cpu_baseline("c3" if wl == "c3" else "c2", max(3.0, a.cpu_seconds / 3), threads=ncpu)
+                out["cpu_baseline_all_cores"] = cpu_baseline("c3" if wl == "c3" else "c2", max(3.0, a.cpu_seconds / 3), threads=ncpu,
+                                                             ndim=a.ndim)
+        if world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
+            # the reference's own system (12-dim, constant mass): the sweep reference parity is claimed for, same run
+            out["reference_system_12dim"] = leg_12dim(lto, synth, ctx, st, torch, a, with_oracle=not a.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if use_coll:
         dist.barrier()

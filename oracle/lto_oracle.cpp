@@ -593,6 +593,7 @@ int lto_o_flow_stm_state_costate_mass(double* y, const double* prm, double span,
 int lto_o_indirect14(const double* XC, const double* t, int n_nodes, const double* prm, int method, int steps, double rtol,
                      double atol, double* Phi, double* defect) {
   int status = 0;
+#pragma omp parallel for schedule(static) reduction(|:status)
   for (int i = 0; i < n_nodes - 1; ++i) {
     double y[14];
     std::memcpy(y, XC + 14 * i, sizeof y);

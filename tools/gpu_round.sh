@@ -8,11 +8,11 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > "$OUT/pytest_gpu.log"
 cat "$OUT/pytest_gpu.log" | tail -8
 python bench.py 2>&1 | tail -3 > "$OUT/bench_c2.json"; cat "$OUT/bench_c2.json"
-python bench.py --workload hbm --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_hbm.json"; cat "$OUT/bench_hbm.json"
+python bench.py --workload hbm --ndim 12 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_hbm.json"; cat "$OUT/bench_hbm.json"
 python bench.py --workload c3 --cpu-seconds 5 2>&1 | tail -1 > "$OUT/bench_c3.json"; cat "$OUT/bench_c3.json"
-python bench.py --ndim 14 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_c2_ndim14.json"; cat "$OUT/bench_c2_ndim14.json"
-python bench.py --method dop853 --no-cpu-baseline --steps 50 2>&1 | tail -1 > "$OUT/bench_c2_dop853.json"; cat "$OUT/bench_c2_dop853.json"
-python bench.py --method rkf78 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_c2_rkf78x4.json"; cat "$OUT/bench_c2_rkf78x4.json"
+python bench.py --ndim 12 --cpu-seconds 5 2>&1 | tail -1 > "$OUT/bench_c2_ndim12.json"; cat "$OUT/bench_c2_ndim12.json"
+python bench.py --ndim 12 --method dop853 --no-cpu-baseline --steps 50 2>&1 | tail -1 > "$OUT/bench_c2_dop853.json"; cat "$OUT/bench_c2_dop853.json"
+python bench.py --ndim 12 --method rkf78 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_c2_rkf78x4.json"; cat "$OUT/bench_c2_rkf78x4.json"
 python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>&1 | tail -1 > "$OUT/bench_c4.json"; cat "$OUT/bench_c4.json"
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>&1 | tail -1 > "$OUT/bench_c5.json"; cat "$OUT/bench_c5.json"
 python bench.py --workload c5_stm --no-cpu-baseline --steps 10 --warmup 2 2>&1 | tail -1 > "$OUT/bench_c5_stm.json"; cat "$OUT/bench_c5_stm.json"

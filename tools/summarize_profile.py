@@ -9,7 +9,8 @@ HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE 
 passes, are in KiB, and on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x (16 B/lane;
 our loads are 8 B/lane, "uncalibrated": both the raw and the doubled figure are recorded, the doubled one is
 the conservative number used for traffic).
-Usage: python tools/summarize_profile.py gpurun_out/r01a r01 c2 "k_indirect"
+Usage: python tools/summarize_profile.py gpurun_out/r01e r01e c2 "k_indirect<14"
+       python tools/summarize_profile.py gpurun_out/r01e r01e c2_ndim12 "k_indirect<12" c2    (12-dim leg of the same trace)
 """
 import csv
 import glob
@@ -29,9 +30,10 @@ def rows(pattern):
 
 def main():
     run, tag, workload, kname = sys.argv[1:5]
+    src = sys.argv[5] if len(sys.argv) > 5 else workload      # prof_<src>/ holds the kernel trace (one trace, several kernels)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     # kernel stats
-    stats = list(rows(os.path.join(run, "prof_%s" % workload, "**", "*_kernel_stats.csv")))
+    stats = list(rows(os.path.join(run, "prof_%s" % src, "**", "*_kernel_stats.csv")))
     out_csv = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, workload))
     with open(out_csv, "w", newline="") as fh:
         w = csv.writer(fh)
