@@ -420,6 +420,102 @@ __device__ __forceinline__ void var_col14(const VarCoef14& v, const double w2, c
   dc[13] = __builtin_fma(v.Lm, mu, __builtin_fma(v.Ln, ld, v.Ll * c[13]));
 }
 
+// Fused base + ONE STM column of the 14-dim system (the COLS = 1 mapping of the BASELINE configs[1] sweep): as
+// rhs12_fused1, G and H are applied through their dyadic structure; the mass couplings of rhs14 / var_col14 are added.
+//   y = (base[14], column[14]) -> k = (base_dot[14], column_dot[14]);  column = (a, b, mu, g, d, nu)
+template <int PM>
+__device__ __forceinline__ void rhs14_fused1(const double (&y)[28], const TrajParams& tp, const double w2, double (&k)[28]) {
+  const double MU = tp.MU;
+  const double x = y[0], yy = y[1], z = y[2], mass = y[6];
+  const double A = x + MU, B = A - 1.0;
+  const double yz2 = __builtin_fma(yy, yy, z * z);
+  const double d1 = __builtin_fma(A, A, yz2), d2 = __builtin_fma(B, B, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
+  const double cs = c1 + c2, omc = 1.0 - cs;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double ee = e1 + e2;
+  const double st = __builtin_fma(e1, A, e2 * B);
+  const double eey = ee * yy, eez = ee * z;
+
+  const double lx = y[10], ly = y[11], lz = y[12], lm = y[13];
+  const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
+  const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
+  const double n = n2 * inv_n;
+  const double inv_m = rcp_nr(mass);
+  const double aL = tp.cT * inv_m;
+  double m, ua, ub, un;
+  bool tlim;
+  control_dispatch<PM, true>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+  const double lhx = lx * inv_n, lhy = ly * inv_n, lhz = lz * inv_n;
+  const double kt = tp.kappa_td;
+
+  const double yzl = __builtin_fma(yy, ly, z * lz);
+  const double s1 = __builtin_fma(A, lx, yzl), s2 = __builtin_fma(B, lx, yzl);
+  const double t1 = e1 * s1, t2 = e2 * s2;
+  const double es = t1 + t2;
+  const double tA = __builtin_fma(t1, A, t2 * B);
+
+  k[0] = y[3]; k[1] = y[4]; k[2] = y[5];
+  k[3] = __builtin_fma(-c1, A, __builtin_fma(-c2, B, __builtin_fma(w2, y[4], x))) - m * lhx;
+  k[4] = __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)) - m * lhy;
+  k[5] = __builtin_fma(-cs, z, -m * lhz);
+  k[6] = -kt * m * mass;
+  k[7] = -__builtin_fma(omc, lx, tA);
+  k[8] = -__builtin_fma(omc, ly, es * yy);
+  k[9] = -__builtin_fma(-cs, lz, es * z);
+  k[10] = __builtin_fma(w2, ly, -y[7]);
+  k[11] = __builtin_fma(-w2, lx, -y[8]);
+  k[12] = -y[9];
+  const double tl = tlim ? 1.0 : 0.0, ntl = 1.0 - tl;      // thrust-limited law (umag ~ 1/m) or not, see rhs14
+  const double m_over_m = m * inv_m;
+  const double mn_over_m = m_over_m * n;
+  k[13] = __builtin_fma(-tl, mn_over_m, ntl * (kt * lm * m));
+
+  // ---- column (a, b, mu, g, d, nu)
+  const double ax = y[14], ay = y[15], az = y[16], mu = y[20];
+  const double dx = y[24], dyv = y[25], dz = y[26], nu = y[27];
+  const double yza = __builtin_fma(yy, ay, z * az);
+  const double r1a = __builtin_fma(A, ax, yza), r2a = __builtin_fma(B, ax, yza);
+  const double u1 = e1 * r1a, u2 = e2 * r2a;
+  const double us = u1 + u2;
+  const double uA = __builtin_fma(u1, A, u2 * B);
+  const double Gax = __builtin_fma(omc, ax, uA), Gay = __builtin_fma(omc, ay, us * yy), Gaz = __builtin_fma(-cs, az, us * z);
+  const double yzd = __builtin_fma(yy, dyv, z * dz);
+  const double r1d = __builtin_fma(A, dx, yzd), r2d = __builtin_fma(B, dx, yzd);
+  const double v1 = e1 * r1d, v2 = e2 * r2d;
+  const double vs = v1 + v2;
+  const double vA = __builtin_fma(v1, A, v2 * B);
+  const double Gdx = __builtin_fma(omc, dx, vA), Gdy = __builtin_fma(omc, dyv, vs * yy), Gdz = __builtin_fma(-cs, dz, vs * z);
+  const double la = __builtin_fma(lx, ax, __builtin_fma(ly, ay, lz * az));
+  const double w1 = (5.0 * i1s) * (t1 * r1a), w2b = (5.0 * i2s) * (t2 * r2a);
+  const double ws = w1 + w2b;
+  const double wA = __builtin_fma(w1, A, w2b * B);
+  const double Hax = __builtin_fma(es, ax, __builtin_fma(la, st, __builtin_fma(us, lx, -wA)));
+  const double Hay = __builtin_fma(es, ay, __builtin_fma(la, eey, __builtin_fma(us, ly, -ws * yy)));
+  const double Haz = __builtin_fma(es, az, __builtin_fma(la, eez, __builtin_fma(us, lz, -ws * z)));
+  // U d + (d u / d m) mu = -ua d + (ub (lhat.d) + um_neg mu) lhat,  um_neg = -d umag / d m = tl umag / m
+  const double ld = __builtin_fma(lhx, dx, __builtin_fma(lhy, dyv, lhz * dz));
+  const double tq = __builtin_fma(ub, ld, (tl * m_over_m) * mu);
+  k[14] = y[17]; k[15] = y[18]; k[16] = y[19];
+  k[17] = Gax + __builtin_fma(w2, y[18], __builtin_fma(-ua, dx, tq * lhx));
+  k[18] = Gay + __builtin_fma(-w2, y[17], __builtin_fma(-ua, dyv, tq * lhy));
+  k[19] = Gaz + __builtin_fma(-ua, dz, tq * lhz);
+  // mu dot = (d mdot / d m) mu + (d mdot / d n) (lhat . d)
+  k[20] = -kt * __builtin_fma(ntl * m, mu, (mass * un) * ld);
+  k[21] = -(Hax + Gdx);
+  k[22] = -(Hay + Gdy);
+  k[23] = -(Haz + Gdz);
+  k[24] = __builtin_fma(w2, dyv, -y[21]);
+  k[25] = __builtin_fma(-w2, dx, -y[22]);
+  k[26] = -y[23];
+  // nu dot = Lm mu + Ln (lhat . d) + Ll nu   (coefficients as in rhs14)
+  const double Lm = tl * (2.0 * mn_over_m * inv_m);
+  const double Ln = __builtin_fma(-tl, __builtin_fma(un, n, m) * inv_m, ntl * (kt * lm * un));
+  k[27] = __builtin_fma(Lm, mu, __builtin_fma(Ln, ld, (ntl * (kt * m)) * nu));
+}
+
 // ------------------------------------------------------------------------------ A2 (direct path)
 // Per-lane constants of one half-segment propagation (prop_EP_deriv.jl:8-61).
 struct DirectLane {

@@ -28,6 +28,10 @@ struct SysIndirect {
       rhs12_fused1<PM>(y, tp, w2, k);
       return;
     }
+    if constexpr (ND == 14 && COLS == 1) {
+      rhs14_fused1<PM>(y, tp, w2, k);
+      return;
+    }
     double yb[ND], kb[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) yb[i] = y[i];

@@ -5,7 +5,7 @@
 using namespace lto;
 extern "C" {
 // F*col for the 14-dim system via device formulas (host-compiled)
-void chk_rhs14(const double* y, const double* tpv, int pm, double* dy, const double* col, double* dcol) {
+void chk_rhs14(const double* y, const double* tpv, int pm, double* dy, const double* col, double* dcol, double* dy_f, double* dcol_f) {
   TrajParams tp; std::memcpy(&tp, tpv, sizeof tp);
   double yy[14], d[14], c[14], dc[14];
   for (int i = 0; i < 14; ++i) { yy[i] = y[i]; c[i] = col[i]; }
@@ -16,6 +16,13 @@ void chk_rhs14(const double* y, const double* tpv, int pm, double* dy, const dou
   else rhs14<PM_PGEN, true>(yy, tp, d, vc);
   var_col14(vc, 2.0 * tp.omega, c, dc);
   for (int i = 0; i < 14; ++i) { dy[i] = d[i]; dcol[i] = dc[i]; }
+  double y28[28], k28[28];
+  for (int i = 0; i < 14; ++i) { y28[i] = y[i]; y28[14 + i] = col[i]; }
+  if (pm == PM_P1) rhs14_fused1<PM_P1>(y28, tp, 2.0 * tp.omega, k28);
+  else if (pm == PM_P2) rhs14_fused1<PM_P2>(y28, tp, 2.0 * tp.omega, k28);
+  else if (pm == PM_P0) rhs14_fused1<PM_P0>(y28, tp, 2.0 * tp.omega, k28);
+  else rhs14_fused1<PM_PGEN>(y28, tp, 2.0 * tp.omega, k28);
+  for (int i = 0; i < 14; ++i) { dy_f[i] = k28[i]; dcol_f[i] = k28[14 + i]; }
 }
 void chk_rhs12(const double* y, const double* tpv, int pm, double* dy, const double* col, double* dcol, double* dy_f, double* dcol_f) {
   TrajParams tp; std::memcpy(&tp, tpv, sizeof tp);

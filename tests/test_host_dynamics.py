@@ -71,10 +71,13 @@ def test_device_formulas_14(chk, oracle):
         prm = [MU, DU, TU, thr, 2000.0, 1.0, p, rho]
         tp = tp_vec(14, thr, 2000.0, 1.0, p, rho)
         col = rng.standard_normal(14)
-        d = np.zeros(14); dc = np.zeros(14)
-        chk.chk_rhs14(P(y), P(tp), pm, P(d), P(col), P(dc))
+        d = np.zeros(14); dc = np.zeros(14); df = np.zeros(14); dcf = np.zeros(14)
+        chk.chk_rhs14(P(y), P(tp), pm, P(d), P(col), P(dc), P(df), P(dcf))
         ref = oracle.rhs_state_costate_mass(y, prm)
         assert np.abs(d - ref).max() < 5e-14 * max(1.0, np.abs(ref).max())
+        # fused base + one column (the COLS = 1 kernel of the BASELINE configs[1] sweep) == the general path
+        assert np.abs(df - d).max() < 5e-14 * max(1.0, np.abs(ref).max())
+        assert np.abs(dcf - dc).max() < 1e-12 * max(1.0, np.abs(dc).max())
         J = np.zeros((14, 14))
         for c in range(14):          # central differences of the oracle RHS (FD noise ~1e-9 relative)
             h = 1e-6 * max(1.0, abs(y[c]))
