@@ -359,6 +359,18 @@ def direct_scatter(Jac_temp, ddefect_dtf=None):
     return J
 
 
+def direct_endpoint_partials(Jac_temp, ddefect_dtf):
+    """The three finite-difference blocks endpointPartials assembles (multiShoot_CRTBP_direct.jl:168-246), read off the
+    analytic Jacobian blocks instead of re-propagating:
+      ddefect_dt     [nstate(n-1)]  partial of all defects wrt tf               (:176-190)  = the tf column
+      d_defect1_dV1  [nstate x 3]   partial of defect 1 wrt an impulse at node 1 (:193-214)  = d defect_1 / d v_1
+      d_defectN_dV2  [nstate x 3]   partial of defect N wrt an impulse at node n (:216-222)  = d defect_N / d v_n
+    (the reference's tau1/tau2 columns use variables that are never defined, :232,:235; they are not reproduced)."""
+    ns = Jac_temp.shape[0]
+    return (np.asarray(ddefect_dtf).reshape(-1, order="F").copy(), Jac_temp[:, 3:6, 0].copy(),
+            Jac_temp[:, ns + 3:ns + 6, -1].copy())
+
+
 def direct_jacobianCalc(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None, with_tf=True):
     """jacobianCalc (+ tf partial) of multiShoot_CRTBP_direct: Jac_full [nstate(n-1) x n(nstate+3)+1]."""
     Jt, dtf, _, _ = direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx)

@@ -579,6 +579,30 @@ def test_direct_jacobian_vs_oracle(gpu_ctx, oracle, nstate):
     assert np.abs(J - J_o).max() < 1e-9
 
 
+@pytest.mark.parametrize("nstate", [6, 7])
+def test_direct_endpoint_partials_vs_reference_finite_differences(gpu_ctx, oracle, nstate):
+    """endpointPartials (direct.jl:168-246): its finite-difference blocks (pert = 1e-5) reproduced with the oracle and
+    compared with the slices of the analytic Jacobian blocks."""
+    X, U, T = synth.direct_problem(12, seed=71, nstate=nstate)
+    X, U, t = X[:, :, 0], U[:, :, 0], T[:, 0]
+    Jt, dtf, d, _ = lto.direct_jacobian_blocks(X, U, t, 10, MU, DU, TU, 2000.0, ctx=gpu_ctx)
+    ddt, dV1, dV2 = lto.direct_endpoint_partials(Jt, dtf)
+    pert = 1e-5
+    d0, _ = oracle.direct_defect(X, U, t, 10, MU, DU, TU, 2000.0)
+    tau = (t - t[0]) / (t[-1] - t[0]) * 2 - 1                                  # :181-183
+    t_mod = t[0] + (tau + 1) / 2 * (t[-1] + pert - t[0])
+    d_mod, _ = oracle.direct_defect(X, U, t_mod, 10, MU, DU, TU, 2000.0)
+    fd_dt = ((d_mod - d0) / pert).reshape(-1, order="F")
+    assert np.abs(ddt - fd_dt).max() < 1e-4 * max(1.0, np.abs(fd_dt).max())
+    for ind in range(3):
+        X0 = X[:, :2].copy(); X0[ind + 3, 0] += pert                              # :199-208
+        dd, _ = oracle.direct_defect(X0, U[:, :2], t[:2], 10, MU, DU, TU, 2000.0)
+        assert np.abs(dV1[:, ind] - (dd[:, 0] - d0[:, 0]) / pert).max() < 1e-4 * max(1.0, np.abs(dV1).max())
+        Xf = X[:, -2:].copy(); Xf[ind + 3, 1] += pert                             # :202-203, :216-222
+        dd, _ = oracle.direct_defect(Xf, U[:, -2:], t[-2:], 10, MU, DU, TU, 2000.0)
+        assert np.abs(dV2[:, ind] - (dd[:, 0] - d0[:, -1]) / pert).max() < 1e-4 * max(1.0, np.abs(dV2).max())
+
+
 def test_direct_full_size_linearity(gpu_ctx):
     """BASELINE configs[2] size (16 384 segments, 6-state, RKF7(8) nsteps = 10, on-device Jacobian blocks):
     finite, small error estimates, and the Jacobian predicts the change of every defect under a perturbation
