@@ -27,9 +27,10 @@ hipError_t launch_indirect14_stm(int pm, int method, int cols, const IndirectArg
   }
   switch (method) {
     case M_RKF78_FIXED: return launch_pm<14, M_RKF78_FIXED, 1>(pm, a, st);
+    case M_RKF78_ADAPTIVE: return launch_pm<14, M_RKF78_ADAPTIVE, 1>(pm, a, st);
     case M_DOP853_ADAPTIVE: return launch_pm<14, M_DOP853_ADAPTIVE, 1>(pm, a, st);
   }
-  return hipErrorInvalidValue;  // RKF78_ADAPTIVE + STM is not instantiated for ND = 14
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_indirect14_dense(int pm, int method, const IndirectArgs& a, const DenseArgs& d, hipStream_t st) {

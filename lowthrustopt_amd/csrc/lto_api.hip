@@ -345,6 +345,7 @@ int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
   if (!p) return LTO_ENULL;
   if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2 or 3");
+  if (p->ndim == 14 && cols == 3) return set_err(p->ctx, LTO_EUNSUPPORTED, "14 STM columns do not split into groups of 3: use 0 (auto), 1 or 2");
   p->cols_per_lane = cols;
   return LTO_OK;
 }

@@ -1,0 +1,141 @@
+"""Seeded random configurations of the indirect sweep (size, batch, dimension, integrator, control-law class, smoothing,
+thrust, segment lengths, time direction, kernel family, columns per lane) against the oracle.  Complements the
+structured cases of test_gpu_parity.py: kernels that are miscompiled or mis-dispatched only for some template
+combination show up here (see DESIGN.md "Compiler hazards")."""
+import numpy as np
+import pytest
+
+import lowthrustopt_amd as lto
+from lowthrustopt_amd import synth
+from lowthrustopt_amd.constants import MU, DU, TU
+
+pytestmark = pytest.mark.gpu
+
+METHODS = [(lto.RK4, 24), (lto.RKF78_FIXED, 5), (lto.RKF78_ADAPTIVE, 0), (lto.DOP853_ADAPTIVE, 0)]
+
+
+def make_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    ndim = int(rng.choice([12, 14]))
+    method, steps = METHODS[int(rng.integers(0, 4))]
+    adaptive = method in (lto.RKF78_ADAPTIVE, lto.DOP853_ADAPTIVE)
+    B = int(rng.choice([1, 1, 2, 5]))
+    n = int(rng.integers(2, 90))
+    lo = 10.0 ** rng.uniform(-3, -1)
+    hi = lo * 10.0 ** rng.uniform(0, 0.8)
+    ps = [float(rng.choice([0.0, 1.0, 2.0, 1.5, 3.0])) for _ in range(B)]
+    # adaptive controllers are compared at smooth settings (the sharp-switch behaviour of ode78 has its own test)
+    rhos = [10.0 ** rng.uniform(-1.0 if adaptive else -4.0, 0.0) for _ in range(B)]
+    thr = [float(rng.choice([0.05, 10.0])) for _ in range(B)]
+    td = float(rng.choice([1.0, 1.0, -1.0]))
+    lam = float(rng.choice([0.1, 0.5, 1.0]))
+    kernel = int(rng.integers(0, 3))
+    cols = int(rng.integers(0, 4))
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=seed, dt_range=(lo, hi), lam_sigma=lam)
+    if ndim == 14:
+        X = np.zeros((14, n, B), order="F")
+        X[:6] = XC[:6]; X[6] = rng.uniform(500.0, 1500.0); X[7:13] = XC[6:]; X[13] = rng.uniform(-0.5, 0.5)
+        slot = 2000.0
+    else:
+        X, slot = XC, 1000.0
+    prm_l = [[MU, DU, TU, thr[b], slot, td, ps[b], rhos[b]] for b in range(B)]
+    return dict(ndim=ndim, method=method, steps=steps, adaptive=adaptive, B=B, n=n, X=X, T=T, prm_l=prm_l, kernel=kernel,
+                cols=cols)
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_indirect_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
+    import torch
+    c = make_case(seed)
+    ndim, n, B, S = c["ndim"], c["n"], c["B"], c["n"] - 1
+    plan = lto.IndirectPlan(gpu_ctx, n, B, [lto.make_params(*q) for q in c["prm_l"]], lto.integrator(c["method"], steps=c["steps"]),
+                            ndim=ndim)
+    plan.set_kernel(c["kernel"])
+    if ndim == 14 and c["cols"] == 3:                # 14 columns do not split into groups of 3: refused, auto is kept
+        with pytest.raises(lto.LtoError) as ei:
+            plan.set_cols_per_lane(3)
+        assert ei.value.code == -3
+    else:
+        plan.set_cols_per_lane(c["cols"])
+    Xd = torch.from_numpy(synth.to_soa_nodes(c["X"])).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(c["T"].T.reshape(-1))).cuda()
+    J = S * B
+    Phi = torch.full((ndim * ndim, J), 3.0, dtype=torch.float64, device="cuda")
+    d = torch.full((ndim, J), 3.0, dtype=torch.float64, device="cuda")
+    d0 = torch.full((ndim, J), 3.0, dtype=torch.float64, device="cuda")
+    plan.jacobian(Xd, n * B, td, B, Phi, J, d, J)
+    plan.defect(Xd, n * B, td, B, d0, J)
+    torch.cuda.synchronize()
+    Pn = Phi.cpu().numpy().reshape(ndim, ndim, J).transpose(1, 0, 2)
+    dn, d0n = d.cpu().numpy(), d0.cpu().numpy()
+    assert np.all(np.isfinite(Pn)) and np.all(np.isfinite(dn)) and np.all(np.isfinite(d0n))
+    tol_d = 1e-10
+    tol_P = 1e-7 if c["adaptive"] else 1e-10
+    for b in range(B):
+        Xb, tb, sl = c["X"][:, :, b], c["T"][:, b], slice(b * S, (b + 1) * S)
+        if ndim == 12:
+            P_o, d_o, rc = oracle.indirect_jacobian(Xb, tb, c["prm_l"][b], c["method"], c["steps"])
+        else:
+            P_o, d_o, rc = oracle.indirect14(Xb, tb, c["prm_l"][b], c["method"], c["steps"])
+        assert rc == 0
+        scale = np.linalg.norm(d_o + Xb[:, 1:])
+        what = "seed %d: ndim %d method %d B %d n %d kernel %d cols %d p %g" % (seed, ndim, c["method"], B, n, c["kernel"],
+                                                                              c["cols"], c["prm_l"][b][6])
+        assert np.linalg.norm(dn[:, sl] - d_o) < tol_d * scale, what
+        assert np.linalg.norm(d0n[:, sl] - d_o) < tol_d * scale, what
+        assert np.abs(Pn[:, :, sl] - P_o).max() < tol_P * np.abs(P_o).max(), what
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_direct_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
+    """Direct transcription: random state size, node count, batch, steps per half segment, Isp, thrust scale (incl.
+    zero-control nodes), segment lengths and Jacobian kernel family against the oracle: defect, RKF7(8) error estimate,
+    Jacobian blocks (exact derivative of the discrete map by dual numbers), tf partial, mid-point states."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    nstate = int(rng.choice([6, 7]))
+    n = int(rng.integers(2, 70))
+    B = int(rng.choice([1, 1, 3]))
+    nsteps = int(rng.integers(2, 13))
+    Isp = float(rng.choice([300.0, 2000.0, 3000.0]))
+    kern = int(rng.integers(0, 3))
+    X, U, T = synth.direct_problem(n, n_batch=B, seed=seed, nstate=nstate, dt_seg=10.0 ** rng.uniform(-2.5, -0.4),
+                                   thrust_sigma=float(rng.choice([0.0, 0.03, 1.0])))
+    if n > 3:
+        U[:, int(rng.integers(0, n)), 0] = 0.0                      # a zero-control node (prop_EP_deriv.jl:35-36)
+    S = n - 1
+    nvar = 2 * (nstate + 3)
+    plan = lto.DirectPlan(gpu_ctx, nstate, n, B, nsteps, MU, DU, TU, Isp)
+    plan.set_kernel(kern)
+    Xs = torch.from_numpy(synth.to_soa_nodes(X)).cuda(); Us = torch.from_numpy(synth.to_soa_nodes(U)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    J = S * B
+    Jac = torch.full((nstate * nvar, J), 3.0, dtype=torch.float64, device="cuda")
+    dtf = torch.full((nstate, J), 3.0, dtype=torch.float64, device="cuda")
+    d = torch.full((nstate, J), 3.0, dtype=torch.float64, device="cuda")
+    e = torch.full((J,), 3.0, dtype=torch.float64, device="cuda")
+    d0 = torch.full((nstate, J), 3.0, dtype=torch.float64, device="cuda")
+    e0 = torch.full((J,), 3.0, dtype=torch.float64, device="cuda")
+    xm = torch.full((nstate, J), 3.0, dtype=torch.float64, device="cuda")
+    plan.jacobian(Xs, n * B, Us, n * B, td, B, Jac, J, dtf, d, J, e)
+    plan.midpoints(Xs, n * B, Us, n * B, td, B, xm, J, d0, J, e0)
+    torch.cuda.synchronize()
+    Jg = Jac.cpu().numpy().reshape(nvar, nstate, J).transpose(1, 0, 2)
+    dtfg, dg, eg, d0g, e0g, xmg = (v.cpu().numpy() for v in (dtf, d, e, d0, e0, xm))
+    what = "seed %d: nstate %d n %d B %d nsteps %d Isp %g kernel %d" % (seed, nstate, n, B, nsteps, Isp, kern)
+    for b in range(B):
+        Xb, Ub, tb, sl = X[:, :, b], U[:, :, b], T[:, b], slice(b * S, (b + 1) * S)
+        d_o, e_o = oracle.direct_defect(Xb, Ub, tb, nsteps, MU, DU, TU, Isp)
+        Jd, dh, dd = oracle.direct_jacobian_dual(Xb, Ub, tb, nsteps, MU, DU, TU, Isp)
+        assert np.abs(dg[:, sl] - d_o).max() < 1e-12 and np.abs(d0g[:, sl] - d_o).max() < 1e-12, what
+        # the estimate is a difference of nearly equal slopes: round-off level noise differs between kernels
+        assert np.abs(eg[sl] - e_o).max() < 1e-3 * e_o.max() + 1e-17 and np.abs(e0g[sl] - e_o).max() < 1e-3 * e_o.max() + 1e-17, what
+        assert np.abs(Jg[:, :, sl] - Jd).max() < 1e-10 * max(1.0, np.abs(Jd).max()), what
+        dtf_exact = dh * (np.diff(tb) / (tb[-1] - tb[0]))[None, :]
+        # the tf partial is the continuous formula (f_f - R f_b) h/(tf - t0); against the derivative of the discrete
+        # map it differs by the RKF7(8) truncation error, which the error estimate bounds
+        assert np.abs(dtfg[:, sl] - dtf_exact).max() < 1e-8 * max(1.0, np.abs(dtf_exact).max()) + 1e3 * e_o.max(), what
+        for i in range(0, S, max(1, S // 5)):
+            ref, _ = oracle.flow_prop_ep(Xb[:, i], Ub[:, i], 1.0, (tb[i + 1] - tb[i]) / 2, oracle.RKF78_FIXED, nsteps - 1,
+                                         MU, DU, TU, Isp)
+            assert np.abs(xmg[:, b * S + i] - ref).max() < 1e-12, what

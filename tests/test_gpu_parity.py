@@ -207,8 +207,6 @@ def test_indirect_mixed_control_law_classes(gpu_ctx, ndim, mname, kernel):
     STM and step counts equal those of single-trajectory sweeps, for every integrator and both STM kernel families."""
     import torch
     method, steps = METHODS[mname]
-    if ndim == 14 and method == lto.RKF78_ADAPTIVE and kernel == "per_lane":
-        pytest.skip("per-lane RKF78-adaptive STM is not instantiated for ND = 14")
     ps = [1.0, 0.0, 2.0, 1.5, 1.0, 2.0, 3.0]
     B, n = len(ps), 8                                          # 7 segments per trajectory: classes interleave in a wave
     XC, T = synth.indirect_problem(n, n_batch=B, seed=31, dt_range=(0.05, 0.3))
@@ -343,8 +341,6 @@ def test_indirect_adaptive_nan_is_poison_not_a_stall(gpu_ctx, ndim, mname, kerne
     import time
     import torch
     method, steps = METHODS[mname]
-    if ndim == 14 and method == lto.RKF78_ADAPTIVE and kernel == "per_lane":
-        pytest.skip("per-lane RKF78-adaptive STM is not instantiated for ND = 14")
     n = 40
     XC, T = synth.indirect_problem(n, seed=21)
     XC, t = XC[:, :, 0], T[:, 0]
@@ -669,8 +665,6 @@ def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, ke
     integrator, ND = 12 and the 14-dim extension, ragged segment count (not a multiple of 16 or 64)."""
     import torch
     method, steps = METHODS[mname]
-    if ndim == 14 and method == lto.RKF78_ADAPTIVE and kernel == "per_lane":
-        pytest.skip("per-lane RKF78-adaptive STM is not instantiated for ND = 14")
     n = 78
     pp, rho, thr, lam = P_CASES[pcase]
     XC, T = synth.indirect_problem(n, seed=11, lam_sigma=lam)
