@@ -139,3 +139,49 @@ def test_direct_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
             ref, _ = oracle.flow_prop_ep(Xb[:, i], Ub[:, i], 1.0, (tb[i + 1] - tb[i]) / 2, oracle.RKF78_FIXED, nsteps - 1,
                                          MU, DU, TU, Isp)
             assert np.abs(xmg[:, b * S + i] - ref).max() < 1e-12, what
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_device_newton_solve_random_sizes_vs_dense(gpu_ctx, seed):
+    """Structured orthogonal cyclic reduction (square system and adjoints-only least squares, fused tail included) at
+    random node counts / batch sizes against numpy's dense least squares on the scattered Jacobian
+    (`-Jac_sparse \\ defect_vec`, indirect.jl:169-182), plus the stored-factorisation re-solve."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    n_nodes = int(rng.integers(2, 140))
+    n_batch = int(rng.choice([1, 1, 2, 4]))
+    adj = bool(rng.integers(0, 2))
+    XC, T = synth.indirect_problem(n_nodes, n_batch=n_batch, seed=seed, dt_range=(0.03, 0.25))
+    prm = lto.make_params(MU, DU, TU, float(rng.choice([0.05, 10.0])), 1000.0, 1.0, float(rng.choice([1.0, 2.0])), 1.0)
+    S, J = (n_nodes - 1) * n_batch, n_nodes * n_batch
+    plan = lto.IndirectPlan(gpu_ctx, n_nodes, n_batch, prm, lto.integrator(lto.RKF78_FIXED, steps=4))
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+    d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    delta = torch.full((12, J), float("nan"), dtype=torch.float64, device="cuda")
+    delta2 = torch.full((12, J), float("nan"), dtype=torch.float64, device="cuda")
+    plan.jacobian(X, J, t, n_batch, Phi, S, d, S)
+    plan.newton_solve(Phi, S, d, S, delta, J, adjoints_only=adj)
+    d2 = d * -0.3 + 0.02
+    plan.newton_solve(None, 0, d2, S, delta2, J, adjoints_only=adj)
+    torch.cuda.synchronize()
+    Pn = Phi.cpu().numpy().reshape(12, 12, n_batch, n_nodes - 1).transpose(1, 0, 3, 2)
+    what = "seed %d: n_nodes %d n_batch %d adjoints_only %s" % (seed, n_nodes, n_batch, adj)
+    for dd, de in ((d, delta), (d2, delta2)):
+        dn = dd.cpu().numpy().reshape(12, n_batch, n_nodes - 1).transpose(0, 2, 1)
+        den = de.cpu().numpy().reshape(12, n_batch, n_nodes).transpose(0, 2, 1)
+        assert np.all(np.isfinite(den)), what
+        for b in range(n_batch):
+            Jd = lto.indirect_scatter(np.asfortranarray(Pn[:, :, :, b]))
+            keep = np.ones(Jd.shape[1], bool)
+            keep[:6] = False; keep[12 * (n_nodes - 1):12 * (n_nodes - 1) + 6] = False       # fixed end states (:141-142)
+            if adj:                                                                          # :169-178
+                for k in range(n_nodes - 1):
+                    keep[12 * k:12 * k + 6] = False
+            rhs = -dn[:, :, b].reshape(-1, order="F")
+            ref = np.zeros(Jd.shape[1])
+            ref[keep] = np.linalg.lstsq(Jd[:, keep], rhs, rcond=None)[0]
+            got = den[:, :, b].reshape(-1, order="F")
+            assert np.all(got[~keep] == 0.0), what
+            assert np.abs(got - ref).max() < 1e-7 * max(1.0, np.abs(ref).max()), what
