@@ -629,6 +629,8 @@ int lto_indirect_solve(lto_ctx* c, int ndim, int n_nodes, const double* XC_in, c
     ++iter;
     if (iter > maxIter) { status = 1; break; }             // :282-286
     rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, 1, d_phi, S, d_def, S);                     // :290
+    // large adaptive problems: the next sweeps of this plan run with the lanes ordered by this sweep's step counts
+    if (rc == LTO_OK && host_order_wanted(p, true)) rc = lto_indirect_plan_rebalance(p, st);
     if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, flag_adjointsOnly, d_del, J);   // :182
     if (rc == LTO_OK) rc = max_abs(d_del, J, 12, J, &h_mx);
     if (rc != LTO_OK) break;
@@ -646,6 +648,7 @@ int lto_indirect_solve(lto_ctx* c, int ndim, int n_nodes, const double* XC_in, c
       e = launch_trial_points(d_X, d_del, J, 12, n_nodes, NA, d_small + 16, d_Xt, J * NA, st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "trial points", e); break; }
       rc = lto_indirect_defect_dev(pl, st, d_Xt, J * NA, d_t, 1, d_deft, S * NA, nullptr);
+      if (rc == LTO_OK && host_order_wanted(pl, false)) rc = lto_indirect_plan_rebalance(pl, st);
       if (rc != LTO_OK) break;
       e = launch_defect_norms(d_deft, S * NA, 12, (int)S, NA, d_small + 40, nullptr, st);          // sum(defect.^2), :240
       if (e == hipSuccess) e = hipMemcpyAsync(h_ss, d_small + 40, sizeof h_ss, hipMemcpyDeviceToHost, st);

@@ -316,3 +316,19 @@ def test_device_newton_loop_equals_python_loop(gpu_ctx, oracle, adjoints_only):
     with pytest.raises(lto.LtoError) as ei:
         lto.indirect_solve(XC, t, lto.make_params(MU, DU, TU, 10.0, 1000.0, 1.0, 0.5, 1.0), None, False, 5, ctx=gpu_ctx)
     assert ei.value.code == 2
+
+
+@pytest.mark.gpu
+def test_device_newton_loop_large_adaptive_problem_rebalances(gpu_ctx):
+    """8 299 segments with the adaptive integrator: lto_indirect_solve orders the lanes of each sweep by the previous
+    sweep's step counts (a pure scheduling change); two iterations agree with the Python loop on the host API."""
+    n = 8300
+    XC, T = synth.indirect_problem(n, seed=81, dt_range=(0.005, 0.04), lam_sigma=0.02)
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, 10.0, 1000.0, 1.0, 2.0, 1.0)
+    Xd, dd, sd, itd, hist = lto.indirect_solve(XC, t, prm, None, False, 2, ctx=gpu_ctx)
+    Xp, dp, sp = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, n, 1000.0, 10.0, False, False, 2, 2.0, 1.0,
+                                                   ops=drivers.HipOps(gpu_ctx), verbose=False)
+    assert sd == sp and len(hist) == min(itd, 2)
+    assert np.all(np.isfinite(Xd)) and np.abs(Xd - Xp).max() < 1e-9 * max(1.0, np.abs(Xp).max())
+    assert np.abs(dd - dp).max() < 1e-9 * max(1.0, np.abs(dp).max())
