@@ -130,6 +130,17 @@ int lto_indirect_solve(lto_ctx* ctx, int ndim, int n_nodes, const double* XC_in,
                        const lto_integrator* integ, int flag_adjointsOnly, int maxIter, double* XC_out, double* defect,
                        int* status_flag, int* iterations, double* history);
 
+/* n_batch independent problems through the same loop, side by side (homotopy / thrust levels, several initial guesses:
+ * the concurrent form of the continuation of src/HelperFunctions.jl:105-193).  Every device operation covers the
+ * whole batch; a trajectory that has left the reference loop (converged, NaN, iteration limit) is frozen by a zero
+ * step length.  Arrays carry a trailing batch dimension: XC [12 x n_nodes x n_batch], t [n_nodes x n_tgrids],
+ * prm [n_prm] (n_tgrids, n_prm = 1 or n_batch), defect [12 x (n_nodes-1) x n_batch], status_flag / iterations
+ * [n_batch], history [2 x maxIter x n_batch]. */
+int lto_indirect_solve_batch(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, const double* XC_in, const double* t,
+                             int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ,
+                             int flag_adjointsOnly, int maxIter, double* XC_out, double* defect, int* status_flag,
+                             int* iterations, double* history);
+
 /* Replaces densify (src/HelperFunctions.jl:51-101) for one trajectory: t_dense = LinRange(t[1], t[end], n_desired),
  * every segment re-propagated from its node and sampled at the t_dense points inside [t_i, t_{i+1}), final propagated
  * state appended.  XC_dense [ndim x n_desired], t_dense [n_desired]. */

@@ -13,7 +13,7 @@ module LowThrustOptHIP
 
 using SparseArrays, LinearAlgebra, Libdl
 
-export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, indirect_solve, densify,
+export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, indirect_solve, indirect_solve_batch, densify,
        direct_defectCalc, direct_jacobianCalc, direct_midpoints, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
 
 const liblto = get(ENV, "LTO_HIP_LIB", joinpath(@__DIR__, "..", "lowthrustopt_amd", "liblto_hip.so"))
@@ -196,6 +196,25 @@ function indirect_solve(ctx::LtoContext, XC_all::Matrix{Float64}, t_TU::Vector{F
         status[] == 1 && println("Reached max iteration count at $(iters[]) iterations")
     end
     (XC_new, defect1, Int(status[]))
+end
+
+"""n_batch independent Newton loops side by side (`lto_indirect_solve_batch`): `XC_all` [12 x n_nodes x n_batch], `t_TU`
+[n_nodes] (shared grid), `params` a vector of n_batch parameter tuples (e.g. one rho per level of a continuation ladder).
+Returns (XC_all, defect, status_flags, iterCounts)."""
+function indirect_solve_batch(ctx::LtoContext, XC_all::Array{Float64,3}, t_TU::Vector{Float64}, params::Vector,
+                              flag_adjointsOnly::Bool, maxIter::Integer; integ::LtoIntegrator = LtoIntegrator())
+    ndim, n_nodes, n_batch = size(XC_all)
+    prm = [LtoParams(q) for q in params]
+    XC_new = zeros(ndim, n_nodes, n_batch)
+    defect1 = zeros(ndim, n_nodes - 1, n_batch)
+    status = zeros(Cint, n_batch); iters = zeros(Cint, n_batch)
+    rc = ccall((:lto_indirect_solve_batch, liblto), Cint,
+               (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{LtoParams}, Cint, Ref{LtoIntegrator}, Cint, Cint,
+                Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}),
+               ctx.handle, ndim, n_nodes, n_batch, XC_all, t_TU, 1, prm, length(prm), Ref(integ), flag_adjointsOnly ? 1 : 0, maxIter,
+               XC_new, defect1, status, iters, C_NULL)
+    check(ctx, rc)
+    (XC_new, defect1, Int.(status), Int.(iters))
 end
 
 # ---------------------------------------------------------------------------------------------- direct

@@ -53,6 +53,8 @@ SIGNATURES = {
                                            C.POINTER(LtoIntegrator), C.c_int, C.c_double, _vp, _vp]),
     "lto_indirect_solve": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.POINTER(LtoParams), C.POINTER(LtoIntegrator), C.c_int,
                                      C.c_int, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
+    "lto_indirect_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
+                                           C.POINTER(LtoIntegrator), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "lto_indirect_densify": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.POINTER(LtoParams), C.POINTER(LtoIntegrator), C.c_int,
                                        _vp, _vp]),
     "lto_direct_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,

@@ -71,9 +71,11 @@ hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa,
 hipError_t launch_unpack_soa(const double* soa, long ld, int ndim, long count, double* aos, hipStream_t st);
 constexpr int LTO_ORDER_BINS = 1024;   // int workspace launch_segment_order needs
 hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bins, int* order, hipStream_t st);
-hipError_t launch_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, const double* alphas, double* Xt,
-                               long ldt, hipStream_t st);
-hipError_t launch_end_states(double* X, long ld, int n, int nrow, double* saved, int restore, hipStream_t st);
+hipError_t launch_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, int na, const double* alphas,
+                               double* Xt, long ldt, hipStream_t st);
+hipError_t launch_axpy_traj(const double* x, const double* d, const double* alpha, double* y, long ld, int ndim, int n, int nb,
+                            hipStream_t st);
+hipError_t launch_end_states(double* X, long ld, int n, int nb, int nrow, double* saved, int restore, hipStream_t st);
 hipError_t launch_defect_norms(const double* defect, long ldd, int ndim, int seg_per_traj, int n_batch, double* sumsq,
                                double* maxabs, hipStream_t st);
 

@@ -147,39 +147,70 @@ hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bi
   return hipGetLastError();
 }
 
-// ---- driver-loop helpers (lto_indirect_solve): line-search trial points and end-state pinning, SoA in / SoA out
-// Xt[c][b*n + k] = X[c][k] + alphas[b] d[c][k]    (the trial trajectories of lineSearch, indirect.jl:227-233)
-__global__ __launch_bounds__(256) void k_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb,
+// ---- driver-loop helpers (lto_indirect_solve[_batch]): SoA in / SoA out, node index j = b*n + k (trajectory b, node k)
+// Xt[c][(b*na + a)*n + k] = X[c][b*n + k] + alphas[a] d[c][b*n + k]: the na trial trajectories of lineSearch
+// (indirect.jl:227-233) of every trajectory of the batch
+__global__ __launch_bounds__(256) void k_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, int na,
                                                       const double* alphas, double* Xt, long ldt) {
-  const long total = (long)ndim * nb * n;
+  const long total = (long)ndim * nb * na * n;
   for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += gridDim.x * 256L) {
     const int k = (int)(q % n);
-    const int b = (int)((q / n) % nb);
-    const int c = (int)(q / ((long)n * nb));
-    Xt[c * ldt + (long)b * n + k] = __builtin_fma(alphas[b], d[c * ld + k], X[c * ld + k]);
+    const long r = q / n;
+    const int a = (int)(r % na);
+    const int b = (int)((r / na) % nb);
+    const int c = (int)(r / ((long)na * nb));
+    const long src = c * ld + (long)b * n + k;
+    Xt[c * ldt + ((long)b * na + a) * n + k] = __builtin_fma(alphas[a], d[src], X[src]);
   }
 }
 
-// save (dir = 0) or restore (dir = 1) the first `nrow` rows of node 0 and node n-1 (indirect.jl:270-271, :324-325)
-__global__ void k_end_states(double* X, long ld, int n, int nrow, double* saved, int dir) {
-  const int r = threadIdx.x;
-  if (r >= 2 * nrow) return;
-  const long idx = (long)(r % nrow) * ld + (r < nrow ? 0 : n - 1);
-  if (dir) X[idx] = saved[r]; else saved[r] = X[idx];
+// y[c][b*n + k] = x[c][b*n + k] + alpha[b] d[c][b*n + k]  (per-trajectory step length; alpha = 0 freezes a trajectory)
+__global__ __launch_bounds__(256) void k_axpy_traj(const double* x, const double* d, const double* alpha, double* y, long ld, int ndim,
+                                                   int n, int nb) {
+  const long per = (long)nb * n;
+  const long total = (long)ndim * per;
+  for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += gridDim.x * 256L) {
+    const long j = q % per;
+    const int c = (int)(q / per);
+    const long idx = c * ld + j;
+    y[idx] = __builtin_fma(alpha[j / n], d[idx], x[idx]);
+  }
 }
 
-hipError_t launch_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, const double* alphas, double* Xt,
-                               long ldt, hipStream_t st) {
-  const long total = (long)ndim * nb * n;
+// save (dir = 0) or restore (dir = 1) the first `nrow` rows of node 0 and node n-1 of every trajectory
+// (indirect.jl:270-271, :324-325); saved [nb][2 nrow]
+__global__ void k_end_states(double* X, long ld, int n, int nrow, double* saved, int dir) {
+  const int b = blockIdx.x;
+  const int r = threadIdx.x;
+  if (r >= 2 * nrow) return;
+  const long idx = (long)(r % nrow) * ld + (long)b * n + (r < nrow ? 0 : n - 1);
+  double* sv = saved + (long)b * 2 * nrow;
+  if (dir) X[idx] = sv[r]; else sv[r] = X[idx];
+}
+
+hipError_t launch_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, int na, const double* alphas,
+                               double* Xt, long ldt, hipStream_t st) {
+  const long total = (long)ndim * nb * na * n;
   if (total <= 0) return hipSuccess;
   long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_trial_points, dim3((unsigned)blocks), dim3(256), 0, st, X, d, ld, ndim, n, nb, alphas, Xt, ldt);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_trial_points, dim3((unsigned)blocks), dim3(256), 0, st, X, d, ld, ndim, n, nb, na, alphas, Xt, ldt);
   return hipGetLastError();
 }
 
-hipError_t launch_end_states(double* X, long ld, int n, int nrow, double* saved, int restore, hipStream_t st) {
-  hipLaunchKernelGGL(k_end_states, dim3(1), dim3(64), 0, st, X, ld, n, nrow, saved, restore);
+hipError_t launch_axpy_traj(const double* x, const double* d, const double* alpha, double* y, long ld, int ndim, int n, int nb,
+                            hipStream_t st) {
+  const long total = (long)ndim * nb * n;
+  if (total <= 0) return hipSuccess;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_axpy_traj, dim3((unsigned)blocks), dim3(256), 0, st, x, d, alpha, y, ld, ndim, n, nb);
+  return hipGetLastError();
+}
+
+hipError_t launch_end_states(double* X, long ld, int n, int nb, int nrow, double* saved, int restore, hipStream_t st) {
+  if (nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_end_states, dim3(nb), dim3(64), 0, st, X, ld, n, nrow, saved, restore);
   return hipGetLastError();
 }
 

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <new>
 
+#include <vector>
+
 #include "../../include/lto.h"
 #include "kernels.hpp"
 
@@ -565,27 +567,46 @@ int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   return rc;
 }
 
-/* Whole Newton loop of multiShoot_CRTBP_indirect (src/multiShoot_CRTBP_indirect.jl:254-345) with the trajectory
+/* Whole Newton loop of multiShoot_CRTBP_indirect (src/multiShoot_CRTBP_indirect.jl:254-345) with the trajectories
  * resident in HBM: per iteration one STM sweep, the structured least-squares step (+ second-order correction), the
  * 20-point line search as ONE batched sweep after iteration 3, end-state pinning and the defect check.  Only scalars
- * cross PCIe inside the loop (max|xc_update|, 20 sums of squares, max|defect|). */
-int lto_indirect_solve(lto_ctx* c, int ndim, int n_nodes, const double* XC_in, const double* t, const lto_params* prm,
-                       const lto_integrator* integ, int flag_adjointsOnly, int maxIter, double* XC_out, double* defect,
-                       int* status_flag, int* iterations, double* history) {
+ * cross PCIe inside the loop (per trajectory: max|xc_update|, 20 sums of squares, max|defect|).
+ * n_batch independent problems (homotopy levels, thrust levels, different guesses) run the loop side by side: every
+ * device operation covers the whole batch; a trajectory that has left the reference loop (converged, NaN, iteration
+ * limit) is frozen by a zero step length and its results are kept. */
+int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, const double* XC_in, const double* t, int n_tgrids,
+                             const lto_params* prm, int n_prm, const lto_integrator* integ, int flag_adjointsOnly, int maxIter,
+                             double* XC_out, double* defect, int* status_flag, int* iterations, double* history) {
   if (!c) return LTO_ENULL;
   if (!XC_in || !t || !prm || !integ || !XC_out || !status_flag) return set_err(c, LTO_ENULL, "XC_in, t, prm, integ, XC_out or status_flag is NULL");
   if (ndim != 12) return set_err(c, LTO_EUNSUPPORTED, "the device Newton loop is built for ndim = 12");
   if (maxIter < 0) return set_err(c, LTO_EINVAL, "maxIter must be >= 0");
+  if (n_batch < 1 || n_nodes < 2) return set_err(c, LTO_EINVAL, "need n_nodes >= 2 and n_batch >= 1");
+  if ((n_tgrids != 1 && n_tgrids != n_batch) || (n_prm != 1 && n_prm != n_batch)) return set_err(c, LTO_EINVAL, "n_tgrids / n_prm must be 1 or n_batch");
   constexpr int NA = 20;                                   // LinRange(0.1, 1, 20), :227
+  const int B = n_batch;
+  if ((long)B * NA * (n_nodes - 1) > 0x7fffffffL) return set_err(c, LTO_EINVAL, "too many line-search segments");
+  // parameters / time grids of the B*NA line-search trial trajectories: trajectory b's, NA times
+  std::vector<lto_params> prm_l;
+  std::vector<double> t_l;
+  if (n_prm != 1) { prm_l.reserve((size_t)B * NA); for (int b = 0; b < B; ++b) for (int a = 0; a < NA; ++a) prm_l.push_back(prm[b]); }
+  if (n_tgrids != 1) {
+    t_l.resize((size_t)B * NA * n_nodes);
+    for (int b = 0; b < B; ++b) for (int a = 0; a < NA; ++a)
+      std::memcpy(&t_l[((size_t)b * NA + a) * n_nodes], t + (size_t)b * n_nodes, sizeof(double) * n_nodes);
+  }
   lto_indirect_plan* p = nullptr;
-  lto_indirect_plan* pl = nullptr;                         // the NA line-search trial trajectories as one batch
-  int rc = lto_indirect_plan_create(c, 12, n_nodes, 1, prm, 1, integ, &p);
+  lto_indirect_plan* pl = nullptr;
+  int rc = lto_indirect_plan_create(c, 12, n_nodes, B, prm, n_prm, integ, &p);
   if (rc) return rc;
-  rc = lto_indirect_plan_create(c, 12, n_nodes, NA, prm, 1, integ, &pl);
+  rc = lto_indirect_plan_create(c, 12, n_nodes, B * NA, n_prm == 1 ? prm : prm_l.data(), n_prm == 1 ? 1 : B * NA, integ, &pl);
   if (rc) { lto_indirect_plan_destroy(p); return rc; }
-  const long J = n_nodes, S = n_nodes - 1;
-  const size_t need = al256(sizeof(double) * 12 * J) * 5 + al256(sizeof(double) * 12 * J * NA) + al256(sizeof(double) * n_nodes) +
-                      al256(sizeof(double) * 12 * S) * 3 + al256(sizeof(double) * 12 * S * NA) + al256(sizeof(double) * 144 * S) + 65536;
+  const long n = n_nodes, J = n * B, S = (n - 1) * B;
+  const int ntl = (n_tgrids == 1) ? 1 : B * NA;
+  const size_t n_small = (size_t)12 * B + NA + 3 * (size_t)B + (size_t)NA * B + 64;
+  const size_t need = al256(sizeof(double) * 12 * J) * 5 + al256(sizeof(double) * 12 * J * NA) + al256(sizeof(double) * n * n_tgrids) +
+                      al256(sizeof(double) * n * ntl) + al256(sizeof(double) * 12 * S) * 3 + al256(sizeof(double) * 12 * S * NA) +
+                      al256(sizeof(double) * 144 * S) + al256(sizeof(double) * n_small) + 65536;
   rc = arena_reserve(c, need);
   if (rc) { lto_indirect_plan_destroy(pl); lto_indirect_plan_destroy(p); return rc; }
   c->arena_top = 0;
@@ -595,77 +616,112 @@ int lto_indirect_solve(lto_ctx* c, int ndim, int n_nodes, const double* XC_in, c
   double* d_del = arena_take<double>(c, (size_t)12 * J);
   double* d_del2 = arena_take<double>(c, (size_t)12 * J);
   double* d_Xt = arena_take<double>(c, (size_t)12 * J * NA);
-  double* d_t = arena_take<double>(c, (size_t)n_nodes);
+  double* d_t = arena_take<double>(c, (size_t)n * n_tgrids);
+  double* d_tl = (n_tgrids == 1) ? d_t : arena_take<double>(c, (size_t)n * ntl);
   double* d_def = arena_take<double>(c, (size_t)12 * S);
   double* d_def2 = arena_take<double>(c, (size_t)12 * S);
   double* d_def_aos = arena_take<double>(c, (size_t)12 * S);
   double* d_deft = arena_take<double>(c, (size_t)12 * S * NA);
   double* d_phi = arena_take<double>(c, (size_t)144 * S);
-  double* d_small = arena_take<double>(c, 64);             // [0..11] saved end states, [16..35] alphas, [40..59] sums, [60] max
+  double* d_small = arena_take<double>(c, n_small);
+  double* d_saved = d_small;                               // [B][12] pinned end states
+  double* d_alphas = d_saved + (size_t)12 * B;             // [NA]   trial step lengths
+  double* d_step = d_alphas + NA;                          // [B]    step length / SOC mask per trajectory
+  double* d_mx = d_step + B;                               // [B]    per-trajectory max norms
+  double* d_ss = d_mx + B;                                 // [NA*B] per-trial sums of squares
   hipStream_t st = c->stream;
-  double alphas[NA], h_ss[NA], h_mx = 0.0;
-  for (int b = 0; b < NA; ++b) alphas[b] = 0.1 + (1.0 - 0.1) / (NA - 1) * b;
+  double alphas[NA];
+  for (int a = 0; a < NA; ++a) alphas[a] = 0.1 + (1.0 - 0.1) / (NA - 1) * a;
   alphas[NA - 1] = 1.0;
+  std::vector<double> h_mx(B), h_er(B, 1.0), h_step(B), h_ss((size_t)NA * B);   // er = 1.0: :279
+  std::vector<int> it(B, 0), status(B, 0);
+  std::vector<char> active(B, 1);
 
   hipError_t e = hipMemcpyAsync(d_aos, XC_in, sizeof(double) * 12 * J, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_small + 16, alphas, sizeof alphas, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n * n_tgrids, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && n_tgrids != 1) e = hipMemcpyAsync(d_tl, t_l.data(), sizeof(double) * n * ntl, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_alphas, alphas, sizeof alphas, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_aos, 12, J, d_X, J, st);
-  if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, 6, d_small, 0, st);          // state_0, state_f  (:270-271)
+  if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, B, 6, d_saved, 0, st);           // state_0, state_f  (:270-271)
   if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage in", e);
 
-  // max |v| of an SoA block [rows][ld] with `count` valid columns -> host (NaN if any entry is NaN)
-  auto max_abs = [&](const double* v, long ld, int rows, long count, double* out) -> int {
-    hipError_t q = launch_defect_norms(v, ld, rows, (int)count, 1, nullptr, d_small + 60, st);
-    if (q == hipSuccess) q = hipMemcpyAsync(out, d_small + 60, sizeof(double), hipMemcpyDeviceToHost, st);
+  // per-trajectory max |v| of an SoA block [rows][ld], `per` columns per trajectory -> host (NaN-propagating)
+  auto max_abs = [&](const double* v, long ld, long per, double* out) -> int {
+    hipError_t q = launch_defect_norms(v, ld, 12, (int)per, B, nullptr, d_mx, st);
+    if (q == hipSuccess) q = hipMemcpyAsync(out, d_mx, sizeof(double) * B, hipMemcpyDeviceToHost, st);
     if (q == hipSuccess) q = hipStreamSynchronize(st);
     return q == hipSuccess ? LTO_OK : set_err(c, LTO_EHIP, "norm", q);
   };
+  auto upload_step = [&]() -> int {
+    hipError_t q = hipMemcpyAsync(d_step, h_step.data(), sizeof(double) * B, hipMemcpyHostToDevice, st);
+    return q == hipSuccess ? LTO_OK : set_err(c, LTO_EHIP, "step upload", q);
+  };
+  auto any_active = [&]() { for (int b = 0; b < B; ++b) if (active[b]) return true; return false; };
 
-  int iter = 0, status = 0;
-  double er = 1.0;                                         // :279
-  if (rc == LTO_OK) rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, 1, d_def, S, nullptr);       // :274
-  while (rc == LTO_OK && er > 1e-10) {                     // :280
-    ++iter;
-    if (iter > maxIter) { status = 1; break; }             // :282-286
-    rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, 1, d_phi, S, d_def, S);                     // :290
+  if (rc == LTO_OK) rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, nullptr);      // :274
+  while (rc == LTO_OK && any_active()) {
+    // `while er > 1e-10` (:280) + the iteration limit (:281-286), trajectory by trajectory
+    for (int b = 0; b < B; ++b) {
+      if (!active[b]) continue;
+      if (!(h_er[b] > 1e-10)) { active[b] = 0; continue; }            // converged, or NaN (the comparison is false)
+      if (++it[b] > maxIter) { status[b] = 1; active[b] = 0; }
+    }
+    if (!any_active()) break;
+    rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);              // :290
     // large adaptive problems: the next sweeps of this plan run with the lanes ordered by this sweep's step counts
     if (rc == LTO_OK && host_order_wanted(p, true)) rc = lto_indirect_plan_rebalance(p, st);
     if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, flag_adjointsOnly, d_del, J);   // :182
-    if (rc == LTO_OK) rc = max_abs(d_del, J, 12, J, &h_mx);
+    if (rc == LTO_OK) rc = max_abs(d_del, J, n, h_mx.data());
     if (rc != LTO_OK) break;
-    if (h_mx == h_mx && h_mx < 1e-1) {                     // second-order correction, :190-214
+    bool soc = false;                                      // second-order correction, :190-214
+    for (int b = 0; b < B; ++b) { h_step[b] = (active[b] && h_mx[b] == h_mx[b] && h_mx[b] < 1e-1) ? 1.0 : 0.0; soc |= h_step[b] != 0.0; }
+    if (soc) {
       e = launch_axpy(d_X, d_del, 1.0, d_X2, 12 * J, st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "axpy", e); break; }
-      rc = lto_indirect_defect_dev(p, st, d_X2, J, d_t, 1, d_def2, S, nullptr);
+      rc = lto_indirect_defect_dev(p, st, d_X2, J, d_t, n_tgrids, d_def2, S, nullptr);
       if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, nullptr, 0, d_def2, S, flag_adjointsOnly, d_del2, J);
+      if (rc == LTO_OK) rc = upload_step();
       if (rc != LTO_OK) break;
-      e = launch_axpy(d_del, d_del2, 1.0, d_del, 12 * J, st);
+      e = launch_axpy_traj(d_del, d_del2, d_step, d_del, J, 12, n_nodes, B, st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "axpy", e); break; }
     }
-    double alpha = 1.0;
-    if (iter > 3) {                                        // :300-302: 20 trial trajectories, one sweep
-      e = launch_trial_points(d_X, d_del, J, 12, n_nodes, NA, d_small + 16, d_Xt, J * NA, st);
+    bool search = false;
+    for (int b = 0; b < B; ++b) { h_step[b] = active[b] ? 1.0 : 0.0; search |= active[b] && it[b] > 3; }
+    if (search) {                                          // :300-302: the 20 trial trajectories of every problem, one sweep
+      e = launch_trial_points(d_X, d_del, J, 12, n_nodes, B, NA, d_alphas, d_Xt, J * NA, st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "trial points", e); break; }
-      rc = lto_indirect_defect_dev(pl, st, d_Xt, J * NA, d_t, 1, d_deft, S * NA, nullptr);
+      rc = lto_indirect_defect_dev(pl, st, d_Xt, J * NA, d_tl, ntl, d_deft, S * NA, nullptr);
       if (rc == LTO_OK && host_order_wanted(pl, false)) rc = lto_indirect_plan_rebalance(pl, st);
       if (rc != LTO_OK) break;
-      e = launch_defect_norms(d_deft, S * NA, 12, (int)S, NA, d_small + 40, nullptr, st);          // sum(defect.^2), :240
-      if (e == hipSuccess) e = hipMemcpyAsync(h_ss, d_small + 40, sizeof h_ss, hipMemcpyDeviceToHost, st);
+      e = launch_defect_norms(d_deft, S * NA, 12, n_nodes - 1, B * NA, d_ss, nullptr, st);         // sum(defect.^2), :240
+      if (e == hipSuccess) e = hipMemcpyAsync(h_ss.data(), d_ss, sizeof(double) * NA * B, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "line search", e); break; }
-      int best = 0;                                        // alpha[er .== minimum(er)][1]: first minimiser (:244-245)
-      for (int b = 1; b < NA; ++b) if (h_ss[b] < h_ss[best]) best = b;
-      alpha = alphas[best];
+      for (int b = 0; b < B; ++b) {
+        if (!active[b] || it[b] <= 3) continue;
+        const double* ss = &h_ss[(size_t)b * NA];
+        int best = 0;                                      // alpha[er .== minimum(er)][1]: first minimiser (:244-245)
+        for (int a = 1; a < NA; ++a) if (ss[a] < ss[best]) best = a;
+        h_step[b] = alphas[best];
+      }
     }
-    e = launch_axpy(d_X, d_del, alpha, d_X, 12 * J, st);                                            // :304
-    if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, 6, d_small, 1, st);                // :324-325
-    if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "update", e); break; }
-    rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, 1, d_def, S, nullptr);                        // :328
-    if (rc == LTO_OK) rc = max_abs(d_def, S, 12, S, &er);                                          // :331
+    rc = upload_step();
     if (rc != LTO_OK) break;
-    if (history && iter <= maxIter) { history[2 * (iter - 1)] = er; history[2 * (iter - 1) + 1] = alpha; }
-    if (er > 1e3) iter += 100;                             // "Not likely to converge. Aborting." (:333-336)
+    e = launch_axpy_traj(d_X, d_del, d_step, d_X, J, 12, n_nodes, B, st);                           // :304
+    if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, B, 6, d_saved, 1, st);             // :324-325
+    if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "update", e); break; }
+    rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, nullptr);                 // :328
+    if (rc == LTO_OK) rc = max_abs(d_def, S, n - 1, h_mx.data());                                  // :331
+    if (rc != LTO_OK) break;
+    for (int b = 0; b < B; ++b) {
+      if (!active[b]) continue;
+      h_er[b] = h_mx[b];
+      if (history && it[b] <= maxIter) {
+        history[((size_t)b * maxIter + (it[b] - 1)) * 2] = h_er[b];
+        history[((size_t)b * maxIter + (it[b] - 1)) * 2 + 1] = h_step[b];
+      }
+      if (h_er[b] > 1e3) it[b] += 100;                     // "Not likely to converge. Aborting." (:333-336)
+    }
   }
   if (rc == LTO_OK) {
     e = launch_unpack_soa(d_X, J, 12, J, d_aos, st);
@@ -674,19 +730,27 @@ int lto_indirect_solve(lto_ctx* c, int ndim, int n_nodes, const double* XC_in, c
       e = launch_unpack_soa(d_def, S, 12, S, d_def_aos, st);
       if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * 12 * S, hipMemcpyDeviceToHost, st);
     }
-    if (e == hipSuccess) e = max_abs(d_def, S, 12, S, &h_mx) == LTO_OK ? hipSuccess : hipErrorUnknown;
+    if (e == hipSuccess) e = max_abs(d_def, S, n - 1, h_mx.data()) == LTO_OK ? hipSuccess : hipErrorUnknown;
     if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
     // :339-341 flags a NaN trajectory; a NaN defect leaves the loop the same way (NaN > 1e-10 is false), so both
     // report status 2 here, as drivers.multiShoot_CRTBP_indirect does
-    if (rc == LTO_OK && (XC_out[0] != XC_out[0] || h_mx != h_mx)) status = 2;
+    if (rc == LTO_OK)
+      for (int b = 0; b < B; ++b)
+        if (XC_out[(size_t)12 * n * b] != XC_out[(size_t)12 * n * b] || h_mx[b] != h_mx[b]) status[b] = 2;
   } else {
     (void)hipStreamSynchronize(st);
   }
-  *status_flag = status;
-  if (iterations) *iterations = iter;
+  for (int b = 0; b < B; ++b) { status_flag[b] = status[b]; if (iterations) iterations[b] = it[b]; }
   lto_indirect_plan_destroy(pl);
   lto_indirect_plan_destroy(p);
   return rc;
+}
+
+int lto_indirect_solve(lto_ctx* c, int ndim, int n_nodes, const double* XC_in, const double* t, const lto_params* prm,
+                       const lto_integrator* integ, int flag_adjointsOnly, int maxIter, double* XC_out, double* defect,
+                       int* status_flag, int* iterations, double* history) {
+  return lto_indirect_solve_batch(c, ndim, n_nodes, 1, XC_in, t, 1, prm, 1, integ, flag_adjointsOnly, maxIter, XC_out, defect,
+                                  status_flag, iterations, history);
 }
 
 /* ------------------------------------------------------------------------------ dense output */

@@ -6,6 +6,8 @@
   reduceFuel_indirect         src/HelperFunctions.jl:105-193   (rho continuation -- SURVEY N3)
   meshRefine_direct           src/multiShoot_CRTBP_direct.jl:597-680   (errors-driven mesh refinement -- SURVEY N4)
   lineSearch_direct           src/multiShoot_CRTBP_direct.jl:405-430   (10 alphas in ONE batched launch -- SURVEY N2)
+  homotopy_solve              concurrent form of the rho continuation (HelperFunctions.jl:105-193): every level of the
+                              ladder is a trajectory of ONE batched device Newton loop (lto_indirect_solve_batch)
   controlLaw_cart             src/multiShoot_CRTBP_indirect.jl:389-440 (costates -> thrust vectors in N: the u_all format
                                                                         of the direct transcription; host post-processing)
 
@@ -324,3 +326,45 @@ def controlLaw_cart(lambda_v, thrustLimit, p, rho, mass, DU=None, TU=None):
     umag = np.where(np.isnan(umag), 0.0, umag)                      # :431-433
     with np.errstate(invalid="ignore", divide="ignore"):
         return -umag * lam / n * mass * DU * 1e3 / TU ** 2          # DU/TU^2 -> N (:439)
+
+
+def homotopy_solve(XC_all, t_TU, MU, DU, TU, mass, thrustLimit, rhos, p=1.0, maxIter=10, max_waves=12, ctx=None, verbose=True):
+    """Solve the whole smoothing ladder rho_0 > rho_1 > ... concurrently.  reduceFuel_indirect walks the
+    ladder one level at a time, halving rho after each success (HelperFunctions.jl:158-188); here every unsolved level is
+    one trajectory of a batched device Newton loop.  Wave 1 starts all levels from XC_all (a solution at or above
+    rho_0); each later wave restarts the levels that failed from the converged solution of the nearest level with a
+    larger rho.  Stops when every level has converged, a wave makes no progress, or after max_waves.
+
+    Returns (XC_levels [12 x n x L], defect [12 x (n-1) x L], status [L] (0 converged, else the last status_flag of the
+    level, 3 = never converged: HelperFunctions.jl:161), waves)."""
+    rhos = np.asarray(rhos, dtype=np.float64)
+    order = np.argsort(-rhos)                                 # descending: neighbours in the list are neighbours in rho
+    L = len(rhos)
+    XC0 = np.array(XC_all, dtype=np.float64, order="F")
+    n = XC0.shape[1]
+    X = np.repeat(XC0[:, :, None], L, axis=2)
+    D = np.full((12, n - 1, L), np.nan)
+    status = np.full(L, 3, dtype=np.int32)
+    solved = np.zeros(L, dtype=bool)
+    waves = 0
+    while not solved.all() and waves < max_waves:
+        waves += 1
+        todo = [k for k in order if not solved[k]]
+        guess = np.empty((12, n, len(todo)), order="F")
+        for j, k in enumerate(todo):                          # nearest converged level with a larger rho, else the input
+            better = [q for q in order if solved[q] and rhos[q] > rhos[k]]
+            guess[:, :, j] = X[:, :, better[-1]] if better else XC0
+        prms = [hotpath.make_params(MU, DU, TU, thrustLimit, mass, 1.0, p, float(rhos[k])) for k in todo]
+        Xo, Do, st, it, _ = hotpath.indirect_solve_batch(guess, t_TU, prms, None, False, maxIter, ctx=ctx)
+        progress = 0
+        for j, k in enumerate(todo):
+            if st[j] == 0:
+                X[:, :, k], D[:, :, k], status[k], solved[k] = Xo[:, :, j], Do[:, :, j], 0, True
+                progress += 1
+            elif status[k] == 3:
+                D[:, :, k] = Do[:, :, j]
+        if verbose:
+            print("wave %d: %d of %d levels converged (%d remaining)" % (waves, progress, len(todo), int((~solved).sum())))
+        if progress == 0:
+            break
+    return np.asfortranarray(X), np.asfortranarray(D), status, waves

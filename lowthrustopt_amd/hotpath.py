@@ -269,6 +269,29 @@ def indirect_solve(XC_all, t_TU, params, integ=None, flag_adjointsOnly=False, ma
     return XC_out, defect, status.value, iters.value, hist[:, :done].T.copy()
 
 
+def indirect_solve_batch(XC_all, t_TU, params, integ=None, flag_adjointsOnly=False, maxIter=10, ctx=None):
+    """n_batch independent Newton loops side by side (lto_indirect_solve_batch): XC_all [12 x n x B], t_TU [n] or
+    [n x B], params one tuple or B.  Returns (XC_all, defect, status_flag[B], iterCount[B], history) with
+    history[b] = array of (max|defect|, alpha) per completed iteration of trajectory b."""
+    ctx = ctx or default_context()
+    integ = integ or integrator()
+    XC = _f64(XC_all)
+    ndim, n, B, batched = _batch_dims(XC)
+    t, ntg = _tgrids(t_TU, n, B)
+    prm, nprm = _params_array(params)
+    XC_out = np.zeros((ndim, n, B), order="F")
+    defect = np.zeros((ndim, n - 1, B), order="F")
+    mi = max(int(maxIter), 1)
+    hist = np.full((2, mi, B), np.nan, order="F")
+    status = np.zeros(B, dtype=np.int32)
+    iters = np.zeros(B, dtype=np.int32)
+    ctx.check(ctx.fn("indirect_solve_batch")(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
+                                             1 if flag_adjointsOnly else 0, int(maxIter), _ptr(XC_out), _ptr(defect),
+                                             _ptr(status), _ptr(iters), _ptr(hist) if maxIter > 0 else None))
+    history = [hist[:, ~np.isnan(hist[1, :, b]), b].T.copy() for b in range(B)]
+    return XC_out, defect, status, iters, history
+
+
 def densify(XC_all, t_TU, params, n_desired, integ=None, ctx=None):
     """densify (src/HelperFunctions.jl:51-101): (XC_dense[ndim x n_desired], t_dense[n_desired]); every segment is
     re-propagated on the GPU and sampled at the uniformly spaced t_dense points that fall inside it."""

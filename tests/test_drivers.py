@@ -332,3 +332,54 @@ def test_device_newton_loop_large_adaptive_problem_rebalances(gpu_ctx):
     assert sd == sp and len(hist) == min(itd, 2)
     assert np.all(np.isfinite(Xd)) and np.abs(Xd - Xp).max() < 1e-9 * max(1.0, np.abs(Xp).max())
     assert np.abs(dd - dp).max() < 1e-9 * max(1.0, np.abs(dp).max())
+
+
+@pytest.mark.gpu
+def test_batched_newton_loop_equals_single_loops(gpu_ctx, oracle):
+    """lto_indirect_solve_batch: independent problems with their own grids, control laws and smoothing run side by side
+    and finish at different iterations; each equals its own lto_indirect_solve."""
+    probs = [consistent_problem(oracle, n_nodes=16, p=pp, rho=rho, thrust=thr, seed=s, pert=pert)
+             for pp, rho, thr, s, pert in ((2.0, 1.0, 10.0, 1, 1e-3), (1.0, 1.0, 0.05, 2, 1e-4), (2.0, 1.0, 10.0, 3, 1e-6),
+                                          (1.0, 0.5, 0.05, 4, 3e-4), (2.0, 1.0, 10.0, 5, 3e-2))]
+    prms = [lto.make_params(MU, DU, TU, thr, 1000.0, 1.0, pp, rho)
+            for pp, rho, thr in ((2.0, 1.0, 10.0), (1.0, 1.0, 0.05), (2.0, 1.0, 10.0), (1.0, 0.5, 0.05), (2.0, 1.0, 10.0))]
+    XC = np.stack([q[0] for q in probs], axis=2)
+    T = np.stack([q[1] * (1.0 + 0.01 * k) for k, q in enumerate(probs)], axis=1)       # per-trajectory grids
+    Xb, Db, stb, itb, hb = lto.indirect_solve_batch(XC, T, prms, None, False, 12, ctx=gpu_ctx)
+    assert Xb.shape == XC.shape and Db.shape == (12, 15, 5) and len(hb) == 5
+    for k in range(5):
+        X1, D1, st1, it1, h1 = lto.indirect_solve(XC[:, :, k], T[:, k], prms[k], None, False, 12, ctx=gpu_ctx)
+        assert stb[k] == st1 and itb[k] == it1, (k, stb, itb, st1, it1)
+        assert np.array_equal(Xb[:, :, k], X1) and np.array_equal(Db[:, :, k], D1)
+        assert np.array_equal(hb[k], h1)
+    assert len(set(int(v) for v in itb)) > 1                      # the trajectories really left the loop at different times
+    # shared grid + shared parameters
+    Xs, Ds, sts, its, _ = lto.indirect_solve_batch(XC[:, :, [0, 2]], T[:, 0], prms[0], None, False, 12, ctx=gpu_ctx)
+    X1, D1, st1, it1, _ = lto.indirect_solve(XC[:, :, 2], T[:, 0], prms[0], None, False, 12, ctx=gpu_ctx)
+    assert sts[1] == st1 and np.array_equal(Xs[:, :, 1], X1)
+
+
+@pytest.mark.gpu
+def test_homotopy_solve_concurrent_ladder(gpu_ctx):
+    """The rho ladder of the demo solved concurrently: same converged trajectories as the sequential
+    reduceFuel_indirect continuation at the levels both visit."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("demo", os.path.join(os.path.dirname(__file__), "..", "examples", "halo_transfer_demo.py"))
+    demo = importlib.util.module_from_spec(spec); spec.loader.exec_module(demo)
+    n = 30
+    X, t = demo.stacked_guess(n)
+    rng = np.random.default_rng(0)
+    XC = np.vstack([X, 0.1 * rng.standard_normal((6, n))])
+    XC[:, 1:-1] += 1e-10 * rng.standard_normal((12, n - 2))
+    XC, _, f = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, n, 1e3, 10.0, False, True, 10, 2.0, 1.0, verbose=False)
+    XC, _, f = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, n, 1e3, 10.0, False, False, 50, 2.0, 1.0, verbose=False)
+    assert f == 0
+    XC1, _, f1 = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, n, 1e3, 0.05, False, False, 30, 1.0, 1.0, verbose=False)
+    assert f1 == 0
+    rhos = 2.0 ** -np.arange(1, 8)                                   # 0.5 ... 1/128: the halving ladder of :179
+    Xl, Dl, st, waves = drivers.homotopy_solve(XC1, t, MU, DU, TU, 1e3, 0.05, rhos, ctx=gpu_ctx, verbose=False)
+    assert np.all(st == 0) and np.abs(Dl).max() <= 1e-10 and waves <= 7
+    Xseq, dseq, fseq = drivers.reduceFuel_indirect(XC1, t, MU, DU, TU, n, 1e3, 0.05, 1.0, float(rhos[-1]), verbose=False)
+    assert fseq == 0
+    assert np.abs(Xl[:, :, -1] - Xseq).max() < 1e-6 * max(1.0, np.abs(Xseq).max())
