@@ -66,7 +66,7 @@ def parse():
                     help="c5: keep the natural segment order (default: lanes ordered by the warm-up sweep's step counts)")
     ap.add_argument("--segments", type=int, default=0, help="segments per GPU (default: the workload's)")
     ap.add_argument("--cols", type=int, default=0, help="STM columns per lane (0 = auto)")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-specialised (cooperative)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-specialised (cooperative), 3 three-role pipeline (RK4)")
     ap.add_argument("--ndim", type=int, default=0, choices=[0, 12, 14],
                     help="14 = state + mass + costates (BASELINE configs[1]; default of c2 / c2_defect / hbm); 12 = the "
                          "reference's own constant-mass system (parity path; default of the other workloads)")

@@ -210,6 +210,9 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 #define LTO_KERNEL_AUTO 0
 #define LTO_KERNEL_PER_LANE 1
 #define LTO_KERNEL_COOP 2
+/* RK4 plans only: base wave, coefficient wave and two column waves per 16 segments run as a software pipeline skewed by
+ * one RK4 step (one workgroup barrier per step); other integrators: LTO_EINVAL. */
+#define LTO_KERNEL_PIPE 3
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3); 0 = choose from S. */
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);

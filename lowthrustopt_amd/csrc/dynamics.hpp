@@ -50,25 +50,46 @@ __device__ __forceinline__ double rcp_nr(double x) {
 }
 // exp(z) for z <= 0 to ~1 ulp without the special-case handling of the general routine:
 // z = n ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial (remainder 4e-18), scaled by 2^n (underflows to 0).
+// SHORT = false: Horner (13 dependent FMAs, fewest instructions: the per-lane kernels have other work to overlap).
+// SHORT = true: four interleaved chains in r^4 (15 instructions, dependent depth 7) for the pipeline kernel's base wave,
+// whose instruction stream IS the sweep's critical path.
+template <bool SHORT = false>
 __device__ __forceinline__ double exp_neg(double z) {
   z = fmax(z, -800.0);  // exp(-800) == 0 in binary64; keeps the reduction finite for rho -> 0
   const double n = __builtin_rint(z * 1.4426950408889634);
   double r = __builtin_fma(n, -6.93147180369123816490e-01, z);
   r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0;
-  p = __builtin_fma(p, r, 1.0 / 479001600.0);
-  p = __builtin_fma(p, r, 1.0 / 39916800.0);
-  p = __builtin_fma(p, r, 1.0 / 3628800.0);
-  p = __builtin_fma(p, r, 1.0 / 362880.0);
-  p = __builtin_fma(p, r, 1.0 / 40320.0);
-  p = __builtin_fma(p, r, 1.0 / 5040.0);
-  p = __builtin_fma(p, r, 1.0 / 720.0);
-  p = __builtin_fma(p, r, 1.0 / 120.0);
-  p = __builtin_fma(p, r, 1.0 / 24.0);
-  p = __builtin_fma(p, r, 1.0 / 6.0);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
+  double p;
+  if (SHORT) {
+    const double r2 = r * r, r4 = r2 * r2;
+    double p0 = __builtin_fma(1.0 / 479001600.0, r4, 1.0 / 40320.0);     // 1, r^4/4!, r^8/8!, r^12/12!
+    double p1 = __builtin_fma(1.0 / 6227020800.0, r4, 1.0 / 362880.0);   // r, r^5/5!, r^9/9!, r^13/13!
+    double p2 = __builtin_fma(1.0 / 3628800.0, r4, 1.0 / 720.0);         // r^2/2!, r^6/6!, r^10/10!
+    double p3 = __builtin_fma(1.0 / 39916800.0, r4, 1.0 / 5040.0);       // r^3/3!, r^7/7!, r^11/11!
+    p0 = __builtin_fma(p0, r4, 1.0 / 24.0);
+    p1 = __builtin_fma(p1, r4, 1.0 / 120.0);
+    p2 = __builtin_fma(p2, r4, 0.5);
+    p3 = __builtin_fma(p3, r4, 1.0 / 6.0);
+    p0 = __builtin_fma(p0, r4, 1.0);
+    p1 = __builtin_fma(p1, r4, 1.0);
+    const double lo = __builtin_fma(p1, r, p0), hi = __builtin_fma(p3, r, p2);
+    p = __builtin_fma(hi, r2, lo);
+  } else {
+    p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+  }
   return __builtin_ldexp(p, (int)n);
 }
 
@@ -84,7 +105,7 @@ struct VarCoef12 {
 //   m = umag, ua = umag / n, ub = ua - un  (so that  U d = -ua d + ub (lhat.d) lhat),
 //   tlim = true when umag is proportional to aL (every law except the unclamped p > 1 branch).
 // `inv_n` is 1/n (0 when n == 0, the reference's NaN guard :59-64).
-template <int PM, bool VAR>
+template <int PM, bool VAR, bool SHORT = false>
 __device__ __forceinline__ void control_law(const TrajParams& tp, const double aL, double n, double inv_n, double& m,
                                             double& ua, double& ub, double& un, bool& tlim) {
   tlim = true;
@@ -96,7 +117,7 @@ __device__ __forceinline__ void control_law(const TrajParams& tp, const double a
   } else if (PM == PM_P1) {  // :41-43  umag = 1/2 (1 + tanh(g / (2 rho))) accelLimit, g = n - 1
     // 1/2 (1 + tanh x) = 1 / (1 + exp(-2x)): evaluated without cancellation or overflow for any rho.
     const double x = (n - 1.0) * tp.inv_2rho;
-    const double e = exp_neg(-2.0 * fabs(x));
+    const double e = exp_neg<SHORT>(-2.0 * fabs(x));
     const double q = rcp_nr(1.0 + e);
     const double sig = (x >= 0.0) ? q : e * q;
     m = aL * sig;
@@ -114,11 +135,11 @@ __device__ __forceinline__ void control_law(const TrajParams& tp, const double a
   }
 }
 
-template <int PM, bool VAR>
+template <int PM, bool VAR, bool SHORT = false>
 __device__ __forceinline__ void control_dispatch(const TrajParams& tp, const double aL, double n, double inv_n, double& m,
                                                  double& ua, double& ub, double& un, bool& tlim) {
   static_assert(PM >= PM_P0 && PM < PM_NCLASS, "kernels are compiled per control-law class");
-  control_law<PM, VAR>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+  control_law<PM, VAR, SHORT>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
 }
 
 // A1: ydot for y = (r, v, lambda_r, lambda_v); optionally the column coefficients.
@@ -514,6 +535,94 @@ __device__ __forceinline__ void rhs14_fused1(const double (&y)[28], const TrajPa
   const double Lm = tl * (2.0 * mn_over_m * inv_m);
   const double Ln = __builtin_fma(-tl, __builtin_fma(un, n, m) * inv_m, ntl * (kt * lm * un));
   k[27] = __builtin_fma(Lm, mu, __builtin_fma(Ln, ld, (ntl * (kt * m)) * nu));
+}
+
+// ------------------------------------------------------------------------------ lean base RHS (pipeline kernel)
+// kernels_indirect_pipe.hip runs the base trajectory, the coefficient build and the STM columns in three different
+// wavefronts.  The base wave's instruction stream is the sweep's critical path, so it evaluates the RHS alone, with
+// G lambda_v applied through its dyadic structure (as rhs*_fused1) and the short-depth exp; the coefficient wave
+// rebuilds G, H, U from the stage argument with rhs12 / rhs14<PM, true>.
+template <int PM>
+__device__ __forceinline__ void rhs12_base(const double (&y)[12], const TrajParams& tp, double (&dy)[12]) {
+  const double MU = tp.MU;
+  const double x = y[0], yy = y[1], z = y[2];
+  const double w2 = 2.0 * tp.omega;
+  const double a = x + MU, b = a - 1.0;
+  const double yz2 = __builtin_fma(yy, yy, z * z);
+  const double d1 = __builtin_fma(a, a, yz2), d2 = __builtin_fma(b, b, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
+  const double cs = c1 + c2, omc = 1.0 - cs;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double lx = y[9], ly = y[10], lz = y[11];
+  const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
+  const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
+  const double n = n2 * inv_n;
+  double m, ua, ub, un;
+  bool tlim;
+  control_dispatch<PM, false, true>(tp, tp.accel_limit, n, inv_n, m, ua, ub, un, tlim);
+  const double lhx = lx * inv_n, lhy = ly * inv_n, lhz = lz * inv_n;
+  const double yzl = __builtin_fma(yy, ly, z * lz);
+  const double s1 = __builtin_fma(a, lx, yzl), s2 = __builtin_fma(b, lx, yzl);
+  const double t1 = e1 * s1, t2 = e2 * s2;
+  const double es = t1 + t2;
+  const double tA = __builtin_fma(t1, a, t2 * b);
+  dy[0] = y[3]; dy[1] = y[4]; dy[2] = y[5];
+  dy[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))) - m * lhx;
+  dy[4] = __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)) - m * lhy;
+  dy[5] = __builtin_fma(-cs, z, -m * lhz);
+  dy[6] = -__builtin_fma(omc, lx, tA);
+  dy[7] = -__builtin_fma(omc, ly, es * yy);
+  dy[8] = -__builtin_fma(-cs, lz, es * z);
+  dy[9] = __builtin_fma(w2, ly, -y[6]);
+  dy[10] = __builtin_fma(-w2, lx, -y[7]);
+  dy[11] = -y[8];
+}
+
+template <int PM>
+__device__ __forceinline__ void rhs14_base(const double (&y)[14], const TrajParams& tp, double (&dy)[14]) {
+  const double MU = tp.MU;
+  const double x = y[0], yy = y[1], z = y[2], mass = y[6];
+  const double w2 = 2.0 * tp.omega;
+  const double a = x + MU, b = a - 1.0;
+  const double yz2 = __builtin_fma(yy, yy, z * z);
+  const double d1 = __builtin_fma(a, a, yz2), d2 = __builtin_fma(b, b, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
+  const double cs = c1 + c2, omc = 1.0 - cs;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double lx = y[10], ly = y[11], lz = y[12], lm = y[13];
+  const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
+  const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
+  const double n = n2 * inv_n;
+  const double inv_m = rcp_nr(mass);
+  const double aL = tp.cT * inv_m;
+  double m, ua, ub, un;
+  bool tlim;
+  control_dispatch<PM, false, true>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+  const double lhx = lx * inv_n, lhy = ly * inv_n, lhz = lz * inv_n;
+  const double kt = tp.kappa_td;
+  const double yzl = __builtin_fma(yy, ly, z * lz);
+  const double s1 = __builtin_fma(a, lx, yzl), s2 = __builtin_fma(b, lx, yzl);
+  const double t1 = e1 * s1, t2 = e2 * s2;
+  const double es = t1 + t2;
+  const double tA = __builtin_fma(t1, a, t2 * b);
+  dy[0] = y[3]; dy[1] = y[4]; dy[2] = y[5];
+  dy[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))) - m * lhx;
+  dy[4] = __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)) - m * lhy;
+  dy[5] = __builtin_fma(-cs, z, -m * lhz);
+  dy[6] = -kt * m * mass;
+  dy[7] = -__builtin_fma(omc, lx, tA);
+  dy[8] = -__builtin_fma(omc, ly, es * yy);
+  dy[9] = -__builtin_fma(-cs, lz, es * z);
+  dy[10] = __builtin_fma(w2, ly, -y[7]);
+  dy[11] = __builtin_fma(-w2, lx, -y[8]);
+  dy[12] = -y[9];
+  const double tl = tlim ? 1.0 : 0.0, ntl = 1.0 - tl;
+  const double mn_over_m = (m * n) * inv_m;
+  dy[13] = __builtin_fma(-tl, mn_over_m, ntl * (kt * lm * m));
 }
 
 // ------------------------------------------------------------------------------ A2 (direct path)

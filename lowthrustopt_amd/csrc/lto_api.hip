@@ -338,8 +338,10 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
 
 int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
-  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE or _COOP");
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP or _PIPE");
+  if (kernel == LTO_KERNEL_PIPE && p->integ.method != LTO_RK4)
+    return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_PIPE is built for fixed-step RK4 plans");
   p->kernel = kernel;
   return LTO_OK;
 }
@@ -414,6 +416,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (kern == LTO_KERNEL_AUTO) kern = (p->integ.method == LTO_RK4) ? LTO_KERNEL_PER_LANE : LTO_KERNEL_COOP;
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
+  else if (kern == LTO_KERNEL_PIPE) e = launch_indirect_stm_pipe(p->ndim, p->pm, a, st);
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);

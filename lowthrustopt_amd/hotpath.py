@@ -431,7 +431,7 @@ class IndirectPlan:
                                                    C.byref(integ), C.byref(h)))
         self.handle = h
 
-    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP = 0, 1, 2
+    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE = 0, 1, 2, 3
 
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))

@@ -3,6 +3,19 @@
 #include <cstring>
 #include "dynamics.hpp"
 using namespace lto;
+// lean base RHS of the pipeline kernel (rhs*_base) against the one-piece rhs*<PM, false>
+template <int PM> static void base12(const double (&y)[12], const TrajParams& tp, double* dy_a, double* dy_b) {
+  double d[12]; VarCoef12 v; rhs12<PM, false>(y, tp, d, v);
+  for (int i = 0; i < 12; ++i) dy_a[i] = d[i];
+  rhs12_base<PM>(y, tp, d);
+  for (int i = 0; i < 12; ++i) dy_b[i] = d[i];
+}
+template <int PM> static void base14(const double (&y)[14], const TrajParams& tp, double* dy_a, double* dy_b) {
+  double d[14]; VarCoef14 v; rhs14<PM, false>(y, tp, d, v);
+  for (int i = 0; i < 14; ++i) dy_a[i] = d[i];
+  rhs14_base<PM>(y, tp, d);
+  for (int i = 0; i < 14; ++i) dy_b[i] = d[i];
+}
 extern "C" {
 // F*col for the 14-dim system via device formulas (host-compiled)
 void chk_rhs14(const double* y, const double* tpv, int pm, double* dy, const double* col, double* dcol, double* dy_f, double* dcol_f) {
@@ -42,6 +55,22 @@ void chk_rhs12(const double* y, const double* tpv, int pm, double* dy, const dou
   else if (pm == PM_P0) rhs12_fused1<PM_P0>(y24, tp, 2.0 * tp.omega, k24);
   else rhs12_fused1<PM_PGEN>(y24, tp, 2.0 * tp.omega, k24);
   for (int i = 0; i < 12; ++i) { dy_f[i] = k24[i]; dcol_f[i] = k24[12 + i]; }
+}
+void chk_base(int ndim, const double* y, const double* tpv, int pm, double* dy_a, double* dy_b) {
+  TrajParams tp; std::memcpy(&tp, tpv, sizeof tp);
+  if (ndim == 12) {
+    double yy[12]; for (int i = 0; i < 12; ++i) yy[i] = y[i];
+    if (pm == PM_P1) base12<PM_P1>(yy, tp, dy_a, dy_b);
+    else if (pm == PM_P2) base12<PM_P2>(yy, tp, dy_a, dy_b);
+    else if (pm == PM_P0) base12<PM_P0>(yy, tp, dy_a, dy_b);
+    else base12<PM_PGEN>(yy, tp, dy_a, dy_b);
+    return;
+  }
+  double yy[14]; for (int i = 0; i < 14; ++i) yy[i] = y[i];
+  if (pm == PM_P1) base14<PM_P1>(yy, tp, dy_a, dy_b);
+  else if (pm == PM_P2) base14<PM_P2>(yy, tp, dy_a, dy_b);
+  else if (pm == PM_P0) base14<PM_P0>(yy, tp, dy_a, dy_b);
+  else base14<PM_PGEN>(yy, tp, dy_a, dy_b);
 }
 int chk_sizeof_tp() { return (int)sizeof(TrajParams); }
 }

@@ -37,6 +37,14 @@ METHODS = {
 }
 
 
+# STM kernel families x integrators: the three-role pipeline kernel is built for fixed-step RK4 only
+KERNEL_METHODS = [(k, m) for k in ("per_lane", "coop") for m in METHODS] + [("pipe", "rk4x64")]
+
+
+def pick_kernel(plan, kernel):
+    plan.set_kernel({"per_lane": plan.KERNEL_PER_LANE, "coop": plan.KERNEL_COOP, "pipe": plan.KERNEL_PIPE}[kernel])
+
+
 def rel_l2(d_gpu, d_ref, x1):
     return np.linalg.norm(d_gpu - d_ref) / np.linalg.norm(d_ref + x1)
 
@@ -199,8 +207,7 @@ def test_indirect_batch_homotopy_levels(gpu_ctx):
 
 
 @pytest.mark.parametrize("ndim", [12, 14])
-@pytest.mark.parametrize("mname", list(METHODS))
-@pytest.mark.parametrize("kernel", ["per_lane", "coop"])
+@pytest.mark.parametrize("kernel,mname", KERNEL_METHODS)
 def test_indirect_mixed_control_law_classes(gpu_ctx, ndim, mname, kernel):
     """A batch whose trajectories use all four control-law classes (p = 0, 1, 2, general p > 1; indirect.jl params
     tuple, stateCostate_deriv.jl:36-53) with segments of different classes inside one wavefront / workgroup: defect,
@@ -222,7 +229,7 @@ def test_indirect_mixed_control_law_classes(gpu_ctx, ndim, mname, kernel):
 
     def run(Xh, Th, pr, nb):
         plan = lto.IndirectPlan(gpu_ctx, n, nb, pr, integ, ndim=ndim)
-        plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
+        pick_kernel(plan, kernel)
         Xd = torch.from_numpy(synth.to_soa_nodes(Xh)).cuda()
         td = torch.from_numpy(np.ascontiguousarray(Th.T.reshape(-1) if Th.ndim == 2 else Th)).cuda()
         J = S * nb
@@ -656,8 +663,7 @@ def test_pack_unpack_and_norms(gpu_ctx):
 
 @pytest.mark.parametrize("pcase", ["p1_rho1", "p2_clamped", "p1.5", "p0"])
 @pytest.mark.parametrize("ndim", [12, 14])
-@pytest.mark.parametrize("mname", list(METHODS))
-@pytest.mark.parametrize("kernel", ["per_lane", "coop"])
+@pytest.mark.parametrize("kernel,mname", KERNEL_METHODS)
 def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, kernel, pcase):
     """Every instantiated STM kernel (family x integrator x dimension x control-law class) against the oracle.
     Both STM kernel families (per-lane: every lane re-integrates the base state; cooperative: base wave + column
@@ -678,7 +684,7 @@ def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, ke
         prm_l = [MU, DU, TU, thr, 1000.0, 1.0, pp, rho]
     S = n - 1
     plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(method, steps=steps), ndim=ndim)
-    plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
+    pick_kernel(plan, kernel)
     Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
     td = torch.from_numpy(np.ascontiguousarray(t)).cuda()
     Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
@@ -925,3 +931,44 @@ def test_device_adjoints_only_least_squares_vs_dense(gpu_ctx, n_nodes, n_batch):
             ref = ref.reshape(12, n_nodes, order="F")
             assert np.all(de[:6, :, b] == 0.0)            # states untouched
             assert np.abs(de[:, :, b] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("ndim", [12, 14])
+@pytest.mark.parametrize("steps", [1, 2, 3, 64])
+def test_indirect_pipeline_kernel_equals_per_lane_at_full_size(gpu_ctx, ndim, steps):
+    """The three-role pipeline kernel (base wave -> coefficient wave -> column waves, skewed by one RK4 step) against the
+    per-lane kernel at the BASELINE configs[1] size (4 096 segments), plus a ragged batch of trajectories, for step
+    counts around the pipeline depth (1, 2, 3 steps: fill and drain dominate) and the configured 64."""
+    import torch
+    for n, nb in ((4097, 1), (37, 5)):
+        XC, T = synth.indirect_problem(n, n_batch=nb, seed=5)
+        if ndim == 14:
+            X = np.zeros((14, n, nb), order="F")
+            X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+            slot = 2000.0
+        else:
+            X, slot = XC, 1000.0
+        prm = lto.make_params(MU, DU, TU, 0.05, slot, 1.0, 1.0, 1.0)
+        S = (n - 1) * nb
+        Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+        td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+        out = {}
+        for kernel in ("per_lane", "pipe"):
+            plan = lto.IndirectPlan(gpu_ctx, n, nb, prm, lto.integrator(lto.RK4, steps=steps), ndim=ndim)
+            pick_kernel(plan, kernel)
+            Phi = torch.full((ndim * ndim, S), 7.0, dtype=torch.float64, device="cuda")
+            d = torch.full((ndim, S), 7.0, dtype=torch.float64, device="cuda")
+            plan.jacobian(Xd, n * nb, td, nb, Phi, S, d, S)
+            torch.cuda.synchronize()
+            out[kernel] = (Phi.cpu().numpy(), d.cpu().numpy())
+        (P1, d1), (P2, d2) = out["per_lane"], out["pipe"]
+        assert np.all(np.isfinite(P2)) and np.all(np.isfinite(d2))
+        assert np.abs(d1 - d2).max() < 1e-12 * max(1.0, np.abs(d1).max())
+        assert np.abs(P1 - P2).max() < 1e-11 * np.abs(P1).max()
+
+
+def test_indirect_pipeline_kernel_is_rk4_only(gpu_ctx):
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    plan = lto.IndirectPlan(gpu_ctx, 8, 1, prm, lto.integrator(lto.DOP853_ADAPTIVE), ndim=12)
+    with pytest.raises(lto.LtoError):
+        plan.set_kernel(plan.KERNEL_PIPE)

@@ -86,3 +86,23 @@ def test_device_formulas_14(chk, oracle):
             J[:, c] = (oracle.rhs_state_costate_mass(yp, prm) - oracle.rhs_state_costate_mass(ym, prm)) / (yp[c] - ym[c])
         Jc = J @ col
         assert np.abs(dc - Jc).max() < 2e-8 * max(1.0, np.abs(J).max() * np.abs(col).max())
+
+
+@pytest.mark.parametrize("ndim", [12, 14])
+def test_lean_base_rhs_of_the_pipeline_kernel(chk, ndim):
+    """rhs*_base (the pipeline kernel's base wave: dyadic G lambda_v, short-depth exp, no variational by-products) gives
+    the slopes of the one-piece rhs* used by the other kernel families."""
+    rng = np.random.default_rng(2)
+    H1 = synth.halo_orbits()[0]
+    for td in (1.0, -1.0):
+        for p, rho, thr, lam, pm in CASES:
+            if ndim == 12:
+                y = np.concatenate([H1[:, rng.integers(0, 99)], lam * rng.standard_normal(6)])
+                tp = tp_vec(12, thr, 1000.0, td, p, rho)
+            else:
+                y = np.concatenate([H1[:, rng.integers(0, 99)], [990.0], lam * rng.standard_normal(6), [0.3]])
+                tp = tp_vec(14, thr, 2000.0, td, p, rho)
+            da = np.zeros(ndim); db = np.zeros(ndim)
+            chk.chk_base(ndim, P(y), P(tp), pm, P(da), P(db))
+            assert np.all(np.isfinite(db))
+            assert np.abs(da - db).max() <= 5e-14 * max(1.0, np.abs(da).max())
