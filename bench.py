@@ -197,7 +197,7 @@ def leg_12dim(lto, synth, ctx, st, torch, a):
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
     out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
            "workload": "C2 on the reference's CRTBP_stateCostate_deriv! system: 12-dim state+costate + 12x12 STM, 4 096 "
-                       "segments, RK4 x 64, fp64", "roofline": roofline("c2", 12, S, kern_ms)}
+                       "segments, RK4 x 64, fp64", "stm_kernel": plan.last_kernel(), "roofline": roofline("c2", 12, S, kern_ms)}
     plan.close()
 
     def add_parity():
@@ -402,6 +402,8 @@ def main():
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
                        "collective": "rccl all_gather(defect), overlapped with the next sweep on a side stream" if use_coll else "none", "integrator": "see workload"},
         }
+        if wl in ("c2", "hbm", "c4", "c5_stm"):
+            out["config"]["stm_kernel"] = plan.last_kernel()
         if (wl, a.ndim) in WORK and not a.method:
             out["roofline"] = roofline(wl, a.ndim, S, kern_ms)
         if c5:

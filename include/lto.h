@@ -204,9 +204,10 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* plan, void* stream, int* acc
 int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
 int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 
-/* Tuning knobs for the STM sweep.  Kernel: AUTO picks the wave-specialised kernel (base wave + column waves per
- * 16 segments, coefficients handed over through LDS) for latency-bound batches and for the 13-stage integrators,
- * and the per-lane kernel (each lane re-integrates the base state with 1-3 columns) once the chip is full. */
+/* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4, the three-role pipeline kernel up to a few
+ * chip-fulls of segments and the per-lane kernel (each lane re-integrates the base state with 1-3 columns) beyond,
+ * and the wave-specialised kernel (base wave + column waves per 16 segments, coefficients handed over through LDS)
+ * for the 13-stage integrators. */
 #define LTO_KERNEL_AUTO 0
 #define LTO_KERNEL_PER_LANE 1
 #define LTO_KERNEL_COOP 2
@@ -214,6 +215,8 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
  * one RK4 step (one workgroup barrier per step); other integrators: LTO_EINVAL. */
 #define LTO_KERNEL_PIPE 3
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
+/* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */
+int lto_indirect_plan_last_kernel(const lto_indirect_plan* plan);
 /* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3); 0 = choose from S. */
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);
 

@@ -55,6 +55,7 @@ struct lto_indirect_plan {
   int swept;           // an adaptive sweep has filled the step counters
   int cols_per_lane;
   int kernel;       // LTO_KERNEL_*
+  int last_kernel;  // family the last STM sweep ran (AUTO resolved)
   double* d_bvp;    // workspace of the device Newton solve (lazily allocated)
   size_t bvp_bytes;
   int bvp_variant;  // -1 none, 0 square system, 1 adjoints-only least squares: what the stored factorisation is
@@ -346,6 +347,8 @@ int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   return LTO_OK;
 }
 
+int lto_indirect_plan_last_kernel(const lto_indirect_plan* p) { return p ? p->last_kernel : LTO_KERNEL_AUTO; }
+
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
   if (!p) return LTO_ENULL;
   if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2 or 3");
@@ -408,12 +411,18 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  // Kernel choice (DESIGN.md "Kernels", measured on MI355X): RK4 -> per-lane kernels (4 096 segments: 131 us vs
-  // 150 us cooperative; the 4-stage state fits the registers and the per-stage barrier costs more than the
-  // redundant base work saves).  13-stage methods -> wave-specialised kernel (DOP853 @1e-13, 4 096 segments:
-  // 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms), whose 12/14-component lanes keep all slopes in registers.
+  // Kernel choice (DESIGN.md "Kernels", measured on MI355X).  RK4: the three-role pipeline kernel while the chip is
+  // not over-subscribed several times (14-dim, 4 096 segments: 108 us vs 171 us per-lane, 242 us cooperative; it stays
+  // ahead up to ~50 000 segments for 14-dim and ~12 000 for 12-dim), beyond that the per-lane kernel with 2-3 columns
+  // per lane.  13-stage methods -> wave-specialised kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms;
+  // RKF7(8) x4: 0.046 ms vs 0.36 ms), whose 12/14-component lanes keep all slopes in registers.
   int kern = p->kernel;
-  if (kern == LTO_KERNEL_AUTO) kern = (p->integ.method == LTO_RK4) ? LTO_KERNEL_PER_LANE : LTO_KERNEL_COOP;
+  if (kern == LTO_KERNEL_AUTO) {
+    if (p->integ.method != LTO_RK4) kern = LTO_KERNEL_COOP;
+    else  // the pipeline needs steps + 2 phases: below ~6 steps per segment its fill and drain outweigh the shorter phase
+      kern = (p->integ.steps >= 6 && p->S <= (p->ndim == 14 ? 49152 : 12288)) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
+  }
+  p->last_kernel = kern;
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
   else if (kern == LTO_KERNEL_PIPE) e = launch_indirect_stm_pipe(p->ndim, p->pm, a, st);

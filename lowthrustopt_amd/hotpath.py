@@ -436,6 +436,10 @@ class IndirectPlan:
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
 
+    def last_kernel(self):
+        """Name of the kernel family the last STM sweep ran (what AUTO resolved to)."""
+        return {0: "none yet", 1: "per-lane", 2: "cooperative", 3: "pipeline"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
+
     def set_cols_per_lane(self, cols):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_cols_per_lane(self.handle, int(cols)))
 

@@ -13,6 +13,7 @@ python bench.py --workload c3 --cpu-seconds 5 2>&1 | tail -1 > "$OUT/bench_c3.js
 python bench.py --ndim 12 --cpu-seconds 5 2>&1 | tail -1 > "$OUT/bench_c2_ndim12.json"; cat "$OUT/bench_c2_ndim12.json"
 python bench.py --ndim 12 --method dop853 --no-cpu-baseline --steps 50 2>&1 | tail -1 > "$OUT/bench_c2_dop853.json"; cat "$OUT/bench_c2_dop853.json"
 python bench.py --ndim 12 --method rkf78 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_c2_rkf78x4.json"; cat "$OUT/bench_c2_rkf78x4.json"
+python bench.py --kernel 1 --no-cpu-baseline 2>&1 | tail -1 > "$OUT/bench_c2_per_lane.json"; cat "$OUT/bench_c2_per_lane.json"
 python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>&1 | tail -1 > "$OUT/bench_c4.json"; cat "$OUT/bench_c4.json"
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>&1 | tail -1 > "$OUT/bench_c5.json"; cat "$OUT/bench_c5.json"
 python bench.py --workload c5_stm --no-cpu-baseline --steps 10 --warmup 2 2>&1 | tail -1 > "$OUT/bench_c5_stm.json"; cat "$OUT/bench_c5_stm.json"
