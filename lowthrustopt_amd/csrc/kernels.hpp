@@ -60,6 +60,8 @@ hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const Indirect
 // three-role pipeline (kernels_indirect_pipe.hip): base wave, coefficient wave and two column waves per 16 segments,
 // skewed by one RK4 step; fixed-step RK4 only
 hipError_t launch_indirect_stm_pipe(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
+// six-wave form: one STM column per lane, coefficients broadcast inside the FMA (v_fmac_f64_dpp row_newbcast)
+hipError_t launch_indirect_stm_pipe6(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian_coop(int nstate, const DirectArgs& a, hipStream_t st);

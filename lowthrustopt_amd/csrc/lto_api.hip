@@ -339,9 +339,9 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
 
 int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
-  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP or _PIPE");
-  if (kernel == LTO_KERNEL_PIPE && p->integ.method != LTO_RK4)
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE && kernel != LTO_KERNEL_PIPE6)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE or _PIPE6");
+  if ((kernel == LTO_KERNEL_PIPE || kernel == LTO_KERNEL_PIPE6) && p->integ.method != LTO_RK4)
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_PIPE is built for fixed-step RK4 plans");
   p->kernel = kernel;
   return LTO_OK;
@@ -419,13 +419,16 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   int kern = p->kernel;
   if (kern == LTO_KERNEL_AUTO) {
     if (p->integ.method != LTO_RK4) kern = LTO_KERNEL_COOP;
-    else  // the pipeline needs steps + 2 phases: below ~6 steps per segment its fill and drain outweigh the shorter phase
-      kern = (p->integ.steps >= 6 && p->S <= (p->ndim == 14 ? 49152 : 12288)) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
+    else if (p->integ.steps < 6 || p->S > (p->ndim == 14 ? 49152 : 12288))
+      kern = LTO_KERNEL_PER_LANE;  // the pipeline needs steps + 2 phases: below ~6 steps its fill and drain outweigh the shorter phase
+    else  // six-wave form (one column per lane, coefficients broadcast inside the FMA): 3-5 % ahead where it fits the CU
+      kern = (p->ndim == 14 || p->S <= 4096) ? LTO_KERNEL_PIPE6 : LTO_KERNEL_PIPE;
   }
   p->last_kernel = kern;
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
   else if (kern == LTO_KERNEL_PIPE) e = launch_indirect_stm_pipe(p->ndim, p->pm, a, st);
+  else if (kern == LTO_KERNEL_PIPE6) e = launch_indirect_stm_pipe6(p->ndim, p->pm, a, st);
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);

@@ -30,7 +30,7 @@ for ndim in (14, 12):
     Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
     for mask, name in [(int(m), "mask %s" % m) for m in os.environ.get("MASKS", "0,6,5,3,7,4,1").split(",")]:
         plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=64, max_steps=(1 << 20) | mask), ndim=ndim)
-        plan.set_kernel(3)
+        plan.set_kernel(int(os.environ.get("KERNEL", "3")))
         ms = timeit(lambda: plan.jacobian(X, n, t, 1, Phi, S, d, S, stream=st), iters=30)
         print("ndim=%d  %-14s %8.1f us" % (ndim, name, ms * 1e3), flush=True)
         plan.close()
