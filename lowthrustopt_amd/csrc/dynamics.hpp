@@ -620,9 +620,13 @@ __device__ __forceinline__ void rhs14_base(const double (&y)[14], const TrajPara
   dy[10] = __builtin_fma(w2, ly, -y[7]);
   dy[11] = __builtin_fma(-w2, lx, -y[8]);
   dy[12] = -y[9];
-  const double tl = tlim ? 1.0 : 0.0, ntl = 1.0 - tl;
   const double mn_over_m = (m * n) * inv_m;
-  dy[13] = __builtin_fma(-tl, mn_over_m, ntl * (kt * lm * m));
+  if constexpr (PM == PM_P0 || PM == PM_P1) {   // always thrust-limited: lambda_m_dot = -umag n / m, no blend needed
+    dy[13] = -mn_over_m;
+  } else {
+    const double tl = tlim ? 1.0 : 0.0, ntl = 1.0 - tl;
+    dy[13] = __builtin_fma(-tl, mn_over_m, ntl * (kt * lm * m));
+  }
 }
 
 // ------------------------------------------------------------------------------ A2 (direct path)
