@@ -4,20 +4,22 @@
 // as ONE lane's instruction stream: the per-lane kernel (indirect_kernel.hpp) spends ~60 % of that stream on work
 // every column lane of a segment repeats (base trajectory, gravity, control law), and the cooperative kernel
 // (kernels_indirect_coop.hip) pays one workgroup barrier per RK stage with the base role's full RHS + coefficient
-// build on the critical path.  Here a workgroup (4 wavefronts, one per SIMD) owns 16 segments and runs three roles
-// that are skewed by one RK4 STEP each, so they execute concurrently and meet at ONE barrier per step:
+// build on the critical path.  Here a workgroup owns 16 segments and runs three roles in different wavefronts,
+// skewed by one RK4 STEP each, so that they execute concurrently and meet at ONE barrier per step:
 //
-//   wave 0  base      integrates the ND-dim base state (rhs*_base: the RHS alone -- the shortest instruction stream)
-//                     and publishes, per stage, the part of the stage argument the coefficients depend on
-//   wave 1  coef      one step behind: lane = (segment, RK stage); builds G, H, U (+ mass couplings) at those
-//                     arguments and publishes them
-//   waves 2,3 columns two steps behind: lane = (segment, PAIR of STM columns); c' = F(t) c with the coefficients
-//                     read from LDS -- no gravity, no control law, no base state in these lanes
+//   base      integrates the ND-dim base state (rhs*_base: the RHS alone -- the shortest instruction stream) and
+//             publishes, per stage, the part of the stage argument the coefficients depend on
+//   coef      one step behind: lane = (segment, RK stage); builds G, H, U (+ mass couplings) at those arguments
+//   columns   two steps behind: c' = F(t) c with the coefficients of the stage -- no gravity, no control law, no base
+//             state in these lanes
 //
-// Both hand-overs are double-buffered per step in LDS (46 KB for ND = 14); a sweep of n steps takes n + 2 phases.
-// Two columns per lane (7 pairs x 16 segments = 112 lanes for ND = 14) is what lets the column role fit the two
-// remaining SIMDs, so that every SIMD carries one wave of ~170-190 fp64 instructions per stage instead of the
-// per-lane kernel's 281.  Every wavefront executes exactly steps + 2 barriers; nothing spins.
+// Both hand-overs are double-buffered per step in LDS; a sweep of n steps takes n + 2 phases; every wavefront executes
+// exactly n + 2 barriers and nothing spins.  Two forms differ in the column role only:
+//
+//   k_indirect_pipe   4 waves, one per SIMD: base, coef, 2 column waves; column lane = (segment, PAIR of columns),
+//                     17 / 25 coefficients read from LDS per stage
+//   k_indirect_pipe6  6 waves: base and coef alone on a SIMD each, 4 column waves two per SIMD; column lane =
+//                     (segment, ONE column) with a DPP row = one segment, coefficients broadcast inside the FMA
 //
 // Replaces the serial loop of jacobianCalc (src/multiShoot_CRTBP_indirect.jl:93-146) for the fixed-step setting.
 #include "kernels.hpp"
@@ -27,8 +29,8 @@ namespace lto {
 constexpr int PIPE_SEG = 16;   // segments per workgroup
 
 // The coefficients of an RK stage are functions of the stage argument's position, lambda_v (and, for ND = 14, mass and
-// lambda_m) only: that is all the base wave publishes (6 / 8 doubles per stage -- LDS stores of a 64-lane wave cost
-// issue time on the critical path), in the order of PipeArg<ND>::idx.
+// lambda_m) only: that is all the base wave publishes (6 / 8 doubles per stage -- an LDS store of a 64-lane wave costs
+// ~25 issue cycles of the critical stream), in the order of PipeArg<ND>::idx.
 template <int ND> struct PipeArg {
   static constexpr int N = 6;
   static constexpr int idx[6] = {0, 1, 2, 9, 10, 11};
@@ -40,193 +42,199 @@ template <> struct PipeArg<14> {
   using Coef = VarCoef14;
 };
 
-template <int ND, int PM>
-__device__ __forceinline__ void pipe_base_rhs(const double (&y)[ND], const TrajParams& tp, double (&k)[ND]) {
-  if constexpr (ND == 12) rhs12_base<PM>(y, tp, k);
-  else rhs14_base<PM>(y, tp, k);
-}
-// G, H, U (+ mass couplings) at the stage argument `arg` (components outside PipeArg<ND>::idx are unused: the slopes
-// this call also produces are dead code)
-template <int ND, int PM>
-__device__ __forceinline__ void pipe_coef(const double (&arg)[ND], const TrajParams& tp, typename PipeArg<ND>::Coef& vc) {
-  double dead[ND];
-  if constexpr (ND == 12) rhs12<PM, true>(arg, tp, dead, vc);
-  else rhs14<PM, true>(arg, tp, dead, vc);
-}
-template <int ND>
-__device__ __forceinline__ void pipe_col(const typename PipeArg<ND>::Coef& vc, const double w2, const double (&c)[ND],
-                                         double (&dc)[ND]) {
-  if constexpr (ND == 12) var_col12(vc, w2, c, dc);
-  else var_col14(vc, w2, c, dc);
-}
+// Layout of the coefficient records in LDS, one record per (step parity, stage, segment).
+struct CoefByValue {     // [value][segment]: what a lane that reads ALL values of its segment wants (k_indirect_pipe)
+  template <int NC> static constexpr int stage_doubles() { return NC * PIPE_SEG; }
+  __device__ static int at(int e, int seg) { return e * PIPE_SEG + seg; }
+};
+struct CoefBySegment {   // [segment][value], records padded to 33 doubles: the coefficient wave's stores (one record per
+  static constexpr int LD = 33;   // lane) and the column rows' loads (one record per row) are both conflict-free
+  template <int NC> static constexpr int stage_doubles() { return PIPE_SEG * LD; }
+  __device__ static int at(int e, int seg) { return seg * LD + e; }
+};
 
-template <int ND, int PM>
-__global__ __launch_bounds__(256) void k_indirect_pipe(const IndirectArgs a) {
-  using Coef = typename PipeArg<ND>::Coef;
-  constexpr int NI = PipeArg<ND>::N;
-  constexpr int NC = sizeof(Coef) / sizeof(double);
-  constexpr int NPAIR = ND / 2;
+// What a lane knows about its segment.
+struct PipeLane {
+  int s;            // segment (after the optional balanced order)
+  long node;        // its first node in the SoA arrays
+  bool in_range;    // stores allowed (not a shadow lane, and of this launch's control-law class)
+  bool mine;
+  double h, w2;
+  TrajParams tp;
+};
 
-  // base -> coef: slab = parity * 4 + stage, [value][segment]; slabs 8..10 take the stores of the base wave's three
-  // spare lane groups, so that publishing needs no EXEC branch (a branch per stage would cut the base role's one
-  // basic block per step into five and keep the scheduler from overlapping the stages' rsqrt / exp chains)
-  __shared__ double s_int[8 + 3][NI][PIPE_SEG];
-  __shared__ double s_coef[2][4][NC][PIPE_SEG];   // coef -> columns: [step parity][stage][value][segment]
-
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int seg = lane & (PIPE_SEG - 1), slot = lane >> 4;
+template <int PM>
+__device__ __forceinline__ PipeLane pipe_lane(const IndirectArgs& a, const int seg) {
+  PipeLane L;
   const int s_raw = blockIdx.x * PIPE_SEG + seg;
   const int s_lin = s_raw < a.S ? s_raw : a.S - 1;             // shadow lanes repeat the last segment
-  const int s = a.order ? a.order[s_lin] : s_lin;
-  const int traj = s / a.seg_per_traj;
-  const int i = s - traj * a.seg_per_traj;
-  const long node = (long)traj * a.n_nodes + i;
+  L.s = a.order ? a.order[s_lin] : s_lin;
+  const int traj = L.s / a.seg_per_traj;
+  const int i = L.s - traj * a.seg_per_traj;
+  L.node = (long)traj * a.n_nodes + i;
   const long tg = (long)traj * a.t_stride + i;
-  const double span = a.t[tg + 1] - a.t[tg];
-  const TrajParams tp = a.tp[(long)traj * a.tp_stride];
-  const double w2 = 2.0 * tp.omega;
+  L.tp = a.tp[(long)traj * a.tp_stride];
+  L.h = (a.t[tg + 1] - a.t[tg]) / (double)a.steps;
+  L.w2 = 2.0 * L.tp.omega;
   // mixed-class batch: segments of another control-law class belong to that class's launch; here they run through the
   // barriers without storing
-  const bool mine = !a.class_filter || p_class(tp.p) == PM;
-  if (!__syncthreads_or(mine)) return;         // workgroup-uniform
+  L.mine = !a.class_filter || p_class(L.tp.p) == PM;
+  L.in_range = (s_raw < a.S) && L.mine;
+  return L;
+}
 
+#ifdef PIPE_PROBE   // development build (make probe, tools/probe_pipe_roles.py): max_steps carries a role mask
+#define PIPE_ROLE_ON(a, bit) (!((a).max_steps & (bit)))
+#else
+#define PIPE_ROLE_ON(a, bit) true
+#endif
+
+// ---------------------------------------------------------------------------------------------------------- base role
+// lane = (segment, lane group); the three spare lane groups repeat group 0's work and store to scratch slabs 8..10, so
+// that publishing needs no EXEC branch (a branch per stage would cut the role's one basic block per step into five).
+// s_int: [8 + 3][NI][PIPE_SEG], slab = step parity * 4 + stage.
+template <int ND, int PM>
+__device__ __forceinline__ void pipe_role_base(const IndirectArgs& a, const PipeLane& L, const int seg, const int slot,
+                                               double* s_int) {
+  constexpr int NI = PipeArg<ND>::N;
   const int steps = a.steps;
-  const double h = span / (double)steps;
-  const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
-
-  const bool in_range = (s_raw < a.S) && mine;
-  const int nphase = steps + 2;   // every role loop below executes exactly nphase barriers
-#ifdef PIPE_PROBE
-  const int probe = a.max_steps;  // development build only: bit 0 / 1 / 2 switches the base / coef / column work off
-#else
-  constexpr int probe = 0;
-#endif
-
-  if (wave == 0) {
-    // -------------------------------------------------------------------- base: step p in phase p
-    double y[ND];
+  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
+  auto rhs = [&](const double (&y)[ND], double (&k)[ND]) {
+    if constexpr (ND == 12) rhs12_base<PM>(y, L.tp, k);
+    else rhs14_base<PM>(y, L.tp, k);
+  };
+  double y[ND];
 #pragma unroll
-    for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + node];
-    for (int p = 0; p < nphase; ++p) {
-      if (p < steps && !(probe & 1)) {
-        const int buf = p & 1;
-        double k[ND], yt[ND], acc[ND];
-        auto publish = [&](int stage, const double (&arg)[ND]) {
-          double* dst = &s_int[slot == 0 ? buf * 4 + stage : 7 + slot][0][seg];
+  for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + L.node];
+  for (int p = 0; p < steps + 2; ++p) {
+    if (p < steps && PIPE_ROLE_ON(a, 1)) {
+      const int buf = p & 1;
+      double k[ND], yt[ND], acc[ND];
+      auto publish = [&](int stage, const double (&arg)[ND]) {
+        double* dst = s_int + ((slot == 0 ? buf * 4 + stage : 7 + slot) * NI) * PIPE_SEG + seg;
 #pragma unroll
-          for (int e = 0; e < NI; ++e) dst[e * PIPE_SEG] = arg[PipeArg<ND>::idx[e]];
-        };
-        publish(0, y);
-        pipe_base_rhs<ND, PM>(y, tp, k);
+        for (int e = 0; e < NI; ++e) dst[e * PIPE_SEG] = arg[PipeArg<ND>::idx[e]];
+      };
+      publish(0, y);
+      rhs(y, k);
 #pragma unroll
-        for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
-        publish(1, yt);
-        pipe_base_rhs<ND, PM>(yt, tp, k);
+      for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
+      publish(1, yt);
+      rhs(yt, k);
 #pragma unroll
-        for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
-        publish(2, yt);
-        pipe_base_rhs<ND, PM>(yt, tp, k);
+      for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
+      publish(2, yt);
+      rhs(yt, k);
 #pragma unroll
-        for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
-        publish(3, yt);
-        pipe_base_rhs<ND, PM>(yt, tp, k);
+      for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
+      publish(3, yt);
+      rhs(yt, k);
 #pragma unroll
-        for (int c = 0; c < ND; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
-      }
-      __syncthreads();
+      for (int c = 0; c < ND; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
     }
-    if (in_range && slot == 0) {
-      if (a.defect) {
+    __syncthreads();
+  }
+  if (L.in_range && slot == 0) {
+    if (a.defect) {
 #pragma unroll
-        for (int c = 0; c < ND; ++c) a.defect[c * a.ldd + s] = y[c] - a.X[c * a.ldx + node + 1];
-      }
-      if (a.errors) a.errors[s] = 0.0;
-      if (a.nacc) a.nacc[s] = steps;
-      if (a.nrej) a.nrej[s] = 0;
+      for (int c = 0; c < ND; ++c) a.defect[c * a.ldd + L.s] = y[c] - a.X[c * a.ldx + L.node + 1];
     }
-  } else if (wave == 1) {
-    // -------------------------------------------------------------------- coefficients of step p - 1 in phase p
-    // lane = (segment, RK stage): the four stages of a step are built side by side
-    for (int p = 0; p < nphase; ++p) {
-      if (p >= 1 && p <= steps && !(probe & 2)) {
-        const int buf = (p - 1) & 1;
-        double arg[ND];
-#pragma unroll
-        for (int c = 0; c < ND; ++c) arg[c] = 0.0;
-        const double* src = &s_int[buf * 4 + slot][0][seg];
-#pragma unroll
-        for (int e = 0; e < NI; ++e) arg[PipeArg<ND>::idx[e]] = src[e * PIPE_SEG];
-        Coef vc;
-        pipe_coef<ND, PM>(arg, tp, vc);
-        const double* o = reinterpret_cast<const double*>(&vc);
-        double* dst = &s_coef[buf][slot][0][seg];
-#pragma unroll
-        for (int e = 0; e < NC; ++e) dst[e * PIPE_SEG] = o[e];
-      }
-      __syncthreads();
-    }
-  } else {
-    // -------------------------------------------------------------------- columns: step p - 2 in phase p
-    const int pair_raw = (wave - 2) * 4 + slot;
-    const bool col_lane = pair_raw < NPAIR;
-    const int pair = col_lane ? pair_raw : 0;        // spare lanes shadow pair 0 and store nothing
-    double y[2][ND];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < ND; ++r) y[j][r] = (r == 2 * pair + j) ? 1.0 : 0.0;
-    for (int p = 0; p < nphase; ++p) {
-      if (p >= 2 && !(probe & 4)) {
-        const int buf = p & 1;
-        double acc[2][ND], yt[2][ND];
-#pragma unroll
-        for (int stage = 0; stage < 4; ++stage) {
-          Coef vc;
-          double* v = reinterpret_cast<double*>(&vc);
-#pragma unroll
-#ifdef PIPE_FEWREADS
-          for (int e = 0; e < NC; ++e) v[e] = s_coef[buf][0][e][seg];
-#else
-          for (int e = 0; e < NC; ++e) v[e] = s_coef[buf][stage][e][seg];
-#endif
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            double k[ND];
-            if (stage == 0) pipe_col<ND>(vc, w2, y[j], k);
-            else pipe_col<ND>(vc, w2, yt[j], k);
-#pragma unroll
-            for (int c = 0; c < ND; ++c) {
-              if (stage == 0) { acc[j][c] = __builtin_fma(h6, k[c], y[j][c]); yt[j][c] = __builtin_fma(h2, k[c], y[j][c]); }
-              else if (stage == 1) { acc[j][c] = __builtin_fma(h3, k[c], acc[j][c]); yt[j][c] = __builtin_fma(h2, k[c], y[j][c]); }
-              else if (stage == 2) { acc[j][c] = __builtin_fma(h3, k[c], acc[j][c]); yt[j][c] = __builtin_fma(h, k[c], y[j][c]); }
-              else y[j][c] = __builtin_fma(h6, k[c], acc[j][c]);
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-    if (in_range && col_lane) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < ND; ++r) a.Phi[(long)((2 * pair + j) * ND + r) * a.ldp + s] = y[j][r];
-    }
+    if (a.errors) a.errors[L.s] = 0.0;
+    if (a.nacc) a.nacc[L.s] = steps;
+    if (a.nrej) a.nrej[L.s] = 0;
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Six-wave form: the column role as ONE column per lane with a DPP row = one segment.
-//
-// In the four-wave kernel above a column lane reads all 17 / 25 coefficients of its segment from LDS at every stage
-// (13 ds_read2_b64 per stage: ~14 issue cycles each, a quarter of the column waves' time).  Here the 16 lanes of a DPP row
-// are the 14 (12) STM columns of ONE segment, lane j of the row holds coefficients j and 16 + j of that segment (one
-// ds_read2_b64 per stage), and every product  coefficient x column entry  is a v_fmac_f64_dpp with row_newbcast:n --
-// the coefficient is read from lane n of the row inside the FMA, no move, no LDS.  A wave now covers 4 segments, so the
-// 16 segments of a workgroup need four column waves; the hardware places the waves of a workgroup on SIMDs round-robin
-// (measured: tools/micro/dpp_probe.hip), so waves 0, 1, 4, 5 (two per SIMD on two SIMDs) take the columns and waves
-// 2 and 3, each alone on its SIMD, the base and coefficient roles.
+// --------------------------------------------------------------------------------------------------- coefficient role
+// lane = (segment, RK stage): the four stages of step p - 1 are built side by side in phase p.  The stage argument's
+// components outside PipeArg<ND>::idx are unused by the coefficients (the slopes rhs* also produces are dead code).
+template <int ND, int PM, class Layout>
+__device__ __forceinline__ void pipe_role_coef(const IndirectArgs& a, const PipeLane& L, const int seg, const int stage,
+                                               const double* s_int, double* s_coef) {
+  using Coef = typename PipeArg<ND>::Coef;
+  constexpr int NI = PipeArg<ND>::N;
+  constexpr int NC = sizeof(Coef) / sizeof(double);
+  const int steps = a.steps;
+  for (int p = 0; p < steps + 2; ++p) {
+    if (p >= 1 && p <= steps && PIPE_ROLE_ON(a, 2)) {
+      const int buf = (p - 1) & 1;
+      double arg[ND], dead[ND];
+#pragma unroll
+      for (int c = 0; c < ND; ++c) arg[c] = 0.0;
+      const double* src = s_int + ((buf * 4 + stage) * NI) * PIPE_SEG + seg;
+#pragma unroll
+      for (int e = 0; e < NI; ++e) arg[PipeArg<ND>::idx[e]] = src[e * PIPE_SEG];
+      Coef vc;
+      if constexpr (ND == 12) rhs12<PM, true>(arg, L.tp, dead, vc);
+      else rhs14<PM, true>(arg, L.tp, dead, vc);
+      const double* o = reinterpret_cast<const double*>(&vc);
+      double* dst = s_coef + (buf * 4 + stage) * Layout::template stage_doubles<NC>();
+#pragma unroll
+      for (int e = 0; e < NC; ++e) dst[Layout::at(e, seg)] = o[e];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------- column role, two columns per lane
+// lane = (segment, pair of columns); coefficients of the stage read from LDS (CoefByValue).
+template <int ND>
+__device__ __forceinline__ void pipe_role_columns2(const IndirectArgs& a, const PipeLane& L, const int seg, const int pair_raw,
+                                                   const double* s_coef) {
+  using Coef = typename PipeArg<ND>::Coef;
+  constexpr int NC = sizeof(Coef) / sizeof(double);
+  const int steps = a.steps;
+  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0), w2 = L.w2;
+  const bool col_lane = pair_raw < ND / 2;
+  const int pair = col_lane ? pair_raw : 0;        // spare lanes shadow pair 0 and store nothing
+  double y[2][ND];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < ND; ++r) y[j][r] = (r == 2 * pair + j) ? 1.0 : 0.0;
+  for (int p = 0; p < steps + 2; ++p) {
+    if (p >= 2 && PIPE_ROLE_ON(a, 4)) {
+      const int buf = p & 1;
+      double acc[2][ND], yt[2][ND];
+#pragma unroll
+      for (int stage = 0; stage < 4; ++stage) {
+        Coef vc;
+        double* v = reinterpret_cast<double*>(&vc);
+        const double* src = s_coef + (buf * 4 + stage) * CoefByValue::stage_doubles<NC>();
+#pragma unroll
+        for (int e = 0; e < NC; ++e) v[e] = src[CoefByValue::at(e, seg)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          double k[ND];
+          if constexpr (ND == 12) { if (stage == 0) var_col12(vc, w2, y[j], k); else var_col12(vc, w2, yt[j], k); }
+          else { if (stage == 0) var_col14(vc, w2, y[j], k); else var_col14(vc, w2, yt[j], k); }
+#pragma unroll
+          for (int c = 0; c < ND; ++c) {
+            if (stage == 0) { acc[j][c] = __builtin_fma(h6, k[c], y[j][c]); yt[j][c] = __builtin_fma(h2, k[c], y[j][c]); }
+            else if (stage == 1) { acc[j][c] = __builtin_fma(h3, k[c], acc[j][c]); yt[j][c] = __builtin_fma(h2, k[c], y[j][c]); }
+            else if (stage == 2) { acc[j][c] = __builtin_fma(h3, k[c], acc[j][c]); yt[j][c] = __builtin_fma(h, k[c], y[j][c]); }
+            else y[j][c] = __builtin_fma(h6, k[c], acc[j][c]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (L.in_range && col_lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < ND; ++r) a.Phi[(long)((2 * pair + j) * ND + r) * a.ldp + L.s] = y[j][r];
+  }
+}
+
+// ----------------------------------------------------------- column role, one column per lane, coefficients through DPP
+// The 16 lanes of a DPP row are the 14 (12) STM columns of ONE segment; lane j of the row holds coefficients j and 16 + j
+// of that segment (one ds_read2_b64 per stage instead of 13), and every product  coefficient x column entry  is a
+// v_fmac_f64_dpp with row_newbcast:n -- the coefficient is read from lane n of the row inside the FMA, no move, no LDS.
+// (Inline asm: the compiler has no pattern that folds a 64-bit DPP move into the FMA.  The DPP source registers are only
+// ever written by the LDS loads below, never by a VALU instruction, so the VALU-write -> DPP-read hazard cannot arise.
+// tools/micro/dpp_probe.hip checks semantics and issue rate on the device.)
 template <int N>
 __device__ __forceinline__ void fmac_b(double& acc, const double c, const double x) {      // acc += c[lane N of the row] * x
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(x), "n"(N));
@@ -238,8 +246,8 @@ __device__ __forceinline__ void fmac_bn(double& acc, const double c, const doubl
 
 // cdot = F c for one STM column with the coefficients spread over the row: cA = value (lane), cB = value (16 + lane) of
 //   [Gxx Gyy Gzz Gxy Gxz Gyz | Hxx Hyy Hzz Hxy Hxz Hyz | ua ub lx ly] [lz | umx umy umz mm mn Lm Ln Ll]   (VarCoef12 / 14)
-// k[7..9] (ND = 14; k[6..8] for ND = 12) return H a + G d, i.e. MINUS the slope (the caller folds the sign into the
-// RK update); every other entry is the slope itself.
+// The lambda_r rows of k return H a + G d, i.e. MINUS the slope (the caller folds the sign into the RK update); every
+// other entry is the slope itself.  Same formulas as var_col12 / var_col14.
 template <int ND>
 __device__ __forceinline__ void col_dpp(const double cA, const double cB, const double w2, const double (&c)[ND], double (&k)[ND]) {
   constexpr int G = (ND == 14) ? 7 : 6;     // first lambda_r row
@@ -274,193 +282,103 @@ __device__ __forceinline__ void col_dpp(const double cA, const double cB, const 
   k[3] = k3; k[4] = k4; k[5] = k5;
 }
 
-constexpr int PIPE6_LDC = 33;   // doubles per (stage, segment) coefficient record: 32 + 1 so that the coefficient wave's
-                                // stores (one record per lane) and the column lanes' loads (one row per record) are
-                                // both free of bank conflicts
-
-template <int ND, int PM>
-__global__ __launch_bounds__(384) void k_indirect_pipe6(const IndirectArgs a) {
-  using Coef = typename PipeArg<ND>::Coef;
-  constexpr int NI = PipeArg<ND>::N;
-  constexpr int NC = sizeof(Coef) / sizeof(double);
+// lane = (row = segment, column); coefficients of the stage: CoefBySegment.
+template <int ND>
+__device__ __forceinline__ void pipe_role_columns_dpp(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
+                                                      const double* s_coef) {
+  constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
   constexpr int G = (ND == 14) ? 7 : 6;
-
-  __shared__ double s_int[8 + 3][NI][PIPE_SEG];             // base -> coef, as in k_indirect_pipe
-  __shared__ double s_coef[2][4][PIPE_SEG][PIPE6_LDC];      // coef -> columns: [step parity][stage][segment][value]
-
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  // base / coefficient waves: lane = (segment, lane group) as in k_indirect_pipe.  Column wave cw: lane = (row, column),
-  // segment = 4 cw + row.
-  const bool col_wave = (wave != 2 && wave != 3);
-  const int cw = wave < 2 ? wave : wave - 2;                  // waves 0, 1, 4, 5 -> 0, 1, 2, 3
-  const int seg = col_wave ? cw * 4 + (lane >> 4) : (lane & (PIPE_SEG - 1));
-  const int slot = lane >> 4;                                 // lane group (base / coef waves)
-  const int col = lane & 15;                                  // STM column (column waves)
-  const int s_raw = blockIdx.x * PIPE_SEG + seg;
-  const int s_lin = s_raw < a.S ? s_raw : a.S - 1;
-  const int s = a.order ? a.order[s_lin] : s_lin;
-  const int traj = s / a.seg_per_traj;
-  const int i = s - traj * a.seg_per_traj;
-  const long node = (long)traj * a.n_nodes + i;
-  const long tg = (long)traj * a.t_stride + i;
-  const double span = a.t[tg + 1] - a.t[tg];
-  const TrajParams tp = a.tp[(long)traj * a.tp_stride];
-  const double w2 = 2.0 * tp.omega;
-  const bool mine = !a.class_filter || p_class(tp.p) == PM;
-  if (!__syncthreads_or(mine)) return;         // workgroup-uniform
-
   const int steps = a.steps;
-  const double h = span / (double)steps;
-  const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
-  const bool in_range = (s_raw < a.S) && mine;
-  const int nphase = steps + 2;
-#ifdef PIPE_PROBE
-  const int probe = a.max_steps;  // development build only: bit 0 / 1 / 2 switches the base / coef / column work off
-#else
-  constexpr int probe = 0;
-#endif
-
-  if (wave == 2) {
-    // -------------------------------------------------------------------- base: step p in phase p
-    double y[ND];
+  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0), w2 = L.w2;
+  double y[ND];
 #pragma unroll
-    for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + node];
-    for (int p = 0; p < nphase; ++p) {
-      if (p < steps && !(probe & 1)) {
-        const int buf = p & 1;
-        double k[ND], yt[ND], acc[ND];
-        auto publish = [&](int stage, const double (&arg)[ND]) {
-          double* dst = &s_int[slot == 0 ? buf * 4 + stage : 7 + slot][0][seg];
+  for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
+  for (int p = 0; p < steps + 2; ++p) {
+    if (p >= 2 && PIPE_ROLE_ON(a, 4)) {
+      const int buf = p & 1;
+      double acc[ND], yt[ND], k[ND];
 #pragma unroll
-          for (int e = 0; e < NI; ++e) dst[e * PIPE_SEG] = arg[PipeArg<ND>::idx[e]];
-        };
-        publish(0, y);
-        pipe_base_rhs<ND, PM>(y, tp, k);
+      for (int stage = 0; stage < 4; ++stage) {
+        const double* rec = s_coef + (buf * 4 + stage) * CoefBySegment::stage_doubles<NC>() + CoefBySegment::at(col, seg);
+        const double cA = rec[0], cB = rec[16];
+        if (stage == 0) col_dpp<ND>(cA, cB, w2, y, k);
+        else col_dpp<ND>(cA, cB, w2, yt, k);
 #pragma unroll
-        for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
-        publish(1, yt);
-        pipe_base_rhs<ND, PM>(yt, tp, k);
-#pragma unroll
-        for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
-        publish(2, yt);
-        pipe_base_rhs<ND, PM>(yt, tp, k);
-#pragma unroll
-        for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
-        publish(3, yt);
-        pipe_base_rhs<ND, PM>(yt, tp, k);
-#pragma unroll
-        for (int c = 0; c < ND; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
-      }
-      __syncthreads();
-    }
-    if (in_range && slot == 0) {
-      if (a.defect) {
-#pragma unroll
-        for (int c = 0; c < ND; ++c) a.defect[c * a.ldd + s] = y[c] - a.X[c * a.ldx + node + 1];
-      }
-      if (a.errors) a.errors[s] = 0.0;
-      if (a.nacc) a.nacc[s] = steps;
-      if (a.nrej) a.nrej[s] = 0;
-    }
-  } else if (wave == 3) {
-    // -------------------------------------------------------------------- coefficients of step p - 1 in phase p
-    for (int p = 0; p < nphase; ++p) {
-      if (p >= 1 && p <= steps && !(probe & 2)) {
-        const int buf = (p - 1) & 1;
-        double arg[ND];
-#pragma unroll
-        for (int c = 0; c < ND; ++c) arg[c] = 0.0;
-        const double* src = &s_int[buf * 4 + slot][0][seg];
-#pragma unroll
-        for (int e = 0; e < NI; ++e) arg[PipeArg<ND>::idx[e]] = src[e * PIPE_SEG];
-        Coef vc;
-        pipe_coef<ND, PM>(arg, tp, vc);
-        const double* o = reinterpret_cast<const double*>(&vc);
-        double* dst = &s_coef[buf][slot][seg][0];
-#pragma unroll
-        for (int e = 0; e < NC; ++e) dst[e] = o[e];
-      }
-      __syncthreads();
-    }
-  } else {
-    // -------------------------------------------------------------------- columns: step p - 2 in phase p
-    double y[ND];
-#pragma unroll
-    for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
-    for (int p = 0; p < nphase; ++p) {
-      if (p >= 2 && !(probe & 4)) {
-        const int buf = p & 1;
-        double acc[ND], yt[ND], k[ND];
-#pragma unroll
-        for (int stage = 0; stage < 4; ++stage) {
-          const double* rec = &s_coef[buf][stage][seg][col];
-          const double cA = rec[0], cB = rec[16];
-          if (stage == 0) col_dpp<ND>(cA, cB, w2, y, k);
-          else col_dpp<ND>(cA, cB, w2, yt, k);
-#pragma unroll
-          for (int c = 0; c < ND; ++c) {
-            const bool neg = (c >= G && c < G + 3);          // k holds minus the slope in the lambda_r rows
-            const double b6 = neg ? -h6 : h6, b3 = neg ? -h3 : h3, a2 = neg ? -h2 : h2, a1 = neg ? -h : h;
-            if (stage == 0) { acc[c] = __builtin_fma(b6, k[c], y[c]); yt[c] = __builtin_fma(a2, k[c], y[c]); }
-            else if (stage == 1) { acc[c] = __builtin_fma(b3, k[c], acc[c]); yt[c] = __builtin_fma(a2, k[c], y[c]); }
-            else if (stage == 2) { acc[c] = __builtin_fma(b3, k[c], acc[c]); yt[c] = __builtin_fma(a1, k[c], y[c]); }
-            else y[c] = __builtin_fma(b6, k[c], acc[c]);
-          }
+        for (int c = 0; c < ND; ++c) {
+          const bool neg = (c >= G && c < G + 3);          // k holds minus the slope in the lambda_r rows
+          const double b6 = neg ? -h6 : h6, b3 = neg ? -h3 : h3, a2 = neg ? -h2 : h2, a1 = neg ? -h : h;
+          if (stage == 0) { acc[c] = __builtin_fma(b6, k[c], y[c]); yt[c] = __builtin_fma(a2, k[c], y[c]); }
+          else if (stage == 1) { acc[c] = __builtin_fma(b3, k[c], acc[c]); yt[c] = __builtin_fma(a2, k[c], y[c]); }
+          else if (stage == 2) { acc[c] = __builtin_fma(b3, k[c], acc[c]); yt[c] = __builtin_fma(a1, k[c], y[c]); }
+          else y[c] = __builtin_fma(b6, k[c], acc[c]);
         }
       }
-      __syncthreads();
     }
-    if (in_range && col < ND) {
+    __syncthreads();
+  }
+  if (L.in_range && col < ND) {
 #pragma unroll
-      for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + s] = y[r];
-    }
+    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = y[r];
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------ kernels
+// Four waves, one per SIMD: wave 0 base, wave 1 coef, waves 2-3 columns (two per lane).  LDS 31 / 61 KB.
 template <int ND, int PM>
-static hipError_t launch_pipe6_one(const IndirectArgs& a, hipStream_t st) {
-  dim3 grid((a.S + PIPE_SEG - 1) / PIPE_SEG);
-  hipLaunchKernelGGL((k_indirect_pipe6<ND, PM>), grid, dim3(384), 0, st, a);
-  return hipGetLastError();
+__global__ __launch_bounds__(256) void k_indirect_pipe(const IndirectArgs a) {
+  constexpr int NI = PipeArg<ND>::N;
+  constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
+  __shared__ double s_int[(8 + 3) * NI * PIPE_SEG];
+  __shared__ double s_coef[2 * 4 * CoefByValue::stage_doubles<NC>()];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int seg = lane & (PIPE_SEG - 1), slot = lane >> 4;
+  const PipeLane L = pipe_lane<PM>(a, seg);
+  if (!__syncthreads_or(L.mine)) return;         // workgroup-uniform
+  if (wave == 0) pipe_role_base<ND, PM>(a, L, seg, slot, s_int);
+  else if (wave == 1) pipe_role_coef<ND, PM, CoefByValue>(a, L, seg, slot, s_int, s_coef);
+  else pipe_role_columns2<ND>(a, L, seg, (wave - 2) * 4 + slot, s_coef);
 }
 
-template <int ND>
-static hipError_t launch_pipe6_pm(int pm, const IndirectArgs& a0, hipStream_t st) {
-  IndirectArgs a = a0;
-  a.class_filter = single_class(pm) ? 0 : 1;
-  hipError_t e = hipSuccess;
-  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_pipe6_one<ND, PM_P0>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_pipe6_one<ND, PM_P1>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_pipe6_one<ND, PM_P2>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_pipe6_one<ND, PM_PGEN>(a, st);
-  return e;
-}
-
-hipError_t launch_indirect_stm_pipe6(int ndim, int pm, const IndirectArgs& a, hipStream_t st) {
-  if (a.S <= 0) return hipSuccess;
-  if (a.steps < 1) return hipErrorInvalidValue;
-  if (ndim == 12) return launch_pipe6_pm<12>(pm, a, st);
-  if (ndim == 14) return launch_pipe6_pm<14>(pm, a, st);
-  return hipErrorInvalidValue;
-}
-
+// Six waves.  The hardware places the waves of a workgroup on the four SIMDs round-robin (measured:
+// tools/micro/dpp_probe.hip), so waves 0, 1, 4, 5 -- two per SIMD on two SIMDs -- take the columns (column wave cw owns
+// segments 4 cw .. 4 cw + 3, one per DPP row) and waves 2 and 3, each alone on its SIMD, the base and coefficient roles.
+// LDS 42 / 45 KB.
 template <int ND, int PM>
+__global__ __launch_bounds__(384) void k_indirect_pipe6(const IndirectArgs a) {
+  constexpr int NI = PipeArg<ND>::N;
+  constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
+  __shared__ double s_int[(8 + 3) * NI * PIPE_SEG];
+  __shared__ double s_coef[2 * 4 * CoefBySegment::stage_doubles<NC>()];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const bool col_wave = (wave != 2 && wave != 3);
+  const int cw = wave < 2 ? wave : wave - 2;                  // waves 0, 1, 4, 5 -> column waves 0, 1, 2, 3
+  const int seg = col_wave ? cw * 4 + (lane >> 4) : (lane & (PIPE_SEG - 1));
+  const PipeLane L = pipe_lane<PM>(a, seg);
+  if (!__syncthreads_or(L.mine)) return;         // workgroup-uniform
+  if (wave == 2) pipe_role_base<ND, PM>(a, L, seg, lane >> 4, s_int);
+  else if (wave == 3) pipe_role_coef<ND, PM, CoefBySegment>(a, L, seg, lane >> 4, s_int, s_coef);
+  else pipe_role_columns_dpp<ND>(a, L, seg, lane & 15, s_coef);
+}
+
+template <int ND, int PM, bool SIX>
 static hipError_t launch_pipe_one(const IndirectArgs& a, hipStream_t st) {
   dim3 grid((a.S + PIPE_SEG - 1) / PIPE_SEG);
-  hipLaunchKernelGGL((k_indirect_pipe<ND, PM>), grid, dim3(256), 0, st, a);
+  if (SIX) hipLaunchKernelGGL((k_indirect_pipe6<ND, PM>), grid, dim3(384), 0, st, a);
+  else hipLaunchKernelGGL((k_indirect_pipe<ND, PM>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
-template <int ND>
+template <int ND, bool SIX>
 static hipError_t launch_pipe_pm(int pm, const IndirectArgs& a0, hipStream_t st) {
   IndirectArgs a = a0;
   a.class_filter = single_class(pm) ? 0 : 1;
   hipError_t e = hipSuccess;
-  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_pipe_one<ND, PM_P0>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_pipe_one<ND, PM_P1>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_pipe_one<ND, PM_P2>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_pipe_one<ND, PM_PGEN>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_pipe_one<ND, PM_P0, SIX>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_pipe_one<ND, PM_P1, SIX>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_pipe_one<ND, PM_P2, SIX>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_pipe_one<ND, PM_PGEN, SIX>(a, st);
   return e;
 }
 
@@ -468,8 +386,16 @@ static hipError_t launch_pipe_pm(int pm, const IndirectArgs& a0, hipStream_t st)
 hipError_t launch_indirect_stm_pipe(int ndim, int pm, const IndirectArgs& a, hipStream_t st) {
   if (a.S <= 0) return hipSuccess;
   if (a.steps < 1) return hipErrorInvalidValue;
-  if (ndim == 12) return launch_pipe_pm<12>(pm, a, st);
-  if (ndim == 14) return launch_pipe_pm<14>(pm, a, st);
+  if (ndim == 12) return launch_pipe_pm<12, false>(pm, a, st);
+  if (ndim == 14) return launch_pipe_pm<14, false>(pm, a, st);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_indirect_stm_pipe6(int ndim, int pm, const IndirectArgs& a, hipStream_t st) {
+  if (a.S <= 0) return hipSuccess;
+  if (a.steps < 1) return hipErrorInvalidValue;
+  if (ndim == 12) return launch_pipe_pm<12, true>(pm, a, st);
+  if (ndim == 14) return launch_pipe_pm<14, true>(pm, a, st);
   return hipErrorInvalidValue;
 }
 

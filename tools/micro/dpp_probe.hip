@@ -38,6 +38,22 @@ template <bool DPP> __global__ void k_rate(double* out, const double* c, int ite
   out[blockIdx.x * blockDim.x + t] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
+// does a VALU instruction get cheaper when only the first 16 lanes are active?  (it does not on gfx950: see main)
+__global__ void k_exec(double* out, const double* c, int iters, int active) {
+  const int t = threadIdx.x;
+  double a0 = 0.1 * t, a1 = 0.2, a2 = 0.3, a3 = 0.4, a4 = 0.5, a5 = 0.6, a6 = 0.7, a7 = 0.8;
+  const double cv = c[t], x = 1e-9;
+  if (t < active) {
+    for (int i = 0; i < iters; ++i) {
+      a0 = __builtin_fma(cv, x, a0); a1 = __builtin_fma(cv, x, a1); a2 = __builtin_fma(cv, x, a2); a3 = __builtin_fma(cv, x, a3);
+      a4 = __builtin_fma(cv, x, a4); a5 = __builtin_fma(cv, x, a5); a6 = __builtin_fma(cv, x, a6); a7 = __builtin_fma(cv, x, a7);
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      asm volatile("" : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    }
+  }
+  out[blockIdx.x * blockDim.x + t] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 __global__ void k_place(int* simd, int* cu) {
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
@@ -79,6 +95,16 @@ int main() {
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (rep) printf("%s: %.3f ms for %d x 8 fmac per wave, one wave per SIMD -> %.2f ns per instruction\n", dpp ? "v_fmac_f64_dpp" : "v_fmac_f64    ", ms, iters, ms * 1e6 / (iters * 8.0));
+    }
+  }
+
+  for (int active = 64; active >= 16; active -= 16) {
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k_exec, dim3(1024), dim3(64), 0, 0, dout, dc, iters, active);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) printf("v_fma_f64 with %2d active lanes: %.2f ns per instruction\n", active, ms * 1e6 / (iters * 8.0));
     }
   }
 
