@@ -325,12 +325,16 @@ __device__ __forceinline__ void pipe_role_columns_dpp(const IndirectArgs& a, con
 // ------------------------------------------------------------------------------------------------------------ kernels
 // Four waves, one per SIMD: wave 0 base, wave 1 coef, waves 2-3 columns (two per lane).  LDS 31 / 61 KB.
 template <int ND, int PM>
-__global__ __launch_bounds__(256) void k_indirect_pipe(const IndirectArgs a) {
+__global__ __launch_bounds__(256, 2) void k_indirect_pipe(const IndirectArgs a) {
   constexpr int NI = PipeArg<ND>::N;
   constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
   __shared__ double s_int[(8 + 3) * NI * PIPE_SEG];
   __shared__ double s_coef[2 * 4 * CoefByValue::stage_doubles<NC>()];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Batches of several chip-fulls: two workgroups share a CU (<= 256 registers per lane), and the hardware gives
+  // wave w of every workgroup on a CU the same SIMD.  Workgroups 256 apart (the ones that meet on a CU under the
+  // round-robin dispatch over 8 XCDs x 32 CUs) therefore swap the role pairs, so that each SIMD carries
+  // base + columns or coef + columns instead of 2 x base, 2 x coef, 2 x columns, 2 x columns.
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) ^ (((blockIdx.x >> 8) & 1) << 1);
   const int lane = threadIdx.x & 63;
   const int seg = lane & (PIPE_SEG - 1), slot = lane >> 4;
   const PipeLane L = pipe_lane<PM>(a, seg);

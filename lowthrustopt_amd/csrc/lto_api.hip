@@ -411,18 +411,19 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  // Kernel choice (DESIGN.md "Kernels", measured on MI355X).  RK4: the three-role pipeline kernel while the chip is
-  // not over-subscribed several times (14-dim, 4 096 segments: 108 us vs 171 us per-lane, 242 us cooperative; it stays
-  // ahead up to ~50 000 segments for 14-dim and ~12 000 for 12-dim), beyond that the per-lane kernel with 2-3 columns
-  // per lane.  13-stage methods -> wave-specialised kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms;
-  // RKF7(8) x4: 0.046 ms vs 0.36 ms), whose 12/14-component lanes keep all slopes in registers.
+  // Kernel choice (DESIGN.md "Kernels", measured on MI355X).  RK4: the three-role pipeline kernels -- the six-wave form
+  // (one column per lane, coefficients broadcast inside the FMA) up to one workgroup per CU (4 096 segments: 14-dim
+  // 103 us against 111 us four-wave, 168 us per-lane, 245 us cooperative), the four-wave form, which fits two
+  // workgroups per CU, beyond: for 14-dim at every size (262 144 segments: 4.9 ms against 6.3 ms per-lane), for 12-dim
+  // up to ~12 000 segments, where the per-lane kernel with 3 columns per lane takes over.  13-stage methods ->
+  // wave-specialised kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms), whose
+  // 12/14-component lanes keep all slopes in registers.
   int kern = p->kernel;
   if (kern == LTO_KERNEL_AUTO) {
     if (p->integ.method != LTO_RK4) kern = LTO_KERNEL_COOP;
-    else if (p->integ.steps < 6 || p->S > (p->ndim == 14 ? 49152 : 12288))
-      kern = LTO_KERNEL_PER_LANE;  // the pipeline needs steps + 2 phases: below ~6 steps its fill and drain outweigh the shorter phase
-    else  // six-wave form (one column per lane, coefficients broadcast inside the FMA): 3-5 % ahead where it fits the CU
-      kern = (p->ndim == 14 || p->S <= 4096) ? LTO_KERNEL_PIPE6 : LTO_KERNEL_PIPE;
+    else if (p->integ.steps < 6) kern = LTO_KERNEL_PER_LANE;   // steps + 2 phases: fill and drain outweigh the shorter phase
+    else if (p->S <= 4096) kern = LTO_KERNEL_PIPE6;
+    else kern = (p->ndim == 14 || p->S <= 12288) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
   }
   p->last_kernel = kern;
   hipError_t e;
