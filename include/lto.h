@@ -204,10 +204,11 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* plan, void* stream, int* acc
 int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
 int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 
-/* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4, the three-role pipeline kernel up to a few
- * chip-fulls of segments and the per-lane kernel (each lane re-integrates the base state with 1-3 columns) beyond,
- * and the wave-specialised kernel (base wave + column waves per 16 segments, coefficients handed over through LDS)
- * for the 13-stage integrators. */
+/* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4 with >= 6 steps per segment, the three-role
+ * pipeline kernels (six-wave form up to 4 096 segments, four-wave form beyond: at every size for ndim = 14, up to
+ * ~12 000 segments for ndim = 12) and otherwise the per-lane kernel (each lane re-integrates the base state with 1-3
+ * columns); for the 13-stage integrators the wave-specialised kernel (base wave + column waves per 16 segments,
+ * coefficients handed over through LDS at every RK stage). */
 #define LTO_KERNEL_AUTO 0
 #define LTO_KERNEL_PER_LANE 1
 #define LTO_KERNEL_COOP 2
