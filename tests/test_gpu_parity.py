@@ -974,3 +974,32 @@ def test_indirect_pipeline_kernel_is_rk4_only(gpu_ctx):
     plan = lto.IndirectPlan(gpu_ctx, 8, 1, prm, lto.integrator(lto.DOP853_ADAPTIVE), ndim=12)
     with pytest.raises(lto.LtoError):
         plan.set_kernel(plan.KERNEL_PIPE)
+
+
+def test_indirect_auto_kernel_choice(gpu_ctx):
+    """What LTO_KERNEL_AUTO resolves to (lto_indirect_plan_last_kernel): RK4 with >= 6 steps -> pipeline kernels (six-wave
+    form up to 4 096 segments, four-wave beyond; 12-dim falls back to the per-lane kernel above 12 288 segments), RK4 with
+    fewer steps -> per-lane, 13-stage integrators -> cooperative."""
+    import torch
+    cases = [(12, 30, lto.RK4, 64, "pipeline6"), (14, 4097, lto.RK4, 64, "pipeline6"), (14, 8193, lto.RK4, 64, "pipeline"),
+             (12, 8193, lto.RK4, 64, "pipeline"), (12, 16385, lto.RK4, 8, "per-lane"), (14, 30, lto.RK4, 2, "per-lane"),
+             (12, 30, lto.DOP853_ADAPTIVE, 0, "cooperative"), (14, 30, lto.RKF78_FIXED, 4, "cooperative")]
+    for ndim, n, method, steps, want in cases:
+        XC, T = synth.indirect_problem(n, seed=2)
+        if ndim == 14:
+            X = np.zeros((14, n, 1), order="F")
+            X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+        else:
+            X = XC
+        prm = lto.make_params(MU, DU, TU, 0.05, 2000.0 if ndim == 14 else 1000.0, 1.0, 1.0, 1.0)
+        plan = lto.IndirectPlan(gpu_ctx, n, 1, prm, lto.integrator(method, steps=steps), ndim=ndim)
+        assert plan.last_kernel() == "none yet"
+        S = n - 1
+        Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+        td = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+        Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+        torch.cuda.synchronize()
+        assert plan.last_kernel() == want, (ndim, n, method, steps, plan.last_kernel())
+        assert bool(torch.isfinite(Phi).all())
