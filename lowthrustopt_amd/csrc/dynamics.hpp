@@ -597,11 +597,22 @@ __device__ __forceinline__ void rhs14_base(const double (&y)[14], const TrajPara
   const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
   const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
   const double n = n2 * inv_n;
-  const double inv_m = rcp_nr(mass);
-  const double aL = tp.cT * inv_m;
-  double m, ua, ub, un;
-  bool tlim;
-  control_dispatch<PM, false, true>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+  double inv_m, m;
+  bool tlim = true;
+  if constexpr (PM == PM_P1) {
+    // umag = (cT / mass) / (1 + e^{-2x}) [x e^{-2|x|} for x < 0]: ONE reciprocal of (1 + e) mass serves both 1 / mass and the
+    // logistic (v_rcp_f64 is a quarter-rate instruction on the critical stream)
+    const double x = (n - 1.0) * tp.inv_2rho;
+    const double e = exp_neg<true>(-2.0 * fabs(x));
+    const double ope = 1.0 + e;
+    const double r = rcp_nr(ope * mass);
+    inv_m = r * ope;
+    m = (tp.cT * r) * ((x >= 0.0) ? 1.0 : e);
+  } else {
+    inv_m = rcp_nr(mass);
+    double ua, ub, un;
+    control_dispatch<PM, false, true>(tp, tp.cT * inv_m, n, inv_n, m, ua, ub, un, tlim);
+  }
   const double lhx = lx * inv_n, lhy = ly * inv_n, lhz = lz * inv_n;
   const double kt = tp.kappa_td;
   const double yzl = __builtin_fma(yy, ly, z * lz);
