@@ -90,9 +90,11 @@ __device__ __forceinline__ PipeLane pipe_lane(const IndirectArgs& a, const int s
 #endif
 
 // ---------------------------------------------------------------------------------------------------------- base role
-// lane = (segment, lane group); the three spare lane groups repeat group 0's work and store to scratch slabs 8..10, so
-// that publishing needs no EXEC branch (a branch per stage would cut the role's one basic block per step into five).
-// s_int: [8 + 3][NI][PIPE_SEG], slab = step parity * 4 + stage.
+// lane = (segment, lane group): the wave holds FOUR identical copies of its 16 segments' base state, one per 16-lane
+// row.  An LDS store costs the issuing wave ~6 FMA slots whatever it carries, so the stage arguments are not stored
+// stage by stage (16 stores per step): row g keeps the argument of stage g in registers (8 moves under that row's EXEC
+// mask) and ONE set of stores at the end of the step publishes all four stages, every lane carrying useful data.
+// s_int: [8][NI][PIPE_SEG], slab = step parity * 4 + stage.
 template <int ND, int PM>
 __device__ __forceinline__ void pipe_role_base(const IndirectArgs& a, const PipeLane& L, const int seg, const int slot,
                                                double* s_int) {
@@ -108,29 +110,32 @@ __device__ __forceinline__ void pipe_role_base(const IndirectArgs& a, const Pipe
   for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + L.node];
   for (int p = 0; p < steps + 2; ++p) {
     if (p < steps && PIPE_ROLE_ON(a, 1)) {
-      const int buf = p & 1;
-      double k[ND], yt[ND], acc[ND];
-      auto publish = [&](int stage, const double (&arg)[ND]) {
-        double* dst = s_int + ((slot == 0 ? buf * 4 + stage : 7 + slot) * NI) * PIPE_SEG + seg;
+      double k[ND], yt[ND], acc[ND], keep[NI];
+      auto remember = [&](int stage, const double (&arg)[ND]) {
+        if (slot == stage) {
 #pragma unroll
-        for (int e = 0; e < NI; ++e) dst[e * PIPE_SEG] = arg[PipeArg<ND>::idx[e]];
+          for (int e = 0; e < NI; ++e) keep[e] = arg[PipeArg<ND>::idx[e]];
+        }
       };
-      publish(0, y);
+      remember(0, y);
       rhs(y, k);
 #pragma unroll
       for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
-      publish(1, yt);
+      remember(1, yt);
       rhs(yt, k);
 #pragma unroll
       for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
-      publish(2, yt);
+      remember(2, yt);
       rhs(yt, k);
 #pragma unroll
       for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
-      publish(3, yt);
+      remember(3, yt);
       rhs(yt, k);
 #pragma unroll
       for (int c = 0; c < ND; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
+      double* dst = s_int + (((p & 1) * 4 + slot) * NI) * PIPE_SEG + seg;
+#pragma unroll
+      for (int e = 0; e < NI; ++e) dst[e * PIPE_SEG] = keep[e];
     }
     __syncthreads();
   }
@@ -328,7 +333,7 @@ template <int ND, int PM>
 __global__ __launch_bounds__(256, 2) void k_indirect_pipe(const IndirectArgs a) {
   constexpr int NI = PipeArg<ND>::N;
   constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
-  __shared__ double s_int[(8 + 3) * NI * PIPE_SEG];
+  __shared__ double s_int[8 * NI * PIPE_SEG];
   __shared__ double s_coef[2 * 4 * CoefByValue::stage_doubles<NC>()];
   // Batches of several chip-fulls: two workgroups share a CU (<= 256 registers per lane), and the hardware gives
   // wave w of every workgroup on a CU the same SIMD.  Workgroups 256 apart (the ones that meet on a CU under the
@@ -352,7 +357,7 @@ template <int ND, int PM>
 __global__ __launch_bounds__(384) void k_indirect_pipe6(const IndirectArgs a) {
   constexpr int NI = PipeArg<ND>::N;
   constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
-  __shared__ double s_int[(8 + 3) * NI * PIPE_SEG];
+  __shared__ double s_int[8 * NI * PIPE_SEG];
   __shared__ double s_coef[2 * 4 * CoefBySegment::stage_doubles<NC>()];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
