@@ -328,7 +328,7 @@ __device__ __forceinline__ void pipe_role_columns_dpp(const IndirectArgs& a, con
 }
 
 // ------------------------------------------------------------------------------------------------------------ kernels
-// Four waves, one per SIMD: wave 0 base, wave 1 coef, waves 2-3 columns (two per lane).  LDS 31 / 61 KB.
+// Four waves, one per SIMD: wave 0 base, wave 1 coef, waves 2-3 columns (two per lane).  LDS 23 / 33 KB (ND = 12 / 14).
 template <int ND, int PM>
 __global__ __launch_bounds__(256, 2) void k_indirect_pipe(const IndirectArgs a) {
   constexpr int NI = PipeArg<ND>::N;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_indirect_pipe(const IndirectArgs a) 
 // Six waves.  The hardware places the waves of a workgroup on the four SIMDs round-robin (measured:
 // tools/micro/dpp_probe.hip), so waves 0, 1, 4, 5 -- two per SIMD on two SIMDs -- take the columns (column wave cw owns
 // segments 4 cw .. 4 cw + 3, one per DPP row) and waves 2 and 3, each alone on its SIMD, the base and coefficient roles.
-// LDS 42 / 45 KB.
+// LDS 39 / 41 KB.
 template <int ND, int PM>
 __global__ __launch_bounds__(384) void k_indirect_pipe6(const IndirectArgs a) {
   constexpr int NI = PipeArg<ND>::N;
