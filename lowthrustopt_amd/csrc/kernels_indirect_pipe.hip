@@ -8,7 +8,7 @@
 // skewed by one RK4 STEP each, so that they execute concurrently and meet at ONE barrier per step:
 //
 //   base      integrates the ND-dim base state (rhs*_base: the RHS alone -- the shortest instruction stream) and
-//             publishes, per stage, the part of the stage argument the coefficients depend on
+//             publishes, once per step, the part of the four stage arguments the coefficients depend on
 //   coef      one step behind: lane = (segment, RK stage); builds G, H, U (+ mass couplings) at those arguments
 //   columns   two steps behind: c' = F(t) c with the coefficients of the stage -- no gravity, no control law, no base
 //             state in these lanes
