@@ -44,11 +44,13 @@ template <> struct PipeArg<14> {
 
 // Layout of the coefficient records in LDS, one record per (step parity, stage, segment).
 struct CoefByValue {     // [value][segment]: what a lane that reads ALL values of its segment wants (k_indirect_pipe)
+  static constexpr bool SCALED = false;
   template <int NC> static constexpr int stage_doubles() { return NC * PIPE_SEG; }
   __device__ static int at(int e, int seg) { return e * PIPE_SEG + seg; }
 };
 struct CoefBySegment {   // [segment][value], records padded to 33 doubles: the coefficient wave's stores (one record per
   static constexpr int LD = 33;   // lane) and the column rows' loads (one record per row) are both conflict-free
+  static constexpr bool SCALED = true;
   template <int NC> static constexpr int stage_doubles() { return PIPE_SEG * LD; }
   __device__ static int at(int e, int seg) { return seg * LD + e; }
 };
@@ -174,8 +176,11 @@ __device__ __forceinline__ void pipe_role_coef(const IndirectArgs& a, const Pipe
       else rhs14<PM, true>(arg, L.tp, dead, vc);
       const double* o = reinterpret_cast<const double*>(&vc);
       double* dst = s_coef + (buf * 4 + stage) * Layout::template stage_doubles<NC>();
+      // Layout::SCALED: every coefficient except the unit vector lhat (entries 14..16) is stored times the stage's
+      // RK4 argument weight (h/2, h/2, h, h/6), so that the column lanes accumulate h a_s F c straight onto y
+      const double as = Layout::SCALED ? ((stage == 2) ? L.h : (stage == 3) ? L.h * (1.0 / 6.0) : 0.5 * L.h) : 1.0;
 #pragma unroll
-      for (int e = 0; e < NC; ++e) dst[Layout::at(e, seg)] = o[e];
+      for (int e = 0; e < NC; ++e) dst[Layout::at(e, seg)] = (Layout::SCALED && (e < 14 || e > 16)) ? o[e] * as : o[e];
     }
     __syncthreads();
   }
@@ -249,75 +254,77 @@ __device__ __forceinline__ void fmac_bn(double& acc, const double c, const doubl
   asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(x), "n"(N));
 }
 
-// cdot = F c for one STM column with the coefficients spread over the row: cA = value (lane), cB = value (16 + lane) of
-//   [Gxx Gyy Gzz Gxy Gxz Gyz | Hxx Hyy Hzz Hxy Hxz Hyz | ua ub lx ly] [lz | umx umy umz mm mn Lm Ln Ll]   (VarCoef12 / 14)
-// The lambda_r rows of k return H a + G d, i.e. MINUS the slope (the caller folds the sign into the RK update); every
-// other entry is the slope itself.  Same formulas as var_col12 / var_col14.
+// One RK4 stage of one STM column with the coefficients spread over the row: cA = value (lane), cB = value (16 + lane) of
+//   [Gxx Gyy Gzz Gxy Gxz Gyz | Hxx Hyy Hzz Hxy Hxz Hyz | ua ub lx ly] [lz | umx umy umz mm mn Lm Ln Ll]   (VarCoef12 / 14),
+// all but lhat pre-multiplied by the stage's weight a (CoefBySegment::SCALED), aw2 = a 2 omega:
+//   out = init + a F(arg) arg
+// The rows with coefficient products accumulate straight onto init (no separate slope, no separate RK update); the
+// Coriolis rows start with a plain FMA, the others with a copy of init.  Same formulas as var_col12 / var_col14.
 template <int ND>
-__device__ __forceinline__ void col_dpp(const double cA, const double cB, const double w2, const double (&c)[ND], double (&k)[ND]) {
+__device__ __forceinline__ void col_dpp_stage(const double cA, const double cB, const double aw2, const double a,
+                                              const double (&arg)[ND], const double (&init)[ND], double (&out)[ND]) {
   constexpr int G = (ND == 14) ? 7 : 6;     // first lambda_r row
   constexpr int D = G + 3;                  // first lambda_v row
-  const double ax = c[0], ay = c[1], az = c[2];
-  const double dx = c[D], dyv = c[D + 1], dz = c[D + 2];
+  const double ax = arg[0], ay = arg[1], az = arg[2];
+  const double dx = arg[D], dyv = arg[D + 1], dz = arg[D + 2];
   double ld = 0.0;
   fmac_b<14>(ld, cA, dx); fmac_b<15>(ld, cA, dyv); fmac_b<0>(ld, cB, dz);
   double tl = 0.0;
-  fmac_b<13>(tl, cA, ld);
-  k[0] = c[3]; k[1] = c[4]; k[2] = c[5];
-  double k3 = w2 * c[4], k4 = -w2 * c[3], k5 = 0.0;
-  fmac_b<0>(k3, cA, ax); fmac_b<3>(k3, cA, ay); fmac_b<4>(k3, cA, az); fmac_bn<12>(k3, cA, dx); fmac_b<14>(k3, cA, tl);
-  fmac_b<3>(k4, cA, ax); fmac_b<1>(k4, cA, ay); fmac_b<5>(k4, cA, az); fmac_bn<12>(k4, cA, dyv); fmac_b<15>(k4, cA, tl);
-  fmac_b<4>(k5, cA, ax); fmac_b<5>(k5, cA, ay); fmac_b<2>(k5, cA, az); fmac_bn<12>(k5, cA, dz); fmac_b<0>(k5, cB, tl);
-  double s7 = 0.0, s8 = 0.0, s9 = 0.0;
-  fmac_b<6>(s7, cA, ax); fmac_b<9>(s7, cA, ay); fmac_b<10>(s7, cA, az); fmac_b<0>(s7, cA, dx); fmac_b<3>(s7, cA, dyv); fmac_b<4>(s7, cA, dz);
-  fmac_b<9>(s8, cA, ax); fmac_b<7>(s8, cA, ay); fmac_b<11>(s8, cA, az); fmac_b<3>(s8, cA, dx); fmac_b<1>(s8, cA, dyv); fmac_b<5>(s8, cA, dz);
-  fmac_b<10>(s9, cA, ax); fmac_b<11>(s9, cA, ay); fmac_b<8>(s9, cA, az); fmac_b<4>(s9, cA, dx); fmac_b<5>(s9, cA, dyv); fmac_b<2>(s9, cA, dz);
-  k[G] = s7; k[G + 1] = s8; k[G + 2] = s9;
-  k[D] = __builtin_fma(w2, dyv, -c[G]);
-  k[D + 1] = __builtin_fma(-w2, dx, -c[G + 1]);
-  k[D + 2] = -c[G + 2];
+  fmac_b<13>(tl, cA, ld);                                    // a ub (lhat . d)
+  out[0] = __builtin_fma(a, arg[3], init[0]); out[1] = __builtin_fma(a, arg[4], init[1]); out[2] = __builtin_fma(a, arg[5], init[2]);
+  double o3 = __builtin_fma(aw2, arg[4], init[3]), o4 = __builtin_fma(-aw2, arg[3], init[4]), o5 = init[5];
+  fmac_b<0>(o3, cA, ax); fmac_b<3>(o3, cA, ay); fmac_b<4>(o3, cA, az); fmac_bn<12>(o3, cA, dx); fmac_b<14>(o3, cA, tl);
+  fmac_b<3>(o4, cA, ax); fmac_b<1>(o4, cA, ay); fmac_b<5>(o4, cA, az); fmac_bn<12>(o4, cA, dyv); fmac_b<15>(o4, cA, tl);
+  fmac_b<4>(o5, cA, ax); fmac_b<5>(o5, cA, ay); fmac_b<2>(o5, cA, az); fmac_bn<12>(o5, cA, dz); fmac_b<0>(o5, cB, tl);
+  double o7 = init[G], o8 = init[G + 1], o9 = init[G + 2];   // lambda_r rows: minus (H a + G d)
+  fmac_bn<6>(o7, cA, ax); fmac_bn<9>(o7, cA, ay); fmac_bn<10>(o7, cA, az); fmac_bn<0>(o7, cA, dx); fmac_bn<3>(o7, cA, dyv); fmac_bn<4>(o7, cA, dz);
+  fmac_bn<9>(o8, cA, ax); fmac_bn<7>(o8, cA, ay); fmac_bn<11>(o8, cA, az); fmac_bn<3>(o8, cA, dx); fmac_bn<1>(o8, cA, dyv); fmac_bn<5>(o8, cA, dz);
+  fmac_bn<10>(o9, cA, ax); fmac_bn<11>(o9, cA, ay); fmac_bn<8>(o9, cA, az); fmac_bn<4>(o9, cA, dx); fmac_bn<5>(o9, cA, dyv); fmac_bn<2>(o9, cA, dz);
+  out[G] = o7; out[G + 1] = o8; out[G + 2] = o9;
+  out[D] = __builtin_fma(aw2, dyv, __builtin_fma(-a, arg[G], init[D]));
+  out[D + 1] = __builtin_fma(-aw2, dx, __builtin_fma(-a, arg[G + 1], init[D + 1]));
+  out[D + 2] = __builtin_fma(-a, arg[G + 2], init[D + 2]);
   if constexpr (ND == 14) {
-    const double mu = c[6];
-    fmac_b<1>(k3, cB, mu); fmac_b<2>(k4, cB, mu); fmac_b<3>(k5, cB, mu);
-    double k6 = 0.0, k13 = 0.0;
-    fmac_b<4>(k6, cB, mu); fmac_b<5>(k6, cB, ld);
-    fmac_b<6>(k13, cB, mu); fmac_b<7>(k13, cB, ld); fmac_b<8>(k13, cB, c[13]);
-    k[6] = k6; k[13] = k13;
+    const double mu = arg[6];
+    fmac_b<1>(o3, cB, mu); fmac_b<2>(o4, cB, mu); fmac_b<3>(o5, cB, mu);
+    double o6 = init[6], o13 = init[13];
+    fmac_b<4>(o6, cB, mu); fmac_b<5>(o6, cB, ld);
+    fmac_b<6>(o13, cB, mu); fmac_b<7>(o13, cB, ld); fmac_b<8>(o13, cB, arg[13]);
+    out[6] = o6; out[13] = o13;
   }
-  k[3] = k3; k[4] = k4; k[5] = k5;
+  out[3] = o3; out[4] = o4; out[5] = o5;
 }
 
-// lane = (row = segment, column); coefficients of the stage: CoefBySegment.
+// lane = (row = segment, column); coefficients of the stage: CoefBySegment (scaled).  RK4 in the form
+//   y+ = -y/3 + Y1/3 + 2 Y2/3 + Y3/3 + (h/6) k4,   Y1 = y + (h/2) k1,  Y2 = y + (h/2) k2,  Y3 = y + h k3
+// so that every stage is one "init + a F arg" accumulation: the stage arguments are the Y themselves.
 template <int ND>
 __device__ __forceinline__ void pipe_role_columns_dpp(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
                                                       const double* s_coef) {
   constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
-  constexpr int G = (ND == 14) ? 7 : 6;
   const int steps = a.steps;
-  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0), w2 = L.w2;
+  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), w2 = L.w2;
+  const double h2w = h2 * w2, hw = h * w2, h6w = h6 * w2;
   double y[ND];
 #pragma unroll
   for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
   for (int p = 0; p < steps + 2; ++p) {
     if (p >= 2 && PIPE_ROLE_ON(a, 4)) {
-      const int buf = p & 1;
-      double acc[ND], yt[ND], k[ND];
+      const double* rec = s_coef + ((p & 1) * 4) * CoefBySegment::stage_doubles<NC>() + CoefBySegment::at(col, seg);
+      constexpr int SD = CoefBySegment::stage_doubles<NC>();
+      double A[ND], Y1[ND], Y2[ND], Y3[ND];
 #pragma unroll
-      for (int stage = 0; stage < 4; ++stage) {
-        const double* rec = s_coef + (buf * 4 + stage) * CoefBySegment::stage_doubles<NC>() + CoefBySegment::at(col, seg);
-        const double cA = rec[0], cB = rec[16];
-        if (stage == 0) col_dpp<ND>(cA, cB, w2, y, k);
-        else col_dpp<ND>(cA, cB, w2, yt, k);
+      for (int c = 0; c < ND; ++c) A[c] = y[c] * (-1.0 / 3.0);
+      col_dpp_stage<ND>(rec[0], rec[16], h2w, h2, y, y, Y1);
 #pragma unroll
-        for (int c = 0; c < ND; ++c) {
-          const bool neg = (c >= G && c < G + 3);          // k holds minus the slope in the lambda_r rows
-          const double b6 = neg ? -h6 : h6, b3 = neg ? -h3 : h3, a2 = neg ? -h2 : h2, a1 = neg ? -h : h;
-          if (stage == 0) { acc[c] = __builtin_fma(b6, k[c], y[c]); yt[c] = __builtin_fma(a2, k[c], y[c]); }
-          else if (stage == 1) { acc[c] = __builtin_fma(b3, k[c], acc[c]); yt[c] = __builtin_fma(a2, k[c], y[c]); }
-          else if (stage == 2) { acc[c] = __builtin_fma(b3, k[c], acc[c]); yt[c] = __builtin_fma(a1, k[c], y[c]); }
-          else y[c] = __builtin_fma(b6, k[c], acc[c]);
-        }
-      }
+      for (int c = 0; c < ND; ++c) A[c] = __builtin_fma(1.0 / 3.0, Y1[c], A[c]);
+      col_dpp_stage<ND>(rec[SD], rec[SD + 16], h2w, h2, Y1, y, Y2);
+#pragma unroll
+      for (int c = 0; c < ND; ++c) A[c] = __builtin_fma(2.0 / 3.0, Y2[c], A[c]);
+      col_dpp_stage<ND>(rec[2 * SD], rec[2 * SD + 16], hw, h, Y2, y, Y3);
+#pragma unroll
+      for (int c = 0; c < ND; ++c) A[c] = __builtin_fma(1.0 / 3.0, Y3[c], A[c]);
+      col_dpp_stage<ND>(rec[3 * SD], rec[3 * SD + 16], h6w, h6, Y3, A, y);
     }
     __syncthreads();
   }
