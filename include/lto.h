@@ -215,9 +215,12 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 /* RK4 plans only: base wave, coefficient wave and column waves per 16 segments run as a software pipeline skewed by
  * one RK4 step (one workgroup barrier per step); other integrators: LTO_EINVAL.  _PIPE: two column waves, two STM
  * columns per lane, coefficients read from LDS.  _PIPE6: four column waves, one column per lane, a DPP row = one
- * segment and the coefficients broadcast inside the FMA (v_fmac_f64_dpp row_newbcast). */
+ * segment and the coefficients broadcast inside the FMA (v_fmac_f64_dpp row_newbcast).  _PIPE8: the DPP column role
+ * with TWO RK4 steps per phase and eight waves -- a fourth of the column work alternates between two SIMDs so that all
+ * four SIMDs of a CU carry the same load (one workgroup per CU: 91 KB of LDS). */
 #define LTO_KERNEL_PIPE 3
 #define LTO_KERNEL_PIPE6 4
+#define LTO_KERNEL_PIPE8 5
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* plan);

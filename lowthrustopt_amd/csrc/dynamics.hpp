@@ -537,11 +537,73 @@ __device__ __forceinline__ void rhs14_fused1(const double (&y)[28], const TrajPa
   k[27] = __builtin_fma(Lm, mu, __builtin_fma(Ln, ld, (ntl * (kt * m)) * nu));
 }
 
-// ------------------------------------------------------------------------------ lean base RHS (pipeline kernel)
-// kernels_indirect_pipe.hip runs the base trajectory, the coefficient build and the STM columns in three different
-// wavefronts.  The base wave's instruction stream is the sweep's critical path, so it evaluates the RHS alone, with
-// G lambda_v applied through its dyadic structure (as rhs*_fused1) and the short-depth exp; the coefficient wave
-// rebuilds G, H, U from the stage argument with rhs12 / rhs14<PM, true>.
+// ------------------------------------------------------------------------------ lean base RHS (pipeline kernels)
+// The pipeline kernels run the base trajectory, the coefficient build and the STM columns in different wavefronts.  The
+// base wave's instruction stream is the sweep's critical path and it is issue-bound (one dependent stream per SIMD), so
+// this form of the RHS minimises the INSTRUCTION COUNT: G lambda_v through its dyadic structure (as rhs*_fused1), no
+// per-lane selects, the thrust vector as -(umag / n) lambda_v, a short exp.  The coefficient wave rebuilds G, H, U from
+// the stage argument with rhs12 / rhs14<PM, true>.
+
+// exp(z) for z in [-700, 690], ~1 ulp: n = rint(z log2 e) through the 1.5 2^52 trick (the integer sits in the low word of
+// the biased sum), Horner polynomial of degree 13 on |r| <= ln2 / 2 (remainder 4e-18), 2^n added to the exponent field.
+// 20 instructions against 25 of exp_neg (no v_rndne, no v_cvt, no v_ldexp).
+// fma(a, b, C) with a loop-invariant constant addend kept in a scalar register pair: written as the three-address
+// v_fma_f64 (hipcc otherwise picks v_mov_b64 + v_fmac_f64 for part of such chains, doubling their issue cost).
+__device__ __forceinline__ double fma_const(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+#else
+  return __builtin_fma(a, b, c);
+#endif
+}
+
+__device__ __forceinline__ double exp_mid(double z) {
+  const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+  const double t = __builtin_fma(z, 1.4426950408889634, MAGIC);
+  const double n = t - MAGIC;
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, z);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma_const(p, r, 1.0 / 479001600.0);
+  p = fma_const(p, r, 1.0 / 39916800.0);
+  p = fma_const(p, r, 1.0 / 3628800.0);
+  p = fma_const(p, r, 1.0 / 362880.0);
+  p = fma_const(p, r, 1.0 / 40320.0);
+  p = fma_const(p, r, 1.0 / 5040.0);
+  p = fma_const(p, r, 1.0 / 720.0);
+  p = fma_const(p, r, 1.0 / 120.0);
+  p = fma_const(p, r, 1.0 / 24.0);
+  p = fma_const(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  // 2^n: n (the low word of the biased sum, two's complement) added to the exponent field
+  return __hiloint2double(__double2hiint(p) + (__double2loint(t) << 20), __double2loint(p));
+}
+
+// 1 / |lambda_v| without a select: n2 = 0 (the reference's NaN guard, stateCostate_deriv.jl:59-64: control = 0) gives a
+// finite 2^500, and the thrust vector -(umag / n) lambda_v is then exactly 0.  Differs from the guarded form only for
+// 0 < |lambda_v| < 2^-500.
+__device__ __forceinline__ double inv_norm_guarded(double n2) { return rsqrt_nr(fmax(n2, 9.33263618503218879e-302)); }
+
+// umag / n (`ua`) and umag (`m`) of the control law for the base wave; p = 1 evaluates the logistic directly,
+//   1/2 (1 + tanh x) = 1 / (1 + e^{-2x}),  -2x = (1 - n) / rho clamped to [-700, 690]
+// (beyond the clamp the value is 1 or < 1e-299 either way), so no per-lane branch on the sign of x is needed.
+template <int PM>
+__device__ __forceinline__ void control_base12(const TrajParams& tp, double n, double inv_n, double& m, double& ua) {
+  if constexpr (PM == PM_P1) {
+    const double z = fmin(fmax((1.0 - n) * tp.inv_rho, -700.0), 690.0);
+    m = tp.accel_limit * rcp_nr(1.0 + exp_mid(z));
+    ua = m * inv_n;
+  } else {
+    double ub, un;
+    bool tlim;
+    control_dispatch<PM, false, true>(tp, tp.accel_limit, n, inv_n, m, ua, ub, un, tlim);
+  }
+}
+
 template <int PM>
 __device__ __forceinline__ void rhs12_base(const double (&y)[12], const TrajParams& tp, double (&dy)[12]) {
   const double MU = tp.MU;
@@ -557,31 +619,32 @@ __device__ __forceinline__ void rhs12_base(const double (&y)[12], const TrajPara
   const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
   const double lx = y[9], ly = y[10], lz = y[11];
   const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
-  const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
+  const double inv_n = inv_norm_guarded(n2);
   const double n = n2 * inv_n;
-  double m, ua, ub, un;
-  bool tlim;
-  control_dispatch<PM, false, true>(tp, tp.accel_limit, n, inv_n, m, ua, ub, un, tlim);
-  const double lhx = lx * inv_n, lhy = ly * inv_n, lhz = lz * inv_n;
+  double m, ua;
+  control_base12<PM>(tp, n, inv_n, m, ua);
   const double yzl = __builtin_fma(yy, ly, z * lz);
   const double s1 = __builtin_fma(a, lx, yzl), s2 = __builtin_fma(b, lx, yzl);
   const double t1 = e1 * s1, t2 = e2 * s2;
   const double es = t1 + t2;
   const double tA = __builtin_fma(t1, a, t2 * b);
   dy[0] = y[3]; dy[1] = y[4]; dy[2] = y[5];
-  dy[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))) - m * lhx;
-  dy[4] = __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)) - m * lhy;
-  dy[5] = __builtin_fma(-cs, z, -m * lhz);
-  dy[6] = -__builtin_fma(omc, lx, tA);
-  dy[7] = -__builtin_fma(omc, ly, es * yy);
-  dy[8] = -__builtin_fma(-cs, lz, es * z);
+  dy[3] = __builtin_fma(-ua, lx, __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))));
+  dy[4] = __builtin_fma(-ua, ly, __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)));
+  dy[5] = __builtin_fma(-ua, lz, -cs * z);
+  dy[6] = __builtin_fma(-omc, lx, -tA);
+  dy[7] = __builtin_fma(-omc, ly, -es * yy);
+  dy[8] = __builtin_fma(cs, lz, -es * z);
   dy[9] = __builtin_fma(w2, ly, -y[6]);
   dy[10] = __builtin_fma(-w2, lx, -y[7]);
   dy[11] = -y[8];
 }
 
-template <int PM>
+// LM = false: lambda_m_dot is not evaluated (dy[13] = 0).  For the always-thrust-limited laws (p = 0, p = 1) nothing else
+// depends on lambda_m, and the eight-wave pipeline kernel integrates it in the coefficient wave, off the critical stream.
+template <int PM, bool LM = true>
 __device__ __forceinline__ void rhs14_base(const double (&y)[14], const TrajParams& tp, double (&dy)[14]) {
+  static_assert(LM || PM == PM_P0 || PM == PM_P1, "lambda_m feeds back into the unclamped p > 1 law");
   const double MU = tp.MU;
   const double x = y[0], yy = y[1], z = y[2], mass = y[6];
   const double w2 = 2.0 * tp.omega;
@@ -595,25 +658,24 @@ __device__ __forceinline__ void rhs14_base(const double (&y)[14], const TrajPara
   const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
   const double lx = y[10], ly = y[11], lz = y[12], lm = y[13];
   const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
-  const double inv_n = (n2 > 0.0) ? rsqrt_nr(n2) : 0.0;
+  const double inv_n = inv_norm_guarded(n2);
   const double n = n2 * inv_n;
-  double inv_m, m;
+  double inv_m, m, ua;
   bool tlim = true;
   if constexpr (PM == PM_P1) {
-    // umag = (cT / mass) / (1 + e^{-2x}) [x e^{-2|x|} for x < 0]: ONE reciprocal of (1 + e) mass serves both 1 / mass and the
-    // logistic (v_rcp_f64 is a quarter-rate instruction on the critical stream)
-    const double x = (n - 1.0) * tp.inv_2rho;
-    const double e = exp_neg<true>(-2.0 * fabs(x));
-    const double ope = 1.0 + e;
+    // umag = (cT / mass) / (1 + e^{-2x}): ONE reciprocal of (1 + e) mass serves both 1 / mass and the logistic
+    // (v_rcp_f64 is a quarter-rate instruction on the critical stream)
+    const double zz = fmin(fmax((1.0 - n) * tp.inv_rho, -700.0), 690.0);
+    const double ope = 1.0 + exp_mid(zz);
     const double r = rcp_nr(ope * mass);
     inv_m = r * ope;
-    m = (tp.cT * r) * ((x >= 0.0) ? 1.0 : e);
+    m = tp.cT * r;
+    ua = m * inv_n;
   } else {
     inv_m = rcp_nr(mass);
-    double ua, ub, un;
+    double ub, un;
     control_dispatch<PM, false, true>(tp, tp.cT * inv_m, n, inv_n, m, ua, ub, un, tlim);
   }
-  const double lhx = lx * inv_n, lhy = ly * inv_n, lhz = lz * inv_n;
   const double kt = tp.kappa_td;
   const double yzl = __builtin_fma(yy, ly, z * lz);
   const double s1 = __builtin_fma(a, lx, yzl), s2 = __builtin_fma(b, lx, yzl);
@@ -621,22 +683,23 @@ __device__ __forceinline__ void rhs14_base(const double (&y)[14], const TrajPara
   const double es = t1 + t2;
   const double tA = __builtin_fma(t1, a, t2 * b);
   dy[0] = y[3]; dy[1] = y[4]; dy[2] = y[5];
-  dy[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))) - m * lhx;
-  dy[4] = __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)) - m * lhy;
-  dy[5] = __builtin_fma(-cs, z, -m * lhz);
-  dy[6] = -kt * m * mass;
-  dy[7] = -__builtin_fma(omc, lx, tA);
-  dy[8] = -__builtin_fma(omc, ly, es * yy);
-  dy[9] = -__builtin_fma(-cs, lz, es * z);
+  dy[3] = __builtin_fma(-ua, lx, __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))));
+  dy[4] = __builtin_fma(-ua, ly, __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)));
+  dy[5] = __builtin_fma(-ua, lz, -cs * z);
+  dy[6] = (-kt * m) * mass;
+  dy[7] = __builtin_fma(-omc, lx, -tA);
+  dy[8] = __builtin_fma(-omc, ly, -es * yy);
+  dy[9] = __builtin_fma(cs, lz, -es * z);
   dy[10] = __builtin_fma(w2, ly, -y[7]);
   dy[11] = __builtin_fma(-w2, lx, -y[8]);
   dy[12] = -y[9];
-  const double mn_over_m = (m * n) * inv_m;
-  if constexpr (PM == PM_P0 || PM == PM_P1) {   // always thrust-limited: lambda_m_dot = -umag n / m, no blend needed
-    dy[13] = -mn_over_m;
+  if constexpr (!LM) {
+    dy[13] = 0.0;
+  } else if constexpr (PM == PM_P0 || PM == PM_P1) {   // always thrust-limited: lambda_m_dot = -umag n / m, no blend needed
+    dy[13] = -(m * n) * inv_m;
   } else {
     const double tl = tlim ? 1.0 : 0.0, ntl = 1.0 - tl;
-    dy[13] = __builtin_fma(-tl, mn_over_m, ntl * (kt * lm * m));
+    dy[13] = __builtin_fma(-tl, (m * n) * inv_m, ntl * (kt * lm * m));
   }
 }
 

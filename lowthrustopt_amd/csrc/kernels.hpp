@@ -23,6 +23,7 @@ struct IndirectArgs {
   int* nacc; int* nrej;            // [S] adaptive step counters or null
   const int* order;                // [S] or null: lane -> segment map of adaptive sweeps (lto_indirect_plan_rebalance)
   int class_filter;                // set by the launchers: 1 = this launch handles only trajectories of the kernel's p-class
+  double stm_scale;                // 3^-(steps mod 256): the DPP column lanes of the pipeline kernels carry 3^k Phi (pipe_common.hpp)
 };
 
 struct DirectArgs {
@@ -62,6 +63,8 @@ hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const Indirect
 hipError_t launch_indirect_stm_pipe(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 // six-wave form: one STM column per lane, coefficients broadcast inside the FMA (v_fmac_f64_dpp row_newbcast)
 hipError_t launch_indirect_stm_pipe6(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
+// eight-wave form (kernels_indirect_pipe8.hip): two RK4 steps per phase, a fourth of the column work alternates between two SIMDs
+hipError_t launch_indirect_stm_pipe8(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian_coop(int nstate, const DirectArgs& a, hipStream_t st);

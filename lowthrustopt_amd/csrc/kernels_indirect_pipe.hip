@@ -22,74 +22,9 @@
 //                     (segment, ONE column) with a DPP row = one segment, coefficients broadcast inside the FMA
 //
 // Replaces the serial loop of jacobianCalc (src/multiShoot_CRTBP_indirect.jl:93-146) for the fixed-step setting.
-#include "kernels.hpp"
+#include "pipe_common.hpp"
 
 namespace lto {
-
-constexpr int PIPE_SEG = 16;   // segments per workgroup
-
-// The coefficients of an RK stage are functions of the stage argument's position, lambda_v (and, for ND = 14, mass and
-// lambda_m) only: that is all the base wave publishes (6 / 8 doubles per stage -- an LDS store of a 64-lane wave costs
-// ~25 issue cycles of the critical stream), in the order of PipeArg<ND>::idx.
-template <int ND> struct PipeArg {
-  static constexpr int N = 6;
-  static constexpr int idx[6] = {0, 1, 2, 9, 10, 11};
-  using Coef = VarCoef12;
-};
-template <> struct PipeArg<14> {
-  static constexpr int N = 8;
-  static constexpr int idx[8] = {0, 1, 2, 6, 10, 11, 12, 13};
-  using Coef = VarCoef14;
-};
-
-// Layout of the coefficient records in LDS, one record per (step parity, stage, segment).
-struct CoefByValue {     // [value][segment]: what a lane that reads ALL values of its segment wants (k_indirect_pipe)
-  static constexpr bool SCALED = false;
-  template <int NC> static constexpr int stage_doubles() { return NC * PIPE_SEG; }
-  __device__ static int at(int e, int seg) { return e * PIPE_SEG + seg; }
-};
-struct CoefBySegment {   // [segment][value], records padded to 33 doubles: the coefficient wave's stores (one record per
-  static constexpr int LD = 33;   // lane) and the column rows' loads (one record per row) are both conflict-free
-  static constexpr bool SCALED = true;
-  template <int NC> static constexpr int stage_doubles() { return PIPE_SEG * LD; }
-  __device__ static int at(int e, int seg) { return seg * LD + e; }
-};
-
-// What a lane knows about its segment.
-struct PipeLane {
-  int s;            // segment (after the optional balanced order)
-  long node;        // its first node in the SoA arrays
-  bool in_range;    // stores allowed (not a shadow lane, and of this launch's control-law class)
-  bool mine;
-  double h, w2;
-  TrajParams tp;
-};
-
-template <int PM>
-__device__ __forceinline__ PipeLane pipe_lane(const IndirectArgs& a, const int seg) {
-  PipeLane L;
-  const int s_raw = blockIdx.x * PIPE_SEG + seg;
-  const int s_lin = s_raw < a.S ? s_raw : a.S - 1;             // shadow lanes repeat the last segment
-  L.s = a.order ? a.order[s_lin] : s_lin;
-  const int traj = L.s / a.seg_per_traj;
-  const int i = L.s - traj * a.seg_per_traj;
-  L.node = (long)traj * a.n_nodes + i;
-  const long tg = (long)traj * a.t_stride + i;
-  L.tp = a.tp[(long)traj * a.tp_stride];
-  L.h = (a.t[tg + 1] - a.t[tg]) / (double)a.steps;
-  L.w2 = 2.0 * L.tp.omega;
-  // mixed-class batch: segments of another control-law class belong to that class's launch; here they run through the
-  // barriers without storing
-  L.mine = !a.class_filter || p_class(L.tp.p) == PM;
-  L.in_range = (s_raw < a.S) && L.mine;
-  return L;
-}
-
-#ifdef PIPE_PROBE   // development build (make probe, tools/probe_pipe_roles.py): max_steps carries a role mask
-#define PIPE_ROLE_ON(a, bit) (!((a).max_steps & (bit)))
-#else
-#define PIPE_ROLE_ON(a, bit) true
-#endif
 
 // ---------------------------------------------------------------------------------------------------------- base role
 // lane = (segment, lane group): the wave holds FOUR identical copies of its 16 segments' base state, one per 16-lane
@@ -100,7 +35,7 @@ __device__ __forceinline__ PipeLane pipe_lane(const IndirectArgs& a, const int s
 template <int ND, int PM>
 __device__ __forceinline__ void pipe_role_base(const IndirectArgs& a, const PipeLane& L, const int seg, const int slot,
                                                double* s_int) {
-  constexpr int NI = PipeArg<ND>::N;
+  constexpr int NI = PipeArg<ND, PM>::N;
   const int steps = a.steps;
   const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
   auto rhs = [&](const double (&y)[ND], double (&k)[ND]) {
@@ -116,7 +51,7 @@ __device__ __forceinline__ void pipe_role_base(const IndirectArgs& a, const Pipe
       auto remember = [&](int stage, const double (&arg)[ND]) {
         if (slot == stage) {
 #pragma unroll
-          for (int e = 0; e < NI; ++e) keep[e] = arg[PipeArg<ND>::idx[e]];
+          for (int e = 0; e < NI; ++e) keep[e] = arg[PipeArg<ND, PM>::idx[e]];
         }
       };
       remember(0, y);
@@ -154,12 +89,12 @@ __device__ __forceinline__ void pipe_role_base(const IndirectArgs& a, const Pipe
 
 // --------------------------------------------------------------------------------------------------- coefficient role
 // lane = (segment, RK stage): the four stages of step p - 1 are built side by side in phase p.  The stage argument's
-// components outside PipeArg<ND>::idx are unused by the coefficients (the slopes rhs* also produces are dead code).
+// components outside PipeArg<ND, PM>::idx are unused by the coefficients (the slopes rhs* also produces are dead code).
 template <int ND, int PM, class Layout>
 __device__ __forceinline__ void pipe_role_coef(const IndirectArgs& a, const PipeLane& L, const int seg, const int stage,
                                                const double* s_int, double* s_coef) {
-  using Coef = typename PipeArg<ND>::Coef;
-  constexpr int NI = PipeArg<ND>::N;
+  using Coef = typename PipeCoef<ND>::type;
+  constexpr int NI = PipeArg<ND, PM>::N;
   constexpr int NC = sizeof(Coef) / sizeof(double);
   const int steps = a.steps;
   for (int p = 0; p < steps + 2; ++p) {
@@ -170,7 +105,7 @@ __device__ __forceinline__ void pipe_role_coef(const IndirectArgs& a, const Pipe
       for (int c = 0; c < ND; ++c) arg[c] = 0.0;
       const double* src = s_int + ((buf * 4 + stage) * NI) * PIPE_SEG + seg;
 #pragma unroll
-      for (int e = 0; e < NI; ++e) arg[PipeArg<ND>::idx[e]] = src[e * PIPE_SEG];
+      for (int e = 0; e < NI; ++e) arg[PipeArg<ND, PM>::idx[e]] = src[e * PIPE_SEG];
       Coef vc;
       if constexpr (ND == 12) rhs12<PM, true>(arg, L.tp, dead, vc);
       else rhs14<PM, true>(arg, L.tp, dead, vc);
@@ -178,9 +113,10 @@ __device__ __forceinline__ void pipe_role_coef(const IndirectArgs& a, const Pipe
       double* dst = s_coef + (buf * 4 + stage) * Layout::template stage_doubles<NC>();
       // Layout::SCALED: every coefficient except the unit vector lhat (entries 14..16) is stored times the stage's
       // RK4 argument weight (h/2, h/2, h, h/6), so that the column lanes accumulate h a_s F c straight onto y
-      const double as = Layout::SCALED ? ((stage == 2) ? L.h : (stage == 3) ? L.h * (1.0 / 6.0) : 0.5 * L.h) : 1.0;
+      // (the last stage carries h/2 = 3 h/6: the column lanes advance 3 y per step, col_dpp_step)
+      const double as = Layout::SCALED ? ((stage == 2) ? L.h : 0.5 * L.h) : 1.0;
 #pragma unroll
-      for (int e = 0; e < NC; ++e) dst[Layout::at(e, seg)] = (Layout::SCALED && (e < 14 || e > 16)) ? o[e] * as : o[e];
+      for (int e = 0; e < NC; ++e) dst[Layout::template at<ND>(e, seg)] = (Layout::SCALED && (e < 14 || e > 16)) ? o[e] * as : o[e];
     }
     __syncthreads();
   }
@@ -191,7 +127,7 @@ __device__ __forceinline__ void pipe_role_coef(const IndirectArgs& a, const Pipe
 template <int ND>
 __device__ __forceinline__ void pipe_role_columns2(const IndirectArgs& a, const PipeLane& L, const int seg, const int pair_raw,
                                                    const double* s_coef) {
-  using Coef = typename PipeArg<ND>::Coef;
+  using Coef = typename PipeCoef<ND>::type;
   constexpr int NC = sizeof(Coef) / sizeof(double);
   const int steps = a.steps;
   const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0), w2 = L.w2;
@@ -212,7 +148,7 @@ __device__ __forceinline__ void pipe_role_columns2(const IndirectArgs& a, const 
         double* v = reinterpret_cast<double*>(&vc);
         const double* src = s_coef + (buf * 4 + stage) * CoefByValue::stage_doubles<NC>();
 #pragma unroll
-        for (int e = 0; e < NC; ++e) v[e] = src[CoefByValue::at(e, seg)];
+        for (int e = 0; e < NC; ++e) v[e] = src[CoefByValue::at<ND>(e, seg)];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           double k[ND];
@@ -238,99 +174,26 @@ __device__ __forceinline__ void pipe_role_columns2(const IndirectArgs& a, const 
   }
 }
 
-// ----------------------------------------------------------- column role, one column per lane, coefficients through DPP
-// The 16 lanes of a DPP row are the 14 (12) STM columns of ONE segment; lane j of the row holds coefficients j and 16 + j
-// of that segment (one ds_read2_b64 per stage instead of 13), and every product  coefficient x column entry  is a
-// v_fmac_f64_dpp with row_newbcast:n -- the coefficient is read from lane n of the row inside the FMA, no move, no LDS.
-// (Inline asm: the compiler has no pattern that folds a 64-bit DPP move into the FMA.  The DPP source registers are only
-// ever written by the LDS loads below, never by a VALU instruction, so the VALU-write -> DPP-read hazard cannot arise.
-// tools/micro/dpp_probe.hip checks semantics and issue rate on the device.)
-template <int N>
-__device__ __forceinline__ void fmac_b(double& acc, const double c, const double x) {      // acc += c[lane N of the row] * x
-  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(x), "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void fmac_bn(double& acc, const double c, const double x) {     // acc -= c[lane N of the row] * x
-  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(x), "n"(N));
-}
 
-// One RK4 stage of one STM column with the coefficients spread over the row: cA = value (lane), cB = value (16 + lane) of
-//   [Gxx Gyy Gzz Gxy Gxz Gyz | Hxx Hyy Hzz Hxy Hxz Hyz | ua ub lx ly] [lz | umx umy umz mm mn Lm Ln Ll]   (VarCoef12 / 14),
-// all but lhat pre-multiplied by the stage's weight a (CoefBySegment::SCALED), aw2 = a 2 omega:
-//   out = init + a F(arg) arg
-// The rows with coefficient products accumulate straight onto init (no separate slope, no separate RK update); the
-// Coriolis rows start with a plain FMA, the others with a copy of init.  Same formulas as var_col12 / var_col14.
-template <int ND>
-__device__ __forceinline__ void col_dpp_stage(const double cA, const double cB, const double aw2, const double a,
-                                              const double (&arg)[ND], const double (&init)[ND], double (&out)[ND]) {
-  constexpr int G = (ND == 14) ? 7 : 6;     // first lambda_r row
-  constexpr int D = G + 3;                  // first lambda_v row
-  const double ax = arg[0], ay = arg[1], az = arg[2];
-  const double dx = arg[D], dyv = arg[D + 1], dz = arg[D + 2];
-  double ld = 0.0;
-  fmac_b<14>(ld, cA, dx); fmac_b<15>(ld, cA, dyv); fmac_b<0>(ld, cB, dz);
-  double tl = 0.0;
-  fmac_b<13>(tl, cA, ld);                                    // a ub (lhat . d)
-  out[0] = __builtin_fma(a, arg[3], init[0]); out[1] = __builtin_fma(a, arg[4], init[1]); out[2] = __builtin_fma(a, arg[5], init[2]);
-  double o3 = __builtin_fma(aw2, arg[4], init[3]), o4 = __builtin_fma(-aw2, arg[3], init[4]), o5 = init[5];
-  fmac_b<0>(o3, cA, ax); fmac_b<3>(o3, cA, ay); fmac_b<4>(o3, cA, az); fmac_bn<12>(o3, cA, dx); fmac_b<14>(o3, cA, tl);
-  fmac_b<3>(o4, cA, ax); fmac_b<1>(o4, cA, ay); fmac_b<5>(o4, cA, az); fmac_bn<12>(o4, cA, dyv); fmac_b<15>(o4, cA, tl);
-  fmac_b<4>(o5, cA, ax); fmac_b<5>(o5, cA, ay); fmac_b<2>(o5, cA, az); fmac_bn<12>(o5, cA, dz); fmac_b<0>(o5, cB, tl);
-  double o7 = init[G], o8 = init[G + 1], o9 = init[G + 2];   // lambda_r rows: minus (H a + G d)
-  fmac_bn<6>(o7, cA, ax); fmac_bn<9>(o7, cA, ay); fmac_bn<10>(o7, cA, az); fmac_bn<0>(o7, cA, dx); fmac_bn<3>(o7, cA, dyv); fmac_bn<4>(o7, cA, dz);
-  fmac_bn<9>(o8, cA, ax); fmac_bn<7>(o8, cA, ay); fmac_bn<11>(o8, cA, az); fmac_bn<3>(o8, cA, dx); fmac_bn<1>(o8, cA, dyv); fmac_bn<5>(o8, cA, dz);
-  fmac_bn<10>(o9, cA, ax); fmac_bn<11>(o9, cA, ay); fmac_bn<8>(o9, cA, az); fmac_bn<4>(o9, cA, dx); fmac_bn<5>(o9, cA, dyv); fmac_bn<2>(o9, cA, dz);
-  out[G] = o7; out[G + 1] = o8; out[G + 2] = o9;
-  out[D] = __builtin_fma(aw2, dyv, __builtin_fma(-a, arg[G], init[D]));
-  out[D + 1] = __builtin_fma(-aw2, dx, __builtin_fma(-a, arg[G + 1], init[D + 1]));
-  out[D + 2] = __builtin_fma(-a, arg[G + 2], init[D + 2]);
-  if constexpr (ND == 14) {
-    const double mu = arg[6];
-    fmac_b<1>(o3, cB, mu); fmac_b<2>(o4, cB, mu); fmac_b<3>(o5, cB, mu);
-    double o6 = init[6], o13 = init[13];
-    fmac_b<4>(o6, cB, mu); fmac_b<5>(o6, cB, ld);
-    fmac_b<6>(o13, cB, mu); fmac_b<7>(o13, cB, ld); fmac_b<8>(o13, cB, arg[13]);
-    out[6] = o6; out[13] = o13;
-  }
-  out[3] = o3; out[4] = o4; out[5] = o5;
-}
-
-// lane = (row = segment, column); coefficients of the stage: CoefBySegment (scaled).  RK4 in the form
-//   y+ = -y/3 + Y1/3 + 2 Y2/3 + Y3/3 + (h/6) k4,   Y1 = y + (h/2) k1,  Y2 = y + (h/2) k2,  Y3 = y + h k3
-// so that every stage is one "init + a F arg" accumulation: the stage arguments are the Y themselves.
+// lane = (row = segment, column); coefficients of the stage: CoefBySegment (scaled); one RK4 step = col_dpp_step.
 template <int ND>
 __device__ __forceinline__ void pipe_role_columns_dpp(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
                                                       const double* s_coef) {
-  constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
+  constexpr int NC = sizeof(typename PipeCoef<ND>::type) / sizeof(double);
+  constexpr int SD = CoefBySegment::stage_doubles<NC>();
   const int steps = a.steps;
-  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), w2 = L.w2;
-  const double h2w = h2 * w2, hw = h * w2, h6w = h6 * w2;
+  const ColStepConst k(L.h, L.w2);
   double y[ND];
 #pragma unroll
   for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
   for (int p = 0; p < steps + 2; ++p) {
-    if (p >= 2 && PIPE_ROLE_ON(a, 4)) {
-      const double* rec = s_coef + ((p & 1) * 4) * CoefBySegment::stage_doubles<NC>() + CoefBySegment::at(col, seg);
-      constexpr int SD = CoefBySegment::stage_doubles<NC>();
-      double A[ND], Y1[ND], Y2[ND], Y3[ND];
-#pragma unroll
-      for (int c = 0; c < ND; ++c) A[c] = y[c] * (-1.0 / 3.0);
-      col_dpp_stage<ND>(rec[0], rec[16], h2w, h2, y, y, Y1);
-#pragma unroll
-      for (int c = 0; c < ND; ++c) A[c] = __builtin_fma(1.0 / 3.0, Y1[c], A[c]);
-      col_dpp_stage<ND>(rec[SD], rec[SD + 16], h2w, h2, Y1, y, Y2);
-#pragma unroll
-      for (int c = 0; c < ND; ++c) A[c] = __builtin_fma(2.0 / 3.0, Y2[c], A[c]);
-      col_dpp_stage<ND>(rec[2 * SD], rec[2 * SD + 16], hw, h, Y2, y, Y3);
-#pragma unroll
-      for (int c = 0; c < ND; ++c) A[c] = __builtin_fma(1.0 / 3.0, Y3[c], A[c]);
-      col_dpp_stage<ND>(rec[3 * SD], rec[3 * SD + 16], h6w, h6, Y3, A, y);
-    }
+    if (p >= 2 && PIPE_ROLE_ON(a, 4) && col < ND)     // the spare lanes of a row stay switched off: they are never DPP sources
+      col_dpp_step<ND, SD>(s_coef + ((p & 1) * 4) * SD + CoefBySegment::lane_base(col, seg), k, p - 2, y);
     __syncthreads();
   }
   if (L.in_range && col < ND) {
 #pragma unroll
-    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = y[r];
+    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = y[r] * a.stm_scale;
   }
 }
 
@@ -338,8 +201,8 @@ __device__ __forceinline__ void pipe_role_columns_dpp(const IndirectArgs& a, con
 // Four waves, one per SIMD: wave 0 base, wave 1 coef, waves 2-3 columns (two per lane).  LDS 23 / 33 KB (ND = 12 / 14).
 template <int ND, int PM>
 __global__ __launch_bounds__(256, 2) void k_indirect_pipe(const IndirectArgs a) {
-  constexpr int NI = PipeArg<ND>::N;
-  constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
+  constexpr int NI = PipeArg<ND, PM>::N;
+  constexpr int NC = sizeof(typename PipeCoef<ND>::type) / sizeof(double);
   __shared__ double s_int[8 * NI * PIPE_SEG];
   __shared__ double s_coef[2 * 4 * CoefByValue::stage_doubles<NC>()];
   // Batches of several chip-fulls: two workgroups share a CU (<= 256 registers per lane), and the hardware gives
@@ -362,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void k_indirect_pipe(const IndirectArgs a) 
 // LDS 39 / 41 KB.
 template <int ND, int PM>
 __global__ __launch_bounds__(384) void k_indirect_pipe6(const IndirectArgs a) {
-  constexpr int NI = PipeArg<ND>::N;
-  constexpr int NC = sizeof(typename PipeArg<ND>::Coef) / sizeof(double);
+  constexpr int NI = PipeArg<ND, PM>::N;
+  constexpr int NC = sizeof(typename PipeCoef<ND>::type) / sizeof(double);
   __shared__ double s_int[8 * NI * PIPE_SEG];
   __shared__ double s_coef[2 * 4 * CoefBySegment::stage_doubles<NC>()];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

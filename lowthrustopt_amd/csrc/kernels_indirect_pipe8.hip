@@ -1,0 +1,326 @@
+// kernels_indirect_pipe8.hip -- eight-wave form of the three-role pipeline for the fixed-step RK4 STM sweep (BASELINE
+// configs[1]); replaces the serial loop of jacobianCalc (src/multiShoot_CRTBP_indirect.jl:93-146).
+//
+// Why another form.  In the six-wave kernel (kernels_indirect_pipe.hip) a workgroup of 16 segments carries, per RK4 step,
+// ~600 issue slots of base wave (alone on its SIMD: the sweep's dependent chain), ~180 of coefficient wave (alone on its
+// SIMD) and 4 x ~350 of column waves, two per SIMD on the remaining two SIMDs: three SIMDs carry ~700 slots per step and
+// the fourth ~180.  A wavefront cannot be split and cannot move, so the only way to level the SIMDs is to let a fourth of
+// the column work ALTERNATE between two SIMDs in time.  Here a phase is TWO RK4 steps (one barrier per phase) and the
+// columns of segments 12..15 are advanced by two wavefronts in turn:
+//
+//   wave  SIMD  role                                         issue slots per phase (two steps)
+//   w0    A     columns of segments 0..3,  both steps        700
+//   w4    A     columns of segments 12..15, EVEN step        350   -> hands the 14 doubles per lane to w5 through LDS
+//   w1    B     columns of segments 4..7,  both steps        700
+//   w5    B     columns of segments 12..15, ODD step         350   <- waits for w4's flag (bounded poll of one LDS word)
+//   w2    C     base trajectory, both steps                  ~1200 (the chain: nothing else on this SIMD)
+//   w6    C     exits at once
+//   w3    D     coefficients of both steps                   ~360
+//   w7    D     columns of segments 8..11, both steps        700
+//
+// (hardware places wave i and wave i + 4 of a workgroup on the same SIMD: tools/micro/sync_probe.hip).  w4 runs with
+// raised priority so that its step finishes early in the phase and w5 can interleave with w1.  Skew as before: the
+// coefficient wave is one phase behind the base wave, the columns two; hand-overs double-buffered per phase in LDS
+// (91 KB: one workgroup per CU); n/2 + 2 phases per sweep.  Every wave executes the same barriers; the only poll is w5
+// waiting for w4 of the same phase, which never waits for anything itself.
+//
+// For the always-thrust-limited control laws (p = 0, p = 1) of the 14-dim system nothing depends on lambda_m, so the base
+// wave integrates 13 components and the coefficient wave -- which evaluates lambda_m_dot at every stage argument anyway --
+// accumulates lambda_m off the critical stream.
+#include "pipe_common.hpp"
+
+namespace lto {
+
+constexpr int P8_SPIN_LIMIT = 1 << 22;
+
+#ifdef PIPE_PROBE   // development build: cycles each wave waits at the phase barriers -> defect[16][16 block + wave] (the probe script passes a defect buffer of 20 rows)
+#define P8_SYNC() do { const long long p8_t = clock64(); __syncthreads(); p8_wait += clock64() - p8_t; } while (0)
+#define P8_WAIT_DECL long long p8_wait = 0
+#define P8_WAIT_REPORT(a) do { if ((threadIdx.x & 63) == 0 && (a).defect) (a).defect[16 * (a).ldd + blockIdx.x * PIPE_SEG + (threadIdx.x >> 6)] = (double)p8_wait; } while (0)
+#else
+#define P8_SYNC() __syncthreads()
+#define P8_WAIT_DECL
+#define P8_WAIT_REPORT(a)
+#endif   // polls of w5 before it gives up and poisons its columns (never hangs)
+
+template <int ND, int PM> struct Pipe8 {
+  using Arg = PipeArg<ND, PM>;
+  static constexpr int NI = Arg::N;
+  static constexpr int NC = sizeof(typename PipeCoef<ND>::type) / sizeof(double);
+  static constexpr int SD = CoefBySegment::stage_doubles<NC>();        // doubles per (step, stage) coefficient slab
+  static constexpr bool LM_OFF = (ND == 14) && !Arg::LM;              // lambda_m integrated by the coefficient wave
+  static constexpr int NB = LM_OFF ? ND - 1 : ND;                     // components the base wave integrates
+  static constexpr int INT_DOUBLES = 2 * 2 * 4 * NI * PIPE_SEG;       // [phase parity][step of pair][stage][value][segment]
+  static constexpr int COEF_DOUBLES = 2 * 2 * 4 * SD;
+  static constexpr int HAND_DOUBLES = ND * 64;                        // [component][lane] of the alternating column job
+};
+
+// ---------------------------------------------------------------------------------------------------------- base role
+// As pipe_role_base (row g of the wave keeps the argument of stage g in registers; ONE set of stores per step publishes all
+// four stages), two steps per phase.  Tried and dropped: rows 1..3 switched off and the stage arguments stored stage by
+// stage from row 0 -- the three redundant rows cost ~5 us of shader clock (the sweep is power-limited), but twelve more
+// LDS stores per step on the chain cost more (S = 29: 79 -> 84 us).
+template <int ND, int PM>
+__device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const PipeLane& L, const int seg, const int slot,
+                                                double* s_int) {
+  using P = Pipe8<ND, PM>;
+  constexpr int NI = P::NI, NB = P::NB;
+  const int steps = a.steps, npairs = (steps + 1) >> 1;
+  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
+  auto rhs = [&](const double (&y)[ND], double (&k)[ND]) {
+    if constexpr (ND == 12) rhs12_base<PM>(y, L.tp, k);
+    else rhs14_base<PM, !P::LM_OFF>(y, L.tp, k);
+  };
+  double y[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + L.node];
+#ifdef PIPE_PROBE
+  const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
+#endif
+  P8_WAIT_DECL;
+  for (int p = 0; p < npairs + 2; ++p) {
+    if (p < npairs && PIPE_ROLE_ON(a, 1) && (PIPE_ROLE_ON(a, 16) || slot == 0)) {
+      for (int j = 0; j < 2; ++j) {
+        if (2 * p + j >= steps) break;
+        double k[ND], yt[ND], acc[ND], keep[NI];
+#pragma unroll
+        for (int c = 0; c < ND; ++c) { yt[c] = y[c]; acc[c] = y[c]; }
+        auto remember = [&](int stage, const double (&arg)[ND]) {
+          if (slot == stage) {
+#pragma unroll
+            for (int e = 0; e < NI; ++e) keep[e] = arg[P::Arg::idx[e]];
+          }
+        };
+        remember(0, y);
+        rhs(y, k);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
+        remember(1, yt);
+        rhs(yt, k);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
+        remember(2, yt);
+        rhs(yt, k);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
+        remember(3, yt);
+        rhs(yt, k);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
+        double* dst = s_int + ((((p & 1) * 2 + j) * 4 + slot) * NI) * PIPE_SEG + seg;
+#pragma unroll
+        for (int e = 0; e < NI; ++e) dst[e * PIPE_SEG] = keep[e];
+      }
+    }
+    P8_SYNC();
+  }
+  P8_WAIT_REPORT(a);
+  if (L.in_range && slot == 0) {
+    if (a.defect) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) a.defect[c * a.ldd + L.s] = y[c] - a.X[c * a.ldx + L.node + 1];
+    }
+    if (a.errors) a.errors[L.s] = 0.0;
+    if (a.nacc) a.nacc[L.s] = steps;
+    if (a.nrej) a.nrej[L.s] = 0;
+#ifdef PIPE_PROBE   // shader clock during the sweep: s_memtime ticks and 100 MHz ticks of the phase loop, per workgroup
+    if (seg == 0 && a.defect) { a.defect[17 * a.ldd + L.s] = (double)(clock64() - probe_c0); a.defect[18 * a.ldd + L.s] = (double)(wall_clock64() - probe_w0); }
+#endif
+  }
+}
+
+// --------------------------------------------------------------------------------------------------- coefficient role
+// lane = (segment, RK stage); one pass per step, two passes per phase, one phase behind the base wave.
+template <int ND, int PM>
+__device__ __forceinline__ void pipe8_role_coef(const IndirectArgs& a, const PipeLane& L, const int seg, const int stage,
+                                                const double* s_int, double* s_coef, double* s_lm) {
+  using P = Pipe8<ND, PM>;
+  using Coef = typename PipeCoef<ND>::type;
+  constexpr int NI = P::NI, NC = P::NC, SD = P::SD;
+  const int steps = a.steps, npairs = (steps + 1) >> 1;
+  // every coefficient except the unit vector lhat (entries 14..16) is stored times the stage's RK4 argument weight
+  // (the last stage carries h/2 = 3 h/6: the column lanes advance 3 y per step, col_dpp_step)
+  const double as = (stage == 2) ? L.h : 0.5 * L.h;
+  const double bw = (stage == 0 || stage == 3) ? L.h * (1.0 / 6.0) : L.h * (1.0 / 3.0);   // RK4 weight of the stage's slope
+  double lm_acc = 0.0;
+  P8_WAIT_DECL;
+  for (int p = 0; p < npairs + 2; ++p) {
+    if (p >= 1 && p <= npairs && PIPE_ROLE_ON(a, 2)) {
+      for (int j = 0; j < 2; ++j) {
+        if (2 * (p - 1) + j >= steps) break;
+        const int slab = (((p - 1) & 1) * 2 + j) * 4 + stage;
+        double arg[ND], dead[ND];
+#pragma unroll
+        for (int c = 0; c < ND; ++c) arg[c] = 0.0;
+        const double* src = s_int + (slab * NI) * PIPE_SEG + seg;
+#pragma unroll
+        for (int e = 0; e < NI; ++e) arg[P::Arg::idx[e]] = src[e * PIPE_SEG];
+        Coef vc;
+        if constexpr (ND == 12) rhs12<PM, true>(arg, L.tp, dead, vc);
+        else rhs14<PM, true>(arg, L.tp, dead, vc);
+        if constexpr (P::LM_OFF) lm_acc = __builtin_fma(bw, dead[ND - 1], lm_acc);   // lambda_m_dot = -umag n / m at this stage
+        const double* o = reinterpret_cast<const double*>(&vc);
+        double* dst = s_coef + slab * SD;
+#pragma unroll
+        for (int e = 0; e < NC; ++e) dst[CoefBySegment::at<ND>(e, seg)] = (e < 14 || e > 16) ? o[e] * as : o[e];
+      }
+    }
+    P8_SYNC();
+  }
+  P8_WAIT_REPORT(a);
+  if constexpr (P::LM_OFF) {
+    // lambda_m(t1) = lambda_m(t0) + sum over steps and stages of b_s h k_s: the four stage rows meet through LDS (same
+    // wavefront: its LDS operations complete in order)
+    s_lm[stage * PIPE_SEG + seg] = lm_acc;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    if (L.in_range && stage == 0 && a.defect) {
+      const double sum = (s_lm[seg] + s_lm[PIPE_SEG + seg]) + (s_lm[2 * PIPE_SEG + seg] + s_lm[3 * PIPE_SEG + seg]);
+      const long r = (long)(ND - 1) * a.ldx + L.node;
+      a.defect[(ND - 1) * a.ldd + L.s] = (a.X[r] + sum) - a.X[r + 1];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ column role, both steps of every phase
+template <int ND, int PM>
+__device__ __forceinline__ void pipe8_role_columns(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
+                                                   const double* s_coef) {
+  using P = Pipe8<ND, PM>;
+  constexpr int SD = P::SD;
+  const int steps = a.steps, npairs = (steps + 1) >> 1;
+  const ColStepConst k(L.h, L.w2);
+  double y[ND];
+#pragma unroll
+  for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
+  P8_WAIT_DECL;
+  for (int p = 0; p < npairs + 2; ++p) {
+    if (p >= 2 && PIPE_ROLE_ON(a, 4) && col < ND) {   // the spare lanes of a row stay switched off: never DPP sources
+      for (int j = 0; j < 2; ++j) {
+        const int step = 2 * (p - 2) + j;
+        if (step >= steps) break;
+        col_dpp_step<ND, SD, P::Arg::LM>(s_coef + (((p & 1) * 2 + j) * 4) * SD + CoefBySegment::lane_base(col, seg), k, step, y);
+      }
+    }
+    P8_SYNC();
+  }
+  P8_WAIT_REPORT(a);
+  if (L.in_range && col < ND) {
+#pragma unroll
+    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = y[r] * a.stm_scale;
+  }
+}
+
+// --------------------------------------------------------------- column role of the alternating job (segments 12..15)
+// ODD = false (w4): step 2q of pair q, then state -> s_hand, flag = q + 1.  ODD = true (w5): waits for flag >= q + 1,
+// state <- s_hand, step 2q + 1, state -> s_hand.  The barrier at the end of the phase orders w5's stores before w4's
+// loads of the next phase.  After the last phase w4 stores the STM columns from s_hand.
+template <int ND, int PM, bool ODD>
+__device__ __forceinline__ void pipe8_role_columns_alt(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
+                                                       const double* s_coef, double* s_hand, int* s_flag) {
+  using P = Pipe8<ND, PM>;
+  constexpr int SD = P::SD;
+  const int steps = a.steps, npairs = (steps + 1) >> 1;
+  const int lane = threadIdx.x & 63;
+  const ColStepConst k(L.h, L.w2);
+  double y[ND];
+#pragma unroll
+  for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
+  auto load = [&]() {
+#pragma unroll
+    for (int r = 0; r < ND; ++r) y[r] = s_hand[r * 64 + lane];
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int r = 0; r < ND; ++r) s_hand[r * 64 + lane] = y[r];
+  };
+  if (!ODD) __builtin_amdgcn_s_setprio(2);
+  P8_WAIT_DECL;
+  for (int p = 0; p < npairs + 2; ++p) {
+    if (p >= 2 && PIPE_ROLE_ON(a, 4) && col < ND) {
+      const int q = p - 2;
+      const double* rec = s_coef + (((p & 1) * 2 + (ODD ? 1 : 0)) * 4) * SD + CoefBySegment::lane_base(col, seg);
+      if (!ODD) {
+        if (q > 0) load();
+        col_dpp_step<ND, SD, P::Arg::LM>(rec, k, 2 * q, y);
+        store();
+        __hip_atomic_store(s_flag, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (2 * q + 1 < steps) {
+        int spins = 0;
+        while (__hip_atomic_load(s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < q + 1 && ++spins < P8_SPIN_LIMIT)
+          __builtin_amdgcn_s_sleep(2);
+        load();
+        if (spins >= P8_SPIN_LIMIT) {   // cannot happen while w4 runs; poison rather than hang or return stale columns
+#pragma unroll
+          for (int r = 0; r < ND; ++r) y[r] = __builtin_nan("");
+        }
+        col_dpp_step<ND, SD, P::Arg::LM>(rec, k, 2 * q + 1, y);
+        store();
+      }
+    }
+    P8_SYNC();
+  }
+  P8_WAIT_REPORT(a);
+  if (!ODD) {
+    load();
+    if (L.in_range && col < ND) {
+#pragma unroll
+      for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = y[r] * a.stm_scale;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------- kernel
+template <int ND, int PM>
+__global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
+  using P = Pipe8<ND, PM>;
+  __shared__ double s_int[P::INT_DOUBLES];
+  __shared__ double s_coef[P::COEF_DOUBLES];
+  __shared__ double s_hand[P::HAND_DOUBLES];
+  __shared__ double s_lm[4 * PIPE_SEG];
+  __shared__ int s_flag;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  // waves 0, 1, 7: column waves 0, 1, 2; waves 4, 5: the alternating column job 3; wave 2 base, wave 3 coefficients
+  const bool col_wave = (wave != 2 && wave != 3);
+  const int cw = (wave == 7) ? 2 : (wave >= 4) ? 3 : wave;
+  const int seg = col_wave ? cw * 4 + (lane >> 4) : (lane & (PIPE_SEG - 1));
+  const PipeLane L = pipe_lane<PM>(a, seg);
+  if (threadIdx.x == 0) s_flag = 0;
+  if (!__syncthreads_or(L.mine)) return;         // workgroup-uniform
+  if (wave == 6) return;                         // shares the base wave's SIMD: leaves before the first phase barrier
+  if (wave == 2) pipe8_role_base<ND, PM>(a, L, seg, lane >> 4, s_int);
+  else if (wave == 3) pipe8_role_coef<ND, PM>(a, L, seg, lane >> 4, s_int, s_coef, s_lm);
+  else if (wave == 4) pipe8_role_columns_alt<ND, PM, false>(a, L, seg, lane & 15, s_coef, s_hand, &s_flag);
+  else if (wave == 5) pipe8_role_columns_alt<ND, PM, true>(a, L, seg, lane & 15, s_coef, s_hand, &s_flag);
+  else pipe8_role_columns<ND, PM>(a, L, seg, lane & 15, s_coef);
+}
+
+template <int ND, int PM>
+static hipError_t launch_pipe8_one(const IndirectArgs& a, hipStream_t st) {
+  dim3 grid((a.S + PIPE_SEG - 1) / PIPE_SEG);
+  hipLaunchKernelGGL((k_indirect_pipe8<ND, PM>), grid, dim3(512), 0, st, a);
+  return hipGetLastError();
+}
+
+template <int ND>
+static hipError_t launch_pipe8_pm(int pm, const IndirectArgs& a0, hipStream_t st) {
+  IndirectArgs a = a0;
+  a.class_filter = single_class(pm) ? 0 : 1;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_pipe8_one<ND, PM_P0>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_pipe8_one<ND, PM_P1>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_pipe8_one<ND, PM_P2>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_pipe8_one<ND, PM_PGEN>(a, st);
+  return e;
+}
+
+// RK4 only; steps >= 1.
+hipError_t launch_indirect_stm_pipe8(int ndim, int pm, const IndirectArgs& a, hipStream_t st) {
+  if (a.S <= 0) return hipSuccess;
+  if (a.steps < 1) return hipErrorInvalidValue;
+  if (ndim == 12) return launch_pipe8_pm<12>(pm, a, st);
+  if (ndim == 14) return launch_pipe8_pm<14>(pm, a, st);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace lto

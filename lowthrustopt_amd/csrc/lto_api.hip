@@ -339,9 +339,10 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
 
 int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
-  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE && kernel != LTO_KERNEL_PIPE6)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE or _PIPE6");
-  if ((kernel == LTO_KERNEL_PIPE || kernel == LTO_KERNEL_PIPE6) && p->integ.method != LTO_RK4)
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE && kernel != LTO_KERNEL_PIPE6 &&
+      kernel != LTO_KERNEL_PIPE8)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE, _PIPE6 or _PIPE8");
+  if ((kernel == LTO_KERNEL_PIPE || kernel == LTO_KERNEL_PIPE6 || kernel == LTO_KERNEL_PIPE8) && p->integ.method != LTO_RK4)
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_PIPE is built for fixed-step RK4 plans");
   p->kernel = kernel;
   return LTO_OK;
@@ -371,6 +372,7 @@ static int fill_indirect_args(lto_indirect_plan* p, const double* X, long ldx, c
   a->steps = p->integ.steps; a->rtol = p->integ.rtol; a->atol = p->integ.atol; a->max_steps = p->integ.max_steps;
   a->nacc = p->d_nacc; a->nrej = p->d_nrej;
   a->order = p->use_order ? p->d_order : nullptr;
+  a->stm_scale = std::pow(3.0, -(double)(p->integ.steps > 0 ? p->integ.steps % 256 : 0));   // pipe_common.hpp COL_RESCALE_EVERY
   p->swept = 1;                                    // every caller launches a sweep right after a successful fill
   return LTO_OK;
 }
@@ -430,6 +432,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
   else if (kern == LTO_KERNEL_PIPE) e = launch_indirect_stm_pipe(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE6) e = launch_indirect_stm_pipe6(p->ndim, p->pm, a, st);
+  else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);

@@ -38,11 +38,12 @@ METHODS = {
 
 
 # STM kernel families x integrators: the three-role pipeline kernel is built for fixed-step RK4 only
-KERNEL_METHODS = [(k, m) for k in ("per_lane", "coop") for m in METHODS] + [("pipe", "rk4x64"), ("pipe6", "rk4x64")]
+KERNEL_METHODS = [(k, m) for k in ("per_lane", "coop") for m in METHODS] + [("pipe", "rk4x64"), ("pipe6", "rk4x64"), ("pipe8", "rk4x64")]
 
 
 def pick_kernel(plan, kernel):
-    plan.set_kernel({"per_lane": plan.KERNEL_PER_LANE, "coop": plan.KERNEL_COOP, "pipe": plan.KERNEL_PIPE, "pipe6": plan.KERNEL_PIPE6}[kernel])
+    plan.set_kernel({"per_lane": plan.KERNEL_PER_LANE, "coop": plan.KERNEL_COOP, "pipe": plan.KERNEL_PIPE, "pipe6": plan.KERNEL_PIPE6,
+                     "pipe8": plan.KERNEL_PIPE8}[kernel])
 
 
 def rel_l2(d_gpu, d_ref, x1):
@@ -953,7 +954,7 @@ def test_indirect_pipeline_kernel_equals_per_lane_at_full_size(gpu_ctx, ndim, st
         Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
         td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
         out = {}
-        for kernel in ("per_lane", "pipe", "pipe6"):
+        for kernel in ("per_lane", "pipe", "pipe6", "pipe8"):
             plan = lto.IndirectPlan(gpu_ctx, n, nb, prm, lto.integrator(lto.RK4, steps=steps), ndim=ndim)
             pick_kernel(plan, kernel)
             Phi = torch.full((ndim * ndim, S), 7.0, dtype=torch.float64, device="cuda")
@@ -962,7 +963,7 @@ def test_indirect_pipeline_kernel_equals_per_lane_at_full_size(gpu_ctx, ndim, st
             torch.cuda.synchronize()
             out[kernel] = (Phi.cpu().numpy(), d.cpu().numpy())
         P1, d1 = out["per_lane"]
-        for kernel in ("pipe", "pipe6"):
+        for kernel in ("pipe", "pipe6", "pipe8"):
             P2, d2 = out[kernel]
             assert np.all(np.isfinite(P2)) and np.all(np.isfinite(d2)), kernel
             assert np.abs(d1 - d2).max() < 1e-12 * max(1.0, np.abs(d1).max()), kernel
