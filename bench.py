@@ -16,6 +16,11 @@ system -- the one reference parity is claimed for -- is timed in the same run an
 N > 1: weak scaling -- every rank sweeps its own 4 096 segments, then one RCCL all-gather of the per-rank
 defect slabs (ndim x 4096 doubles) gives every rank the full defect vector.
 
+Timing: the K steps of the timed region are enqueued back to back with NO event in between (an event pair per launch
+serialises the queue and costs ~12 us per step at the contract size); `value` = segments x K / that wall time, so it does
+not depend on K.  Kernel launch durations (`roofline.kernel_ms`) are sampled in a separate pass after the timed region:
+N_SAMPLE isolated launches, each bracketed by a HIP event pair on the launch stream.
+
 Other workloads (`--workload c3|c4|c5|hbm`) are measurement aids for DESIGN.md, not the contract line.
 """
 import argparse
@@ -32,6 +37,7 @@ if ROOT not in sys.path:
 
 PEAK_FP64_TFLOPS = 78.6   # MI355X vector (= matrix) FP64 peak
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+N_SAMPLE = 8              # isolated launches timed with an event pair each, after the timed region
 
 # Algorithmic work per unit (DESIGN.md "Roofline"): flops = steps*(stages*F_rhs + C_tab*dim)
 # F_rhs (model flops: + - x / sqrt tanh = 1, FMA = 2): 12-dim 95, + 12x12 variational 1070; 14-dim 110,
@@ -43,6 +49,7 @@ WORK = {
     ("c2_defect", 12): (64 * (4 * 95 + 14 * 12), 304),
     ("c2_defect", 14): (64 * (4 * 110 + 14 * 14), 352),
     ("c3", 12): (18 * (13 * 232 + 132 * 60), 1080 + 48),  # direct 6-dim + Phi + Psi, RKF7(8) 9 steps x 2 halves
+    ("c4", 12): (64 * (4 * 1070 + 14 * 156), 1456),       # homotopy sweep: the 12-dim + STM unit, per-level rho
     ("hbm", 12): (1 * (4 * 1070 + 14 * 156), 1456),       # 1 RK4 step + full STM output: the HBM evidence point
     ("hbm", 14): (1 * (4 * 1490 + 14 * 210), 1920),
 }
@@ -76,9 +83,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(workload, seconds, threads=1, ndim=12):
+def cpu_baseline(workload, seconds, threads=1, ndim=12, reference_algorithm=False):
     """Oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload.  threads = 1 is
-    the reference's own execution model (serial loop over segments); threads > 1 parallelises that loop with OpenMP."""
+    the reference's own execution model (serial loop over segments); threads > 1 parallelises that loop with OpenMP.
+    reference_algorithm: the indirect sweep as the reference executes it -- adaptive order-8 pair at
+    reltol = abstol = 1e-13 with the Jacobian by dual numbers pushed through the solver (indirect.jl:79,107-110,121),
+    12-dim -- instead of the fixed RK4 x 64 discrete map the GPU line integrates."""
     from oracle import oracle as O
     import lowthrustopt_amd as lto
     from lowthrustopt_amd import synth
@@ -97,17 +107,23 @@ def cpu_baseline(workload, seconds, threads=1, ndim=12):
     else:
         XC, T = synth.indirect_problem(nseg + 1, seed=0)
         XC, t = XC[:, :, 0], T[:, 0]
-        if ndim == 14:
+        if reference_algorithm:
+            def run():
+                O.indirect_jacobian(XC, t, prm, O.DOP853_ADAPTIVE)
+            what = ("indirect 12-dim + 12x12 STM as the reference computes it: adaptive order-8 pair (DOP853 standing in for Vern8) at "
+                    "rtol = atol = 1e-13, Jacobian by dual numbers through the solver (indirect.jl:79,107-110,121)")
+        elif ndim == 14:
             XC = to14(XC)
             prm14 = [lto.MU, lto.DU, lto.TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
 
             def run():
                 O.indirect14(XC, t, prm14, O.RK4, 64)
+            what = "indirect 14-dim + 14x14 STM by dual numbers through RK4 x 64 (same discrete map as the GPU run)"
         else:
             def run():
                 O.indirect_jacobian(XC, t, prm, O.RK4, 64)
+            what = "indirect 12-dim + 12x12 STM by dual numbers through RK4 x 64 (same discrete map as the GPU run)"
         per_call = nseg
-        what = "indirect %d-dim + %dx%d STM by dual numbers through RK4 x 64 (same discrete map as the GPU run)" % (ndim, ndim, ndim)
     O.lib()
     used = O.set_threads(threads)
     run()
@@ -124,36 +140,46 @@ def cpu_baseline(workload, seconds, threads=1, ndim=12):
             "sample": "%d segments x %d sweeps in %.1f s; %s; host has %d cores" % (per_call, calls, el, what, os.cpu_count() or 0)}
 
 
-event_stride_used = [1]
+def sample_launches(torch, sweep, n=N_SAMPLE):
+    """Durations (ms) of n isolated launches of `sweep`, each bracketed by a HIP event pair on the current stream (the
+    stream the kernels are launched on).  Run after the timed region: nothing here perturbs `value`."""
+    out = []
+    for _ in range(n):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(); sweep(); e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1))
+    return out
 
 
-def event_stride(steps):
-    """Launch durations are sampled with a HIP event pair around every `stride`-th launch of the timed region, not around
-    every launch: an event pair serialises the queue (the next sweep cannot start on CUs the previous one has already
-    left, plus two signal packets), which costs ~12 us per step at the contract size -- measured: 98.6 us per step for
-    back-to-back sweeps against 111 us with a pair per step."""
-    event_stride_used[0] = max(1, steps // 25)
-    return event_stride_used[0]
+# DOP853 trial step (csrc/rk.hpp dop853_try): 12 RHS evaluations + tableau arithmetic 2 x (50 a_ij + 8 b + 8 e3 + 8 e5) per component
+def dop853_flops(trial_steps, f_rhs, dim):
+    return trial_steps * (12 * f_rhs + 148 * dim)
 
 
-def roofline(wl, ndim, S, kern_ms):
-    flops, nbytes = WORK[(wl, ndim)]
+def roofline(wl, ndim, S, kern_ms, work=None, samples=None):
+    flops, nbytes = work if work is not None else WORK[(wl, ndim)]
     dur = kern_ms * 1e-3
     ach_tf = flops * S / dur / 1e12
     ach_gb = nbytes * S / dur / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_%s%s.json" % (wl, "" if ndim == 14 or wl == "c3" else "_ndim12"))
+    traffic, traffic_from = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_%s%s.json" % (wl, "" if ndim == 14 or wl in ("c3", "c4", "c5_stm") else "_ndim12"))
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc))
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_from = "stored rocprofv3 --pmc profile of this command (FETCH_SIZE x 2 + WRITE_SIZE, separate passes): profiles/%s, %s" % (
+                os.path.basename(pmc), rec.get("source", "?"))
         except Exception:
             traffic = None
     return {
         # schema value "mfma" = the compute roof: the dense FP64 matrix peak of MI355X (78.6 TFLOP/s) is numerically the
         # FP64 vector peak, and the vector pipe is what this kernel runs on (compute_pipe); the HBM roof is in "hbm"
         "bound": "mfma", "compute_pipe": "fp64_valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-        "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
-        "kernel_ms": kern_ms, "kernel_ms_from": "HIP event pairs around every %d-th launch of the timed region" % event_stride_used[0],
+        "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_from": traffic_from,
+        "kernel_ms": kern_ms, "kernel_ms_from": "mean of %d isolated launches after the timed region, one HIP event pair each" % N_SAMPLE,
+        "kernel_ms_samples": samples,
         "flops_per_segment": flops, "bytes_per_segment": nbytes,
         "hbm": {"achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBS},
         "note": "register-resident fp64 ODE integration: compute-bound on the FP64 vector pipe (no MFMA instruction is "
@@ -198,22 +224,17 @@ def leg_12dim(lto, synth, ctx, st, torch, a):
     Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
     for _ in range(a.warmup):
         plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)
-    stride = event_stride(a.steps)
-    ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, a.steps, stride)}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        if k in ev:
-            ev[k][0].record()
         plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)
-        if k in ev:
-            ev[k][1].record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev.values()]))
+    samples = sample_launches(torch, lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st))
+    kern_ms = float(np.mean(samples))
     out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
            "workload": "C2 on the reference's CRTBP_stateCostate_deriv! system: 12-dim state+costate + 12x12 STM, 4 096 "
-                       "segments, RK4 x 64, fp64", "stm_kernel": plan.last_kernel(), "roofline": roofline("c2", 12, S, kern_ms)}
+                       "segments, RK4 x 64, fp64", "stm_kernel": plan.last_kernel(), "roofline": roofline("c2", 12, S, kern_ms, samples=samples)}
     plan.close()
 
     def add_parity():
@@ -356,6 +377,12 @@ def main():
                 dist.all_gather_into_tensor(gathered[b], dbufs[b])   # RCCL over xGMI
                 ev_done[b].record(comm_stream)
 
+    ref12 = None
+    if rank == 0 and world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
+        # the reference's own system (12-dim, constant mass): the sweep reference parity is claimed for, same run, timed
+        # the same way (W warm-up + K timed steps) BEFORE the contract leg
+        ref12 = leg_12dim(lto, synth, ctx, st, torch, a)
+
     for k in range(a.warmup):
         step(k)
     rebalanced = False
@@ -364,8 +391,6 @@ def main():
         rebalanced = True
     if use_coll:
         comm_stream.synchronize()
-    stride = event_stride(a.steps)
-    ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, a.steps, stride)}
     if use_coll:
         dist.barrier()
     torch.cuda.synchronize()
@@ -374,11 +399,7 @@ def main():
         b = k % len(dbufs)
         if use_coll and (k >= len(dbufs) or a.warmup >= len(dbufs)):
             main.wait_event(ev_done[b])
-        if k in ev:
-            ev[k][0].record()
         sweep(dbufs[b])
-        if k in ev:
-            ev[k][1].record()
         if use_coll:
             ev_ready[b].record(main)
             comm_stream.wait_event(ev_ready[b])
@@ -390,7 +411,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev.values()]))
+    samples = sample_launches(torch, lambda: sweep(dbufs[0]))     # separate pass: launch durations of the dominant kernel
+    kern_ms = float(np.mean(samples))
 
     if use_coll:
         for b in range(len(dbufs)):
@@ -401,12 +423,6 @@ def main():
         kt = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
         kern_ms = float(kt.item())
-
-    ref12 = None
-    if rank == 0 and world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
-        # the reference's own system (12-dim, constant mass): the sweep reference parity is claimed for, same run.
-        # Timed here, before the CPU baselines start their threads.
-        ref12 = leg_12dim(lto, synth, ctx, st, torch, a)
 
     # sanity: the sweep produced finite numbers (a failed launch would leave zeros / raise earlier)
     assert bool(torch.isfinite(defect).all()), "non-finite defect in benchmark sweep"
@@ -424,7 +440,15 @@ def main():
         if wl in ("c2", "hbm", "c4", "c5_stm"):
             out["config"]["stm_kernel"] = plan.last_kernel()
         if (wl, a.ndim) in WORK and not a.method:
-            out["roofline"] = roofline(wl, a.ndim, S, kern_ms)
+            out["roofline"] = roofline(wl, a.ndim, S, kern_ms, samples=samples)
+        elif wl == "c2" and a.method == "dop853":
+            # the reference's own integrator setting (adaptive order 8 @ 1e-13 + STM): flops from the step counts of this sweep
+            acc, rej = plan.step_counts(stream=st)
+            trial = float((acc + rej).sum())
+            f_rhs, dim, nbytes = (1490, 210, 1920) if a.ndim == 14 else (1070, 156, 1456)
+            out["roofline"] = roofline(wl, a.ndim, S, kern_ms, work=(dop853_flops(trial, f_rhs, dim) / S, nbytes), samples=samples)
+            out["roofline"]["flops_from"] = ("measured step counts of this sweep: %.2f accepted + %.2f rejected trial steps per segment (max %d) x "
+                                             "(12 x %d + 148 x %d)" % (acc.mean(), rej.mean(), int((acc + rej).max()), f_rhs, dim))
         if c5:
             # wavefront-divergence / load-balance study: a wave runs until its slowest lane has finished
             acc, rej = plan.step_counts(stream=st)
@@ -435,6 +459,11 @@ def main():
             def eff(v):
                 w = np.concatenate([v, np.zeros(pad)]).reshape(-1, grp)
                 return float(v.sum() / (w.max(axis=1).sum() * grp))
+            # work actually done: accepted + rejected trial steps of every segment (DOP853: 12 RHS evaluations per trial step)
+            f_rhs, dim = (1070, 156) if wl == "c5_stm" else (95, 12)
+            work = (dop853_flops(float(tot.sum()), f_rhs, dim) / S, 1456 if wl == "c5_stm" else 304)
+            out["roofline"] = roofline(wl, 12, S, kern_ms, work=work, samples=samples)
+            out["roofline"]["flops_from"] = "measured step counts of this sweep: %.2f trial steps per segment x (12 x %d + 148 x %d)" % (tot.mean(), f_rhs, dim)
             out["adaptive"] = {"steps_accepted_mean": float(acc.mean()), "steps_accepted_max": int(acc.max()),
                                "steps_rejected_mean": float(rej.mean()), "steps_rejected_max": int(rej.max()),
                                "wavefront_efficiency_natural_order": eff(tot),
@@ -445,6 +474,9 @@ def main():
                                        "lto_indirect_plan_rebalance ordered the lanes by the warm-up sweep's step counts"}
         if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and not a.method:
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds, ndim=a.ndim)
+            if wl == "c2":
+                # the same sweep the way the reference executes it (adaptive order 8 @ 1e-13 + dual numbers, 12-dim)
+                out["cpu_baseline_reference_algorithm"] = cpu_baseline("c2", max(3.0, a.cpu_seconds / 2), ndim=12, reference_algorithm=True)
             if wl == "c2":
                 # the metric's second half: defect L2 error of this very run against the oracle (checker), 256-segment sample
                 out["parity"] = parity_vs_oracle(a.ndim, XC, T, defect, Phi, S)
@@ -460,6 +492,7 @@ def main():
     if use_coll:
         dist.barrier()
         dist.destroy_process_group()
+    plan.close()       # plans before their context (lto_destroy frees what lto_*_plan_destroy touches)
     ctx.close()
 
 

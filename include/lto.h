@@ -205,8 +205,8 @@ int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
 int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 
 /* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4 with >= 6 steps per segment, the three-role
- * pipeline kernels (six-wave form up to 4 096 segments, four-wave form beyond: at every size for ndim = 14, up to
- * ~12 000 segments for ndim = 12) and otherwise the per-lane kernel (each lane re-integrates the base state with 1-3
+ * pipeline kernels (eight-wave form up to 4 096 segments and, for ndim = 14, up to ~130 000; four-wave form beyond: at
+ * every size for ndim = 14, up to ~12 000 segments for ndim = 12) and otherwise the per-lane kernel (each lane re-integrates the base state with 1-3
  * columns); for the 13-stage integrators the wave-specialised kernel (base wave + column waves per 16 segments,
  * coefficients handed over through LDS at every RK stage). */
 #define LTO_KERNEL_AUTO 0

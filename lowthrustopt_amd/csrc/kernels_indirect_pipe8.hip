@@ -2,36 +2,44 @@
 // configs[1]); replaces the serial loop of jacobianCalc (src/multiShoot_CRTBP_indirect.jl:93-146).
 //
 // Why another form.  In the six-wave kernel (kernels_indirect_pipe.hip) a workgroup of 16 segments carries, per RK4 step,
-// ~600 issue slots of base wave (alone on its SIMD: the sweep's dependent chain), ~180 of coefficient wave (alone on its
-// SIMD) and 4 x ~350 of column waves, two per SIMD on the remaining two SIMDs: three SIMDs carry ~700 slots per step and
-// the fourth ~180.  A wavefront cannot be split and cannot move, so the only way to level the SIMDs is to let a fourth of
-// the column work ALTERNATE between two SIMDs in time.  Here a phase is TWO RK4 steps (one barrier per phase) and the
-// columns of segments 12..15 are advanced by two wavefronts in turn:
+// ~560 instructions of base wave (alone on its SIMD: the sweep's dependent chain), ~180 of coefficient wave (alone on its
+// SIMD) and 4 x ~340 of column waves, two per SIMD on the remaining two SIMDs.  A wavefront cannot be split and cannot
+// move, so the only way to level the SIMDs is to let a fourth of the column work ALTERNATE between two SIMDs in time.
+// Here a phase is TWO RK4 steps (one workgroup barrier per phase) and the columns of segments 12..15 are advanced by two
+// wavefronts in turn:
 //
-//   wave  SIMD  role                                         issue slots per phase (two steps)
-//   w0    A     columns of segments 0..3,  both steps        700
-//   w4    A     columns of segments 12..15, EVEN step        350   -> hands the 14 doubles per lane to w5 through LDS
-//   w1    B     columns of segments 4..7,  both steps        700
-//   w5    B     columns of segments 12..15, ODD step         350   <- waits for w4's flag (bounded poll of one LDS word)
-//   w2    C     base trajectory, both steps                  ~1200 (the chain: nothing else on this SIMD)
+//   wave  SIMD  role                                         instructions per phase (two steps)
+//   w0    A     columns of segments 0..3,  both steps        680
+//   w4    A     columns of segments 12..15, EVEN step        340   -> hands the 14 doubles per lane to w5 through LDS
+//   w1    B     columns of segments 4..7,  both steps        680
+//   w5    B     columns of segments 12..15, ODD step         340   <- waits for w4's flag
+//   w2    C     base trajectory, both steps                  ~1100 (the chain: nothing else on this SIMD)
 //   w6    C     exits at once
 //   w3    D     coefficients of both steps                   ~360
-//   w7    D     columns of segments 8..11, both steps        700
+//   w7    D     columns of segments 8..11, both steps        680
 //
 // (hardware places wave i and wave i + 4 of a workgroup on the same SIMD: tools/micro/sync_probe.hip).  w4 runs with
-// raised priority so that its step finishes early in the phase and w5 can interleave with w1.  Skew as before: the
-// coefficient wave is one phase behind the base wave, the columns two; hand-overs double-buffered per phase in LDS
-// (91 KB: one workgroup per CU); n/2 + 2 phases per sweep.  Every wave executes the same barriers; the only poll is w5
-// waiting for w4 of the same phase, which never waits for anything itself.
+// raised priority so that its step finishes early in the phase and w5 can interleave with w1.
 //
-// For the always-thrust-limited control laws (p = 0, p = 1) of the 14-dim system nothing depends on lambda_m, so the base
-// wave integrates 13 components and the coefficient wave -- which evaluates lambda_m_dot at every stage argument anyway --
-// accumulates lambda_m off the critical stream.
+// Skew: ONE RK4 step per hand-over, as in the one-step-per-phase kernels, although the barrier comes every two steps.  In
+// phase p the base wave integrates steps 2p, 2p + 1; the coefficient wave builds steps 2p - 1 (published before the last
+// barrier) and 2p (published during this phase: it waits for the base wave's counter); the column waves advance steps
+// 2p - 2 (coefficients complete since the last barrier) and 2p - 1 (built during this phase: they wait for the coefficient
+// wave's counter, which by then is long set).  Both hand-overs are rings of four steps in LDS (91 KB in all: one
+// workgroup per CU); steps / 2 + 1 phases per sweep.  Waiting: a wave only ever waits (bounded poll of one LDS word) for a
+// wave that, in this phase, waits for nothing that depends on the waiter -- base: never; coefficients: base; w4: nothing;
+// columns: coefficients' first pass; w5: w4 -- so every wave reaches every barrier.  A poll that runs out (it cannot
+// while the producer runs) raises a workgroup flag that turns the workgroup's outputs into NaN instead of hanging.
+//
+// For the always-thrust-limited control laws (p = 0, p = 1) of the 14-dim system nothing depends on lambda_m: the base
+// wave integrates 13 components, the coefficient wave -- which evaluates lambda_m_dot at every stage argument anyway --
+// accumulates lambda_m off the critical stream, and the STM column d/d lambda_m(t0) is the unit vector, so its lane stays
+// switched off (the sweep is power-limited: every idle lane buys shader clock).
 #include "pipe_common.hpp"
 
 namespace lto {
 
-constexpr int P8_SPIN_LIMIT = 1 << 22;
+constexpr int P8_SPIN_LIMIT = 1 << 22;   // polls before a waiting wave gives up (never hangs)
 
 #ifdef PIPE_PROBE   // development build: cycles each wave waits at the phase barriers -> defect[16][16 block + wave] (the probe script passes a defect buffer of 20 rows)
 #define P8_SYNC() do { const long long p8_t = clock64(); __syncthreads(); p8_wait += clock64() - p8_t; } while (0)
@@ -41,7 +49,7 @@ constexpr int P8_SPIN_LIMIT = 1 << 22;
 #define P8_SYNC() __syncthreads()
 #define P8_WAIT_DECL
 #define P8_WAIT_REPORT(a)
-#endif   // polls of w5 before it gives up and poisons its columns (never hangs)
+#endif
 
 template <int ND, int PM> struct Pipe8 {
   using Arg = PipeArg<ND, PM>;
@@ -50,10 +58,35 @@ template <int ND, int PM> struct Pipe8 {
   static constexpr int SD = CoefBySegment::stage_doubles<NC>();        // doubles per (step, stage) coefficient slab
   static constexpr bool LM_OFF = (ND == 14) && !Arg::LM;              // lambda_m integrated by the coefficient wave
   static constexpr int NB = LM_OFF ? ND - 1 : ND;                     // components the base wave integrates
-  static constexpr int INT_DOUBLES = 2 * 2 * 4 * NI * PIPE_SEG;       // [phase parity][step of pair][stage][value][segment]
-  static constexpr int COEF_DOUBLES = 2 * 2 * 4 * SD;
+  static constexpr int NA = LM_OFF ? ND - 1 : ND;                     // STM columns a row integrates (the rest: unit vectors)
+  static constexpr int INT_DOUBLES = 4 * 4 * NI * PIPE_SEG;           // ring [step & 3][stage][value][segment]
+  static constexpr int COEF_DOUBLES = 4 * 4 * SD;                     // ring [step & 3][stage][record]
   static constexpr int HAND_DOUBLES = ND * 64;                        // [component][lane] of the alternating column job
 };
+
+struct Pipe8Flags {
+  int base_steps;    // steps whose stage arguments the base wave has published
+  int coef_steps;    // steps whose coefficients are complete
+  int hand;          // phases in which w4 has handed its state to w5
+  int fail;          // a poll ran out
+};
+
+// wait until *flag >= want (flags only grow); wave-uniform
+__device__ __forceinline__ void p8_wait_for(int* flag, const int want, int* fail) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+    if (++spins >= P8_SPIN_LIMIT) { __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+// The LDS operations of one wavefront execute in order, so a plain store issued after the data stores is a release for a
+// reader that acquires; the empty asm keeps the compiler from moving the data stores below it.  (A release store proper
+// makes the wave wait for its outstanding LDS stores first: ~90 cycles per phase on the base wave's chain.)
+__device__ __forceinline__ void p8_signal(int* flag, const int value) {
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
 
 // ---------------------------------------------------------------------------------------------------------- base role
 // As pipe_role_base (row g of the wave keeps the argument of stage g in registers; ONE set of stores per step publishes all
@@ -62,7 +95,7 @@ template <int ND, int PM> struct Pipe8 {
 // LDS stores per step on the chain cost more (S = 29: 79 -> 84 us).
 template <int ND, int PM>
 __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const PipeLane& L, const int seg, const int slot,
-                                                double* s_int) {
+                                                double* s_int, Pipe8Flags* fl) {
   using P = Pipe8<ND, PM>;
   constexpr int NI = P::NI, NB = P::NB;
   const int steps = a.steps, npairs = (steps + 1) >> 1;
@@ -78,10 +111,11 @@ __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const Pip
   const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
 #endif
   P8_WAIT_DECL;
-  for (int p = 0; p < npairs + 2; ++p) {
+  for (int p = 0; p < npairs + 1; ++p) {
     if (p < npairs && PIPE_ROLE_ON(a, 1) && (PIPE_ROLE_ON(a, 16) || slot == 0)) {
       for (int j = 0; j < 2; ++j) {
-        if (2 * p + j >= steps) break;
+        const int step = 2 * p + j;
+        if (step >= steps) break;
         double k[ND], yt[ND], acc[ND], keep[NI];
 #pragma unroll
         for (int c = 0; c < ND; ++c) { yt[c] = y[c]; acc[c] = y[c]; }
@@ -107,33 +141,35 @@ __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const Pip
         rhs(yt, k);
 #pragma unroll
         for (int c = 0; c < NB; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
-        double* dst = s_int + ((((p & 1) * 2 + j) * 4 + slot) * NI) * PIPE_SEG + seg;
+        double* dst = s_int + (((step & 3) * 4 + slot) * NI) * PIPE_SEG + seg;
 #pragma unroll
         for (int e = 0; e < NI; ++e) dst[e * PIPE_SEG] = keep[e];
+        if (j == 0) p8_signal(&fl->base_steps, step + 1);   // the phase's first step: the coefficient wave is waiting for it
       }
     }
     P8_SYNC();
   }
   P8_WAIT_REPORT(a);
   if (L.in_range && slot == 0) {
+    const bool fail = fl->fail != 0;
     if (a.defect) {
 #pragma unroll
-      for (int c = 0; c < NB; ++c) a.defect[c * a.ldd + L.s] = y[c] - a.X[c * a.ldx + L.node + 1];
+      for (int c = 0; c < NB; ++c) a.defect[c * a.ldd + L.s] = fail ? __builtin_nan("") : y[c] - a.X[c * a.ldx + L.node + 1];
     }
     if (a.errors) a.errors[L.s] = 0.0;
     if (a.nacc) a.nacc[L.s] = steps;
     if (a.nrej) a.nrej[L.s] = 0;
-#ifdef PIPE_PROBE   // shader clock during the sweep: s_memtime ticks and 100 MHz ticks of the phase loop, per workgroup
+#ifdef PIPE_PROBE   // s_memtime ticks and 100 MHz ticks of the phase loop, per workgroup
     if (seg == 0 && a.defect) { a.defect[17 * a.ldd + L.s] = (double)(clock64() - probe_c0); a.defect[18 * a.ldd + L.s] = (double)(wall_clock64() - probe_w0); }
 #endif
   }
 }
 
 // --------------------------------------------------------------------------------------------------- coefficient role
-// lane = (segment, RK stage); one pass per step, two passes per phase, one phase behind the base wave.
+// lane = (segment, RK stage); phase p: step 2p - 1, then step 2p as soon as the base wave has published it.
 template <int ND, int PM>
 __device__ __forceinline__ void pipe8_role_coef(const IndirectArgs& a, const PipeLane& L, const int seg, const int stage,
-                                                const double* s_int, double* s_coef, double* s_lm) {
+                                                const double* s_int, double* s_coef, double* s_lm, Pipe8Flags* fl) {
   using P = Pipe8<ND, PM>;
   using Coef = typename PipeCoef<ND>::type;
   constexpr int NI = P::NI, NC = P::NC, SD = P::SD;
@@ -143,26 +179,34 @@ __device__ __forceinline__ void pipe8_role_coef(const IndirectArgs& a, const Pip
   const double as = (stage == 2) ? L.h : 0.5 * L.h;
   const double bw = (stage == 0 || stage == 3) ? L.h * (1.0 / 6.0) : L.h * (1.0 / 3.0);   // RK4 weight of the stage's slope
   double lm_acc = 0.0;
+  auto build = [&](const int step) {
+    const int slab = (step & 3) * 4 + stage;
+    double arg[ND], dead[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c) arg[c] = 0.0;
+    const double* src = s_int + (slab * NI) * PIPE_SEG + seg;
+#pragma unroll
+    for (int e = 0; e < NI; ++e) arg[P::Arg::idx[e]] = src[e * PIPE_SEG];
+    Coef vc;
+    if constexpr (ND == 12) rhs12<PM, true>(arg, L.tp, dead, vc);
+    else rhs14<PM, true>(arg, L.tp, dead, vc);
+    if constexpr (P::LM_OFF) lm_acc = __builtin_fma(bw, dead[ND - 1], lm_acc);   // lambda_m_dot = -umag n / m at this stage
+    const double* o = reinterpret_cast<const double*>(&vc);
+    double* dst = s_coef + slab * SD;
+    constexpr int NST = P::LM_OFF ? NC - 1 : NC;     // d lambda_m_dot / d lambda_m = 0 for these laws: never read
+#pragma unroll
+    for (int e = 0; e < NST; ++e) dst[CoefBySegment::at<P::NA>(e, seg)] = (e < 14 || e > 16) ? o[e] * as : o[e];
+  };
   P8_WAIT_DECL;
-  for (int p = 0; p < npairs + 2; ++p) {
-    if (p >= 1 && p <= npairs && PIPE_ROLE_ON(a, 2)) {
-      for (int j = 0; j < 2; ++j) {
-        if (2 * (p - 1) + j >= steps) break;
-        const int slab = (((p - 1) & 1) * 2 + j) * 4 + stage;
-        double arg[ND], dead[ND];
-#pragma unroll
-        for (int c = 0; c < ND; ++c) arg[c] = 0.0;
-        const double* src = s_int + (slab * NI) * PIPE_SEG + seg;
-#pragma unroll
-        for (int e = 0; e < NI; ++e) arg[P::Arg::idx[e]] = src[e * PIPE_SEG];
-        Coef vc;
-        if constexpr (ND == 12) rhs12<PM, true>(arg, L.tp, dead, vc);
-        else rhs14<PM, true>(arg, L.tp, dead, vc);
-        if constexpr (P::LM_OFF) lm_acc = __builtin_fma(bw, dead[ND - 1], lm_acc);   // lambda_m_dot = -umag n / m at this stage
-        const double* o = reinterpret_cast<const double*>(&vc);
-        double* dst = s_coef + slab * SD;
-#pragma unroll
-        for (int e = 0; e < NC; ++e) dst[CoefBySegment::at<ND>(e, seg)] = (e < 14 || e > 16) ? o[e] * as : o[e];
+  for (int p = 0; p < npairs + 1; ++p) {
+    if (PIPE_ROLE_ON(a, 2)) {
+      if (p >= 1 && 2 * p - 1 < steps) {
+        build(2 * p - 1);
+        p8_signal(&fl->coef_steps, 2 * p);
+      }
+      if (2 * p < steps) {
+        if (PIPE_ROLE_ON(a, 1)) p8_wait_for(&fl->base_steps, 2 * p + 1, &fl->fail);
+        build(2 * p);
       }
     }
     P8_SYNC();
@@ -176,84 +220,95 @@ __device__ __forceinline__ void pipe8_role_coef(const IndirectArgs& a, const Pip
     if (L.in_range && stage == 0 && a.defect) {
       const double sum = (s_lm[seg] + s_lm[PIPE_SEG + seg]) + (s_lm[2 * PIPE_SEG + seg] + s_lm[3 * PIPE_SEG + seg]);
       const long r = (long)(ND - 1) * a.ldx + L.node;
-      a.defect[(ND - 1) * a.ldd + L.s] = (a.X[r] + sum) - a.X[r + 1];
+      a.defect[(ND - 1) * a.ldd + L.s] = fl->fail ? __builtin_nan("") : (a.X[r] + sum) - a.X[r + 1];
     }
+  }
+}
+
+// STM column `col` of the lane's segment to global memory: y carries 3^k Phi (stm_scale undoes it); columns the row does
+// not integrate (col >= NA) are unit vectors.
+template <int ND, int NA>
+__device__ __forceinline__ void pipe8_store_column(const IndirectArgs& a, const PipeLane& L, const int col, const double (&y)[ND],
+                                                   const bool fail) {
+  if (L.in_range && col < ND) {
+    const double sc = (col < NA) ? a.stm_scale : 1.0;
+#pragma unroll
+    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = fail ? __builtin_nan("") : y[r] * sc;
   }
 }
 
 // ------------------------------------------------------------------------------ column role, both steps of every phase
 template <int ND, int PM>
 __device__ __forceinline__ void pipe8_role_columns(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
-                                                   const double* s_coef) {
+                                                   const double* s_coef, Pipe8Flags* fl) {
   using P = Pipe8<ND, PM>;
   constexpr int SD = P::SD;
   const int steps = a.steps, npairs = (steps + 1) >> 1;
   const ColStepConst k(L.h, L.w2);
+  const double* rec = s_coef + CoefBySegment::lane_base(col, seg);
   double y[ND];
 #pragma unroll
   for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
   P8_WAIT_DECL;
-  for (int p = 0; p < npairs + 2; ++p) {
-    if (p >= 2 && PIPE_ROLE_ON(a, 4) && col < ND) {   // the spare lanes of a row stay switched off: never DPP sources
-      for (int j = 0; j < 2; ++j) {
-        const int step = 2 * (p - 2) + j;
-        if (step >= steps) break;
-        col_dpp_step<ND, SD, P::Arg::LM>(s_coef + (((p & 1) * 2 + j) * 4) * SD + CoefBySegment::lane_base(col, seg), k, step, y);
+  for (int p = 0; p < npairs + 1; ++p) {
+    if (p >= 1 && PIPE_ROLE_ON(a, 4)) {
+      const int s0 = 2 * p - 2, s1 = 2 * p - 1;
+      if (col < P::NA) col_dpp_step<ND, SD, P::Arg::LM, P::NA>(rec + ((s0 & 3) * 4) * SD, k, s0, y);   // spare lanes stay off: never DPP sources
+      if (s1 < steps) {
+        if (PIPE_ROLE_ON(a, 2)) p8_wait_for(&fl->coef_steps, s1 + 1, &fl->fail);
+        if (col < P::NA) col_dpp_step<ND, SD, P::Arg::LM, P::NA>(rec + ((s1 & 3) * 4) * SD, k, s1, y);
       }
     }
     P8_SYNC();
   }
   P8_WAIT_REPORT(a);
-  if (L.in_range && col < ND) {
-#pragma unroll
-    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = y[r] * a.stm_scale;
-  }
+  pipe8_store_column<ND, P::NA>(a, L, col, y, fl->fail != 0);
 }
 
 // --------------------------------------------------------------- column role of the alternating job (segments 12..15)
-// ODD = false (w4): step 2q of pair q, then state -> s_hand, flag = q + 1.  ODD = true (w5): waits for flag >= q + 1,
-// state <- s_hand, step 2q + 1, state -> s_hand.  The barrier at the end of the phase orders w5's stores before w4's
-// loads of the next phase.  After the last phase w4 stores the STM columns from s_hand.
+// ODD = false (w4): step 2p - 2 in phase p, then state -> s_hand, hand = p.  ODD = true (w5): waits for the coefficients
+// of step 2p - 1 and for hand >= p, state <- s_hand, step 2p - 1, state -> s_hand.  The barrier at the end of the phase
+// orders w5's stores before w4's loads of the next phase.  After the last phase w4 stores the STM columns from s_hand.
 template <int ND, int PM, bool ODD>
 __device__ __forceinline__ void pipe8_role_columns_alt(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
-                                                       const double* s_coef, double* s_hand, int* s_flag) {
+                                                       const double* s_coef, double* s_hand, Pipe8Flags* fl) {
   using P = Pipe8<ND, PM>;
   constexpr int SD = P::SD;
   const int steps = a.steps, npairs = (steps + 1) >> 1;
   const int lane = threadIdx.x & 63;
   const ColStepConst k(L.h, L.w2);
+  const double* rec = s_coef + CoefBySegment::lane_base(col, seg);
+  const bool on = col < P::NA;
   double y[ND];
 #pragma unroll
   for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
   auto load = [&]() {
+    if (on) {
 #pragma unroll
-    for (int r = 0; r < ND; ++r) y[r] = s_hand[r * 64 + lane];
+      for (int r = 0; r < ND; ++r) y[r] = s_hand[r * 64 + lane];
+    }
   };
   auto store = [&]() {
+    if (on) {
 #pragma unroll
-    for (int r = 0; r < ND; ++r) s_hand[r * 64 + lane] = y[r];
+      for (int r = 0; r < ND; ++r) s_hand[r * 64 + lane] = y[r];
+    }
   };
   if (!ODD) __builtin_amdgcn_s_setprio(2);
   P8_WAIT_DECL;
-  for (int p = 0; p < npairs + 2; ++p) {
-    if (p >= 2 && PIPE_ROLE_ON(a, 4) && col < ND) {
-      const int q = p - 2;
-      const double* rec = s_coef + (((p & 1) * 2 + (ODD ? 1 : 0)) * 4) * SD + CoefBySegment::lane_base(col, seg);
+  for (int p = 0; p < npairs + 1; ++p) {
+    if (p >= 1 && PIPE_ROLE_ON(a, 4)) {
+      const int step = 2 * p - 2 + (ODD ? 1 : 0);
       if (!ODD) {
-        if (q > 0) load();
-        col_dpp_step<ND, SD, P::Arg::LM>(rec, k, 2 * q, y);
+        if (p > 1) load();
+        if (on) col_dpp_step<ND, SD, P::Arg::LM, P::NA>(rec + ((step & 3) * 4) * SD, k, step, y);
         store();
-        __hip_atomic_store(s_flag, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else if (2 * q + 1 < steps) {
-        int spins = 0;
-        while (__hip_atomic_load(s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < q + 1 && ++spins < P8_SPIN_LIMIT)
-          __builtin_amdgcn_s_sleep(2);
+        p8_signal(&fl->hand, p);
+      } else if (step < steps) {
+        if (PIPE_ROLE_ON(a, 2)) p8_wait_for(&fl->coef_steps, step + 1, &fl->fail);
+        p8_wait_for(&fl->hand, p, &fl->fail);
         load();
-        if (spins >= P8_SPIN_LIMIT) {   // cannot happen while w4 runs; poison rather than hang or return stale columns
-#pragma unroll
-          for (int r = 0; r < ND; ++r) y[r] = __builtin_nan("");
-        }
-        col_dpp_step<ND, SD, P::Arg::LM>(rec, k, 2 * q + 1, y);
+        if (on) col_dpp_step<ND, SD, P::Arg::LM, P::NA>(rec + ((step & 3) * 4) * SD, k, step, y);
         store();
       }
     }
@@ -262,10 +317,7 @@ __device__ __forceinline__ void pipe8_role_columns_alt(const IndirectArgs& a, co
   P8_WAIT_REPORT(a);
   if (!ODD) {
     load();
-    if (L.in_range && col < ND) {
-#pragma unroll
-      for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = y[r] * a.stm_scale;
-    }
+    pipe8_store_column<ND, P::NA>(a, L, col, y, fl->fail != 0);
   }
 }
 
@@ -277,7 +329,7 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   __shared__ double s_coef[P::COEF_DOUBLES];
   __shared__ double s_hand[P::HAND_DOUBLES];
   __shared__ double s_lm[4 * PIPE_SEG];
-  __shared__ int s_flag;
+  __shared__ Pipe8Flags s_fl;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // waves 0, 1, 7: column waves 0, 1, 2; waves 4, 5: the alternating column job 3; wave 2 base, wave 3 coefficients
@@ -285,14 +337,14 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   const int cw = (wave == 7) ? 2 : (wave >= 4) ? 3 : wave;
   const int seg = col_wave ? cw * 4 + (lane >> 4) : (lane & (PIPE_SEG - 1));
   const PipeLane L = pipe_lane<PM>(a, seg);
-  if (threadIdx.x == 0) s_flag = 0;
+  if (threadIdx.x == 0) { s_fl.base_steps = 0; s_fl.coef_steps = 0; s_fl.hand = 0; s_fl.fail = 0; }
   if (!__syncthreads_or(L.mine)) return;         // workgroup-uniform
   if (wave == 6) return;                         // shares the base wave's SIMD: leaves before the first phase barrier
-  if (wave == 2) pipe8_role_base<ND, PM>(a, L, seg, lane >> 4, s_int);
-  else if (wave == 3) pipe8_role_coef<ND, PM>(a, L, seg, lane >> 4, s_int, s_coef, s_lm);
-  else if (wave == 4) pipe8_role_columns_alt<ND, PM, false>(a, L, seg, lane & 15, s_coef, s_hand, &s_flag);
-  else if (wave == 5) pipe8_role_columns_alt<ND, PM, true>(a, L, seg, lane & 15, s_coef, s_hand, &s_flag);
-  else pipe8_role_columns<ND, PM>(a, L, seg, lane & 15, s_coef);
+  if (wave == 2) pipe8_role_base<ND, PM>(a, L, seg, lane >> 4, s_int, &s_fl);
+  else if (wave == 3) pipe8_role_coef<ND, PM>(a, L, seg, lane >> 4, s_int, s_coef, s_lm, &s_fl);
+  else if (wave == 4) pipe8_role_columns_alt<ND, PM, false>(a, L, seg, lane & 15, s_coef, s_hand, &s_fl);
+  else if (wave == 5) pipe8_role_columns_alt<ND, PM, true>(a, L, seg, lane & 15, s_coef, s_hand, &s_fl);
+  else pipe8_role_columns<ND, PM>(a, L, seg, lane & 15, s_coef, &s_fl);
 }
 
 template <int ND, int PM>

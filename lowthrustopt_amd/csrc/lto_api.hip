@@ -413,19 +413,22 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  // Kernel choice (DESIGN.md "Kernels", measured on MI355X).  RK4: the three-role pipeline kernels -- the six-wave form
-  // (one column per lane, coefficients broadcast inside the FMA) up to one workgroup per CU (4 096 segments: 14-dim
-  // 103 us against 111 us four-wave, 168 us per-lane, 245 us cooperative), the four-wave form, which fits two
-  // workgroups per CU, beyond: for 14-dim at every size (262 144 segments: 4.9 ms against 6.3 ms per-lane), for 12-dim
-  // up to ~12 000 segments, where the per-lane kernel with 3 columns per lane takes over.  13-stage methods ->
-  // wave-specialised kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms), whose
-  // 12/14-component lanes keep all slopes in registers.
+  // Kernel choice (DESIGN.md "Kernels", measured on MI355X, tools/probe_kernels.py).  RK4: the three-role pipeline
+  // kernels -- the eight-wave form (two steps per phase, a fourth of the column work alternating between two SIMDs) up
+  // to one workgroup per CU (4 096 segments, 14-dim: 81 us against 89 us six-wave, 104 us four-wave, 174 us per-lane,
+  // 243 us cooperative; 12-dim: 78 / 80 / 87 / 134 / 142 us) and, for 14-dim, on to ~130 000 segments (65 536: 1.27 ms
+  // against 1.29 ms four-wave, 1.59 ms per-lane); beyond that the four-wave form, which fits two workgroups per CU
+  // (262 144 segments 14-dim: 4.8 ms against 5.0 ms eight-wave, 6.3 ms per-lane).  12-dim above 4 096 segments: four-wave
+  // form up to ~12 000 segments, then the per-lane kernel with 3 columns per lane.  13-stage methods -> wave-specialised
+  // kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms), whose 12/14-component
+  // lanes keep all slopes in registers.
   int kern = p->kernel;
   if (kern == LTO_KERNEL_AUTO) {
     if (p->integ.method != LTO_RK4) kern = LTO_KERNEL_COOP;
-    else if (p->integ.steps < 6) kern = LTO_KERNEL_PER_LANE;   // steps + 2 phases: fill and drain outweigh the shorter phase
-    else if (p->S <= 4096) kern = LTO_KERNEL_PIPE6;
-    else kern = (p->ndim == 14 || p->S <= 12288) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
+    else if (p->integ.steps < 6) kern = LTO_KERNEL_PER_LANE;   // fill and drain phases outweigh the shorter phase
+    else if (p->S <= 4096) kern = LTO_KERNEL_PIPE8;
+    else if (p->ndim == 14) kern = (p->S <= 131072) ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PIPE;
+    else kern = (p->S <= 12288) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
   }
   p->last_kernel = kern;
   hipError_t e;

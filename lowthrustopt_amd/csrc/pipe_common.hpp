@@ -38,9 +38,9 @@ struct CoefBySegment {   // [segment][value], records padded to 33 doubles: the 
   static constexpr bool SCALED = true;
   template <int NC> static constexpr int stage_doubles() { return PIPE_SEG * LD; }
   // column lane j of a row reads doubles j and 16 + j of its segment's record; value e of VarCoef12 / 14 sits in the
-  // first double of lane e for e < ND and in the second double of lane e - ND beyond, so that only the ND column lanes
-  // of a row are ever DPP sources and the two (four) spare lanes can stay switched off
-  template <int ND> __device__ static int at(int e, int seg) { return seg * LD + (e < ND ? e : 16 + e - ND); }
+  // first double of lane e for e < NA and in the second double of lane e - NA beyond (NA = active column lanes of a
+  // row), so that only active lanes are ever DPP sources and the spare lanes can stay switched off
+  template <int NA> __device__ static int at(int e, int seg) { return seg * LD + (e < NA ? e : 16 + e - NA); }
   __device__ static int lane_base(int lane, int seg) { return seg * LD + lane; }
 };
 
@@ -97,10 +97,11 @@ __device__ __forceinline__ void fmac_bn(double& acc, const double c, const doubl
 }
 
 // acc (+/-)= value E of the segment's VarCoef12 / 14 record (CoefBySegment placement) * x
-template <int ND, int E, bool NEG = false>
+template <int NA, int E, bool NEG = false>
 __device__ __forceinline__ void fmac_c(double& acc, const double cA, const double cB, const double x) {
-  if constexpr (E < ND) { if constexpr (NEG) fmac_bn<E>(acc, cA, x); else fmac_b<E>(acc, cA, x); }
-  else { if constexpr (NEG) fmac_bn<E - ND>(acc, cB, x); else fmac_b<E - ND>(acc, cB, x); }
+  static_assert(E < 2 * NA && NA <= 16, "record value outside the active lanes");
+  if constexpr (E < NA) { if constexpr (NEG) fmac_bn<E>(acc, cA, x); else fmac_b<E>(acc, cA, x); }
+  else { if constexpr (NEG) fmac_bn<E - NA>(acc, cB, x); else fmac_b<E - NA>(acc, cB, x); }
 }
 
 // One RK4 stage of one STM column with the coefficients spread over the row (cA, cB: this lane's two doubles of the record
@@ -110,7 +111,7 @@ __device__ __forceinline__ void fmac_c(double& acc, const double cA, const doubl
 // The rows with coefficient products accumulate straight onto init (no separate slope, no separate RK update); the
 // Coriolis rows start with a plain FMA, the others with a copy of init.  Same formulas as var_col12 / var_col14.
 // LM = false (always-thrust-limited laws of the 14-dim system): d lambda_m_dot / d lambda_m = 0, that term is skipped.
-template <int ND, bool LM = true>
+template <int ND, bool LM = true, int NA = ND>
 __device__ __forceinline__ void col_dpp_stage(const double cA, const double cB, const double aw2, const double a,
                                               const double (&arg)[ND], const double (&init)[ND], double (&out)[ND]) {
   constexpr int G = (ND == 14) ? 7 : 6;     // first lambda_r row
@@ -118,8 +119,8 @@ __device__ __forceinline__ void col_dpp_stage(const double cA, const double cB, 
   enum { Gxx, Gyy, Gzz, Gxy, Gxz, Gyz, Hxx, Hyy, Hzz, Hxy, Hxz, Hyz, Ua, Ub, Lx, Ly, Lz, Umx, Umy, Umz, Mm, Mn, LLm, LLn, LLl };
   const double ax = arg[0], ay = arg[1], az = arg[2];
   const double dx = arg[D], dyv = arg[D + 1], dz = arg[D + 2];
-#define FM(E, acc, x) fmac_c<ND, E, false>(acc, cA, cB, x)
-#define FN(E, acc, x) fmac_c<ND, E, true>(acc, cA, cB, x)
+#define FM(E, acc, x) fmac_c<NA, E, false>(acc, cA, cB, x)
+#define FN(E, acc, x) fmac_c<NA, E, true>(acc, cA, cB, x)
   double ld = 0.0;
   FM(Lx, ld, dx); FM(Ly, ld, dyv); FM(Lz, ld, dz);
   double tl = 0.0;
@@ -165,19 +166,19 @@ struct ColStepConst {
   double h2, h, h2w, hw;
   __device__ __forceinline__ ColStepConst(double hh, double w2) : h2(0.5 * hh), h(hh), h2w(0.5 * hh * w2), hw(hh * w2) {}
 };
-template <int ND, int SD, bool LM = true>
+template <int ND, int SD, bool LM = true, int NA = ND>
 __device__ __forceinline__ void col_dpp_step(const double* rec, const ColStepConst& k, const int step, double (&y)[ND]) {
   double B[ND], V1[ND], V2[ND], V3[ND];
-  col_dpp_stage<ND, LM>(rec[0], rec[16], k.h2w, k.h2, y, y, V1);
+  col_dpp_stage<ND, LM, NA>(rec[0], rec[16], k.h2w, k.h2, y, y, V1);
 #pragma unroll
   for (int c = 0; c < ND; ++c) B[c] = V1[c] - y[c];
-  col_dpp_stage<ND, LM>(rec[SD], rec[SD + 16], k.h2w, k.h2, V1, y, V2);
+  col_dpp_stage<ND, LM, NA>(rec[SD], rec[SD + 16], k.h2w, k.h2, V1, y, V2);
 #pragma unroll
   for (int c = 0; c < ND; ++c) B[c] = __builtin_fma(2.0, V2[c], B[c]);
-  col_dpp_stage<ND, LM>(rec[2 * SD], rec[2 * SD + 16], k.hw, k.h, V2, y, V3);
+  col_dpp_stage<ND, LM, NA>(rec[2 * SD], rec[2 * SD + 16], k.hw, k.h, V2, y, V3);
 #pragma unroll
   for (int c = 0; c < ND; ++c) B[c] += V3[c];
-  col_dpp_stage<ND, LM>(rec[3 * SD], rec[3 * SD + 16], k.h2w, k.h2, V3, B, y);
+  col_dpp_stage<ND, LM, NA>(rec[3 * SD], rec[3 * SD + 16], k.h2w, k.h2, V3, B, y);
   if (((step + 1) & (COL_RESCALE_EVERY - 1)) == 0) {
 #pragma unroll
     for (int c = 0; c < ND; ++c) y[c] *= COL_RESCALE;

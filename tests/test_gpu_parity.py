@@ -978,11 +978,12 @@ def test_indirect_pipeline_kernel_is_rk4_only(gpu_ctx):
 
 
 def test_indirect_auto_kernel_choice(gpu_ctx):
-    """What LTO_KERNEL_AUTO resolves to (lto_indirect_plan_last_kernel): RK4 with >= 6 steps -> pipeline kernels (six-wave
-    form up to 4 096 segments, four-wave beyond; 12-dim falls back to the per-lane kernel above 12 288 segments), RK4 with
+    """What LTO_KERNEL_AUTO resolves to (lto_indirect_plan_last_kernel): RK4 with >= 6 steps -> pipeline kernels (eight-wave
+    form up to 4 096 segments and for 14-dim beyond, four-wave for 12-dim beyond; 12-dim falls back to the per-lane kernel above
+    12 288 segments), RK4 with
     fewer steps -> per-lane, 13-stage integrators -> cooperative."""
     import torch
-    cases = [(12, 30, lto.RK4, 64, "pipeline6"), (14, 4097, lto.RK4, 64, "pipeline6"), (14, 8193, lto.RK4, 64, "pipeline"),
+    cases = [(12, 30, lto.RK4, 64, "pipeline8"), (14, 4097, lto.RK4, 64, "pipeline8"), (14, 8193, lto.RK4, 64, "pipeline8"),
              (12, 8193, lto.RK4, 64, "pipeline"), (12, 16385, lto.RK4, 8, "per-lane"), (14, 30, lto.RK4, 2, "per-lane"),
              (12, 30, lto.DOP853_ADAPTIVE, 0, "cooperative"), (14, 30, lto.RKF78_FIXED, 4, "cooperative")]
     for ndim, n, method, steps, want in cases:
