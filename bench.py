@@ -210,6 +210,32 @@ def parity_vs_oracle(ndim, XC, T, defect, Phi, S):
             "sample_segments": ns, "oracle_rc": int(rc), "tolerance": 1e-10, "against": against}
 
 
+def leg_host_api(lto, ctx, XC, T, prm, integ, ndim, S, calls=30):
+    """The host-pointer ABI a Julia `ccall` binds (lto_indirect_jacobian): column-major host arrays in, Phi + defect out;
+    per call: plan looked up in the context's cache, H2D, sweep, D2H, one synchronise.  Wall time per call with
+    preallocated pageable outputs and with page-locked buffers from lto_host_alloc.  PCIe-inclusive -- never `value`."""
+    X = np.asfortranarray(XC[:, :, 0]); t = np.ascontiguousarray(T[:, 0])
+    n = S + 1
+    out_page = (np.zeros((ndim, ndim, S, 1), order="F"), np.zeros((ndim, S, 1), order="F"))
+    out_pin = (ctx.pinned_empty((ndim, ndim, S, 1)), ctx.pinned_empty((ndim, S, 1)))
+    X_pin = ctx.pinned_empty((ndim, n)); X_pin[:] = X
+    t_pin = ctx.pinned_empty((n,)); t_pin[:] = t
+
+    def per_call(fn):
+        fn(); fn()
+        ts = []
+        for _ in range(calls):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
+    ms_page = per_call(lambda: lto.indirect_stm(X, t, prm, integ, ctx=ctx, out=out_page))
+    ms_pin = per_call(lambda: lto.indirect_stm(X_pin, t_pin, prm, integ, ctx=ctx, out=out_pin))
+    assert np.array_equal(out_page[0], out_pin[0])
+    return {"entry_point": "lto_indirect_jacobian (Phi + defect), %d-dim, %d segments, through ctypes" % (ndim, S),
+            "ms_per_call_pageable": ms_page, "ms_per_call_page_locked": ms_pin, "calls": calls, "statistic": "median",
+            "segments_per_s_page_locked": S / (ms_pin * 1e-3), "bytes_out": 8 * (ndim * ndim + ndim) * S, "bytes_in": 8 * (ndim + 1) * n,
+            "note": "PCIe-inclusive host-buffer path (what a Julia ccall takes); `value` is the device-resident rate"}
+
+
 def leg_12dim(lto, synth, ctx, st, torch, a):
     """C2 on the reference's own 12-dim system: same segments, integrator, step count and timing method.  Returns the
     result object and a closure that adds the oracle parity figures (run after all GPU timing is done)."""
@@ -484,6 +510,8 @@ def main():
             if ncpu > 1:   # same restatement with the segment loop spread over every host core (reported, not the target)
                 out["cpu_baseline_all_cores"] = cpu_baseline("c3" if wl == "c3" else "c2", max(3.0, a.cpu_seconds / 3), threads=ncpu,
                                                              ndim=a.ndim)
+        if world == 1 and wl == "c2" and not a.method and not a.segments:
+            out["host_api"] = leg_host_api(lto, ctx, XC, T, prm, integ, a.ndim, S)
         if ref12 is not None:
             out["reference_system_12dim"] = ref12[0]
             if not a.no_cpu_baseline:

@@ -23,6 +23,8 @@
 #ifndef LTO_H
 #define LTO_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -72,9 +74,19 @@ typedef struct lto_direct_params {
 
 /* ------------------------------------------------------------------------------- context */
 /* One context per GPU (one process per GPU under torch.distributed / one Julia task).  device_id
- * is the HIP ordinal.  Owns a stream and grow-only device staging buffers. */
+ * is the HIP ordinal.  Owns a stream, grow-only device staging buffers and the plans of the host-pointer
+ * API (kept between calls: a Newton iteration calls with the same shapes and parameters every time).
+ * Lifetime: plans from lto_*_plan_create keep their context alive -- lto_destroy with such plans
+ * outstanding only marks the context, and the last lto_*_plan_destroy frees it (a garbage collector may
+ * run the finalizers of a context and of its plans in any order). */
 int lto_create(lto_ctx** out, int device_id);
 void lto_destroy(lto_ctx* ctx);
+/* Page-locked host memory for the arrays of the host-pointer API: with buffers from here the H2D / D2H
+ * copies of a call are plain DMA at link speed (the 4.7 MB of Phi of a 4 096-segment sweep: ~0.1 ms);
+ * pageable buffers work too and are staged by the HIP runtime (~3x slower).  Julia: unsafe_wrap the
+ * pointer as an Array and free it in a finalizer (julia/LowThrustOptHIP.jl: pinned_array). */
+int lto_host_alloc(lto_ctx* ctx, size_t bytes, void** out);
+int lto_host_free(lto_ctx* ctx, void* ptr);
 const char* lto_last_error(const lto_ctx* ctx);
 int lto_version(void);
 void* lto_ctx_stream(lto_ctx* ctx); /* the context's own non-blocking hipStream_t */
@@ -83,7 +95,9 @@ void* lto_ctx_stream(lto_ctx* ctx); /* the context's own non-blocking hipStream_
 int lto_set_timing(lto_ctx* ctx, int enabled);
 double lto_last_kernel_ms(lto_ctx* ctx);
 
-/* --------------------------------------------------------- host-pointer API (what Julia ccalls) */
+/* --------------------------------------------------------- host-pointer API (what Julia ccalls)
+ * Each call: plan looked up in the context's cache by (shape, integrator, parameter values) -> H2D ->
+ * sweep -> D2H -> one stream synchronise.  The caller's buffers are only touched inside the call. */
 
 /* Replaces defectCalc of multiShoot_CRTBP_indirect (src/multiShoot_CRTBP_indirect.jl:63-90).
  *   XC      [ndim x n_nodes x n_batch]   ndim = 12: the reference's state+costate system.

@@ -41,6 +41,8 @@ SIGNATURES = {
     "lto_version": (C.c_int, []),
     "lto_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "lto_destroy": (None, [_vp]),
+    "lto_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "lto_host_free": (C.c_int, [_vp, _vp]),
     "lto_last_error": (C.c_char_p, [_vp]),
     "lto_ctx_stream": (_vp, [_vp]),
     "lto_set_timing": (C.c_int, [_vp, C.c_int]),

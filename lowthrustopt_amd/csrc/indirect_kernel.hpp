@@ -94,6 +94,12 @@ __device__ __forceinline__ void run_rkf78_adaptive(const Sys& sys, const double 
     if (delta == 0.0) delta = 1e-16;
     h = fmin(hmax, 0.8 * h * sqrt(sqrt(sqrt(tau / delta))));
   }
+  // not at t1 (max_steps used up, ode78's step-size floor ode.jl:479,524, or a decreasing grid: forward integration
+  // only): no result -- NaN, never a state at some t < t1 that looks propagated
+  if (t < span || span < 0.0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) y[i] = __builtin_nan("");
+  }
 }
 
 // Adaptive DOP853 (DESIGN.md 'Integrators'): initial step by Hairer's d0/d1/d2 rule, accept if err < 1, factor = min(10, 0.9 err^(-1/8)) (<= 1 after a rejection),
@@ -104,7 +110,13 @@ __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, co
   constexpr int D = Sys::DIM;
   double K[13][D];
   nacc = 0; nrej = 0;
-  if (!(span > 0.0)) return;
+  if (!(span > 0.0)) {
+    if (span != 0.0) {     // decreasing grid (forward integration only) or NaN span: no result
+#pragma unroll
+      for (int i = 0; i < D; ++i) y[i] = __builtin_nan("");
+    }
+    return;
+  }
   sys.rhs(y, K[0]);
   double h_abs;
   {
@@ -164,6 +176,10 @@ __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, co
         t = span;
       }
     }
+  }
+  if (t < span) {                             // max_steps trial steps used up before t1: no result
+#pragma unroll
+    for (int i = 0; i < D; ++i) y[i] = __builtin_nan("");
   }
 }
 

@@ -37,6 +37,20 @@ struct lto_ctx {
   int* order_cache;      // [order_S + LTO_ORDER_BINS]
   long order_S;
   int order_ndim;
+  // plans of the host-pointer API, kept between calls (a Newton iteration calls with the same shapes and parameters
+  // every time: no parameter upload, no device allocation per call); owned by the context
+  struct HostPlan {
+    lto_indirect_plan* plan;
+    int ndim, n_nodes, n_batch, n_prm;
+    lto_integrator integ;
+    lto_params* prm;       // [n_prm] copy of the caller's parameters (the key)
+    unsigned long stamp;   // last use
+  } host_plans[4];
+  unsigned long stamp;
+  // lifetime: plans handed to the caller keep the context alive.  lto_destroy with such plans outstanding (a garbage
+  // collector runs finalizers in any order) only marks the context; the last lto_*_plan_destroy frees it.
+  int live_plans;
+  bool closing;
   char err[512];
 };
 
@@ -187,6 +201,11 @@ void timing_end(lto_ctx* c, hipStream_t st) {
 
 extern "C" {
 
+static void plan_free(lto_indirect_plan* p);
+static void ctx_free(lto_ctx* c);
+static int host_plan_acquire(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
+                             const lto_integrator* integ, lto_indirect_plan** out);
+
 int lto_version(void) { return LTO_VERSION; }
 
 int lto_create(lto_ctx** out, int device_id) {
@@ -214,8 +233,14 @@ int lto_create(lto_ctx** out, int device_id) {
 
 void lto_destroy(lto_ctx* c) {
   if (!c) return;
+  if (c->live_plans > 0) { c->closing = true; return; }   // freed by the last lto_*_plan_destroy
+  ctx_free(c);
+}
+
+static void ctx_free(lto_ctx* c) {
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)hipDeviceSynchronize();
+  for (auto& h : c->host_plans) { if (h.plan) plan_free(h.plan); std::free(h.prm); h.plan = nullptr; h.prm = nullptr; }
   if (c->arena) (void)hipFree(c->arena);
   if (c->order_cache) (void)hipFree(c->order_cache);
   for (int i = 0; i < 8; ++i) if (c->pool[i].ptr) (void)hipFree(c->pool[i].ptr);
@@ -245,8 +270,10 @@ double lto_last_kernel_ms(lto_ctx* c) {
 }
 
 /* ------------------------------------------------------------------------------ indirect plans */
-int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
-                             const lto_integrator* integ, lto_indirect_plan** out) {
+
+// plan construction without lifetime bookkeeping (the library's own short-lived and cached plans)
+static int plan_build(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
+                      const lto_integrator* integ, lto_indirect_plan** out) {
   if (!c || !out) return LTO_ENULL;
   *out = nullptr;
   if (!prm) return set_err(c, LTO_ENULL, "prm is NULL");
@@ -278,14 +305,34 @@ int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
     if (e == hipSuccess) e = pool_alloc(c, (void**)&p->d_nrej, sizeof(int) * (size_t)p->S);
   }
   if (e != hipSuccess) {
-    lto_indirect_plan_destroy(p);
+    plan_free(p);
     return set_err(c, LTO_EHIP, "plan allocation", e);
   }
   *out = p;
   return LTO_OK;
 }
 
+int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
+                             const lto_integrator* integ, lto_indirect_plan** out) {
+  const int rc = plan_build(c, ndim, n_nodes, n_batch, prm, n_prm, integ, out);
+  if (rc == LTO_OK) ++c->live_plans;
+  return rc;
+}
+
+// The caller may have launched sweeps of this plan on its own streams: the plan's device blocks go back to the
+// context's block cache (pool_free) and may be handed to the next plan at once, so everything in flight on the device
+// has to finish first.  Destroying a plan is rare; the library's own short-lived plans use plan_free after
+// synchronising the one stream they used.
 void lto_indirect_plan_destroy(lto_indirect_plan* p) {
+  if (!p) return;
+  lto_ctx* c = p->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  plan_free(p);
+  if (--c->live_plans <= 0 && c->closing) ctx_free(c);
+}
+
+static void plan_free(lto_indirect_plan* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
   pool_free(p->ctx, p->d_tp, sizeof(TrajParams) * (size_t)p->n_prm);
@@ -487,6 +534,7 @@ static bool host_order_wanted(const lto_indirect_plan* p, bool stm) {
 }
 
 static void host_order_adopt(lto_ctx* c, lto_indirect_plan* p, bool stm) {
+  if (p->order_borrowed) { p->d_order = nullptr; p->use_order = 0; p->order_borrowed = 0; }   // cached plan: the context's order may have moved
   if (!host_order_wanted(p, stm) || !c->order_cache || c->order_S != p->S || c->order_ndim != p->ndim) return;
   p->d_order = c->order_cache; p->order_borrowed = 1; p->use_order = 1;
 }
@@ -517,16 +565,16 @@ int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
                              double soc_threshold, double* xc_update, double* defect) {
   if (!c) return LTO_ENULL;
   if (!XC || !t || !xc_update) return set_err(c, LTO_ENULL, "XC, t or xc_update is NULL");
+  if (ndim != 12) return set_err(c, LTO_EUNSUPPORTED, "device Newton step is built for ndim = 12");
+  if (n_tgrids != 1 && n_tgrids != n_batch) return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
   lto_indirect_plan* p = nullptr;
-  int rc = lto_indirect_plan_create(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);
+  int rc = host_plan_acquire(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);   // cached between calls, owned by the context
   if (rc) return rc;
-  if (ndim != 12) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EUNSUPPORTED, "device Newton step is built for ndim = 12"); }
-  if (n_tgrids != 1 && n_tgrids != n_batch) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
   const long J = (long)n_nodes * n_batch, S = p->S;
   const size_t need = al256(sizeof(double) * 12 * J) * 5 + al256(sizeof(double) * n_nodes * n_tgrids) +
                       al256(sizeof(double) * 12 * S) * 3 + al256(sizeof(double) * 144 * S) + 16384;
   rc = arena_reserve(c, need);
-  if (rc) { lto_indirect_plan_destroy(p); return rc; }
+  if (rc) return rc;
   c->arena_top = 0;
   double* d_aos = arena_take<double>(c, (size_t)12 * J);
   double* d_X = arena_take<double>(c, (size_t)12 * J);
@@ -542,7 +590,7 @@ int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * 12 * J, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_aos, 12, J, d_X, J, st);
-  if (e != hipSuccess) { (void)hipStreamSynchronize(st); lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  if (e != hipSuccess) { (void)hipStreamSynchronize(st); return set_err(c, LTO_EHIP, "stage in", e); }
   host_order_adopt(c, p, true);
   rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
   if (rc == LTO_OK) host_order_refresh(c, p, true, st);
@@ -585,7 +633,6 @@ int lto_indirect_newton_step(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
     (void)hipStreamSynchronize(st);
   }
   std::free(h_del);
-  lto_indirect_plan_destroy(p);
   return rc;
 }
 
@@ -619,10 +666,10 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   }
   lto_indirect_plan* p = nullptr;
   lto_indirect_plan* pl = nullptr;
-  int rc = lto_indirect_plan_create(c, 12, n_nodes, B, prm, n_prm, integ, &p);
+  int rc = plan_build(c, 12, n_nodes, B, prm, n_prm, integ, &p);
   if (rc) return rc;
-  rc = lto_indirect_plan_create(c, 12, n_nodes, B * NA, n_prm == 1 ? prm : prm_l.data(), n_prm == 1 ? 1 : B * NA, integ, &pl);
-  if (rc) { lto_indirect_plan_destroy(p); return rc; }
+  rc = plan_build(c, 12, n_nodes, B * NA, n_prm == 1 ? prm : prm_l.data(), n_prm == 1 ? 1 : B * NA, integ, &pl);
+  if (rc) { plan_free(p); return rc; }
   const long n = n_nodes, J = n * B, S = (n - 1) * B;
   const int ntl = (n_tgrids == 1) ? 1 : B * NA;
   const size_t n_small = (size_t)12 * B + NA + 3 * (size_t)B + (size_t)NA * B + 64;
@@ -630,7 +677,7 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
                       al256(sizeof(double) * n * ntl) + al256(sizeof(double) * 12 * S) * 3 + al256(sizeof(double) * 12 * S * NA) +
                       al256(sizeof(double) * 144 * S) + al256(sizeof(double) * n_small) + 65536;
   rc = arena_reserve(c, need);
-  if (rc) { lto_indirect_plan_destroy(pl); lto_indirect_plan_destroy(p); return rc; }
+  if (rc) { plan_free(pl); plan_free(p); return rc; }
   c->arena_top = 0;
   double* d_aos = arena_take<double>(c, (size_t)12 * J);
   double* d_X = arena_take<double>(c, (size_t)12 * J);
@@ -763,8 +810,8 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
     (void)hipStreamSynchronize(st);
   }
   for (int b = 0; b < B; ++b) { status_flag[b] = status[b]; if (iterations) iterations[b] = it[b]; }
-  lto_indirect_plan_destroy(pl);
-  lto_indirect_plan_destroy(p);
+  plan_free(pl);
+  plan_free(p);
   return rc;
 }
 
@@ -798,8 +845,8 @@ int lto_indirect_dense_dev(lto_indirect_plan* p, void* stream, const double* X, 
 }
 
 /* ------------------------------------------------------------------------------ direct plans */
-int lto_direct_plan_create(lto_ctx* c, int nstate, int n_nodes, int n_batch, int nsteps, const lto_direct_params* prm,
-                           lto_direct_plan** out) {
+static int direct_plan_build(lto_ctx* c, int nstate, int n_nodes, int n_batch, int nsteps, const lto_direct_params* prm,
+                             lto_direct_plan** out) {
   if (!c || !out) return LTO_ENULL;
   *out = nullptr;
   if (!prm) return set_err(c, LTO_ENULL, "prm is NULL");
@@ -815,7 +862,20 @@ int lto_direct_plan_create(lto_ctx* c, int nstate, int n_nodes, int n_batch, int
   return LTO_OK;
 }
 
-void lto_direct_plan_destroy(lto_direct_plan* p) { delete p; }
+// user-visible direct plans keep the context alive like indirect ones (lto_destroy)
+int lto_direct_plan_create(lto_ctx* c, int nstate, int n_nodes, int n_batch, int nsteps, const lto_direct_params* prm,
+                           lto_direct_plan** out) {
+  const int rc = direct_plan_build(c, nstate, n_nodes, n_batch, nsteps, prm, out);
+  if (rc == LTO_OK) ++c->live_plans;
+  return rc;
+}
+
+void lto_direct_plan_destroy(lto_direct_plan* p) {
+  if (!p) return;
+  lto_ctx* c = p->ctx;
+  delete p;
+  if (--c->live_plans <= 0 && c->closing) ctx_free(c);
+}
 
 int lto_direct_plan_set_kernel(lto_direct_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
@@ -945,21 +1005,75 @@ int lto_defect_norms_dev(lto_ctx* c, void* stream, const double* defect, long ld
 
 /* ------------------------------------------------------------------------------ host-pointer API
  * H2D (Julia layout) -> pack to SoA -> sweep -> unpack -> D2H, all on the context's stream, then one
- * stream synchronise.  The caller's buffers are only touched inside the call. */
+ * stream synchronise.  The caller's buffers are only touched inside the call.  Pass buffers from lto_host_alloc
+ * (page-locked) and the copies are plain DMA at link speed; pageable buffers are staged by the HIP runtime. */
+
+// The plan of a host-pointer call: looked up in the context's small cache by (shape, integrator, parameter values),
+// built on a miss (least recently used entry replaced).  Owned by the context.
+static int host_plan_acquire(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
+                             const lto_integrator* integ, lto_indirect_plan** out) {
+  *out = nullptr;
+  if (!prm || !integ) return set_err(c, LTO_ENULL, "prm or integrator is NULL");
+  if (n_prm != 1 && n_prm != n_batch) return set_err(c, LTO_EINVAL, "n_prm must be 1 or n_batch");
+  lto_ctx::HostPlan* slot = nullptr;               // an empty entry, else the least recently used one
+  for (auto& h : c->host_plans) {
+    if (h.plan && h.ndim == ndim && h.n_nodes == n_nodes && h.n_batch == n_batch && h.n_prm == n_prm &&
+        std::memcmp(&h.integ, integ, sizeof *integ) == 0 && std::memcmp(h.prm, prm, sizeof(lto_params) * (size_t)n_prm) == 0) {
+      h.stamp = ++c->stamp;
+      *out = h.plan;
+      return LTO_OK;
+    }
+    if (!slot || (slot->plan && (!h.plan || h.stamp < slot->stamp))) slot = &h;
+  }
+  lto_ctx::HostPlan* lru = slot;
+  lto_indirect_plan* p = nullptr;
+  int rc = plan_build(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);
+  if (rc) return rc;
+  lto_params* key = (lto_params*)std::malloc(sizeof(lto_params) * (size_t)n_prm);
+  if (!key) { plan_free(p); return set_err(c, LTO_EHIP, "host allocation failed"); }
+  std::memcpy(key, prm, sizeof(lto_params) * (size_t)n_prm);
+  if (lru->plan) {                                  // the evicted plan's blocks are recycled: nothing of it may be in flight
+    (void)hipStreamSynchronize(c->stream);
+    plan_free(lru->plan);
+    std::free(lru->prm);
+  }
+  lru->plan = p; lru->prm = key; lru->ndim = ndim; lru->n_nodes = n_nodes; lru->n_batch = n_batch; lru->n_prm = n_prm;
+  lru->integ = *integ; lru->stamp = ++c->stamp;
+  *out = p;
+  return LTO_OK;
+}
+
+int lto_host_alloc(lto_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return LTO_ENULL;
+  *out = nullptr;
+  int rc = bind_device(c);
+  if (rc) return rc;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "hipHostMalloc", e);
+  return LTO_OK;
+}
+
+int lto_host_free(lto_ctx* c, void* ptr) {
+  if (!c) return LTO_ENULL;
+  if (!ptr) return LTO_OK;
+  hipError_t e = hipHostFree(ptr);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "hipHostFree", e);
+  return LTO_OK;
+}
 
 int lto_indirect_defect(lto_ctx* c, int ndim, int n_nodes, int n_batch, const double* XC, const double* t, int n_tgrids,
                         const lto_params* prm, int n_prm, const lto_integrator* integ, double* defect, double* errors) {
   if (!c) return LTO_ENULL;
   if (!XC || !t || !defect) return set_err(c, LTO_ENULL, "XC, t or defect is NULL");
+  if (n_tgrids != 1 && n_tgrids != n_batch) return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
   lto_indirect_plan* p = nullptr;
-  int rc = lto_indirect_plan_create(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);
+  int rc = host_plan_acquire(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);   // cached between calls, owned by the context
   if (rc) return rc;
-  if (n_tgrids != 1 && n_tgrids != n_batch) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
   const long J = (long)n_nodes * n_batch, S = p->S;
   const size_t need = al256(sizeof(double) * ndim * J) * 2 + al256(sizeof(double) * n_nodes * n_tgrids) +
                       al256(sizeof(double) * ndim * S) * 2 + al256(sizeof(double) * S) + 4096;
   rc = arena_reserve(c, need);
-  if (rc) { lto_indirect_plan_destroy(p); return rc; }
+  if (rc) return rc;
   c->arena_top = 0;
   double* d_aos = arena_take<double>(c, (size_t)ndim * J);
   double* d_X = arena_take<double>(c, (size_t)ndim * J);
@@ -971,7 +1085,7 @@ int lto_indirect_defect(lto_ctx* c, int ndim, int n_nodes, int n_batch, const do
   hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * ndim * J, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
-  if (e != hipSuccess) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  if (e != hipSuccess) { (void)hipStreamSynchronize(st); return set_err(c, LTO_EHIP, "stage in", e); }
   host_order_adopt(c, p, false);
   rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, errors ? d_err : nullptr);
   if (rc == LTO_OK) host_order_refresh(c, p, false, st);
@@ -984,7 +1098,6 @@ int lto_indirect_defect(lto_ctx* c, int ndim, int n_nodes, int n_batch, const do
   } else {
     (void)hipStreamSynchronize(st);
   }
-  lto_indirect_plan_destroy(p);
   return rc;
 }
 
@@ -992,16 +1105,16 @@ int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const 
                           const lto_params* prm, int n_prm, const lto_integrator* integ, double* Phi, double* defect) {
   if (!c) return LTO_ENULL;
   if (!XC || !t || !Phi) return set_err(c, LTO_ENULL, "XC, t or Phi is NULL");
+  if (n_tgrids != 1 && n_tgrids != n_batch) return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
   lto_indirect_plan* p = nullptr;
-  int rc = lto_indirect_plan_create(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);
+  int rc = host_plan_acquire(c, ndim, n_nodes, n_batch, prm, n_prm, integ, &p);   // cached between calls, owned by the context
   if (rc) return rc;
-  if (n_tgrids != 1 && n_tgrids != n_batch) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
   const long J = (long)n_nodes * n_batch, S = p->S;
   const int nn = ndim * ndim;
   const size_t need = al256(sizeof(double) * ndim * J) * 2 + al256(sizeof(double) * n_nodes * n_tgrids) +
                       al256(sizeof(double) * ndim * S) * 2 + al256(sizeof(double) * nn * S) * 2 + 4096;
   rc = arena_reserve(c, need);
-  if (rc) { lto_indirect_plan_destroy(p); return rc; }
+  if (rc) return rc;
   c->arena_top = 0;
   double* d_aos = arena_take<double>(c, (size_t)ndim * J);
   double* d_X = arena_take<double>(c, (size_t)ndim * J);
@@ -1014,7 +1127,7 @@ int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const 
   hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * ndim * J, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
-  if (e != hipSuccess) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  if (e != hipSuccess) { (void)hipStreamSynchronize(st); return set_err(c, LTO_EHIP, "stage in", e); }
   host_order_adopt(c, p, true);
   rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
   if (rc == LTO_OK) host_order_refresh(c, p, true, st);
@@ -1030,7 +1143,6 @@ int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const 
   } else {
     (void)hipStreamSynchronize(st);
   }
-  lto_indirect_plan_destroy(p);
   return rc;
 }
 
@@ -1043,11 +1155,11 @@ int lto_indirect_densify(lto_ctx* c, int ndim, int n_nodes, const double* XC, co
   if (!XC || !t || !XC_dense || !t_dense) return set_err(c, LTO_ENULL, "XC, t, XC_dense or t_dense is NULL");
   if (n_desired < 2) return set_err(c, LTO_EINVAL, "n_desired must be >= 2");
   lto_indirect_plan* p = nullptr;
-  int rc = lto_indirect_plan_create(c, ndim, n_nodes, 1, prm, 1, integ, &p);
+  int rc = plan_build(c, ndim, n_nodes, 1, prm, 1, integ, &p);
   if (rc) return rc;
   const int S = p->S;
   int* h_first = (int*)std::malloc(sizeof(int) * (size_t)(S + 1));
-  if (!h_first) { lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "host allocation failed"); }
+  if (!h_first) { plan_free(p); return set_err(c, LTO_EHIP, "host allocation failed"); }
   const double t0 = t[0], tn = t[n_nodes - 1];
   for (int k = 0; k < n_desired; ++k) {
     const double tau = (double)k / (double)(n_desired - 1);
@@ -1064,7 +1176,7 @@ int lto_indirect_densify(lto_ctx* c, int ndim, int n_nodes, const double* XC, co
   const size_t need = al256(sizeof(double) * ndim * J) * 2 + al256(sizeof(double) * n_nodes) + al256(sizeof(int) * (S + 1)) +
                       al256(sizeof(double) * n_desired) * 2 + al256(sizeof(double) * ndim * n_desired) * 2 + 8192;
   rc = arena_reserve(c, need);
-  if (rc) { std::free(h_first); lto_indirect_plan_destroy(p); return rc; }
+  if (rc) { std::free(h_first); plan_free(p); return rc; }
   c->arena_top = 0;
   double* d_aos = arena_take<double>(c, (size_t)ndim * J);
   double* d_X = arena_take<double>(c, (size_t)ndim * J);
@@ -1079,7 +1191,7 @@ int lto_indirect_densify(lto_ctx* c, int ndim, int n_nodes, const double* XC, co
   if (e == hipSuccess) e = hipMemcpyAsync(d_first, h_first, sizeof(int) * (S + 1), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_td, t_dense, sizeof(double) * n_desired, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
-  if (e != hipSuccess) { (void)hipStreamSynchronize(st); std::free(h_first); lto_indirect_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  if (e != hipSuccess) { (void)hipStreamSynchronize(st); std::free(h_first); plan_free(p); return set_err(c, LTO_EHIP, "stage in", e); }
   // the final state lands in the last column of Y: final_state[c * n_batch + traj] with ld = n_desired, offset n_desired-1
   // is not expressible through the [ND][n_batch] layout, so take it into the tail of d_Yaos and splice on the host side
   double* d_final = d_Yaos;   // [ndim] (n_batch = 1); overwritten by the unpack afterwards, so copy it out first
@@ -1096,7 +1208,7 @@ int lto_indirect_densify(lto_ctx* c, int ndim, int n_nodes, const double* XC, co
     (void)hipStreamSynchronize(st);
   }
   std::free(h_first);
-  lto_indirect_plan_destroy(p);
+  plan_free(p);
   return rc;
 }
 
@@ -1104,9 +1216,9 @@ static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const d
                        int n_tgrids, int nsteps, const lto_direct_params* prm, double* Jac_temp, double* ddefect_dtf,
                        double* defect, double* errors, bool want_jac, double* x_mid = nullptr) {
   lto_direct_plan* p = nullptr;
-  int rc = lto_direct_plan_create(c, nstate, n_nodes, n_batch, nsteps, prm, &p);
+  int rc = direct_plan_build(c, nstate, n_nodes, n_batch, nsteps, prm, &p);
   if (rc) return rc;
-  if (n_tgrids != 1 && n_tgrids != n_batch) { lto_direct_plan_destroy(p); return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
+  if (n_tgrids != 1 && n_tgrids != n_batch) { delete p; return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch"); }
   const long J = (long)n_nodes * n_batch, S = p->S;
   const int nvar = 2 * (nstate + 3), nj = nstate * nvar;
   size_t need = al256(sizeof(double) * nstate * J) * 2 + al256(sizeof(double) * 3 * J) * 2 +
@@ -1114,7 +1226,7 @@ static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const d
                 al256(sizeof(double) * S) + 8192;
   if (want_jac) need += al256(sizeof(double) * nj * S) * 2;
   rc = arena_reserve(c, need);
-  if (rc) { lto_direct_plan_destroy(p); return rc; }
+  if (rc) { delete p; return rc; }
   c->arena_top = 0;
   double* d_xa = arena_take<double>(c, (size_t)nstate * J);
   double* d_X = arena_take<double>(c, (size_t)nstate * J);
@@ -1134,7 +1246,7 @@ static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const d
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = launch_pack_soa(d_xa, nstate, J, d_X, J, st);
   if (e == hipSuccess) e = launch_pack_soa(d_ua, 3, J, d_U, J, st);
-  if (e != hipSuccess) { lto_direct_plan_destroy(p); return set_err(c, LTO_EHIP, "stage in", e); }
+  if (e != hipSuccess) { delete p; return set_err(c, LTO_EHIP, "stage in", e); }
   if (want_jac)
     rc = lto_direct_jacobian_dev(p, st, d_X, J, d_U, J, d_t, n_tgrids, d_jac, S, d_dtf, d_def, S, d_err);
   else   // the dtf staging buffers are free on this path: they carry the mid-point states
@@ -1162,7 +1274,7 @@ static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const d
   } else {
     (void)hipStreamSynchronize(st);
   }
-  lto_direct_plan_destroy(p);
+  delete p;
   return rc;
 }
 

@@ -105,10 +105,16 @@ def lineSearch(XC_all, xc_update, t_TU, params, ops):
 def multiShoot_CRTBP_indirect(XC_all, t_TU, MU, DU, TU, n_nodes, mass0, thrustLimit, plot_yn, flag_adjointsOnly,
                               maxIter, p, rho, ops=None, verbose=True):
     """Indirect multiple shooting with fixed end states (indirect.jl:58-61, :254-345).
-    Returns (XC_all, defect, status_flag): 0 converged, 1 maxIter reached, 2 NaN."""
-    if ops is None and np.asarray(XC_all).shape[0] == 12:
+    Returns (XC_all, defect, status_flag): 0 converged, 1 maxIter reached, 2 NaN.
+    The driver is the reference's: 12 rows (state + costate, constant mass `mass0`).  The 14-dim extension (mass and mass
+    costate as states, Isp in the parameter tuple's mass slot) exists for the sweeps only (indirect_defectCalc /
+    indirect_stm with ndim = 14) -- the reference's loop pins XC_all[1:6] and solves 12x12 blocks (indirect.jl:324-325)."""
+    if np.asarray(XC_all).shape[0] != 12:
+        raise ValueError("multiShoot_CRTBP_indirect drives the reference's 12-row state+costate system; got %d rows "
+                         "(the 14-dim extension is available through indirect_defectCalc / indirect_stm only)" % np.asarray(XC_all).shape[0])
+    if ops is None:
         # product default: the whole loop below is one library call with the trajectory resident on the device
-        # (lto_indirect_solve); the Python loop remains for injected back ends and for the 14-dim extension
+        # (lto_indirect_solve); the Python loop remains for injected back ends
         params = hotpath.make_params(MU, DU, TU, thrustLimit, mass0, 1.0, p, rho)
         XC_out, defect, status_flag, iterCount, hist = hotpath.indirect_solve(XC_all, t_TU, params, None, flag_adjointsOnly, maxIter)
         if verbose:

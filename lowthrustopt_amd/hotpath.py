@@ -13,6 +13,8 @@ library and a GPU every call raises.
 """
 import ctypes as C
 
+import weakref
+
 import numpy as np
 
 from . import _lib
@@ -59,11 +61,30 @@ class Context:
             raise LtoError(rc, "lto_create failed (no gfx950 device visible?)")
         self.handle = h
         self.device = int(device)
+        self._plans = weakref.WeakSet()      # device-resident plans created on this context
+        self._pinned = []                    # page-locked host blocks handed out by pinned_empty
 
     def close(self):
+        """Plans first, then the context.  (The C library tolerates the other order too -- lto_destroy defers while
+        plans are alive -- but a closed Context should not leave live handles behind.)"""
         if getattr(self, "handle", None):
+            for pl in list(self._plans):
+                pl.close()
+            for ptr in self._pinned:
+                self.lib.lto_host_free(self.handle, ptr)
+            self._pinned = []
             self.lib.lto_destroy(self.handle)
             self.handle = None
+
+    def pinned_empty(self, shape, order="F"):
+        """numpy float64 array in page-locked host memory (lto_host_alloc): H2D / D2H of the host-pointer API then run
+        as plain DMA.  The memory lives until the context is closed."""
+        n = int(np.prod(shape))
+        ptr = C.c_void_p()
+        self.check(self.lib.lto_host_alloc(self.handle, max(n, 1) * 8, C.byref(ptr)))
+        self._pinned.append(ptr)
+        buf = (C.c_double * max(n, 1)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape, order=order)
 
     def __del__(self):
         try:
@@ -180,17 +201,23 @@ def indirect_defectCalc(XC_all, t_TU, params, integ=None, ctx=None):
     return defect, errors
 
 
-def indirect_stm(XC_all, t_TU, params, integ=None, ctx=None):
+def indirect_stm(XC_all, t_TU, params, integ=None, ctx=None, out=None):
     """Compact Jacobian blocks: Phi[12 x 12 x (n-1)] with Phi[:,:,i] = d x(t_{i+1}) / d XC_all[:,i]
-    (the ForwardDiff.jacobian(f, x0) of :121), plus the defect."""
+    (the ForwardDiff.jacobian(f, x0) of :121), plus the defect.  out = (Phi, defect): Fortran-ordered float64 arrays of
+    shapes (ndim, ndim, n-1, B) and (ndim, n-1, B) written in place (e.g. from Context.pinned_empty)."""
     ctx = ctx or default_context()
     integ = integ or integrator()
     XC = _f64(XC_all)
     ndim, n, B, batched = _batch_dims(XC)
     t, ntg = _tgrids(t_TU, n, B)
     prm, nprm = _params_array(params)
-    Phi = np.zeros((ndim, ndim, n - 1, B), order="F")
-    defect = np.zeros((ndim, n - 1, B), order="F")
+    if out is not None:
+        Phi, defect = out
+        if Phi.shape != (ndim, ndim, n - 1, B) or defect.shape != (ndim, n - 1, B) or not (Phi.flags.f_contiguous and defect.flags.f_contiguous):
+            raise LtoError(-1, "out arrays must be Fortran-ordered (ndim, ndim, n-1, B) and (ndim, n-1, B)")
+    else:
+        Phi = np.empty((ndim, ndim, n - 1, B), order="F")
+        defect = np.empty((ndim, n - 1, B), order="F")
     ctx.check(ctx.fn("indirect_jacobian")(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
                                             _ptr(Phi), _ptr(defect)))
     if not batched:
@@ -430,6 +457,7 @@ class IndirectPlan:
         ctx.check(ctx.lib.lto_indirect_plan_create(ctx.handle, self.ndim, self.n_nodes, self.n_batch, prm, nprm,
                                                    C.byref(integ), C.byref(h)))
         self.handle = h
+        ctx._plans.add(self)
 
     KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE, KERNEL_PIPE6, KERNEL_PIPE8 = 0, 1, 2, 3, 4, 5
 
@@ -480,6 +508,7 @@ class IndirectPlan:
         if getattr(self, "handle", None):
             self.ctx.lib.lto_indirect_plan_destroy(self.handle)
             self.handle = None
+            self.ctx._plans.discard(self)
 
     def __del__(self):
         try:
@@ -498,6 +527,7 @@ class DirectPlan:
         ctx.check(ctx.lib.lto_direct_plan_create(ctx.handle, self.nstate, self.n_nodes, self.n_batch, self.nsteps,
                                                  C.byref(prm), C.byref(h)))
         self.handle = h
+        ctx._plans.add(self)
 
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_direct_plan_set_kernel(self.handle, int(kernel)))
@@ -520,6 +550,7 @@ class DirectPlan:
         if getattr(self, "handle", None):
             self.ctx.lib.lto_direct_plan_destroy(self.handle)
             self.handle = None
+            self.ctx._plans.discard(self)
 
     def __del__(self):
         try:

@@ -69,6 +69,16 @@ def test_driver_status_flags(oracle):
     assert status == 2                      # NaN (indirect.jl:339-341)
 
 
+def test_driver_rejects_the_14_row_extension(oracle):
+    """The driver is the reference's 12-row loop (end-state pinning of rows 1:6, 12x12 blocks); 14 rows used to run into
+    LTO_EUNSUPPORTED on the first Newton step with the mass slot silently read as Isp."""
+    XC, t, _ = consistent_problem(oracle)
+    X14 = np.zeros((14, XC.shape[1]))
+    X14[:6] = XC[:6]; X14[6] = 1000.0; X14[7:13] = XC[6:]
+    with pytest.raises(ValueError, match="12-row"):
+        drivers.multiShoot_CRTBP_indirect(X14, t, MU, DU, TU, 8, 1000.0, 10.0, False, False, 5, 2.0, 1.0, ops=OracleOps(oracle), verbose=False)
+
+
 def test_adjoints_only_mask_and_linesearch(oracle):
     XC, t, exact = consistent_problem(oracle, pert=0.0)
     rng = np.random.default_rng(5)

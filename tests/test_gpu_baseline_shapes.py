@@ -1,0 +1,154 @@
+"""GPU parity at BASELINE.json's stated shapes: each test runs the HIP path through the C ABI at
+the full configured size, compares an oracle sample of it (bit-level for integer-like properties, <= 1e-10 for floating
+point: same tableau and step grid on both sides, so differences are round-off), and checks a size-independent property.
+
+  configs[1]  indirect 14-dim + 14x14 STM, 4 096 segments, RK4 x 64, AUTO kernel
+  configs[2]  direct 6-state, 16 384 segments, RKF7(8) nsteps = 10, Jacobian blocks
+  configs[3]  homotopy sweep, 256 rho levels x 1 024 segments, 12-dim + STM, RK4 x 64
+  reference data: L2_Anderson_{1,2} halo tables fed to the HIP direct defect (CRTBP_Multishoot_indirect_demo.jl:66-70)
+"""
+import numpy as np
+import pytest
+
+import lowthrustopt_amd as lto
+from lowthrustopt_amd import synth
+from lowthrustopt_amd.constants import MU, DU, TU
+
+pytestmark = pytest.mark.gpu
+
+
+def test_configs3_homotopy_sweep_256_levels_x_1024_segments_with_stm(gpu_ctx, oracle):
+    """BASELINE configs[3] as written: 256 rho levels (1 -> 1e-4, reduceFuel_indirect's range) x 1 024 segments each
+    (n = 1025, B = 256), defect + 12x12 STM in ONE batched launch: finite; equals per-level launches bit for bit (a level's
+    result does not depend on its neighbours in the batch); a sample of segments on several levels equals the oracle's
+    dual-number STM; levels that share nodes but differ in rho differ."""
+    import torch
+    n, B = 1025, 256
+    S = (n - 1) * B
+    XC1, T1 = synth.indirect_problem(n, seed=10)
+    XC = np.asfortranarray(np.repeat(XC1, B, axis=2))             # every level starts from the same node set
+    T = np.asfortranarray(np.repeat(T1, B, axis=1))
+    rhos = synth.homotopy_rhos(B)
+    prm_l = [[MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, float(r)] for r in rhos]
+    prms = [lto.make_params(*q) for q in prm_l]
+    integ = lto.integrator(lto.RK4, steps=64)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()          # [level][node]
+    plan = lto.IndirectPlan(gpu_ctx, n, B, prms, integ)
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+    d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(X, n * B, t, B, Phi, S, d, S)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(Phi).all()) and bool(torch.isfinite(d).all())
+    kernel = plan.last_kernel()
+    plan.close()
+    Xs = torch.from_numpy(synth.to_soa_nodes(XC1)).cuda()
+    ts = torch.from_numpy(np.ascontiguousarray(T1[:, 0])).cuda()
+    S1 = n - 1
+    for b in (0, 1, 100, 255):
+        p1 = lto.IndirectPlan(gpu_ctx, n, 1, prms[b], integ)
+        p1.set_kernel({"per-lane": p1.KERNEL_PER_LANE, "pipeline": p1.KERNEL_PIPE, "pipeline6": p1.KERNEL_PIPE6,
+                       "pipeline8": p1.KERNEL_PIPE8, "cooperative": p1.KERNEL_COOP}[kernel])    # the family the batch ran
+        if kernel == "per-lane":
+            p1.set_cols_per_lane(3)           # what AUTO picks for the 262 144-segment batch (kernels_indirect.hip)
+        Phi1 = torch.zeros(144, S1, dtype=torch.float64, device="cuda")
+        d1 = torch.zeros(12, S1, dtype=torch.float64, device="cuda")
+        p1.jacobian(Xs, n, ts, 1, Phi1, S1, d1, S1)
+        torch.cuda.synchronize()
+        sl = slice(b * S1, (b + 1) * S1)
+        assert torch.equal(Phi[:, sl], Phi1) and torch.equal(d[:, sl], d1), "level %d" % b
+        p1.close()
+        Pn = Phi1.cpu().numpy().reshape(12, 12, S1).transpose(1, 0, 2)
+        dn = d1.cpu().numpy()
+        for i in (0, 511, 1023):
+            y, P_o, rc, _, _ = oracle.flow_stm_state_costate(XC1[:, i, 0], prm_l[b], T1[i + 1, 0] - T1[i, 0], oracle.RK4, 64)
+            assert rc == 0
+            assert np.abs(Pn[:, :, i] - P_o).max() < 1e-10 * np.abs(P_o).max()
+            assert np.linalg.norm(dn[:, i] - (y - XC1[:, i + 1, 0])) < 1e-10 * np.linalg.norm(y)
+    assert float((d[:, :S1] - d[:, 255 * S1:]).abs().max()) > 1e-6       # rho = 1 vs rho = 1e-4 on the same nodes
+
+
+def test_configs1_14dim_4096_segments_auto_kernel_vs_oracle(gpu_ctx, oracle):
+    """BASELINE configs[1] as benchmarked: 14-dim state + mass + costates with the 14x14 STM, 4 096 segments, RK4 x 64,
+    LTO_KERNEL_AUTO (the eight-wave pipeline kernel).  Four blocks of 16 consecutive segments spread over the sweep (64
+    segments) equal the oracle's dual-number STM and defect; det Phi = 1 for every segment (the vector field is
+    divergence-free: trace F = 0 also with the mass rows)."""
+    import torch
+    S = 4096
+    n = S + 1
+    XC, T = synth.indirect_problem(n, seed=0)
+    X = np.zeros((14, n), order="F")
+    X[:6] = XC[:6, :, 0]; X[6] = 1000.0 - 0.01 * np.arange(n); X[7:13] = XC[6:, :, 0]; X[13] = 0.1
+    t = np.ascontiguousarray(T[:, 0])
+    prm_l = [MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(lto.RK4, steps=64), ndim=14)
+    Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+    td = torch.from_numpy(t).cuda()
+    Phi = torch.zeros(196, S, dtype=torch.float64, device="cuda")
+    d = torch.zeros(14, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+    torch.cuda.synchronize()
+    assert plan.last_kernel() == "pipeline8"
+    P = Phi.cpu().numpy().reshape(14, 14, S).transpose(1, 0, 2)
+    dn = d.cpu().numpy()
+    assert np.all(np.isfinite(P)) and np.all(np.isfinite(dn))
+    n_checked = 0
+    for i0 in (0, 1357, 2048, S - 16):
+        P_o, d_o, rc = oracle.indirect14(X[:, i0:i0 + 17], t[i0:i0 + 17], prm_l, oracle.RK4, 64)
+        assert rc == 0
+        assert np.linalg.norm(dn[:, i0:i0 + 16] - d_o) / np.linalg.norm(d_o + X[:, i0 + 1:i0 + 17]) < 1e-10
+        assert np.abs(P[:, :, i0:i0 + 16] - P_o).max() < 1e-10 * np.abs(P_o).max()
+        n_checked += 16
+    assert n_checked >= 64
+    dets = np.linalg.det(P.transpose(2, 0, 1))
+    assert np.abs(dets - 1.0).max() < 1e-7
+    # d/d lambda_m(t0) of everything but lambda_m itself is zero for p = 1 (always thrust-limited): the unit column
+    assert np.array_equal(P[:, 13, :], np.repeat(np.eye(14)[:, 13:14], S, axis=1))
+
+
+def test_configs2_direct_16384_segments_oracle_sample(gpu_ctx, oracle):
+    """BASELINE configs[2] size (16 384 segments, 6-state, RKF7(8) nsteps = 10, on-device Jacobian blocks): blocks of 8
+    consecutive segments spread over the sweep equal the oracle -- defect and errors of the reference's two-sided shooting
+    (direct.jl:66-109), Jacobian blocks against the dual-number derivative of the same discrete map, tf column against
+    the oracle's d/dh."""
+    import torch
+    S = 16384
+    n = S + 1
+    X, U, T = synth.direct_problem(n, seed=3)
+    Xs = torch.from_numpy(synth.to_soa_nodes(X)).cuda(); Us = torch.from_numpy(synth.to_soa_nodes(U)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    plan = lto.DirectPlan(gpu_ctx, 6, n, 1, 10, MU, DU, TU, 2000.0)
+    d = torch.zeros(6, S, dtype=torch.float64, device="cuda"); e = torch.zeros(S, dtype=torch.float64, device="cuda")
+    Jac = torch.zeros(108, S, dtype=torch.float64, device="cuda"); dtf = torch.zeros(6, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(Xs, n, Us, n, t, 1, Jac, S, dtf, d, S, e)
+    torch.cuda.synchronize()
+    dn, en = d.cpu().numpy(), e.cpu().numpy()
+    J = Jac.cpu().numpy().reshape(18, 6, S).transpose(1, 0, 2)       # [row, var, s]
+    dtfn = dtf.cpu().numpy()
+    Xh, Uh, th = X[:, :, 0], U[:, :, 0], T[:, 0]
+    span = th[-1] - th[0]
+    for i0 in (0, 4099, 8192, 12345, S - 8):
+        sl = slice(i0, i0 + 9)
+        d_o, e_o = oracle.direct_defect(Xh[:, sl], Uh[:, sl], th[sl], 10, MU, DU, TU, 2000.0)
+        Jd, dh, _ = oracle.direct_jacobian_dual(Xh[:, sl], Uh[:, sl], th[sl], 10, MU, DU, TU, 2000.0)
+        assert np.abs(dn[:, i0:i0 + 8] - d_o).max() < 1e-12
+        assert np.abs(en[i0:i0 + 8] - e_o).max() < 1e-3 * e_o.max() + 1e-18
+        assert np.abs(J[:, :, i0:i0 + 8] - Jd).max() < 1e-11 * max(1.0, np.abs(Jd).max())
+        dtf_exact = dh * (np.diff(th[sl]) / span)[None, :]
+        assert np.abs(dtfn[:, i0:i0 + 8] - dtf_exact).max() < 1e-9
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_reference_halo_tables_through_the_hip_direct_defect(gpu_ctx, which):
+    """The only data the reference ships (L2_Anderson_1.txt / _2.txt: two closed Earth-Moon L2 halo orbits, 100 equally
+    spaced columns, loaded by CRTBP_Multishoot_indirect_demo.jl:66-70).  Consecutive columns as shooting nodes with zero
+    control are a ballistic trajectory, so the HIP direct defect (two-sided RKF7(8) shooting, direct.jl:66-109) must
+    vanish to the tables' precision: |defect| <= 1e-8 on all 99 segments, and the RKF 8th-order error estimate is tiny."""
+    tab = synth.halo_orbits()[which]
+    n = tab.shape[1]
+    t = synth.HALO_DT[which] * np.arange(n)
+    U = np.zeros((3, n), order="F")
+    d, e = lto.direct_defectCalc(np.asfortranarray(tab), U, t, 10, MU, DU, TU, 2000.0, ctx=gpu_ctx)
+    assert d.shape == (6, n - 1) and e.shape == (n - 1,)
+    assert np.abs(d).max() <= 1e-8
+    assert e.max() < 1e-12

@@ -392,6 +392,74 @@ def test_indirect_adaptive_nan_is_poison_not_a_stall(gpu_ctx, ndim, mname, kerne
     assert np.array_equal(Phi_n[:, keep], Phi_ok[:, keep])
 
 
+@pytest.mark.parametrize("ndim", [12, 14])
+@pytest.mark.parametrize("mname", ["rkf78_adaptive", "dop853_adaptive"])
+@pytest.mark.parametrize("kernel", ["per_lane", "coop"])
+def test_indirect_adaptive_unfinished_segment_is_nan(gpu_ctx, ndim, mname, kernel):
+    """An adaptive segment that does not reach t_{i+1} has no result: when max_steps trial steps are used up, or when the
+    time grid decreases (the adaptive controllers integrate forward only), defect and STM of that segment are NaN --
+    the driver's status_flag = 2 (indirect.jl:339-341) -- never a state at some t < t_{i+1} that looks propagated.
+    Segments that do finish are untouched; a zero-length segment is the identity."""
+    import torch
+    method, steps = METHODS[mname]
+    n = 24
+    XC, T = synth.indirect_problem(n, seed=5, dt_range=(0.05, 0.4))
+    XC, t = XC[:, :, 0], T[:, 0].copy()
+    if ndim == 14:
+        X = np.zeros((14, n), order="F")
+        X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+        prm_l = [MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+    else:
+        X = XC.copy()
+        prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+    S = n - 1
+    Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+
+    def sweep(tgrid, max_steps):
+        plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(method, steps=steps, max_steps=max_steps), ndim=ndim)
+        plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
+        td = torch.from_numpy(np.ascontiguousarray(tgrid)).cuda()
+        Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        d0 = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+        torch.cuda.synchronize()
+        acc, rej = plan.step_counts()
+        plan.defect(Xd, n, td, 1, d0, S)
+        torch.cuda.synchronize()
+        acc0, rej0 = plan.step_counts()
+        plan.close()
+        return Phi.cpu().numpy(), d.cpu().numpy(), d0.cpu().numpy(), acc + rej, acc0 + rej0
+
+    Phi_ok, d_ok, d0_ok, trials, trials0 = sweep(t, 100000)
+    assert np.all(np.isfinite(Phi_ok)) and np.all(np.isfinite(d_ok)) and np.all(np.isfinite(d0_ok))
+    # (1) a cap below what some segments need: those are NaN, the others bit-identical (the STM sweep and the defect-only
+    # sweep take their own step sequences: the former controls the error of the partials too)
+    cap = int(np.sort(np.concatenate([trials, trials0]))[S])
+    Phi_c, d_c, d0_c, _, _ = sweep(t, cap)
+    short, short0 = trials > cap, trials0 > cap
+    assert (short.any() or short0.any()) and (~short).any() and (~short0).any()
+    assert np.all(np.isnan(d_c[:, short])) and np.all(np.isnan(d0_c[:, short0]))
+    assert np.array_equal(d_c[:, ~short], d_ok[:, ~short]) and np.array_equal(d0_c[:, ~short0], d0_ok[:, ~short0])
+    if kernel == "coop":      # one step sequence per segment: the whole block is NaN or the whole block is untouched
+        assert np.all(np.isnan(Phi_c[:, short])) and np.array_equal(Phi_c[:, ~short], Phi_ok[:, ~short])
+    else:                     # per-lane kernel: every (segment, column group) lane takes its own steps -- the counters are
+        #                       those of the lane that also carries the defect (first column group)
+        assert np.all(np.isnan(Phi_c[:ndim, short])) and np.all(np.isfinite(Phi_c[:ndim, ~short]))
+        fin = np.isfinite(Phi_c)
+        assert np.array_equal(Phi_c[fin], Phi_ok[fin])
+    # (2) a decreasing interval and a zero-length one
+    t2 = t.copy()
+    t2[8] = t2[7] - 0.05            # segment 7 runs backwards, segment 8 is longer
+    t2[15] = t2[14]                 # segment 14 has zero length
+    Phi_d, d_d, d0_d, _, _ = sweep(t2, 100000)
+    assert np.all(np.isnan(d_d[:, 7])) and np.all(np.isnan(Phi_d[:, 7])) and np.all(np.isnan(d0_d[:, 7]))
+    eye = np.eye(ndim).reshape(-1, order="F")
+    assert np.array_equal(Phi_d[:, 14], eye) and np.array_equal(d_d[:, 14], X[:, 14] - X[:, 15])
+    ok = np.ones(S, bool); ok[[7, 8, 14, 15]] = False
+    assert np.array_equal(d_d[:, ok], d_ok[:, ok]) and np.array_equal(Phi_d[:, ok], Phi_ok[:, ok])
+
+
 def test_indirect_homotopy_full_size_properties(gpu_ctx, oracle):
     """BASELINE configs[3] size (64 trajectories x 64 rho-levels x 64 segments = 262 144 segments, RK4 x 64, defect
     only): the batched launch equals per-level launches bit for bit on a sample of levels, matches the oracle on a
