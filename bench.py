@@ -370,6 +370,8 @@ def main():
         U = torch.from_numpy(synth.to_soa_nodes(Ud)).to(dev)
         t = torch.from_numpy(np.ascontiguousarray(Td[:, 0])).to(dev)
         plan = lto.DirectPlan(ctx, 6, n, 1, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        if a.kernel:
+            plan.set_kernel(a.kernel)
         defect = torch.zeros(6, S, **f64)
         errs = torch.zeros(S, **f64)
         Jac = torch.zeros(108, S, **f64)

@@ -262,8 +262,10 @@ int lto_indirect_dense_dev(lto_indirect_plan* plan, void* stream, const double* 
 int lto_direct_plan_create(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, int nsteps,
                            const lto_direct_params* prm, lto_direct_plan** out);
 void lto_direct_plan_destroy(lto_direct_plan* plan);
-/* Jacobian kernel: LTO_KERNEL_PER_LANE (each lane re-integrates the half-arc with one sensitivity column) or
- * LTO_KERNEL_COOP (base wave + column waves per 16 segments, coefficients through LDS); AUTO = PER_LANE (measured equal, simpler). */
+/* Jacobian kernel: LTO_KERNEL_PER_LANE (each lane re-integrates the half-arc with one sensitivity column),
+ * LTO_KERNEL_COOP (base wave + column waves per 16 segments, coefficients through LDS, one barrier per RK stage) or
+ * LTO_KERNEL_PIPE (base wave + one wave per sensitivity column for 32 segments, skewed by one RKF7(8) step: one barrier
+ * per step).  AUTO = PIPE from 3 072 segments, PER_LANE below. */
 int lto_direct_plan_set_kernel(lto_direct_plan* plan, int kernel);
 int lto_direct_defect_dev(lto_direct_plan* plan, void* stream, const double* X, long ldx, const double* U, long ldu,
                           const double* t, int n_tgrids, double* defect, long ldd, double* errors);

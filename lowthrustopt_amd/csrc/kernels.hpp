@@ -68,6 +68,8 @@ hipError_t launch_indirect_stm_pipe8(int ndim, int pm, const IndirectArgs& a, hi
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian_coop(int nstate, const DirectArgs& a, hipStream_t st);
+// base wave + one wave per sensitivity column for 32 segments, skewed by one RKF7(8) step (one barrier per step)
+hipError_t launch_direct_jacobian_pipe(int nstate, const DirectArgs& a, hipStream_t st);
 
 // Newton step of the indirect method on the device (kernels_bvp.hip): structured orthogonal cyclic reduction.
 size_t bvp_workspace_doubles(int n_nodes, int n_batch);

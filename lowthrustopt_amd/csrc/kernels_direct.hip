@@ -332,6 +332,164 @@ __global__ __launch_bounds__(384) void k_direct_jacobian_coop(const DirectArgs a
   }
 }
 
+// K4'': software-pipelined Jacobian kernel (BASELINE configs[2]).  In the per-lane kernel every sensitivity column lane
+// re-integrates the half-arc base state (RHS, gravity gradient and the stage arguments of the base: ~85 of its ~125
+// instructions per RK stage), nine times per arc (arc = segment x direction); the cooperative kernel removes that but
+// meets at a barrier every RK stage with a half-empty base wave on the critical path.  Here a workgroup owns 32 segments
+// = 64 arcs and runs, skewed by one RKF7(8) STEP:
+//   wave 0          base role, lane = arc (all 64 lanes busy): the NS-dim half-arc; publishes the variational
+//                   coefficients (G, k/m [, dv/dm]) of all 13 stages of its current step to LDS
+//   waves 1..NS+3   wave w = sensitivity column w - 1 of [Phi | Psi] for all 64 arcs (wave-uniform column: no divergence,
+//                   LDS reads with lane = arc are conflict-free); one step behind, c' = A(t) c + forcing only
+// One barrier per step (half_steps + 1 phases), coefficient slabs double-buffered (93 / 133 KB of LDS: one workgroup per CU,
+// three waves per SIMD).  Per arc and stage ~9.3 wave-instructions against ~17.6 in the per-lane kernel.  Same tableau, step
+// grid, arithmetic per column and output layout as k_direct_jacobian.
+template <int NS>
+__global__ __launch_bounds__(64 * (NS + 4)) void k_direct_jacobian_pipe(const DirectArgs a) {
+  constexpr int ARCS = 64;
+  constexpr int NC = (NS == 7) ? 10 : 7;       // doubles handed over per (arc, stage)
+  __shared__ double s_coef[2][13][NC][ARCS];
+  __shared__ double s_x[2 * NS + 1][ARCS];     // mid-point exchange: [xe (NS) | R f (NS) | maxErr][arc]
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), arc = threadIdx.x & 63;
+  const bool is_base = (wave == 0);
+  const int j = is_base ? 0 : wave - 1;        // sensitivity column of this wave
+  const int seg = arc >> 1, dir = arc & 1;     // forward / backward half-arcs of a segment are lane neighbours
+  const int s_raw = blockIdx.x * (ARCS / 2) + seg;
+  const int s = s_raw < a.S ? s_raw : a.S - 1; // shadow lanes repeat the last segment, store nothing
+  const bool writer = s_raw < a.S;
+
+  const int traj = s / a.seg_per_traj;
+  const int i = s - traj * a.seg_per_traj;
+  const long node = (long)traj * a.n_nodes + i + dir;
+  const long tg = (long)traj * a.t_stride;
+  const double hhalf = 0.5 * (a.t[tg + i + 1] - a.t[tg + i]);            // direct.jl:70
+  const double span_total = a.t[tg + a.n_nodes - 1] - a.t[tg];           // direct.jl:506-510
+  const double td = dir ? -1.0 : 1.0;
+  DirectLane L;
+  L.MU = a.MU; L.w2 = 2.0 * td; L.kk = a.kk;
+  L.cx = a.U[0 * a.ldu + node]; L.cy = a.U[1 * a.ldu + node]; L.cz = a.U[2 * a.ldu + node];
+  const double nc = sqrt(__builtin_fma(L.cx, L.cx, __builtin_fma(L.cy, L.cy, L.cz * L.cz)));
+  L.mdot = -td * nc / a.isp_g0 * a.TU;                                   // prop_EP_deriv.jl:42
+
+  double y[NS], K[13][NS];
+  const bool is_ctrl = j >= NS;
+  const int jc = j - NS;
+  double fx = 0.0, fy = 0.0, fz = 0.0, fm = 0.0;
+  if (is_base) {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) y[c] = a.X[c * a.ldx + node];
+    if (dir) { y[3] = -y[3]; y[4] = -y[4]; y[5] = -y[5]; }               // direct.jl:92
+  } else {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) y[c] = (c == j) ? 1.0 : 0.0;
+    fx = (is_ctrl && jc == 0) ? 1.0 : 0.0;
+    fy = (is_ctrl && jc == 1) ? 1.0 : 0.0;
+    fz = (is_ctrl && jc == 2) ? 1.0 : 0.0;
+    if (NS == 7 && is_ctrl) {
+      const double cj = (jc == 0) ? L.cx : (jc == 1 ? L.cy : L.cz);
+      const double dn = (nc > 0.0) ? cj / nc : 1.0;
+      fm = -td * dn / a.isp_g0 * a.TU;
+    }
+  }
+
+  const int steps = a.half_steps;
+  const double h = hhalf / (double)steps;
+  double maxErr = 0.0;
+  // one RKF7(8) step of this lane's NS components; slope(st, arg, out) evaluates stage st
+  auto rk_step = [&](auto&& slope) {
+#pragma unroll
+    for (int st = 0; st < 13; ++st) {
+      double arg[NS];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < st; ++k)
+          if (TabRKF78::A[st][k] != 0.0) acc = __builtin_fma(TabRKF78::A[st][k], K[k][c], acc);
+        arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc, y[c]);
+      }
+      slope(st, arg, K[st]);
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 13; ++k)
+        if (TabRKF78::B[k] != 0.0) acc = __builtin_fma(TabRKF78::B[k], K[k][c], acc);
+      if (is_base) maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
+      y[c] = __builtin_fma(h, acc, y[c]);
+    }
+  };
+
+  for (int p = 0; p < steps + 1; ++p) {
+    if (is_base) {
+      if (p < steps) {
+        double (*slab)[NC][ARCS] = s_coef[p & 1];
+        rk_step([&](int st, const double (&arg)[NS], double (&out)[NS]) {
+          VarCoef6 vc;
+          rhs_direct<NS, true>(arg, L, out, vc);
+          slab[st][0][arc] = vc.Gxx; slab[st][1][arc] = vc.Gyy; slab[st][2][arc] = vc.Gzz;
+          slab[st][3][arc] = vc.Gxy; slab[st][4][arc] = vc.Gxz; slab[st][5][arc] = vc.Gyz;
+          slab[st][6][arc] = vc.k_over_m;
+          if (NS == 7) { slab[st][7][arc] = vc.dvdm_x; slab[st][8][arc] = vc.dvdm_y; slab[st][9][arc] = vc.dvdm_z; }
+        });
+      }
+    } else if (p >= 1) {
+      const double (*slab)[NC][ARCS] = s_coef[(p - 1) & 1];
+      rk_step([&](int st, const double (&arg)[NS], double (&out)[NS]) {
+        VarCoef6 vc;
+        vc.Gxx = slab[st][0][arc]; vc.Gyy = slab[st][1][arc]; vc.Gzz = slab[st][2][arc];
+        vc.Gxy = slab[st][3][arc]; vc.Gxz = slab[st][4][arc]; vc.Gyz = slab[st][5][arc];
+        vc.k_over_m = slab[st][6][arc];
+        if (NS == 7) { vc.dvdm_x = slab[st][7][arc]; vc.dvdm_y = slab[st][8][arc]; vc.dvdm_z = slab[st][9][arc]; }
+        var_col_direct<NS>(vc, L.w2, arg, fx * vc.k_over_m, fy * vc.k_over_m, fz * vc.k_over_m, fm, out);
+      });
+    }
+    __syncthreads();
+  }
+
+  if (!is_base) {
+    if (writer && a.Jac) {
+      const int col = is_ctrl ? (2 * NS + 3 * dir + jc) : (NS * dir + j);
+      const double rj = (!is_ctrl && j >= 3 && j < 6) ? -1.0 : 1.0;
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        const double rr = (r >= 3 && r < 6) ? -1.0 : 1.0;
+        a.Jac[(long)(col * NS + r) * a.ldj + s] = dir ? -(rr * rj) * y[r] : y[r];
+      }
+    }
+  } else {
+    // forward and backward halves meet: publish (x_end, R f(x_end), maxErr), combine on the forward lane
+    double f[NS];
+    VarCoef6 vc;
+    rhs_direct<NS, false>(y, L, f, vc);
+    if (dir) { y[3] = -y[3]; y[4] = -y[4]; y[5] = -y[5]; f[3] = -f[3]; f[4] = -f[4]; f[5] = -f[5]; }   // direct.jl:98
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { s_x[c][arc] = y[c]; s_x[NS + c][arc] = f[c]; }
+    s_x[2 * NS][arc] = maxErr;
+  }
+  __syncthreads();
+  if (is_base && writer && dir == 0) {
+    const double scale = hhalf / span_total;     // d(half length) / d tf
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+      if (a.defect) a.defect[c * a.ldd + s] = s_x[c][arc] - s_x[c][arc + 1];                            // :101
+      if (a.dtf) a.dtf[c * a.ldd + s] = (s_x[NS + c][arc] - s_x[NS + c][arc + 1]) * scale;
+    }
+    if (a.errors) a.errors[s] = fmax(s_x[2 * NS][arc], s_x[2 * NS][arc + 1]);                            // :104
+  }
+}
+
+hipError_t launch_direct_jacobian_pipe(int nstate, const DirectArgs& a, hipStream_t st) {
+  if (a.S <= 0) return hipSuccess;
+  dim3 grid((a.S + 31) / 32);
+  if (nstate == 6) hipLaunchKernelGGL((k_direct_jacobian_pipe<6>), grid, dim3(64 * 10), 0, st, a);
+  else if (nstate == 7) hipLaunchKernelGGL((k_direct_jacobian_pipe<7>), grid, dim3(64 * 11), 0, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st) {
   if (a.S <= 0) return hipSuccess;
   dim3 grid((2 * (long)a.S + 63) / 64);

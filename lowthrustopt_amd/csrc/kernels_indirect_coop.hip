@@ -58,7 +58,17 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
   constexpr bool DOP = (METHOD == M_DOP853_ADAPTIVE);
   constexpr int NSL = DOP ? 13 : NS;         // slopes kept (DOP853: + FSAL slope)
 
-  __shared__ double s_coef[2][NC][COOP_SEG];
+  // ND = 12 (the reference's system): the base lane evaluates the lean RHS only (rhs12_base) and publishes the six numbers
+  // the variational coefficients depend on (r, lambda_v); every column lane rebuilds G, H, U from them itself (rhs12<PM,
+  // true> on that argument).  Per stage the base stream shrinks from ~380 to ~245 instructions (54 stage-argument FMAs,
+  // 130 RHS, ~60 AGPR moves) and the column streams grow from ~195 to ~390, so the barrier interval barely moves: measured
+  // 0.308 -> 0.297 ms at 4 096 segments, DOP853 @ 1e-13.  What would pay is publishing the base lane's by-products (c_b,
+  // i_b^2, ua, ub, 1/n: seven more doubles) so that the columns skip the reciprocal square roots and the control law: ~275
+  // against ~240 instructions per stage.  Not done yet.  (ND = 14 keeps the coefficient hand-over: there wave 3 runs base
+  // and column lanes one after the other.)
+  constexpr bool LEAN = (ND == 12);
+  constexpr int NPUB = LEAN ? 6 : NC;
+  __shared__ double s_coef[2][NPUB][COOP_SEG];
   __shared__ double s_part[3][ND + 1][COOP_SEG];   // partial norms: [which][role][segment]
   __shared__ double s_scale[ND][COOP_SEG];          // 1 / (atol + rtol |base value|): the error scale of row r
   __shared__ CoopCtrl s_ctrl[COOP_SEG];
@@ -104,19 +114,34 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
   // waves consume them after the barrier.  Called by ALL threads (one barrier inside).
   auto slope = [&](const double (&arg)[ND], double (&out)[ND], int buf) {
     if (is_base) {
-      Coef vc;
-      if constexpr (ND == 12) rhs12<PM, true>(arg, tp, out, vc);
-      else rhs14<PM, true>(arg, tp, out, vc);
-      const double* v = reinterpret_cast<const double*>(&vc);
+      if constexpr (LEAN) {
+        rhs12_base<PM>(arg, tp, out);
+        s_coef[buf][0][seg] = arg[0]; s_coef[buf][1][seg] = arg[1]; s_coef[buf][2][seg] = arg[2];
+        s_coef[buf][3][seg] = arg[9]; s_coef[buf][4][seg] = arg[10]; s_coef[buf][5][seg] = arg[11];
+      } else {
+        Coef vc;
+        if constexpr (ND == 12) rhs12<PM, true>(arg, tp, out, vc);
+        else rhs14<PM, true>(arg, tp, out, vc);
+        const double* v = reinterpret_cast<const double*>(&vc);
 #pragma unroll
-      for (int e = 0; e < NC; ++e) s_coef[buf][e][seg] = v[e];
+        for (int e = 0; e < NC; ++e) s_coef[buf][e][seg] = v[e];
+      }
     }
     __syncthreads();
     if (!is_base) {
       Coef vc;
-      double* v = reinterpret_cast<double*>(&vc);
+      if constexpr (LEAN) {
+        double barg[ND], dead[ND];
 #pragma unroll
-      for (int e = 0; e < NC; ++e) v[e] = s_coef[buf][e][seg];
+        for (int c = 0; c < ND; ++c) barg[c] = 0.0;
+        barg[0] = s_coef[buf][0][seg]; barg[1] = s_coef[buf][1][seg]; barg[2] = s_coef[buf][2][seg];
+        barg[9] = s_coef[buf][3][seg]; barg[10] = s_coef[buf][4][seg]; barg[11] = s_coef[buf][5][seg];
+        rhs12<PM, true>(barg, tp, dead, vc);     // G, H, U at the base argument (the slopes are dead code)
+      } else {
+        double* v = reinterpret_cast<double*>(&vc);
+#pragma unroll
+        for (int e = 0; e < NC; ++e) v[e] = s_coef[buf][e][seg];
+      }
       if constexpr (ND == 12) var_col12(vc, w2, arg, out);
       else var_col14(vc, w2, arg, out);
     }

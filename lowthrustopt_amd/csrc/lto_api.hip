@@ -879,8 +879,8 @@ void lto_direct_plan_destroy(lto_direct_plan* p) {
 
 int lto_direct_plan_set_kernel(lto_direct_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
-  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE or _COOP");
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP or _PIPE");
   p->kernel = kernel;
   return LTO_OK;
 }
@@ -957,10 +957,17 @@ int lto_direct_jacobian_dev(lto_direct_plan* p, void* stream, const double* X, l
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  // measured (MI355X, 16 384 segments): per-lane 0.180 ms, wave-specialised 0.176 ms; 131 072: 1.30 vs 1.33 ms --
-  // no gain (6-dim columns are cheap, the base wave + barrier per stage eat the saved work), so AUTO = per-lane
-  hipError_t e = (p->kernel == LTO_KERNEL_COOP) ? launch_direct_jacobian_coop(p->nstate, a, st)
-                                                : launch_direct_jacobian(p->nstate, a, st);
+  // measured (MI355X, bench.py --workload c3, ms per sweep; per-lane / wave-specialised / software-pipelined):
+  //   29 segments 0.032 / - / 0.047;  2 048: 0.036 / - / 0.049;  4 096: 0.069 / - / 0.051;  8 192: 0.108 / - / 0.055;
+  //   16 384 (BASELINE configs[2]): 0.181 / 0.176 / 0.106;  65 536: 0.592 / - / 0.383
+  // The pipelined kernel does ~half the arithmetic (the half-arc base state is integrated once per arc, not once per
+  // sensitivity column) but needs 10 waves of one workgroup resident per 32 segments: it wins once the per-lane kernel no
+  // longer fits the chip in one round.
+  int kern = p->kernel;
+  if (kern == LTO_KERNEL_AUTO) kern = (p->S >= 3072) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
+  hipError_t e = (kern == LTO_KERNEL_COOP)   ? launch_direct_jacobian_coop(p->nstate, a, st)
+                 : (kern == LTO_KERNEL_PIPE) ? launch_direct_jacobian_pipe(p->nstate, a, st)
+                                             : launch_direct_jacobian(p->nstate, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_direct_jacobian", e);
   return LTO_OK;

@@ -892,8 +892,8 @@ def test_newton_step_entry_point_converges(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("nstate", [6, 7])
 def test_direct_jacobian_kernel_variants_agree(gpu_ctx, oracle, nstate):
-    """Per-lane and wave-specialised direct Jacobian kernels: same blocks (round-off), both == oracle duals; ragged
-    segment count."""
+    """Per-lane, wave-specialised and software-pipelined direct Jacobian kernels: same blocks (round-off), all == oracle
+    duals; ragged segment count (not a multiple of the 16 / 32 segments a workgroup owns)."""
     import torch
     n = 55
     X, U, T = synth.direct_problem(n, seed=5, nstate=nstate)
@@ -904,7 +904,7 @@ def test_direct_jacobian_kernel_variants_agree(gpu_ctx, oracle, nstate):
     plan = lto.DirectPlan(gpu_ctx, nstate, n, 1, 10, MU, DU, TU, 2000.0)
     nvar = 2 * (nstate + 3)
     out = {}
-    for kern in (1, 2):
+    for kern in (1, 2, 3):
         plan.set_kernel(kern)
         Jac = torch.zeros(nstate * nvar, S, dtype=torch.float64, device="cuda")
         dtf = torch.zeros(nstate, S, dtype=torch.float64, device="cuda")
@@ -913,12 +913,13 @@ def test_direct_jacobian_kernel_variants_agree(gpu_ctx, oracle, nstate):
         plan.jacobian(Xs, n, Us, n, t, 1, Jac, S, dtf, d, S, e)
         torch.cuda.synchronize()
         out[kern] = [v.cpu().numpy() for v in (Jac, dtf, d, e)]
-    for a_, b_ in zip(out[1], out[2]):
-        assert np.abs(a_ - b_).max() < 1e-13 * max(1.0, np.abs(a_).max())
     Jd, dh, dd = oracle.direct_jacobian_dual(X[:, :, 0], U[:, :, 0], T[:, 0], 10, MU, DU, TU, 2000.0)
-    Jg = out[2][0].reshape(nvar, nstate, S).transpose(1, 0, 2)
-    assert np.abs(Jg - Jd).max() < 1e-11 * max(1.0, np.abs(Jd).max())
-    assert np.abs(out[2][2] - dd).max() < 1e-12
+    for kern in (2, 3):
+        for a_, b_ in zip(out[1], out[kern]):
+            assert np.abs(a_ - b_).max() < 1e-13 * max(1.0, np.abs(a_).max())
+        Jg = out[kern][0].reshape(nvar, nstate, S).transpose(1, 0, 2)
+        assert np.abs(Jg - Jd).max() < 1e-11 * max(1.0, np.abs(Jd).max())
+        assert np.abs(out[kern][2] - dd).max() < 1e-12
 
 
 def test_api_misuse_and_edge_sizes(gpu_ctx):
