@@ -30,6 +30,7 @@ import sys
 import time
 
 import numpy as np
+from ctypes import c_void_p as C_void_p
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -383,6 +384,21 @@ def main():
         gather_rows = 6
 
     use_coll = dist is not None
+    # The collective of the product: the library's own RCCL all-gather (lto_comm_allgather_dev; communicator created from an
+    # id that rank 0 makes and torch.distributed hands round).  If any rank cannot set it up, every rank falls back to
+    # torch.distributed's all_gather_into_tensor (also RCCL) and the JSON line says so.
+    native, native_note = None, None
+    if use_coll:
+        try:
+            box = [lto.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, device=dev)
+            native = lto.Comm(ctx, world, rank, box[0])
+        except Exception as ex:      # noqa: BLE001 -- any failure means "use the torch path"
+            native, native_note = None, "%s: %s" % (type(ex).__name__, ex)
+        ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and native is not None:
+            native.close(); native = None; native_note = "another rank could not create its communicator"
     # N > 1: the defect slab of step k is all-gathered (RCCL) on a side stream while step k+1 propagates: two defect /
     # gather buffers alternate, events order producer -> collective -> buffer reuse.  All collectives complete before
     # the closing barrier + synchronize, so every one of the K steps is fully inside the timed region.
@@ -393,6 +409,14 @@ def main():
     ev_ready = [torch.cuda.Event() for _ in dbufs]     # sweep into buffer b finished
     main = torch.cuda.current_stream()
 
+    def gather(b):
+        with torch.cuda.stream(comm_stream):
+            if native is not None:
+                native.allgather(dbufs[b], gathered[b], gather_rows * S, stream=C_void_p(comm_stream.cuda_stream))   # RCCL over xGMI
+            else:
+                dist.all_gather_into_tensor(gathered[b], dbufs[b])
+            ev_done[b].record(comm_stream)
+
     def step(k):
         b = k % len(dbufs)
         if use_coll and k >= len(dbufs):
@@ -401,9 +425,7 @@ def main():
         if use_coll:
             ev_ready[b].record(main)
             comm_stream.wait_event(ev_ready[b])
-            with torch.cuda.stream(comm_stream):
-                dist.all_gather_into_tensor(gathered[b], dbufs[b])   # RCCL over xGMI
-                ev_done[b].record(comm_stream)
+            gather(b)
 
     ref12 = None
     if rank == 0 and world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
@@ -431,9 +453,7 @@ def main():
         if use_coll:
             ev_ready[b].record(main)
             comm_stream.wait_event(ev_ready[b])
-            with torch.cuda.stream(comm_stream):
-                dist.all_gather_into_tensor(gathered[b], dbufs[b])
-                ev_done[b].record(comm_stream)
+            gather(b)
     if use_coll:
         comm_stream.synchronize()
         dist.barrier()
@@ -463,7 +483,11 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
-                       "collective": "rccl all_gather(defect), overlapped with the next sweep on a side stream" if use_coll else "none", "integrator": "see workload"},
+                       "collective": ("none" if not use_coll else
+                                      "lto_comm_allgather_dev (the library's RCCL all-gather of the defect slabs), overlapped with the next sweep on a side stream"
+                                      if native is not None else
+                                      "torch.distributed all_gather_into_tensor (RCCL), overlapped with the next sweep on a side stream; the library's "
+                                      "communicator was not used: %s" % native_note), "integrator": "see workload"},
         }
         if wl in ("c2", "hbm", "c4", "c5_stm"):
             out["config"]["stm_kernel"] = plan.last_kernel()
@@ -519,6 +543,8 @@ def main():
             if not a.no_cpu_baseline:
                 ref12[1]()
         print(json.dumps(out), flush=True)
+    if native is not None:
+        native.close()
     if use_coll:
         dist.barrier()
         dist.destroy_process_group()

@@ -90,6 +90,7 @@ int lto_host_free(lto_ctx* ctx, void* ptr);
 const char* lto_last_error(const lto_ctx* ctx);
 int lto_version(void);
 void* lto_ctx_stream(lto_ctx* ctx); /* the context's own non-blocking hipStream_t */
+int lto_ctx_device(const lto_ctx* ctx); /* HIP ordinal the context was created on */
 /* When enabled, every sweep brackets its dominant kernel with HIP events on the launch stream;
  * lto_last_kernel_ms blocks on the stop event and returns that kernel's duration. */
 int lto_set_timing(lto_ctx* ctx, int enabled);
@@ -301,6 +302,7 @@ int lto_group_create(int n_devices, const int* device_ids, lto_group** out);
 void lto_group_destroy(lto_group* group);
 const char* lto_group_last_error(const lto_group* group);
 int lto_group_size(const lto_group* group);
+lto_ctx* lto_group_ctx(lto_group* group, int k); /* member k's context (owned by the group): device-resident plans and sweeps per GPU */
 int lto_group_indirect_defect(lto_group* group, int ndim, int n_nodes, int n_batch, const double* XC, const double* t,
                               int n_tgrids, const lto_params* prm, int n_prm, const lto_integrator* integ, double* defect,
                               double* errors);
@@ -313,6 +315,42 @@ int lto_group_direct_defect(lto_group* group, int nstate, int n_nodes, int n_bat
 int lto_group_direct_jacobian(lto_group* group, int nstate, int n_nodes, int n_batch, const double* X, const double* U,
                               const double* t, int n_tgrids, int nsteps, const lto_direct_params* prm, double* Jac_temp,
                               double* ddefect_dtf, double* defect, double* errors);
+
+/* ------------------------------------------------------------------------------- collectives (RCCL over xGMI)
+ * The one exchange step of the path.  A sweep shards with no data-path collective (segment i needs nodes i, i+1 only:
+ * multiShoot_CRTBP_indirect.jl:71-86); what every rank needs afterwards is the full defect vector or its norms for the
+ * convergence test and the line-search decision (indirect.jl:240 sum(defect.^2), :331 norm(defect, Inf)).  These entry
+ * points do that device to device -- nothing returns to the host between sweep and decision:
+ *   sweep (lto_*_dev) -> lto_defect_norms_dev on the local slab -> lto_comm_allreduce_dev(SUM / MAX), or
+ *   sweep -> lto_comm_allgather_dev of the slabs -> lto_defect_norms_dev on the gathered vector.
+ * RCCL is bound at run time (dlopen): without it these calls return LTO_EUNSUPPORTED and everything else works. */
+#define LTO_COMM_ID_BYTES 128
+#define LTO_COMM_SUM 0
+#define LTO_COMM_MAX 1
+typedef struct lto_comm lto_comm;
+int lto_comm_available(void);
+/* One process per GPU: one rank calls lto_comm_unique_id, the launcher (torch.distributed, MPI, a file) hands the 128
+ * bytes to every rank, every rank calls lto_comm_create (collective: ncclCommInitRank on the context's device). */
+int lto_comm_unique_id(void* id128);
+int lto_comm_create(lto_ctx* ctx, int world, int rank, const void* id128, lto_comm** out);
+void lto_comm_destroy(lto_comm* comm);
+const char* lto_comm_last_error(const lto_comm* comm);
+int lto_comm_size(const lto_comm* comm);
+int lto_comm_rank(const lto_comm* comm);
+/* recv [world][count] <- send [count] of every rank (equal counts); asynchronous on `stream` (hipStream_t). */
+int lto_comm_allgather_dev(lto_comm* comm, void* stream, const double* send, double* recv, long count);
+/* buf [count] <- LTO_COMM_SUM / LTO_COMM_MAX over ranks, in place; asynchronous on `stream`. */
+int lto_comm_allreduce_dev(lto_comm* comm, void* stream, double* buf, long count, int op);
+/* One host process, several GPUs: the communicators of an lto_group (ncclCommInitAll over its devices).  send[k] /
+ * recv[k] / buf[k] live on member k's device; the work is enqueued on member k's context stream (lto_ctx_stream), after
+ * the sweep that produced send[k] there.  A group that repeats one device (1-GPU boxes) uses device copies instead. */
+typedef struct lto_group_comm lto_group_comm;
+int lto_group_comm_create(lto_group* group, lto_group_comm** out);
+void lto_group_comm_destroy(lto_group_comm* comm);
+const char* lto_group_comm_last_error(const lto_group_comm* comm);
+int lto_group_comm_uses_rccl(const lto_group_comm* comm);
+int lto_group_comm_allgather_dev(lto_group_comm* comm, const double* const* send, double* const* recv, long count);
+int lto_group_comm_allreduce_dev(lto_group_comm* comm, double* const* buf, long count, int op);
 
 #ifdef __cplusplus
 }

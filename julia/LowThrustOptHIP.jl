@@ -13,6 +13,9 @@ module LowThrustOptHIP
 
 using SparseArrays, LinearAlgebra, Libdl
 
+export LtoIndirectPlan, LtoDirectPlan, LtoComm, pinned_array, pack_soa!, unpack_soa!, defect_norms!, indirect_defect_dev!,
+       indirect_jacobian_dev!, newton_solve_dev!, axpy_dev!, direct_defect_dev!, direct_jacobian_dev!, rebalance!, set_kernel!,
+       comm_unique_id, allgather_dev!, allreduce_dev!, ctx_stream
 export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, indirect_solve, indirect_solve_batch, densify,
        direct_defectCalc, direct_jacobianCalc, direct_midpoints, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
 
@@ -274,5 +277,157 @@ function direct_jacobianCalc(ctx::LtoHandle, X_all::Matrix{Float64}, u_all::Matr
     Jac_full[:, end] = ddefect_dt[:]
     (Jac_full, defect1, errors)
 end
+
+# ------------------------------------------------------------------------------------------- device-resident API
+# The operands stay in HBM between calls (struct-of-arrays, see include/lto.h "device-resident API"); every function
+# below takes RAW DEVICE POINTERS (`Ptr{Cvoid}`) and a `hipStream_t` (`Ptr{Cvoid}`, C_NULL = HIP's default stream) and
+# returns as soon as the work is enqueued.  With AMDGPU.jl: `p = Ptr{Cvoid}(UInt(pointer(A)))` for a `ROCArray{Float64}`
+# `A`, `AMDGPU.stream()` for the stream; without it, device memory can come from any HIP allocation in the process.
+# This is how a Julia Newton loop keeps the trajectory on the GPU: pack once (`pack_soa!`), then per iteration
+# `indirect_jacobian_dev!` -> `newton_solve_dev!` -> `axpy_dev!` -> `indirect_defect_dev!` -> `defect_norms!`, copying two
+# scalars per trajectory back.  ctypes twins (executed by the GPU tests): hotpath.IndirectPlan / DirectPlan / pack_soa /
+# unpack_soa / defect_norms / Comm / Context.pinned_empty.
+const DevPtr = Ptr{Cvoid}
+devptr(p::Ptr) = convert(Ptr{Cvoid}, p)
+devptr(p::Integer) = Ptr{Cvoid}(UInt(p))
+devptr(::Nothing) = C_NULL
+
+"hipStream_t owned by the context (non-blocking); pass it as `stream` to keep library work off the default stream."
+ctx_stream(ctx::LtoContext) = ccall((:lto_ctx_stream, liblto), Ptr{Cvoid}, (Ptr{Cvoid},), ctx.handle)
+
+"""`Array{Float64}` of the given size in page-locked host memory (lto_host_alloc): with such arrays the H2D / D2H copies of the
+host-pointer API are plain DMA at link speed (Phi of a 4 096-segment sweep: ~0.1 ms instead of ~0.3 ms).  Freed by a finalizer."""
+function pinned_array(ctx::LtoContext, dims::Integer...)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx, ccall((:lto_host_alloc, liblto), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, 8 * prod(dims), p))
+    A = unsafe_wrap(Array, convert(Ptr{Float64}, p[]), dims; own = false)
+    finalizer(_ -> ccall((:lto_host_free, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.handle, p[]), A)
+    A
+end
+
+"""lto_indirect_plan: per-trajectory parameters uploaded once, then repeated asynchronous sweeps.  `params` = one tuple or a
+vector of n_batch tuples (homotopy levels, line-search trial points).  The plan keeps its context alive (lto.h, lifetime)."""
+mutable struct LtoIndirectPlan
+    handle::Ptr{Cvoid}
+    ctx::LtoContext
+    ndim::Int; n_nodes::Int; n_batch::Int
+    function LtoIndirectPlan(ctx::LtoContext, ndim::Integer, n_nodes::Integer, n_batch::Integer, params; integ::LtoIntegrator = LtoIntegrator())
+        prm = params isa Tuple ? [LtoParams(params)] : [LtoParams(q) for q in params]
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ctx, ccall((:lto_indirect_plan_create, liblto), Cint,
+                         (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{LtoParams}, Cint, Ref{LtoIntegrator}, Ref{Ptr{Cvoid}}),
+                         ctx.handle, ndim, n_nodes, n_batch, prm, length(prm), Ref(integ), h))
+        pl = new(h[], ctx, ndim, n_nodes, n_batch)
+        finalizer(q -> (q.handle == C_NULL || ccall((:lto_indirect_plan_destroy, liblto), Cvoid, (Ptr{Cvoid},), q.handle); q.handle = C_NULL), pl)
+        pl
+    end
+end
+nseg(pl::LtoIndirectPlan) = (pl.n_nodes - 1) * pl.n_batch
+
+"defect[c*ldd + s] (SoA) of every segment; X[c*ldx + j], t[g*n_nodes + k] on the device.  Replaces indirect.jl:63-90."
+function indirect_defect_dev!(pl::LtoIndirectPlan, stream, X, ldx::Integer, t, n_tgrids::Integer, defect, ldd::Integer; errors = nothing)
+    check(pl.ctx, ccall((:lto_indirect_defect_dev, liblto), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, DevPtr, Cint, DevPtr, Clong, DevPtr),
+                        pl.handle, devptr(stream), devptr(X), ldx, devptr(t), n_tgrids, devptr(defect), ldd, devptr(errors)))
+end
+
+"Phi[(col*ndim+row)*ldp + s] and (optionally) the defect.  Replaces indirect.jl:93-146 (compact blocks)."
+function indirect_jacobian_dev!(pl::LtoIndirectPlan, stream, X, ldx::Integer, t, n_tgrids::Integer, Phi, ldp::Integer; defect = nothing, ldd::Integer = 0)
+    check(pl.ctx, ccall((:lto_indirect_jacobian_dev, liblto), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, DevPtr, Cint, DevPtr, Clong, DevPtr, Clong),
+                        pl.handle, devptr(stream), devptr(X), ldx, devptr(t), n_tgrids, devptr(Phi), ldp, devptr(defect), ldd))
+end
+
+"delta = -Jac_full \\ defect on the device (indirect.jl:181-182; `Phi = nothing` re-uses the factorisation: the SOC re-solve :190-214)."
+function newton_solve_dev!(pl::LtoIndirectPlan, stream, Phi, ldp::Integer, defect, ldd::Integer, delta, ldx::Integer; adjoints_only::Bool = false)
+    check(pl.ctx, ccall((:lto_indirect_newton_solve_dev, liblto), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, DevPtr, Clong, Cint, DevPtr, Clong),
+                        pl.handle, devptr(stream), devptr(Phi), ldp, devptr(defect), ldd, adjoints_only ? 1 : 0, devptr(delta), ldx))
+end
+
+"y = x + alpha d over `count` doubles on the device (trial points, update accumulation)."
+axpy_dev!(ctx::LtoContext, stream, x, d, alpha::Real, y, count::Integer) =
+    check(ctx, ccall((:lto_axpy_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, DevPtr, Cdouble, DevPtr, Clong),
+                     ctx.handle, devptr(stream), devptr(x), devptr(d), alpha, devptr(y), count))
+
+"Order the lanes of the following adaptive sweeps by the last sweep's step counts (results unchanged)."
+rebalance!(pl::LtoIndirectPlan, stream) = check(pl.ctx, ccall((:lto_indirect_plan_rebalance, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), pl.handle, devptr(stream)))
+"LTO_KERNEL_*: 0 auto, 1 per-lane, 2 cooperative, 3 / 4 / 5 pipeline forms (RK4 plans)."
+set_kernel!(pl::LtoIndirectPlan, kernel::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_kernel, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, kernel))
+
+"Julia column-major [ndim x count] on the device -> SoA [ndim][ld] (and back)."
+pack_soa!(ctx::LtoContext, stream, aos, ndim::Integer, count::Integer, soa, ld::Integer) =
+    check(ctx, ccall((:lto_pack_soa_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Cint, Clong, DevPtr, Clong),
+                     ctx.handle, devptr(stream), devptr(aos), ndim, count, devptr(soa), ld))
+unpack_soa!(ctx::LtoContext, stream, soa, ld::Integer, ndim::Integer, count::Integer, aos) =
+    check(ctx, ccall((:lto_unpack_soa_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, Cint, Clong, DevPtr),
+                     ctx.handle, devptr(stream), devptr(soa), ld, ndim, count, devptr(aos)))
+
+"sumsq[b] = sum(defect_b.^2) (indirect.jl:240), maxabs[b] = norm(defect_b[:], Inf) (:331) on the device."
+defect_norms!(ctx::LtoContext, stream, defect, ldd::Integer, ndim::Integer, seg_per_traj::Integer, n_batch::Integer, sumsq, maxabs) =
+    check(ctx, ccall((:lto_defect_norms_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, Cint, Cint, Cint, DevPtr, DevPtr),
+                     ctx.handle, devptr(stream), devptr(defect), ldd, ndim, seg_per_traj, n_batch, devptr(sumsq), devptr(maxabs)))
+
+mutable struct LtoDirectPlan
+    handle::Ptr{Cvoid}
+    ctx::LtoContext
+    function LtoDirectPlan(ctx::LtoContext, nstate::Integer, n_nodes::Integer, n_batch::Integer, nsteps::Integer, MU, DU, TU, Isp)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ctx, ccall((:lto_direct_plan_create, liblto), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ref{LtoDirectParams}, Ref{Ptr{Cvoid}}),
+                         ctx.handle, nstate, n_nodes, n_batch, nsteps, Ref(LtoDirectParams(MU, DU, TU, Isp)), h))
+        pl = new(h[], ctx)
+        finalizer(q -> (q.handle == C_NULL || ccall((:lto_direct_plan_destroy, liblto), Cvoid, (Ptr{Cvoid},), q.handle); q.handle = C_NULL), pl)
+        pl
+    end
+end
+
+"Replaces direct.jl:66-109 with operands in HBM: X[c*ldx + j], U[c*ldu + j] (N), t; defect[c*ldd + s], errors[s]."
+function direct_defect_dev!(pl::LtoDirectPlan, stream, X, ldx::Integer, U, ldu::Integer, t, n_tgrids::Integer, defect, ldd::Integer; errors = nothing)
+    check(pl.ctx, ccall((:lto_direct_defect_dev, liblto), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, DevPtr, Clong, DevPtr, Cint, DevPtr, Clong, DevPtr),
+                        pl.handle, devptr(stream), devptr(X), ldx, devptr(U), ldu, devptr(t), n_tgrids, devptr(defect), ldd, devptr(errors)))
+end
+
+"Replaces direct.jl:111-166 + :503-516: Jac[(col*nstate+row)*ldj + s], dtf[c*ldd + s], defect, errors."
+function direct_jacobian_dev!(pl::LtoDirectPlan, stream, X, ldx::Integer, U, ldu::Integer, t, n_tgrids::Integer, Jac, ldj::Integer;
+                              dtf = nothing, defect = nothing, ldd::Integer = 0, errors = nothing)
+    check(pl.ctx, ccall((:lto_direct_jacobian_dev, liblto), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, DevPtr, Clong, DevPtr, Cint, DevPtr, Clong, DevPtr, DevPtr, Clong, DevPtr),
+                        pl.handle, devptr(stream), devptr(X), ldx, devptr(U), ldu, devptr(t), n_tgrids, devptr(Jac), ldj, devptr(dtf),
+                        devptr(defect), ldd, devptr(errors)))
+end
+
+# ------------------------------------------------------------------------------------------- collectives (RCCL)
+# One Julia process (Distributed worker / MPI rank) per GPU: rank 0 calls comm_unique_id(), ships the 128 bytes to every
+# rank (MPI.Bcast!, a RemoteChannel, a file), every rank builds LtoComm(ctx, world, rank, id).  allgather_dev! gives every
+# rank the full defect vector, allreduce_dev! its norms -- device to device, nothing returns to the host in between.
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    rc = ccall((:lto_comm_unique_id, liblto), Cint, (Ptr{UInt8},), id)
+    rc == 0 || error("lto_comm_unique_id failed with code $rc (no RCCL in the process?)")
+    id
+end
+
+mutable struct LtoComm
+    handle::Ptr{Cvoid}
+    ctx::LtoContext
+    world::Int; rank::Int
+    function LtoComm(ctx::LtoContext, world::Integer, rank::Integer, id::Vector{UInt8})
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:lto_comm_create, liblto), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}), ctx.handle, world, rank, id, h)
+        rc == 0 || error("lto_comm_create failed with code $rc")
+        c = new(h[], ctx, world, rank)
+        finalizer(q -> (q.handle == C_NULL || ccall((:lto_comm_destroy, liblto), Cvoid, (Ptr{Cvoid},), q.handle); q.handle = C_NULL), c)
+        c
+    end
+end
+comm_check(c::LtoComm, rc::Cint) = rc == 0 || error("lto_comm error $rc: " * unsafe_string(ccall((:lto_comm_last_error, liblto), Cstring, (Ptr{Cvoid},), c.handle)))
+
+"recv [world][count] <- send [count] of every rank (device pointers), asynchronous on `stream`."
+allgather_dev!(c::LtoComm, stream, send, recv, count::Integer) =
+    comm_check(c, ccall((:lto_comm_allgather_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, DevPtr, Clong), c.handle, devptr(stream), devptr(send), devptr(recv), count))
+"buf [count] <- sum (op = 0) or max (op = 1) over ranks, in place."
+allreduce_dev!(c::LtoComm, stream, buf, count::Integer, op::Integer) =
+    comm_check(c, ccall((:lto_comm_allreduce_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, Cint), c.handle, devptr(stream), devptr(buf), count, op))
 
 end # module

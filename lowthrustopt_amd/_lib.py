@@ -45,6 +45,7 @@ SIGNATURES = {
     "lto_host_free": (C.c_int, [_vp, _vp]),
     "lto_last_error": (C.c_char_p, [_vp]),
     "lto_ctx_stream": (_vp, [_vp]),
+    "lto_ctx_device": (C.c_int, [_vp]),
     "lto_set_timing": (C.c_int, [_vp, C.c_int]),
     "lto_last_kernel_ms": (C.c_double, [_vp]),
     "lto_indirect_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
@@ -105,6 +106,23 @@ SIGNATURES = {
     "lto_pack_soa_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_long, _vp, C.c_long]),
     "lto_unpack_soa_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, C.c_int, C.c_long, _vp]),
     "lto_defect_norms_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    # collectives (RCCL over xGMI)
+    "lto_comm_available": (C.c_int, []),
+    "lto_comm_unique_id": (C.c_int, [_vp]),
+    "lto_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "lto_comm_destroy": (None, [_vp]),
+    "lto_comm_last_error": (C.c_char_p, [_vp]),
+    "lto_comm_size": (C.c_int, [_vp]),
+    "lto_comm_rank": (C.c_int, [_vp]),
+    "lto_comm_allgather_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_long]),
+    "lto_comm_allreduce_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, C.c_int]),
+    "lto_group_ctx": (_vp, [_vp, C.c_int]),
+    "lto_group_comm_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "lto_group_comm_destroy": (None, [_vp]),
+    "lto_group_comm_last_error": (C.c_char_p, [_vp]),
+    "lto_group_comm_uses_rccl": (C.c_int, [_vp]),
+    "lto_group_comm_allgather_dev": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_long]),
+    "lto_group_comm_allreduce_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_long, C.c_int]),
 }
 
 _LIB = None

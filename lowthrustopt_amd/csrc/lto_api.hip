@@ -253,6 +253,7 @@ static void ctx_free(lto_ctx* c) {
 const char* lto_last_error(const lto_ctx* c) { return c ? c->err : "null context"; }
 
 void* lto_ctx_stream(lto_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int lto_ctx_device(const lto_ctx* c) { return c ? c->device : -1; }
 
 int lto_set_timing(lto_ctx* c, int enabled) {
   if (!c) return LTO_ENULL;

@@ -98,6 +98,8 @@ const char* lto_group_last_error(const lto_group* g) { return g ? g->err : "null
 
 int lto_group_size(const lto_group* g) { return g ? (int)g->ctx.size() : 0; }
 
+lto_ctx* lto_group_ctx(lto_group* g, int k) { return (g && k >= 0 && k < (int)g->ctx.size()) ? g->ctx[k] : nullptr; }
+
 int lto_group_indirect_defect(lto_group* g, int ndim, int n_nodes, int n_batch, const double* XC, const double* t, int n_tgrids,
                               const lto_params* prm, int n_prm, const lto_integrator* integ, double* defect, double* errors) {
   if (!g) return LTO_ENULL;

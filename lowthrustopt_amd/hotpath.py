@@ -150,6 +150,127 @@ class Group:
             pass
 
 
+class Comm:
+    """lto_comm: RCCL communicator of one rank (one process per GPU).  `uid` = 128 bytes from Comm.unique_id() on one rank,
+    handed to every rank by the launcher (torch.distributed broadcast, MPI, a file).  Operands are device pointers
+    (torch tensors or ints); the collectives are asynchronous on `stream`."""
+
+    @staticmethod
+    def available():
+        return bool(_lib.load_library().lto_comm_available())
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = _lib.load_library().lto_comm_unique_id(buf)
+        if rc != 0:
+            raise LtoError(rc, "lto_comm_unique_id failed (no RCCL in the process?)")
+        return buf.raw
+
+    def __init__(self, ctx, world, rank, uid):
+        self.ctx, self.lib = ctx, ctx.lib
+        h = C.c_void_p()
+        rc = self.lib.lto_comm_create(ctx.handle, int(world), int(rank), C.create_string_buffer(bytes(uid), 128), C.byref(h))
+        if rc != 0:
+            raise LtoError(rc, "lto_comm_create failed")
+        self.handle = h
+        self.world, self.rank = int(world), int(rank)
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.lto_comm_last_error(self.handle)
+            raise LtoError(rc, msg.decode() if msg else "")
+
+    def allgather(self, send, recv, count, stream=None):
+        """recv [world][count] <- send [count] of every rank."""
+        self.check(self.lib.lto_comm_allgather_dev(self.handle, stream, _dptr(send), _dptr(recv), int(count)))
+
+    def allreduce(self, buf, count, op="sum", stream=None):
+        self.check(self.lib.lto_comm_allreduce_dev(self.handle, stream, _dptr(buf), int(count), 0 if op == "sum" else 1))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lto_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _MemberContext(Context):
+    """A group member's context as a Context object (owned by the group: close() only forgets it)."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+        self.device = int(lib.lto_ctx_device(handle))
+        self._plans = weakref.WeakSet()
+        self._pinned = []
+
+    def close(self):
+        for pl in list(self._plans):
+            pl.close()
+        self.handle = None
+
+
+class GroupComm:
+    """lto_group_comm: the collectives of an lto_group (one host process, several GPUs).  member(k) is member k's Context
+    for device-resident plans; allgather / allreduce take one device pointer per member and run on the members' streams."""
+
+    def __init__(self, group):
+        self.group, self.lib = group, group.lib
+        h = C.c_void_p()
+        rc = self.lib.lto_group_comm_create(group.handle, C.byref(h))
+        if rc != 0:
+            raise LtoError(rc, "lto_group_comm_create failed")
+        self.handle = h
+        self.n = len(group)
+        self.members = [_MemberContext(self.lib, C.c_void_p(self.lib.lto_group_ctx(group.handle, k))) for k in range(self.n)]
+
+    def uses_rccl(self):
+        return bool(self.lib.lto_group_comm_uses_rccl(self.handle))
+
+    def member(self, k):
+        return self.members[k]
+
+    def stream(self, k):
+        return C.c_void_p(self.lib.lto_ctx_stream(self.members[k].handle))
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.lto_group_comm_last_error(self.handle)
+            raise LtoError(rc, msg.decode() if msg else "")
+
+    def _ptrs(self, bufs):
+        return (C.c_void_p * self.n)(*[_dptr(b) for b in bufs])
+
+    def allgather(self, send, recv, count):
+        self.check(self.lib.lto_group_comm_allgather_dev(self.handle, self._ptrs(send), self._ptrs(recv), int(count)))
+
+    def allreduce(self, bufs, count, op="sum"):
+        self.check(self.lib.lto_group_comm_allreduce_dev(self.handle, self._ptrs(bufs), int(count), 0 if op == "sum" else 1))
+
+    def synchronize(self):
+        import torch
+        for k in range(self.n):
+            torch.cuda.synchronize(self.members[k].device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            for m in self.members:
+                m.close()
+            self.lib.lto_group_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _DEFAULT_CTX = {}
 
 

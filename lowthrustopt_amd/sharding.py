@@ -29,11 +29,13 @@ def local_nodes(nodes, t, world, rank):
     return nodes[:, start:start + count + 1], t[start:start + count + 1], start, count
 
 
-def all_gather_defect(local_defect, n_seg_total, world, rank, group=None):
+def all_gather_defect(local_defect, n_seg_total, world, rank, group=None, comm=None):
     """All-gather ragged per-rank defect slabs [ndim x count_r] into the full [ndim x n_seg_total] on every rank.
 
-    Slabs are padded to the largest block so that ONE all_gather_into_tensor moves everything (the collective
-    is latency-bound: 12 x 4096 doubles per rank at BASELINE configs[1])."""
+    Slabs are padded to the largest block so that ONE collective moves everything (it is latency-bound: 12 x 4096 doubles
+    per rank at BASELINE configs[1]).  comm = a hotpath.Comm: the library's own RCCL all-gather (lto_comm_allgather_dev,
+    device to device on torch's current stream); otherwise torch.distributed's all_gather_into_tensor on `group` (RCCL
+    when its backend is "nccl", gloo in the CPU tests)."""
     import torch
     import torch.distributed as dist
     ndim = local_defect.shape[0]
@@ -41,7 +43,10 @@ def all_gather_defect(local_defect, n_seg_total, world, rank, group=None):
     pad = torch.zeros(ndim, cmax, dtype=local_defect.dtype, device=local_defect.device)
     pad[:, :local_defect.shape[1]] = local_defect
     out = torch.empty(world, ndim, cmax, dtype=local_defect.dtype, device=local_defect.device)
-    if world > 1:
+    if comm is not None:
+        from .hotpath import current_stream_ptr
+        comm.allgather(pad, out, ndim * cmax, stream=current_stream_ptr())
+    elif world > 1:
         # concatenation form [world*ndim, cmax] <- [ndim, cmax]: accepted by both RCCL and gloo
         dist.all_gather_into_tensor(out.view(world * ndim, cmax), pad.contiguous(), group=group)
     else:
@@ -53,7 +58,7 @@ def all_gather_defect(local_defect, n_seg_total, world, rank, group=None):
     return full
 
 
-def sharded_defect(sweep, nodes, t, world, rank, group=None, device=None):
+def sharded_defect(sweep, nodes, t, world, rank, group=None, device=None, comm=None):
     """Run `sweep(local_nodes [ndim x (count+1)], local_t [count+1]) -> defect [ndim x count]` (numpy in/out or
     torch in/out) on this rank's block and all-gather.  Returns the full defect as a torch tensor."""
     import torch
@@ -67,7 +72,7 @@ def sharded_defect(sweep, nodes, t, world, rank, group=None, device=None):
         d = torch.from_numpy(np.ascontiguousarray(d))
     if device is not None:
         d = d.to(device)
-    return all_gather_defect(d, n_seg, world, rank, group)
+    return all_gather_defect(d, n_seg, world, rank, group, comm=comm)
 
 
 def partition_batch(n_batch, world, rank):

@@ -53,3 +53,34 @@ def test_product_never_touches_oracle():
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
                 assert "lto_oracle" not in text and "liblto_oracle" not in text, f
                 assert not re.search(r"#include\s+[\"<].*oracle", text), f
+
+
+def _julia_ccalls():
+    """(symbol, number of argument types) of every ccall in julia/LowThrustOptHIP.jl."""
+    text = open(os.path.join(ROOT, "julia", "LowThrustOptHIP.jl")).read()
+    out = []
+    for m in re.finditer(r"ccall\(\s*(\(:(lto_[a-z0-9_]+), liblto\)|entry\(ctx, :([a-z_]+)\))\s*,\s*[A-Za-z{}]+\s*,\s*\(", text):
+        name = m.group(2) or ("lto_" + m.group(3))
+        depth, i = 1, m.end()
+        while depth:                      # the argument-type tuple, up to its closing parenthesis
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        types = text[m.end():i - 1]
+        n = 0 if not types.strip().strip(",") else len([t for t in re.split(r",(?![^{]*\})", types) if t.strip()])
+        out.append((name, n))
+    return out
+
+
+def test_every_julia_ccall_has_a_ctypes_twin_with_the_same_arity():
+    """The Julia glue cannot run here (no julia binary); what can be checked statically is that every `ccall` names an
+    exported entry point and passes as many arguments as the ctypes prototype the GPU tests execute."""
+    calls = _julia_ccalls()
+    assert len(calls) >= 35
+    lib = ctypes.CDLL(lto.LIB_PATH)
+    for name, nargs in calls:
+        assert name in _lib.SIGNATURES, "julia ccall of %s has no ctypes twin" % name
+        assert hasattr(lib, name)
+        assert nargs == len(_lib.SIGNATURES[name][1]), "%s: julia passes %d arguments, the ctypes twin %d" % (name, nargs, len(_lib.SIGNATURES[name][1]))
+    # the group forms share the argument lists of the single-context sweeps
+    for sweep in ("indirect_defect", "indirect_jacobian", "direct_defect", "direct_jacobian"):
+        assert len(_lib.SIGNATURES["lto_" + sweep][1]) == len(_lib.SIGNATURES["lto_group_" + sweep][1])

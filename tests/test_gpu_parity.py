@@ -580,6 +580,56 @@ def test_indirect_rebalance_changes_order_not_results(gpu_ctx, ndim, kernel):
         assert ei.value.code == -1
 
 
+def test_host_api_plan_cache_and_page_locked_buffers(gpu_ctx, oracle):
+    """Host-pointer ABI (what a Julia ccall takes): the context keeps the plan of a call and finds it again by shape,
+    integrator and parameter VALUES -- a call with other parameters must not hit it -- also after more distinct calls than
+    the cache holds; outputs written in place into page-locked arrays (lto_host_alloc, Julia: pinned_array) equal the
+    ones returned in fresh arrays."""
+    XC, T = synth.indirect_problem(40, seed=13)
+    XC, t = XC[:, :, 0], T[:, 0]
+    integ = lto.integrator(lto.RK4, steps=16)
+    rhos = [1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125]             # six parameter sets > four cache entries
+    ref = {}
+    for rho in rhos:
+        prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, rho]
+        P_o, d_o, rc = oracle.indirect_jacobian(XC, t, prm_l, oracle.RK4, 16)
+        assert rc == 0
+        ref[rho] = (P_o, d_o)
+    Phi_pin = gpu_ctx.pinned_empty((12, 12, 39, 1)); d_pin = gpu_ctx.pinned_empty((12, 39, 1))
+    X_pin = gpu_ctx.pinned_empty((12, 40)); X_pin[:] = XC
+    for rho in rhos + rhos[::-1] + [rhos[0], rhos[0]]:
+        prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, rho)
+        Phi, d = lto.indirect_stm(XC, t, prm, integ, ctx=gpu_ctx)
+        lto.indirect_stm(X_pin, t, prm, integ, ctx=gpu_ctx, out=(Phi_pin, d_pin))
+        assert np.array_equal(Phi, Phi_pin[:, :, :, 0]) and np.array_equal(d, d_pin[:, :, 0])
+        P_o, d_o = ref[rho]
+        assert np.abs(Phi - P_o).max() < 1e-10 * np.abs(P_o).max() and rel_l2(d, d_o, XC[:, 1:]) < 1e-10
+    # same shapes, other integrator: another plan
+    Phi2, _ = lto.indirect_stm(XC, t, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), lto.integrator(lto.RK4, steps=17), ctx=gpu_ctx)
+    assert not np.array_equal(Phi2, ref[1.0][0]) and np.abs(Phi2 - ref[1.0][0]).max() < 1e-6 * np.abs(Phi2).max()
+
+
+def test_plans_keep_their_context_alive(gpu_ctx):
+    """lto_destroy while a plan is outstanding only marks the context (a garbage collector runs finalizers in any
+    order); the plan still works and the last lto_*_plan_destroy frees the context."""
+    import torch
+    ctx = lto.Context(0)
+    n = 20
+    XC, T = synth.indirect_problem(n, seed=3)
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=8))
+    dplan = lto.DirectPlan(ctx, 6, n, 1, 10, MU, DU, TU, 2000.0)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda(); td = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    d1 = torch.zeros(12, n - 1, dtype=torch.float64, device="cuda"); d2 = torch.zeros_like(d1)
+    plan.defect(X, n, td, 1, d1, n - 1)
+    ctx.lib.lto_destroy(ctx.handle)           # context "closed" first, as a GC might
+    plan.defect(X, n, td, 1, d2, n - 1)       # the plan is still usable
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d2) and bool(torch.isfinite(d1).all())
+    ctx._plans.clear(); ctx.handle = None     # the Python wrapper must not destroy it a second time
+    plan.close(); dplan.close()               # last one frees the context
+
+
 def test_host_api_reuses_step_order_between_calls(gpu_ctx):
     """The host-pointer API builds a plan per call; for large adaptive sweeps the context remembers the lane order
     derived from the previous call's step counts (consecutive Newton iterations sweep the same problem).  Results are

@@ -49,7 +49,7 @@ def main():
                                 "max_ns": float(dom[0]["MaxNs"])} if dom else None, "pmc": {}}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         acc = {}
-        for r in rows(os.path.join(run, sub, "**", "*_counter_collection.csv")):
+        for r in list(rows(os.path.join(run, sub, "**", "*_counter_collection.csv"))) + list(rows(os.path.join(run, src, sub, "**", "*_counter_collection.csv"))):
             if kname not in r["Kernel_Name"]:
                 continue
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
