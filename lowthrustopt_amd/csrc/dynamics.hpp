@@ -640,6 +640,95 @@ __device__ __forceinline__ void rhs12_base(const double (&y)[12], const TrajPara
   dy[11] = -y[8];
 }
 
+// By-products of the lean base RHS that the variational coefficients can be rebuilt from without a reciprocal square
+// root, an exponential or a division (cooperative kernel: the base lane publishes them, the column lanes assemble G, H, U).
+struct BaseParts12 {
+  double c1, c2;      // kappa_b / d_b^{3/2}
+  double i1s, i2s;    // 1 / d_b
+  double ua, ub;      // umag / n and ua - d umag / d n   (U d = -ua d + ub (lhat.d) lhat)
+  double inv_n;       // 1 / |lambda_v| (guarded)
+};
+
+// rhs12_base plus the parts.  Same arithmetic for the slopes.
+template <int PM>
+__device__ __forceinline__ void rhs12_base_parts(const double (&y)[12], const TrajParams& tp, double (&dy)[12], BaseParts12& bp) {
+  const double MU = tp.MU;
+  const double x = y[0], yy = y[1], z = y[2];
+  const double w2 = 2.0 * tp.omega;
+  const double a = x + MU, b = a - 1.0;
+  const double yz2 = __builtin_fma(yy, yy, z * z);
+  const double d1 = __builtin_fma(a, a, yz2), d2 = __builtin_fma(b, b, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
+  const double cs = c1 + c2, omc = 1.0 - cs;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double lx = y[9], ly = y[10], lz = y[11];
+  const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
+  const double inv_n = inv_norm_guarded(n2);
+  const double n = n2 * inv_n;
+  double m, ua, ub;
+  if constexpr (PM == PM_P1) {
+    const double zz = fmin(fmax((1.0 - n) * tp.inv_rho, -700.0), 690.0);
+    const double e = exp_mid(zz);
+    const double q = rcp_nr(1.0 + e);
+    m = tp.accel_limit * q;
+    ua = m * inv_n;
+    ub = __builtin_fma(-(tp.accel_limit * tp.inv_rho) * (e * q), q, ua);   // ua - aL/(4 rho) sech^2 x
+  } else {
+    double un;
+    bool tlim;
+    control_dispatch<PM, true, true>(tp, tp.accel_limit, n, inv_n, m, ua, ub, un, tlim);
+  }
+  const double yzl = __builtin_fma(yy, ly, z * lz);
+  const double s1 = __builtin_fma(a, lx, yzl), s2 = __builtin_fma(b, lx, yzl);
+  const double t1 = e1 * s1, t2 = e2 * s2;
+  const double es = t1 + t2;
+  const double tA = __builtin_fma(t1, a, t2 * b);
+  dy[0] = y[3]; dy[1] = y[4]; dy[2] = y[5];
+  dy[3] = __builtin_fma(-ua, lx, __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, y[4], x))));
+  dy[4] = __builtin_fma(-ua, ly, __builtin_fma(-cs, yy, __builtin_fma(-w2, y[3], yy)));
+  dy[5] = __builtin_fma(-ua, lz, -cs * z);
+  dy[6] = __builtin_fma(-omc, lx, -tA);
+  dy[7] = __builtin_fma(-omc, ly, -es * yy);
+  dy[8] = __builtin_fma(cs, lz, -es * z);
+  dy[9] = __builtin_fma(w2, ly, -y[6]);
+  dy[10] = __builtin_fma(-w2, lx, -y[7]);
+  dy[11] = -y[8];
+  bp.c1 = c1; bp.c2 = c2; bp.i1s = i1s; bp.i2s = i2s; bp.ua = ua; bp.ub = ub; bp.inv_n = inv_n;
+}
+
+// G, H, U of the 12-dim system from the base argument's position r, lambda_v and the base lane's by-products: the
+// VAR block of rhs12 without its reciprocal square roots and control law.
+__device__ __forceinline__ void coef12_from_parts(const double x, const double yy, const double z, const double lx0, const double ly0,
+                                                  const double lz0, const BaseParts12& bp, const double MU, VarCoef12& vc) {
+  const double a = x + MU, b = a - 1.0;
+  const double c1 = bp.c1, c2 = bp.c2, i1s = bp.i1s, i2s = bp.i2s;
+  const double cs = c1 + c2;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double ee = e1 + e2;
+  const double sa = e1 * a, tb = e2 * b;
+  const double st = sa + tb;
+  vc.Gxx = __builtin_fma(sa, a, __builtin_fma(tb, b, 1.0 - cs));
+  vc.Gyy = __builtin_fma(ee * yy, yy, 1.0 - cs);
+  vc.Gzz = __builtin_fma(ee * z, z, -cs);
+  vc.Gxy = st * yy; vc.Gxz = st * z; vc.Gyz = ee * yy * z;
+  vc.ua = bp.ua; vc.ub = bp.ub;
+  vc.lx = lx0 * bp.inv_n; vc.ly = ly0 * bp.inv_n; vc.lz = lz0 * bp.inv_n;
+  const double yzl = __builtin_fma(yy, ly0, z * lz0);
+  const double s1 = __builtin_fma(a, lx0, yzl), s2 = __builtin_fma(b, lx0, yzl);
+  const double q1 = 5.0 * e1 * i1s * s1, q2 = 5.0 * e2 * i2s * s2;
+  const double es = __builtin_fma(e1, s1, e2 * s2);
+  const double qq = q1 + q2;
+  const double qa = __builtin_fma(q1, a, q2 * b);
+  vc.Hxx = es + 2.0 * st * lx0 - __builtin_fma(q1 * a, a, q2 * b * b);
+  vc.Hyy = es + 2.0 * ee * yy * ly0 - qq * yy * yy;
+  vc.Hzz = es + 2.0 * ee * z * lz0 - qq * z * z;
+  vc.Hxy = __builtin_fma(st, ly0, ee * yy * lx0) - qa * yy;
+  vc.Hxz = __builtin_fma(st, lz0, ee * z * lx0) - qa * z;
+  vc.Hyz = ee * __builtin_fma(yy, lz0, z * ly0) - qq * yy * z;
+}
+
 // LM = false: lambda_m_dot is not evaluated (dy[13] = 0).  For the always-thrust-limited laws (p = 0, p = 1) nothing else
 // depends on lambda_m, and the eight-wave pipeline kernel integrates it in the coefficient wave, off the critical stream.
 template <int PM, bool LM = true>

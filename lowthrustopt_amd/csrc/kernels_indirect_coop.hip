@@ -58,16 +58,16 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
   constexpr bool DOP = (METHOD == M_DOP853_ADAPTIVE);
   constexpr int NSL = DOP ? 13 : NS;         // slopes kept (DOP853: + FSAL slope)
 
-  // ND = 12 (the reference's system): the base lane evaluates the lean RHS only (rhs12_base) and publishes the six numbers
-  // the variational coefficients depend on (r, lambda_v); every column lane rebuilds G, H, U from them itself (rhs12<PM,
-  // true> on that argument).  Per stage the base stream shrinks from ~380 to ~245 instructions (54 stage-argument FMAs,
-  // 130 RHS, ~60 AGPR moves) and the column streams grow from ~195 to ~390, so the barrier interval barely moves: measured
-  // 0.308 -> 0.297 ms at 4 096 segments, DOP853 @ 1e-13.  What would pay is publishing the base lane's by-products (c_b,
-  // i_b^2, ua, ub, 1/n: seven more doubles) so that the columns skip the reciprocal square roots and the control law: ~275
-  // against ~240 instructions per stage.  Not done yet.  (ND = 14 keeps the coefficient hand-over: there wave 3 runs base
-  // and column lanes one after the other.)
+  // ND = 12 (the reference's system): the base lane is the long pole of every RK stage when it also builds the coefficients
+  // (~380 instructions against ~195 in a column lane), and the other way round when every column lane rebuilds them from
+  // the bare argument (~245 / ~390: measured 0.308 -> 0.297 ms, DOP853 @ 1e-13, 4 096 segments).  So the work is split
+  // where it balances: the base lane evaluates the lean RHS and publishes its argument (r, lambda_v) plus the by-products
+  // the coefficients need (c_b, 1/d_b, ua, ub, 1/n: 13 doubles, rhs12_base_parts); the column lanes assemble G, H, U
+  // from them without a reciprocal square root, an exponential or a division (coef12_from_parts): ~280 / ~245
+  // instructions per stage.  (ND = 14 keeps the coefficient hand-over: there wave 3 runs base and column lanes one
+  // after the other.)
   constexpr bool LEAN = (ND == 12);
-  constexpr int NPUB = LEAN ? 6 : NC;
+  constexpr int NPUB = LEAN ? 13 : NC;
   __shared__ double s_coef[2][NPUB][COOP_SEG];
   __shared__ double s_part[3][ND + 1][COOP_SEG];   // partial norms: [which][role][segment]
   __shared__ double s_scale[ND][COOP_SEG];          // 1 / (atol + rtol |base value|): the error scale of row r
@@ -115,9 +115,12 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
   auto slope = [&](const double (&arg)[ND], double (&out)[ND], int buf) {
     if (is_base) {
       if constexpr (LEAN) {
-        rhs12_base<PM>(arg, tp, out);
+        BaseParts12 bp;
+        rhs12_base_parts<PM>(arg, tp, out, bp);
         s_coef[buf][0][seg] = arg[0]; s_coef[buf][1][seg] = arg[1]; s_coef[buf][2][seg] = arg[2];
         s_coef[buf][3][seg] = arg[9]; s_coef[buf][4][seg] = arg[10]; s_coef[buf][5][seg] = arg[11];
+        s_coef[buf][6][seg] = bp.c1; s_coef[buf][7][seg] = bp.c2; s_coef[buf][8][seg] = bp.i1s; s_coef[buf][9][seg] = bp.i2s;
+        s_coef[buf][10][seg] = bp.ua; s_coef[buf][11][seg] = bp.ub; s_coef[buf][12][seg] = bp.inv_n;
       } else {
         Coef vc;
         if constexpr (ND == 12) rhs12<PM, true>(arg, tp, out, vc);
@@ -131,12 +134,11 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
     if (!is_base) {
       Coef vc;
       if constexpr (LEAN) {
-        double barg[ND], dead[ND];
-#pragma unroll
-        for (int c = 0; c < ND; ++c) barg[c] = 0.0;
-        barg[0] = s_coef[buf][0][seg]; barg[1] = s_coef[buf][1][seg]; barg[2] = s_coef[buf][2][seg];
-        barg[9] = s_coef[buf][3][seg]; barg[10] = s_coef[buf][4][seg]; barg[11] = s_coef[buf][5][seg];
-        rhs12<PM, true>(barg, tp, dead, vc);     // G, H, U at the base argument (the slopes are dead code)
+        BaseParts12 bp;
+        bp.c1 = s_coef[buf][6][seg]; bp.c2 = s_coef[buf][7][seg]; bp.i1s = s_coef[buf][8][seg]; bp.i2s = s_coef[buf][9][seg];
+        bp.ua = s_coef[buf][10][seg]; bp.ub = s_coef[buf][11][seg]; bp.inv_n = s_coef[buf][12][seg];
+        coef12_from_parts(s_coef[buf][0][seg], s_coef[buf][1][seg], s_coef[buf][2][seg], s_coef[buf][3][seg], s_coef[buf][4][seg],
+                          s_coef[buf][5][seg], bp, tp.MU, vc);
       } else {
         double* v = reinterpret_cast<double*>(&vc);
 #pragma unroll

@@ -16,6 +16,16 @@ template <int PM> static void base14(const double (&y)[14], const TrajParams& tp
   rhs14_base<PM>(y, tp, d);
   for (int i = 0; i < 14; ++i) dy_b[i] = d[i];
 }
+// by-products path of the cooperative kernel: rhs12_base_parts + coef12_from_parts against rhs12<PM, true>
+template <int PM> static void parts12(const double (&y)[12], const TrajParams& tp, double* dy_a, double* vc_a, double* dy_b, double* vc_b) {
+  double d[12]; VarCoef12 v; rhs12<PM, true>(y, tp, d, v);
+  for (int i = 0; i < 12; ++i) dy_a[i] = d[i];
+  std::memcpy(vc_a, &v, sizeof v);
+  BaseParts12 bp; rhs12_base_parts<PM>(y, tp, d, bp);
+  for (int i = 0; i < 12; ++i) dy_b[i] = d[i];
+  VarCoef12 w; coef12_from_parts(y[0], y[1], y[2], y[9], y[10], y[11], bp, tp.MU, w);
+  std::memcpy(vc_b, &w, sizeof w);
+}
 extern "C" {
 // F*col for the 14-dim system via device formulas (host-compiled)
 void chk_rhs14(const double* y, const double* tpv, int pm, double* dy, const double* col, double* dcol, double* dy_f, double* dcol_f) {
@@ -71,6 +81,14 @@ void chk_base(int ndim, const double* y, const double* tpv, int pm, double* dy_a
   else if (pm == PM_P2) base14<PM_P2>(yy, tp, dy_a, dy_b);
   else if (pm == PM_P0) base14<PM_P0>(yy, tp, dy_a, dy_b);
   else base14<PM_PGEN>(yy, tp, dy_a, dy_b);
+}
+void chk_parts12(const double* y, const double* tpv, int pm, double* dy_a, double* vc_a, double* dy_b, double* vc_b) {
+  TrajParams tp; std::memcpy(&tp, tpv, sizeof tp);
+  double yy[12]; for (int i = 0; i < 12; ++i) yy[i] = y[i];
+  if (pm == PM_P1) parts12<PM_P1>(yy, tp, dy_a, vc_a, dy_b, vc_b);
+  else if (pm == PM_P2) parts12<PM_P2>(yy, tp, dy_a, vc_a, dy_b, vc_b);
+  else if (pm == PM_P0) parts12<PM_P0>(yy, tp, dy_a, vc_a, dy_b, vc_b);
+  else parts12<PM_PGEN>(yy, tp, dy_a, vc_a, dy_b, vc_b);
 }
 int chk_sizeof_tp() { return (int)sizeof(TrajParams); }
 }

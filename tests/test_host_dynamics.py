@@ -106,3 +106,20 @@ def test_lean_base_rhs_of_the_pipeline_kernel(chk, ndim):
             chk.chk_base(ndim, P(y), P(tp), pm, P(da), P(db))
             assert np.all(np.isfinite(db))
             assert np.abs(da - db).max() <= 5e-14 * max(1.0, np.abs(da).max())
+
+
+def test_by_products_path_of_the_cooperative_kernel(chk):
+    """rhs12_base_parts (base lane: lean RHS + by-products c_b, 1/d_b, ua, ub, 1/n) and coef12_from_parts (column lanes:
+    G, H, U rebuilt from them without reciprocal square roots or the control law) give the slopes and the 17 variational
+    coefficients of the one-piece rhs12<PM, true>, for every control-law class, both time directions, rho down to 1e-4."""
+    rng = np.random.default_rng(4)
+    H1 = synth.halo_orbits()[0]
+    for td in (1.0, -1.0):
+        for p, rho, thr, lam, pm in CASES:
+            y = np.concatenate([H1[:, rng.integers(0, 99)], lam * rng.standard_normal(6)])
+            tp = tp_vec(12, thr, 1000.0, td, p, rho)
+            da = np.zeros(12); db = np.zeros(12); va = np.zeros(17); vb = np.zeros(17)
+            chk.chk_parts12(P(y), P(tp), pm, P(da), P(va), P(db), P(vb))
+            assert np.all(np.isfinite(vb)) and np.all(np.isfinite(db))
+            assert np.abs(da - db).max() <= 5e-14 * max(1.0, np.abs(da).max())
+            assert np.abs(va - vb).max() <= 1e-13 * max(1.0, np.abs(va).max())
