@@ -1089,6 +1089,40 @@ def test_indirect_pipeline_kernel_equals_per_lane_at_full_size(gpu_ctx, ndim, st
             assert np.abs(P1 - P2).max() < 1e-11 * np.abs(P1).max(), kernel
 
 
+@pytest.mark.parametrize("ndim", [12, 14])
+@pytest.mark.parametrize("steps", [255, 256, 257, 600])
+def test_indirect_pipeline_column_rescaling_at_many_steps(gpu_ctx, oracle, ndim, steps):
+    """The DPP column lanes carry 3^k Phi and multiply by 3^-256 every 256 steps (pipe_common.hpp): step counts around and
+    beyond that period, six- and eight-wave forms, against the oracle's dual-number STM of the same discrete map."""
+    import torch
+    n = 20
+    XC, T = synth.indirect_problem(n, seed=17)
+    if ndim == 14:
+        X = np.zeros((14, n), order="F")
+        X[:6] = XC[:6, :, 0]; X[6] = 1000.0; X[7:13] = XC[6:, :, 0]; X[13] = 0.2
+        prm_l = [MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+        P_o, d_o, rc = oracle.indirect14(X, T[:, 0], prm_l, oracle.RK4, steps)
+    else:
+        X = XC[:, :, 0]
+        prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+        P_o, d_o, rc = oracle.indirect_jacobian(X, T[:, 0], prm_l, oracle.RK4, steps)
+    assert rc == 0
+    S = n - 1
+    Xd = torch.from_numpy(synth.to_soa_nodes(np.asfortranarray(X)[:, :, None])).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    for kernel in ("pipe6", "pipe8"):
+        plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(lto.RK4, steps=steps), ndim=ndim)
+        pick_kernel(plan, kernel)
+        Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+        torch.cuda.synchronize()
+        P = Phi.cpu().numpy().reshape(ndim, ndim, S).transpose(1, 0, 2)
+        assert np.abs(P - P_o).max() < 1e-10 * np.abs(P_o).max(), kernel
+        assert np.linalg.norm(d.cpu().numpy() - d_o) / np.linalg.norm(d_o + X[:, 1:]) < 1e-10, kernel
+        plan.close()
+
+
 def test_indirect_pipeline_kernel_is_rk4_only(gpu_ctx):
     prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
     plan = lto.IndirectPlan(gpu_ctx, 8, 1, prm, lto.integrator(lto.DOP853_ADAPTIVE), ndim=12)
