@@ -34,7 +34,7 @@
 // For the always-thrust-limited control laws (p = 0, p = 1) of the 14-dim system nothing depends on lambda_m: the base
 // wave integrates 13 components, the coefficient wave -- which evaluates lambda_m_dot at every stage argument anyway --
 // accumulates lambda_m off the critical stream, and the STM column d/d lambda_m(t0) is the unit vector, so its lane stays
-// switched off (the sweep is power-limited: every idle lane buys shader clock).
+// switched off (idle lanes let the device raise its clocks faster in short bursts; in steady state they cost nothing).
 #include "pipe_common.hpp"
 
 namespace lto {
@@ -91,7 +91,7 @@ __device__ __forceinline__ void p8_signal(int* flag, const int value) {
 // ---------------------------------------------------------------------------------------------------------- base role
 // As pipe_role_base (row g of the wave keeps the argument of stage g in registers; ONE set of stores per step publishes all
 // four stages), two steps per phase.  Tried and dropped: rows 1..3 switched off and the stage arguments stored stage by
-// stage from row 0 -- the three redundant rows cost ~5 us of shader clock (the sweep is power-limited), but twelve more
+// stage from row 0 -- the three redundant rows cost ~5 us while the device is still raising its clocks (nothing in steady state), but twelve more
 // LDS stores per step on the chain cost more (S = 29: 79 -> 84 us).
 template <int ND, int PM>
 __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const PipeLane& L, const int seg, const int slot,
@@ -330,6 +330,10 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   __shared__ double s_hand[P::HAND_DOUBLES];
   __shared__ double s_lm[4 * PIPE_SEG];
   __shared__ Pipe8Flags s_fl;
+#ifdef PIPE_PROBE
+  __shared__ long long s_probe_t0;
+  if (threadIdx.x == 128) s_probe_t0 = wall_clock64();     // kernel entry, as seen by the base wave's first lane
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // waves 0, 1, 7: column waves 0, 1, 2; waves 4, 5: the alternating column job 3; wave 2 base, wave 3 coefficients
@@ -340,6 +344,9 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   if (threadIdx.x == 0) { s_fl.base_steps = 0; s_fl.coef_steps = 0; s_fl.hand = 0; s_fl.fail = 0; }
   if (!__syncthreads_or(L.mine)) return;         // workgroup-uniform
   if (wave == 6) return;                         // shares the base wave's SIMD: leaves before the first phase barrier
+#ifdef PIPE_PROBE
+  if (threadIdx.x == 128 && a.defect) a.defect[19 * a.ldd + blockIdx.x * PIPE_SEG] = (double)(wall_clock64() - s_probe_t0);   // prologue: entry -> roles start (100 MHz ticks)
+#endif
   if (wave == 2) pipe8_role_base<ND, PM>(a, L, seg, lane >> 4, s_int, &s_fl);
   else if (wave == 3) pipe8_role_coef<ND, PM>(a, L, seg, lane >> 4, s_int, s_coef, s_lm, &s_fl);
   else if (wave == 4) pipe8_role_columns_alt<ND, PM, false>(a, L, seg, lane & 15, s_coef, s_hand, &s_fl);

@@ -31,10 +31,12 @@ for ndim in (14, 12):
     for mask, name in [(int(m), "mask %s" % m) for m in os.environ.get("MASKS", "0,6,5,3,7,4,1").split(",")]:
         plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=64, max_steps=(1 << 20) | mask), ndim=ndim)
         plan.set_kernel(int(os.environ.get("KERNEL", "3")))
-        ms = timeit(lambda: plan.jacobian(X, n, t, 1, Phi, S, d, S, stream=st), iters=30)
+        ms = timeit(lambda: plan.jacobian(X, n, t, 1, Phi, S, d, S, stream=st), iters=int(os.environ.get('ITERS', '30')), warm=int(os.environ.get('WARM', '5')))
         dh = d.cpu().numpy()
         cyc, wall = dh[17, ::16], dh[18, ::16]
         clk = " loop %.1f us, %.0f kcycles, shader clock %.3f GHz" % (np.median(wall) / 100.0, np.median(cyc) / 1e3, np.median(cyc / wall) * 0.1) if np.median(wall) > 100 else ""
+        if os.environ.get("KERNEL", "3") == "5":
+            clk += "  prologue %.2f us" % (np.median(dh[19, ::16]) / 100.0)
         if os.environ.get("KERNEL", "3") == "5":     # pipe8 probe build: cycles every wave waited at the phase barriers
             w = dh[16].reshape(-1, 16)[:, :8]
             clk += "  barrier wait kcycles by wave " + " ".join("%.0f" % (np.median(w[:, i]) / 1e3) for i in range(8))
