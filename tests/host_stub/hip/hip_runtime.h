@@ -7,6 +7,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __constant__ static const
 using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::exp; using std::pow; using std::cbrt;
 static inline double __builtin_amdgcn_rsq(double x) { return (double)(float)(1.0 / std::sqrt(x)); }
 static inline double __builtin_amdgcn_rcp(double x) { return (double)(float)(1.0 / x); }
