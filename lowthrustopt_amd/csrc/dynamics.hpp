@@ -48,6 +48,14 @@ __device__ __forceinline__ double rcp_nr(double x) {
   const double e = __builtin_fma(-x, y, 1.0);
   return __builtin_fma(y, __builtin_fma(e, e, e), y);
 }
+// Taylor coefficients 1/k!, k = 13 .. 3, of the exp polynomials (exp_neg's Horner branch, exp_mid).  They live in constant memory on purpose: a scalar
+// load puts them into SGPR pairs, and `fma(p, r, <sgpr>)` is then a three-address v_fma_f64 the scheduler can interleave
+// freely.  (As literals hipcc materialises them in VGPRs and turns part of the Horner chain into v_mov_b64 + v_fmac_f64,
+// doubling its issue cost; inline asm with "s" operands fixes the encoding but fences the scheduler: the 13 dependent
+// FMAs then run back to back at 8.5 ticks each instead of 5.2 interleaved with the gravity terms.)
+__constant__ double kExpTaylor[11] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                                      1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0};
+
 // exp(z) for z <= 0 to ~1 ulp without the special-case handling of the general routine:
 // z = n ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial (remainder 4e-18), scaled by 2^n (underflows to 0).
 // SHORT = false: Horner (13 dependent FMAs, fewest instructions: the per-lane kernels have other work to overlap).
@@ -75,17 +83,9 @@ __device__ __forceinline__ double exp_neg(double z) {
     const double lo = __builtin_fma(p1, r, p0), hi = __builtin_fma(p3, r, p2);
     p = __builtin_fma(hi, r2, lo);
   } else {
-    p = 1.0 / 6227020800.0;
-    p = __builtin_fma(p, r, 1.0 / 479001600.0);
-    p = __builtin_fma(p, r, 1.0 / 39916800.0);
-    p = __builtin_fma(p, r, 1.0 / 3628800.0);
-    p = __builtin_fma(p, r, 1.0 / 362880.0);
-    p = __builtin_fma(p, r, 1.0 / 40320.0);
-    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = kExpTaylor[0];
+#pragma unroll
+    for (int k = 1; k < 11; ++k) p = __builtin_fma(p, r, kExpTaylor[k]);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -547,14 +547,6 @@ __device__ __forceinline__ void rhs14_fused1(const double (&y)[28], const TrajPa
 // exp(z) for z in [-700, 690], ~1 ulp: n = rint(z log2 e) through the 1.5 2^52 trick (the integer sits in the low word of
 // the biased sum), Horner polynomial of degree 13 on |r| <= ln2 / 2 (remainder 4e-18), 2^n added to the exponent field.
 // 20 instructions against 25 of exp_neg (no v_rndne, no v_cvt, no v_ldexp).
-// Taylor coefficients 1/k!, k = 13 .. 3, of exp_mid's polynomial.  They live in constant memory on purpose: a scalar
-// load puts them into SGPR pairs, and `fma(p, r, <sgpr>)` is then a three-address v_fma_f64 the scheduler can interleave
-// freely.  (As literals hipcc materialises them in VGPRs and turns part of the Horner chain into v_mov_b64 + v_fmac_f64,
-// doubling its issue cost; inline asm with "s" operands fixes the encoding but fences the scheduler: the 13 dependent
-// FMAs then run back to back at 8.5 ticks each instead of 5.2 interleaved with the gravity terms.)
-__constant__ double kExpTaylor[11] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
-                                      1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0};
-
 __device__ __forceinline__ double exp_mid(double z) {
   const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
   const double t = __builtin_fma(z, 1.4426950408889634, MAGIC);
