@@ -13,11 +13,15 @@ constexpr int THREADS = 256;
 constexpr int MAXDIM = 512;
 constexpr int LDS_BUDGET_DOUBLES = 8192;  // 64 KiB tile
 
-// nodes per tile: as many as fit the LDS budget, at most 256, a multiple of 32 when possible
-static int tile_nodes(int ndim) {
+// nodes per tile: as many as fit the LDS budget, at most 256, a multiple of 32 when possible -- and fewer when that leaves
+// the launch under 512 workgroups: the AoS side may be page-locked host memory behind the link (lto_api.hip, stage_in /
+// stage_out), where every trip of a thread's copy loop is a round trip of ~2 us, so a small batch wants one or two elements
+// per thread and its tiles spread over the chip (12 x 4 097 doubles read from the host: 20.5 us with 17 tiles of 256 nodes).
+static int tile_nodes(int ndim, long count) {
   int n = LDS_BUDGET_DOUBLES / (ndim + 1);
   if (n > 256) n = 256;
   if (n >= 32) n &= ~31;
+  while (n >= 64 && (count + n - 1) / n < 512) n >>= 1;
   return n < 1 ? 1 : n;
 }
 
@@ -217,7 +221,7 @@ hipError_t launch_end_states(double* X, long ld, int n, int nb, int nrow, double
 hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st) {
   if (count <= 0) return hipSuccess;
   if (ndim < 1 || ndim > MAXDIM) return hipErrorInvalidValue;
-  const int tn = tile_nodes(ndim);
+  const int tn = tile_nodes(ndim, count);
   const unsigned blocks = (unsigned)((count + tn - 1) / tn);
   hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(THREADS), sizeof(double) * tn * (ndim + 1), st, aos, ndim, count, soa, ld, tn);
   return hipGetLastError();
@@ -226,7 +230,7 @@ hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa,
 hipError_t launch_unpack_soa(const double* soa, long ld, int ndim, long count, double* aos, hipStream_t st) {
   if (count <= 0) return hipSuccess;
   if (ndim < 1 || ndim > MAXDIM) return hipErrorInvalidValue;
-  const int tn = tile_nodes(ndim);
+  const int tn = tile_nodes(ndim, count);
   const unsigned blocks = (unsigned)((count + tn - 1) / tn);
   hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(THREADS), sizeof(double) * tn * (ndim + 1), st, soa, ld, ndim, count, aos, tn);
   return hipGetLastError();

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -51,6 +52,11 @@ struct lto_ctx {
   // collector runs finalizers in any order) only marks the context; the last lto_*_plan_destroy frees it.
   int live_plans;
   bool closing;
+  // page-locked blocks handed out by lto_host_alloc.  The GPU addresses them directly, so the host-pointer API reads and
+  // writes a caller's buffer that lies inside one of them in place: the AoS <-> SoA kernels are the transfer, and no
+  // copy-engine operation (about 10 us of latency each) is queued.
+  struct Pinned { char* host; char* dev; size_t bytes; };
+  std::vector<Pinned> pinned;
   char err[512];
 };
 
@@ -1016,6 +1022,52 @@ int lto_defect_norms_dev(lto_ctx* c, void* stream, const double* defect, long ld
  * stream synchronise.  The caller's buffers are only touched inside the call.  Pass buffers from lto_host_alloc
  * (page-locked) and the copies are plain DMA at link speed; pageable buffers are staged by the HIP runtime. */
 
+// End of a host-pointer call: poll the stream for up to ~1 ms before blocking in the runtime.  A 4 096-segment sweep is
+// over in 0.2 ms, and the wake-up of a blocked hipStreamSynchronize is a visible part of that.
+static hipError_t stream_wait(hipStream_t st) {
+  const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(1);
+  do {
+    for (int k = 0; k < 16; ++k) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q != hipErrorNotReady) return q;
+    }
+  } while (std::chrono::steady_clock::now() < give_up);
+  return hipStreamSynchronize(st);
+}
+
+// Device view of a caller's buffer that lies wholly inside a block from lto_host_alloc; nullptr for any other memory.
+static double* pinned_view(lto_ctx* c, const double* host, size_t bytes) {
+  const char* h = (const char*)host;
+  for (const lto_ctx::Pinned& b : c->pinned) {
+    if (h >= b.host && bytes <= b.bytes && (size_t)(h - b.host) <= b.bytes - bytes) return (double*)(b.dev + (h - b.host));
+  }
+  return nullptr;
+}
+// host AoS [ndim x count] -> device SoA rows of pitch ld.  Page-locked source: the pack kernel reads it over the link;
+// otherwise a copy into d_aos first.
+static hipError_t stage_in(lto_ctx* c, const double* host, int ndim, long count, double* d_aos, double* d_soa, long ld,
+                           hipStream_t st) {
+  if (const double* z = pinned_view(c, host, sizeof(double) * (size_t)ndim * count)) return launch_pack_soa(z, ndim, count, d_soa, ld, st);
+  hipError_t e = hipMemcpyAsync(d_aos, host, sizeof(double) * (size_t)ndim * count, hipMemcpyHostToDevice, st);
+  return e == hipSuccess ? launch_pack_soa(d_aos, ndim, count, d_soa, ld, st) : e;
+}
+// device SoA -> host AoS [ndim x count]; the unpack kernel writes a page-locked destination directly.
+static hipError_t stage_out(lto_ctx* c, const double* d_soa, long ld, int ndim, long count, double* d_aos, double* host,
+                            hipStream_t st) {
+  if (double* z = pinned_view(c, host, sizeof(double) * (size_t)ndim * count)) return launch_unpack_soa(d_soa, ld, ndim, count, z, st);
+  hipError_t e = launch_unpack_soa(d_soa, ld, ndim, count, d_aos, st);
+  return e == hipSuccess ? hipMemcpyAsync(host, d_aos, sizeof(double) * (size_t)ndim * count, hipMemcpyDeviceToHost, st) : e;
+}
+// plain vectors (time grids, per-segment error estimates): a one-row pack / unpack is a copy kernel
+static hipError_t vec_in(lto_ctx* c, const double* host, long count, double* dev, hipStream_t st) {
+  if (const double* z = pinned_view(c, host, sizeof(double) * (size_t)count)) return launch_pack_soa(z, 1, count, dev, count, st);
+  return hipMemcpyAsync(dev, host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, st);
+}
+static hipError_t vec_out(lto_ctx* c, const double* dev, long count, double* host, hipStream_t st) {
+  if (double* z = pinned_view(c, host, sizeof(double) * (size_t)count)) return launch_unpack_soa(dev, count, 1, count, z, st);
+  return hipMemcpyAsync(host, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st);
+}
+
 // The plan of a host-pointer call: looked up in the context's small cache by (shape, integrator, parameter values),
 // built on a miss (least recently used entry replaced).  Owned by the context.
 static int host_plan_acquire(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
@@ -1058,12 +1110,19 @@ int lto_host_alloc(lto_ctx* c, size_t bytes, void** out) {
   if (rc) return rc;
   hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "hipHostMalloc", e);
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, *out, 0) == hipSuccess && dev)
+    c->pinned.push_back({(char*)*out, (char*)dev, bytes ? bytes : 1});
+  else
+    (void)hipGetLastError();   // still page-locked: the copy engine moves it
   return LTO_OK;
 }
 
 int lto_host_free(lto_ctx* c, void* ptr) {
   if (!c) return LTO_ENULL;
   if (!ptr) return LTO_OK;
+  for (size_t k = 0; k < c->pinned.size(); ++k)
+    if (c->pinned[k].host == (char*)ptr) { c->pinned[k] = c->pinned.back(); c->pinned.pop_back(); break; }
   hipError_t e = hipHostFree(ptr);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "hipHostFree", e);
   return LTO_OK;
@@ -1090,18 +1149,16 @@ int lto_indirect_defect(lto_ctx* c, int ndim, int n_nodes, int n_batch, const do
   double* d_def_aos = arena_take<double>(c, (size_t)ndim * S);
   double* d_err = arena_take<double>(c, (size_t)S);
   hipStream_t st = c->stream;
-  hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * ndim * J, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
+  hipError_t e = stage_in(c, XC, ndim, J, d_aos, d_X, J, st);
+  if (e == hipSuccess) e = vec_in(c, t, (long)n_nodes * n_tgrids, d_t, st);
   if (e != hipSuccess) { (void)hipStreamSynchronize(st); return set_err(c, LTO_EHIP, "stage in", e); }
   host_order_adopt(c, p, false);
   rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, errors ? d_err : nullptr);
   if (rc == LTO_OK) host_order_refresh(c, p, false, st);
   if (rc == LTO_OK) {
-    e = launch_unpack_soa(d_def, S, ndim, S, d_def_aos, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * ndim * S, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && errors) e = hipMemcpyAsync(errors, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    e = stage_out(c, d_def, S, ndim, S, d_def_aos, defect, st);
+    if (e == hipSuccess && errors) e = vec_out(c, d_err, S, errors, st);
+    if (e == hipSuccess) e = stream_wait(st);
     if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
   } else {
     (void)hipStreamSynchronize(st);
@@ -1132,21 +1189,16 @@ int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const 
   double* d_phi = arena_take<double>(c, (size_t)nn * S);
   double* d_phi_aos = arena_take<double>(c, (size_t)nn * S);
   hipStream_t st = c->stream;
-  hipError_t e = hipMemcpyAsync(d_aos, XC, sizeof(double) * ndim * J, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = launch_pack_soa(d_aos, ndim, J, d_X, J, st);
+  hipError_t e = stage_in(c, XC, ndim, J, d_aos, d_X, J, st);
+  if (e == hipSuccess) e = vec_in(c, t, (long)n_nodes * n_tgrids, d_t, st);
   if (e != hipSuccess) { (void)hipStreamSynchronize(st); return set_err(c, LTO_EHIP, "stage in", e); }
   host_order_adopt(c, p, true);
   rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
   if (rc == LTO_OK) host_order_refresh(c, p, true, st);
   if (rc == LTO_OK) {
-    e = launch_unpack_soa(d_phi, S, nn, S, d_phi_aos, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(Phi, d_phi_aos, sizeof(double) * nn * S, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && defect) {
-      e = launch_unpack_soa(d_def, S, ndim, S, d_def_aos, st);
-      if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * ndim * S, hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    e = stage_out(c, d_phi, S, nn, S, d_phi_aos, Phi, st);
+    if (e == hipSuccess && defect) e = stage_out(c, d_def, S, ndim, S, d_def_aos, defect, st);
+    if (e == hipSuccess) e = stream_wait(st);
     if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
   } else {
     (void)hipStreamSynchronize(st);
@@ -1210,7 +1262,7 @@ int lto_indirect_densify(lto_ctx* c, int ndim, int n_nodes, const double* XC, co
       e = hipMemcpyAsync(d_Y + (size_t)cc * n_desired + (n_desired - 1), d_final + cc, sizeof(double), hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = launch_unpack_soa(d_Y, n_desired, ndim, n_desired, d_Yaos, st);
     if (e == hipSuccess) e = hipMemcpyAsync(XC_dense, d_Yaos, sizeof(double) * ndim * n_desired, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = stream_wait(st);
     if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
   } else {
     (void)hipStreamSynchronize(st);
@@ -1249,35 +1301,23 @@ static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const d
   double* d_jac = want_jac ? arena_take<double>(c, (size_t)nj * S) : nullptr;
   double* d_jac_aos = want_jac ? arena_take<double>(c, (size_t)nj * S) : nullptr;
   hipStream_t st = c->stream;
-  hipError_t e = hipMemcpyAsync(d_xa, X, sizeof(double) * nstate * J, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_ua, U, sizeof(double) * 3 * J, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n_nodes * n_tgrids, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = launch_pack_soa(d_xa, nstate, J, d_X, J, st);
-  if (e == hipSuccess) e = launch_pack_soa(d_ua, 3, J, d_U, J, st);
+  hipError_t e = stage_in(c, X, nstate, J, d_xa, d_X, J, st);
+  if (e == hipSuccess) e = stage_in(c, U, 3, J, d_ua, d_U, J, st);
+  if (e == hipSuccess) e = vec_in(c, t, (long)n_nodes * n_tgrids, d_t, st);
   if (e != hipSuccess) { delete p; return set_err(c, LTO_EHIP, "stage in", e); }
   if (want_jac)
     rc = lto_direct_jacobian_dev(p, st, d_X, J, d_U, J, d_t, n_tgrids, d_jac, S, d_dtf, d_def, S, d_err);
   else   // the dtf staging buffers are free on this path: they carry the mid-point states
     rc = direct_defect_launch(p, st, d_X, J, d_U, J, d_t, n_tgrids, d_def, S, d_err, x_mid ? d_dtf : nullptr, S);
   if (rc == LTO_OK) {
-    if (x_mid) {
-      e = launch_unpack_soa(d_dtf, S, nstate, S, d_dtf_aos, st);
-      if (e == hipSuccess) e = hipMemcpyAsync(x_mid, d_dtf_aos, sizeof(double) * nstate * S, hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess && defect) {
-      e = launch_unpack_soa(d_def, S, nstate, S, d_def_aos, st);
-      if (e == hipSuccess) e = hipMemcpyAsync(defect, d_def_aos, sizeof(double) * nstate * S, hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess && errors) e = hipMemcpyAsync(errors, d_err, sizeof(double) * S, hipMemcpyDeviceToHost, st);
+    if (x_mid) e = stage_out(c, d_dtf, S, nstate, S, d_dtf_aos, x_mid, st);
+    if (e == hipSuccess && defect) e = stage_out(c, d_def, S, nstate, S, d_def_aos, defect, st);
+    if (e == hipSuccess && errors) e = vec_out(c, d_err, S, errors, st);
     if (e == hipSuccess && want_jac) {
-      e = launch_unpack_soa(d_jac, S, nj, S, d_jac_aos, st);
-      if (e == hipSuccess) e = hipMemcpyAsync(Jac_temp, d_jac_aos, sizeof(double) * nj * S, hipMemcpyDeviceToHost, st);
-      if (e == hipSuccess && ddefect_dtf) {
-        e = launch_unpack_soa(d_dtf, S, nstate, S, d_dtf_aos, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(ddefect_dtf, d_dtf_aos, sizeof(double) * nstate * S, hipMemcpyDeviceToHost, st);
-      }
+      e = stage_out(c, d_jac, S, nj, S, d_jac_aos, Jac_temp, st);
+      if (e == hipSuccess && ddefect_dtf) e = stage_out(c, d_dtf, S, nstate, S, d_dtf_aos, ddefect_dtf, st);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = stream_wait(st);
     if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
   } else {
     (void)hipStreamSynchronize(st);

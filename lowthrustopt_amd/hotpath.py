@@ -77,8 +77,9 @@ class Context:
             self.handle = None
 
     def pinned_empty(self, shape, order="F"):
-        """numpy float64 array in page-locked host memory (lto_host_alloc): H2D / D2H of the host-pointer API then run
-        as plain DMA.  The memory lives until the context is closed."""
+        """numpy float64 array in page-locked host memory (lto_host_alloc).  The host-pointer API reads and writes such
+        arrays (and contiguous views into them) in place from the GPU: no copy-engine operation per operand.  The
+        memory lives until the context is closed."""
         n = int(np.prod(shape))
         ptr = C.c_void_p()
         self.check(self.lib.lto_host_alloc(self.handle, max(n, 1) * 8, C.byref(ptr)))
@@ -303,18 +304,24 @@ def _tgrids(t, n_nodes, n_batch):
     return t, n_batch
 
 
-def indirect_defectCalc(XC_all, t_TU, params, integ=None, ctx=None):
+def indirect_defectCalc(XC_all, t_TU, params, integ=None, ctx=None, out=None):
     """defectCalc of multiShoot_CRTBP_indirect (:63-90): returns (defect[12 x (n-1)], errors[n-1]).
     A trailing batch axis on XC_all sweeps several trajectories (line-search trial points, homotopy levels)
-    in one launch; params may then be one tuple or one per trajectory."""
+    in one launch; params may then be one tuple or one per trajectory.  out = (defect, errors): Fortran-ordered float64
+    arrays of shapes (ndim, n-1, B) and (n-1, B) written in place."""
     ctx = ctx or default_context()
     integ = integ or integrator()
     XC = _f64(XC_all)
     ndim, n, B, batched = _batch_dims(XC)
     t, ntg = _tgrids(t_TU, n, B)
     prm, nprm = _params_array(params)
-    defect = np.zeros((ndim, n - 1, B), order="F")
-    errors = np.zeros((n - 1, B), order="F")
+    if out is not None:
+        defect, errors = out
+        if defect.shape != (ndim, n - 1, B) or errors.shape != (n - 1, B) or not (defect.flags.f_contiguous and errors.flags.f_contiguous):
+            raise LtoError(-1, "out arrays must be Fortran-ordered (ndim, n-1, B) and (n-1, B)")
+    else:
+        defect = np.zeros((ndim, n - 1, B), order="F")
+        errors = np.zeros((n - 1, B), order="F")
     ctx.check(ctx.fn("indirect_defect")(ctx.handle, ndim, n, B, _ptr(XC), _ptr(t), ntg, prm, nprm, C.byref(integ),
                                           _ptr(defect), _ptr(errors)))
     if not batched:
@@ -493,9 +500,10 @@ def direct_midpoints(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
     return x_mid, defect, errors
 
 
-def direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None):
+def direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None, out=None):
     """Compact direct Jacobian: (Jac_temp[nstate x nvar x (n-1)], ddefect_dtf[nstate x (n-1)], defect, errors);
-    nvar = 2(nstate+3), variable order [x_i; x_{i+1}; u_i; u_{i+1}] (:125)."""
+    nvar = 2(nstate+3), variable order [x_i; x_{i+1}; u_i; u_{i+1}] (:125).  out = (Jac_temp, ddefect_dtf, defect, errors):
+    Fortran-ordered float64 arrays with the trailing batch axis, written in place (e.g. from Context.pinned_empty)."""
     ctx = ctx or default_context()
     X = _f64(X_all)
     U = _f64(u_all)
@@ -503,10 +511,16 @@ def direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None
     nvar = 2 * (ns + 3)
     t, ntg = _tgrids(t_TU, n, B)
     prm = LtoDirectParams(float(MU), float(DU), float(TU), float(Isp))
-    Jt = np.zeros((ns, nvar, n - 1, B), order="F")
-    dtf = np.zeros((ns, n - 1, B), order="F")
-    defect = np.zeros((ns, n - 1, B), order="F")
-    errors = np.zeros((n - 1, B), order="F")
+    if out is not None:
+        Jt, dtf, defect, errors = out
+        shapes = ((ns, nvar, n - 1, B), (ns, n - 1, B), (ns, n - 1, B), (n - 1, B))
+        if any(a.shape != sh or not a.flags.f_contiguous or a.dtype != np.float64 for a, sh in zip(out, shapes)):
+            raise LtoError(-1, "out arrays must be Fortran-ordered float64 of shapes %s" % (shapes,))
+    else:
+        Jt = np.zeros((ns, nvar, n - 1, B), order="F")
+        dtf = np.zeros((ns, n - 1, B), order="F")
+        defect = np.zeros((ns, n - 1, B), order="F")
+        errors = np.zeros((n - 1, B), order="F")
     ctx.check(ctx.fn("direct_jacobian")(ctx.handle, ns, n, B, _ptr(X), _ptr(U), _ptr(t), ntg, int(nsteps), C.byref(prm),
                                           _ptr(Jt), _ptr(dtf), _ptr(defect), _ptr(errors)))
     if not batched:

@@ -609,6 +609,54 @@ def test_host_api_plan_cache_and_page_locked_buffers(gpu_ctx, oracle):
     assert not np.array_equal(Phi2, ref[1.0][0]) and np.abs(Phi2 - ref[1.0][0]).max() < 1e-6 * np.abs(Phi2).max()
 
 
+def test_host_api_page_locked_operands_in_place(gpu_ctx):
+    """Operands inside blocks from lto_host_alloc are read and written by the GPU in place (the AoS <-> SoA kernels are the
+    transfer).  Every mix -- all page-locked, views at an odd offset inside a larger block, page-locked inputs with pageable
+    outputs and the reverse -- returns bit for bit what the pageable path returns: indirect defect / Jacobian (RK4 and the
+    adaptive integrator with its error output) and the direct defect / Jacobian blocks."""
+    n = 70
+    XC, T = synth.indirect_problem(n, seed=23)
+    XC, t = np.asfortranarray(XC[:, :, 0]), np.ascontiguousarray(T[:, 0])
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 0.3)
+    S = n - 1
+
+    def view(shape, offset=0):
+        cnt = int(np.prod(shape))
+        block = gpu_ctx.pinned_empty((cnt + offset,))
+        block[:] = -7.0
+        return block[offset:].reshape(shape, order="F")
+
+    for integ in (lto.integrator(lto.RK4, steps=12), lto.integrator()):
+        Phi0, d0 = lto.indirect_stm(XC, t, prm, integ, ctx=gpu_ctx)
+        dd0, e0 = lto.indirect_defectCalc(XC, t, prm, integ, ctx=gpu_ctx)
+        for off in (0, 5):
+            Xp = view((12, n), off); Xp[:] = XC
+            tp = view((n,), off); tp[:] = t
+            for pin_in, pin_out in ((True, True), (True, False), (False, True)):
+                Phi = view((12, 12, S, 1), off) if pin_out else np.full((12, 12, S, 1), -7.0, order="F")
+                d = view((12, S, 1), off) if pin_out else np.full((12, S, 1), -7.0, order="F")
+                e = view((S, 1), off) if pin_out else np.full((S, 1), -7.0, order="F")
+                d2 = view((12, S, 1), off) if pin_out else np.full((12, S, 1), -7.0, order="F")
+                Xi, ti = (Xp, tp) if pin_in else (XC, t)
+                lto.indirect_stm(Xi, ti, prm, integ, ctx=gpu_ctx, out=(Phi, d))
+                lto.indirect_defectCalc(Xi, ti, prm, integ, ctx=gpu_ctx, out=(d2, e))
+                assert np.array_equal(Phi[..., 0], Phi0) and np.array_equal(d[..., 0], d0)
+                assert np.array_equal(d2[..., 0], dd0) and np.array_equal(e[:, 0], e0)
+    for nstate in (6, 7):
+        X, U, Td = synth.direct_problem(n, seed=4, nstate=nstate)
+        X, U, td = np.asfortranarray(X[:, :, 0]), np.asfortranarray(U[:, :, 0]), np.ascontiguousarray(Td[:, 0])
+        ref = lto.direct_jacobian_blocks(X, U, td, 10, MU, DU, TU, 2000.0, ctx=gpu_ctx)
+        nvar = 2 * (nstate + 3)
+        for off in (0, 3):
+            Xp = view((nstate, n), off); Xp[:] = X
+            Up = view((3, n), off); Up[:] = U
+            tp = view((n,), off); tp[:] = td
+            out = (view((nstate, nvar, S, 1), off), view((nstate, S, 1), off), view((nstate, S, 1), off), view((S, 1), off))
+            lto.direct_jacobian_blocks(Xp, Up, tp, 10, MU, DU, TU, 2000.0, ctx=gpu_ctx, out=out)
+            for a, b in zip(out, ref):
+                assert np.array_equal(a[..., 0], b)
+
+
 def test_plans_keep_their_context_alive(gpu_ctx):
     """lto_destroy while a plan is outstanding only marks the context (a garbage collector runs finalizers in any
     order); the plan still works and the last lto_*_plan_destroy frees the context."""
