@@ -18,8 +18,10 @@ defect slabs (ndim x 4096 doubles) gives every rank the full defect vector.
 
 Timing: the K steps of the timed region are enqueued back to back with NO event in between (an event pair per launch
 serialises the queue and costs ~12 us per step at the contract size); `value` = segments x K / that wall time, so it does
-not depend on K.  Kernel launch durations (`roofline.kernel_ms`) are sampled in a separate pass after the timed region:
-N_SAMPLE isolated launches, each bracketed by a HIP event pair on the launch stream.
+not depend on K.  The dominant kernel's launch duration (`roofline.kernel_ms`) comes from a separate pass right after the
+timed region, at the same ramped clocks: one HIP event pair on the launch stream around a burst of back-to-back launches,
+divided by their number (so the ~1.5 us between consecutive launches is counted against the kernel).  N_SAMPLE isolated
+launches with an event pair each are reported beside it (`kernel_ms_isolated`): the device drops its clocks between them.
 
 Device clocks: the device ramps its clocks over the first ~20 ms of load, so a 25-launch run measures the ramp (91 us per
 step) and not the sweep (80 us).  The W + K region is therefore run twice: from cold clocks first (`cold_clocks` in the JSON
@@ -43,6 +45,7 @@ if ROOT not in sys.path:
 PEAK_FP64_TFLOPS = 78.6   # MI355X vector (= matrix) FP64 peak
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 N_SAMPLE = 8              # isolated launches timed with an event pair each, after the timed region
+N_BURST = 200             # back-to-back launches inside one event pair (fewer for millisecond kernels)
 
 # Algorithmic work per unit (DESIGN.md "Roofline"): flops = steps*(stages*F_rhs + C_tab*dim)
 # F_rhs (model flops: + - x / sqrt tanh = 1, FMA = 2): 12-dim 95, + 12x12 variational 1070; 14-dim 110,
@@ -148,16 +151,31 @@ def cpu_baseline(workload, seconds, threads=1, ndim=12, reference_algorithm=Fals
 
 
 def sample_launches(torch, sweep, n=N_SAMPLE):
-    """Durations (ms) of n isolated launches of `sweep`, each bracketed by a HIP event pair on the current stream (the
-    stream the kernels are launched on).  Run after the timed region: nothing here perturbs `value`."""
-    out = []
+    """(burst_ms, burst_n, isolated): average launch period (ms) of a burst of back-to-back launches of `sweep` inside ONE
+    HIP event pair on the current stream (the stream the kernels are launched on), and the durations of n isolated
+    launches with an event pair each.  Run straight after the timed region (clocks still ramped): nothing here perturbs
+    `value`."""
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(); sweep(); e1.record()
+    torch.cuda.synchronize()
+    first = e0.elapsed_time(e1)
+    burst_n = int(max(8, min(N_BURST, 200.0 / max(first, 1e-3))))     # about 0.2 s at most
+    for _ in range(4):
+        sweep()
+    e0.record()
+    for _ in range(burst_n):
+        sweep()
+    e1.record()
+    torch.cuda.synchronize()
+    burst_ms = e0.elapsed_time(e1) / burst_n
+    iso = []
     for _ in range(n):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record(); sweep(); e1.record()
         torch.cuda.synchronize()
-        out.append(e0.elapsed_time(e1))
-    return out
+        iso.append(e0.elapsed_time(e1))
+    return burst_ms, burst_n, iso
 
 
 # DOP853 trial step (csrc/rk.hpp dop853_try): 12 RHS evaluations + tableau arithmetic 2 x (50 a_ij + 8 b + 8 e3 + 8 e5) per component
@@ -165,7 +183,7 @@ def dop853_flops(trial_steps, f_rhs, dim):
     return trial_steps * (12 * f_rhs + 148 * dim)
 
 
-def roofline(wl, ndim, S, kern_ms, work=None, samples=None):
+def roofline(wl, ndim, S, kern_ms, work=None, samples=None, burst_n=N_BURST):
     flops, nbytes = work if work is not None else WORK[(wl, ndim)]
     dur = kern_ms * 1e-3
     ach_tf = flops * S / dur / 1e12
@@ -185,8 +203,10 @@ def roofline(wl, ndim, S, kern_ms, work=None, samples=None):
         # FP64 vector peak, and the vector pipe is what this kernel runs on (compute_pipe); the HBM roof is in "hbm"
         "bound": "mfma", "compute_pipe": "fp64_valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
         "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_from": traffic_from,
-        "kernel_ms": kern_ms, "kernel_ms_from": "mean of %d isolated launches after the timed region, one HIP event pair each" % N_SAMPLE,
-        "kernel_ms_samples": samples,
+        "kernel_ms": kern_ms,
+        "kernel_ms_from": "one HIP event pair on the launch stream around %d back-to-back launches right after the timed region, "
+                          "divided by their number (launch period: includes the gap between consecutive launches)" % burst_n,
+        "kernel_ms_isolated": samples,
         "flops_per_segment": flops, "bytes_per_segment": nbytes,
         "hbm": {"achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBS},
         "note": "register-resident fp64 ODE integration: compute-bound on the FP64 vector pipe (no MFMA instruction is "
@@ -263,11 +283,10 @@ def leg_12dim(lto, synth, ctx, st, torch, a):
         plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    samples = sample_launches(torch, lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st))
-    kern_ms = float(np.mean(samples))
+    kern_ms, burst_n, samples = sample_launches(torch, lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st))
     out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
            "workload": "C2 on the reference's CRTBP_stateCostate_deriv! system: 12-dim state+costate + 12x12 STM, 4 096 "
-                       "segments, RK4 x 64, fp64", "stm_kernel": plan.last_kernel(), "roofline": roofline("c2", 12, S, kern_ms, samples=samples)}
+                       "segments, RK4 x 64, fp64", "stm_kernel": plan.last_kernel(), "roofline": roofline("c2", 12, S, kern_ms, samples=samples, burst_n=burst_n)}
     plan.close()
 
     def add_parity():
@@ -490,8 +509,7 @@ def main():
         plan.rebalance(stream=st)                      # lanes ordered by the warm-up sweep's step counts (on device)
         rebalanced = True
     elapsed = timed_leg()
-    samples = sample_launches(torch, lambda: sweep(dbufs[0]))     # separate pass: launch durations of the dominant kernel
-    kern_ms = float(np.mean(samples))
+    kern_ms, burst_n, samples = sample_launches(torch, lambda: sweep(dbufs[0]))   # separate pass: the dominant kernel alone
 
     if use_coll:
         for b in range(len(dbufs)):
@@ -526,13 +544,13 @@ def main():
         if wl in ("c2", "hbm", "c4", "c5_stm"):
             out["config"]["stm_kernel"] = plan.last_kernel()
         if (wl, a.ndim) in WORK and not a.method:
-            out["roofline"] = roofline(wl, a.ndim, S, kern_ms, samples=samples)
+            out["roofline"] = roofline(wl, a.ndim, S, kern_ms, samples=samples, burst_n=burst_n)
         elif wl == "c2" and a.method == "dop853":
             # the reference's own integrator setting (adaptive order 8 @ 1e-13 + STM): flops from the step counts of this sweep
             acc, rej = plan.step_counts(stream=st)
             trial = float((acc + rej).sum())
             f_rhs, dim, nbytes = (1490, 210, 1920) if a.ndim == 14 else (1070, 156, 1456)
-            out["roofline"] = roofline(wl, a.ndim, S, kern_ms, work=(dop853_flops(trial, f_rhs, dim) / S, nbytes), samples=samples)
+            out["roofline"] = roofline(wl, a.ndim, S, kern_ms, work=(dop853_flops(trial, f_rhs, dim) / S, nbytes), samples=samples, burst_n=burst_n)
             out["roofline"]["flops_from"] = ("measured step counts of this sweep: %.2f accepted + %.2f rejected trial steps per segment (max %d) x "
                                              "(12 x %d + 148 x %d)" % (acc.mean(), rej.mean(), int((acc + rej).max()), f_rhs, dim))
         if c5:
@@ -548,7 +566,7 @@ def main():
             # work actually done: accepted + rejected trial steps of every segment (DOP853: 12 RHS evaluations per trial step)
             f_rhs, dim = (1070, 156) if wl == "c5_stm" else (95, 12)
             work = (dop853_flops(float(tot.sum()), f_rhs, dim) / S, 1456 if wl == "c5_stm" else 304)
-            out["roofline"] = roofline(wl, 12, S, kern_ms, work=work, samples=samples)
+            out["roofline"] = roofline(wl, 12, S, kern_ms, work=work, samples=samples, burst_n=burst_n)
             out["roofline"]["flops_from"] = "measured step counts of this sweep: %.2f trial steps per segment x (12 x %d + 148 x %d)" % (tot.mean(), f_rhs, dim)
             out["adaptive"] = {"steps_accepted_mean": float(acc.mean()), "steps_accepted_max": int(acc.max()),
                                "steps_rejected_mean": float(rej.mean()), "steps_rejected_max": int(rej.max()),

@@ -79,6 +79,11 @@ hipError_t launch_axpy(const double* x, const double* d, double alpha, double* y
 
 hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st);
 hipError_t launch_unpack_soa(const double* soa, long ld, int ndim, long count, double* aos, hipStream_t st);
+// two pack / unpack jobs in one launch
+hipError_t launch_pack_soa2(const double* aos_a, int ndim_a, long count_a, double* soa_a, long ld_a, const double* aos_b, int ndim_b,
+                            long count_b, double* soa_b, long ld_b, hipStream_t st);
+hipError_t launch_unpack_soa2(const double* soa_a, long ld_a, int ndim_a, long count_a, double* aos_a, const double* soa_b, long ld_b,
+                              int ndim_b, long count_b, double* aos_b, hipStream_t st);
 constexpr int LTO_ORDER_BINS = 1024;   // int workspace launch_segment_order needs
 hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bins, int* order, hipStream_t st);
 hipError_t launch_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, int na, const double* alphas,

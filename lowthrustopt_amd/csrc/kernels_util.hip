@@ -5,6 +5,7 @@
 //                  the HBM reads and the HBM writes are unit-stride across the wavefront.
 //  defect_norms  : per trajectory sum(defect.^2) (line-search cost, multiShoot_CRTBP_indirect.jl:240,
 //                  multiShoot_CRTBP_direct.jl:424) and max|defect| (convergence test, :331 / :588).
+#include <algorithm>
 #include "kernels.hpp"
 
 namespace lto {
@@ -12,6 +13,8 @@ namespace lto {
 constexpr int THREADS = 256;
 constexpr int MAXDIM = 512;
 constexpr int LDS_BUDGET_DOUBLES = 8192;  // 64 KiB tile
+
+struct PackJob { const double* aos; double* soa; long count, ld; int ndim, tn, tiles; };
 
 // nodes per tile: as many as fit the LDS budget, at most 256, a multiple of 32 when possible -- and fewer when that leaves
 // the launch under 512 workgroups: the AoS side may be page-locked host memory behind the link (lto_api.hip, stage_in /
@@ -26,10 +29,9 @@ static int tile_nodes(int ndim, long count) {
 }
 
 // LDS tile [tn][ndim+1]: the +1 pad breaks the regular row stride (bank conflicts).
-__global__ __launch_bounds__(THREADS) void k_pack(const double* __restrict__ aos, int ndim, long count,
-                                                  double* __restrict__ soa, long ld, int tn) {
-  extern __shared__ double tile[];
-  const long j0 = (long)blockIdx.x * tn;
+__device__ __forceinline__ void pack_tile(double* tile, const double* __restrict__ aos, int ndim, long count, double* __restrict__ soa,
+                                          long ld, int tn, long tile_id) {
+  const long j0 = tile_id * tn;
   const int nj = (int)((count - j0 < tn) ? (count - j0) : tn);
   const int pitch = ndim + 1;
   const double* src = aos + j0 * ndim;
@@ -44,10 +46,9 @@ __global__ __launch_bounds__(THREADS) void k_pack(const double* __restrict__ aos
   }
 }
 
-__global__ __launch_bounds__(THREADS) void k_unpack(const double* __restrict__ soa, long ld, int ndim, long count,
-                                                    double* __restrict__ aos, int tn) {
-  extern __shared__ double tile[];
-  const long j0 = (long)blockIdx.x * tn;
+__device__ __forceinline__ void unpack_tile(double* tile, const double* __restrict__ soa, long ld, int ndim, long count,
+                                            double* __restrict__ aos, int tn, long tile_id) {
+  const long j0 = tile_id * tn;
   const int nj = (int)((count - j0 < tn) ? (count - j0) : tn);
   const int pitch = ndim + 1;
   for (int e = threadIdx.x; e < nj * ndim; e += THREADS) {
@@ -60,6 +61,33 @@ __global__ __launch_bounds__(THREADS) void k_unpack(const double* __restrict__ s
     const int j = e / ndim, c = e - j * ndim;
     dst[e] = tile[j * pitch + c];
   }
+}
+
+__global__ __launch_bounds__(THREADS) void k_pack(const double* __restrict__ aos, int ndim, long count,
+                                                  double* __restrict__ soa, long ld, int tn) {
+  extern __shared__ double tile[];
+  pack_tile(tile, aos, ndim, count, soa, ld, tn, blockIdx.x);
+}
+
+__global__ __launch_bounds__(THREADS) void k_unpack(const double* __restrict__ soa, long ld, int ndim, long count,
+                                                    double* __restrict__ aos, int tn) {
+  extern __shared__ double tile[];
+  unpack_tile(tile, soa, ld, ndim, count, aos, tn, blockIdx.x);
+}
+
+// Two layout jobs in one launch (the host-pointer API's page-locked path: node array + time grid in, STM + defect out;
+// behind the link every launch is a few microseconds of latency that two jobs can share).  Workgroups [0, a.tiles) serve
+// job a, the rest job b.
+__global__ __launch_bounds__(THREADS) void k_pack2(const PackJob a, const PackJob b) {
+  extern __shared__ double tile[];
+  if ((int)blockIdx.x < a.tiles) pack_tile(tile, a.aos, a.ndim, a.count, a.soa, a.ld, a.tn, blockIdx.x);
+  else pack_tile(tile, b.aos, b.ndim, b.count, b.soa, b.ld, b.tn, (long)blockIdx.x - a.tiles);
+}
+
+__global__ __launch_bounds__(THREADS) void k_unpack2(const PackJob a, const PackJob b) {
+  extern __shared__ double tile[];
+  if ((int)blockIdx.x < a.tiles) unpack_tile(tile, a.soa, a.ld, a.ndim, a.count, const_cast<double*>(a.aos), a.tn, blockIdx.x);
+  else unpack_tile(tile, b.soa, b.ld, b.ndim, b.count, const_cast<double*>(b.aos), b.tn, (long)blockIdx.x - a.tiles);
 }
 
 // One workgroup per trajectory; NaN-propagating max (a NaN defect must surface, status_flag = 2 path).
@@ -233,6 +261,33 @@ hipError_t launch_unpack_soa(const double* soa, long ld, int ndim, long count, d
   const int tn = tile_nodes(ndim, count);
   const unsigned blocks = (unsigned)((count + tn - 1) / tn);
   hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(THREADS), sizeof(double) * tn * (ndim + 1), st, soa, ld, ndim, count, aos, tn);
+  return hipGetLastError();
+}
+
+static bool pack_job(PackJob& j, const double* aos, int ndim, long count, double* soa, long ld) {
+  if (ndim < 1 || ndim > MAXDIM || count <= 0) return false;
+  j.aos = aos; j.soa = soa; j.ndim = ndim; j.count = count; j.ld = ld;
+  j.tn = tile_nodes(ndim, count);
+  j.tiles = (int)((count + j.tn - 1) / j.tn);
+  return true;
+}
+
+hipError_t launch_pack_soa2(const double* aos_a, int ndim_a, long count_a, double* soa_a, long ld_a, const double* aos_b, int ndim_b,
+                            long count_b, double* soa_b, long ld_b, hipStream_t st) {
+  PackJob a, b;
+  if (!pack_job(a, aos_a, ndim_a, count_a, soa_a, ld_a) || !pack_job(b, aos_b, ndim_b, count_b, soa_b, ld_b)) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * (size_t)std::max(a.tn * (a.ndim + 1), b.tn * (b.ndim + 1));
+  hipLaunchKernelGGL(k_pack2, dim3((unsigned)(a.tiles + b.tiles)), dim3(THREADS), lds, st, a, b);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_soa2(const double* soa_a, long ld_a, int ndim_a, long count_a, double* aos_a, const double* soa_b, long ld_b,
+                              int ndim_b, long count_b, double* aos_b, hipStream_t st) {
+  PackJob a, b;
+  if (!pack_job(a, aos_a, ndim_a, count_a, const_cast<double*>(soa_a), ld_a) ||
+      !pack_job(b, aos_b, ndim_b, count_b, const_cast<double*>(soa_b), ld_b)) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * (size_t)std::max(a.tn * (a.ndim + 1), b.tn * (b.ndim + 1));
+  hipLaunchKernelGGL(k_unpack2, dim3((unsigned)(a.tiles + b.tiles)), dim3(THREADS), lds, st, a, b);
   return hipGetLastError();
 }
 

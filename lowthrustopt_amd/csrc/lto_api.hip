@@ -1189,15 +1189,30 @@ int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const 
   double* d_phi = arena_take<double>(c, (size_t)nn * S);
   double* d_phi_aos = arena_take<double>(c, (size_t)nn * S);
   hipStream_t st = c->stream;
-  hipError_t e = stage_in(c, XC, ndim, J, d_aos, d_X, J, st);
-  if (e == hipSuccess) e = vec_in(c, t, (long)n_nodes * n_tgrids, d_t, st);
+  // all operands page-locked: node array and time grid come in with one launch, STM and defect leave with one
+  const long nt = (long)n_nodes * n_tgrids;
+  const double* zX = pinned_view(c, XC, sizeof(double) * (size_t)ndim * J);
+  const double* zt = pinned_view(c, t, sizeof(double) * (size_t)nt);
+  double* zPhi = pinned_view(c, Phi, sizeof(double) * (size_t)nn * S);
+  double* zdef = defect ? pinned_view(c, defect, sizeof(double) * (size_t)ndim * S) : nullptr;
+  hipError_t e;
+  if (zX && zt) {
+    e = launch_pack_soa2(zX, ndim, J, d_X, J, zt, 1, nt, d_t, nt, st);
+  } else {
+    e = stage_in(c, XC, ndim, J, d_aos, d_X, J, st);
+    if (e == hipSuccess) e = vec_in(c, t, nt, d_t, st);
+  }
   if (e != hipSuccess) { (void)hipStreamSynchronize(st); return set_err(c, LTO_EHIP, "stage in", e); }
   host_order_adopt(c, p, true);
   rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);
   if (rc == LTO_OK) host_order_refresh(c, p, true, st);
   if (rc == LTO_OK) {
-    e = stage_out(c, d_phi, S, nn, S, d_phi_aos, Phi, st);
-    if (e == hipSuccess && defect) e = stage_out(c, d_def, S, ndim, S, d_def_aos, defect, st);
+    if (zPhi && zdef) {
+      e = launch_unpack_soa2(d_phi, S, nn, S, zPhi, d_def, S, ndim, S, zdef, st);
+    } else {
+      e = stage_out(c, d_phi, S, nn, S, d_phi_aos, Phi, st);
+      if (e == hipSuccess && defect) e = stage_out(c, d_def, S, ndim, S, d_def_aos, defect, st);
+    }
     if (e == hipSuccess) e = stream_wait(st);
     if (e != hipSuccess) rc = set_err(c, LTO_EHIP, "stage out", e);
   } else {
