@@ -295,8 +295,9 @@ devptr(::Nothing) = C_NULL
 "hipStream_t owned by the context (non-blocking); pass it as `stream` to keep library work off the default stream."
 ctx_stream(ctx::LtoContext) = ccall((:lto_ctx_stream, liblto), Ptr{Cvoid}, (Ptr{Cvoid},), ctx.handle)
 
-"""`Array{Float64}` of the given size in page-locked host memory (lto_host_alloc): with such arrays the H2D / D2H copies of the
-host-pointer API are plain DMA at link speed (Phi of a 4 096-segment sweep: ~0.1 ms instead of ~0.3 ms).  Freed by a finalizer."""
+"""`Array{Float64}` of the given size in page-locked host memory (lto_host_alloc): the GPU reads and writes such arrays (and
+contiguous views into them) in place during a host-pointer call -- no copy is queued (Jacobian call at 4 096 segments: 0.215 ms
+instead of 0.31 ms with ordinary arrays).  Freed by a finalizer."""
 function pinned_array(ctx::LtoContext, dims::Integer...)
     p = Ref{Ptr{Cvoid}}(C_NULL)
     check(ctx, ccall((:lto_host_alloc, liblto), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, 8 * prod(dims), p))
