@@ -237,6 +237,10 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 #define LTO_KERNEL_PIPE 3
 #define LTO_KERNEL_PIPE6 4
 #define LTO_KERNEL_PIPE8 5
+/* ndim = 12, DOP853_ADAPTIVE plans only: the cooperative kernel with every 12-component state split over two lanes (top /
+ * bottom halves of a column in different waves, the two halves of the base state in neighbouring DPP banks): six components
+ * per lane keep all slopes of the 13-stage method in addressable registers.  Other plans: LTO_EINVAL. */
+#define LTO_KERNEL_COOP2 6
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* plan);

@@ -680,6 +680,132 @@ __device__ __forceinline__ void rhs12_base_parts(const double (&y)[12], const Tr
   bp.c1 = c1; bp.c2 = c2; bp.i1s = i1s; bp.i2s = i2s; bp.ua = ua; bp.ub = ub; bp.inv_n = inv_n;
 }
 
+// The base slopes of one HALF of the 12-dim state in a lane (cooperative kernel, two lanes per segment): lane A owns
+// (r, v), lane B owns (lambda_v, lambda_r).  Both lanes hold R = r and L = lambda_v (three doubles each crossed over by DPP)
+// and their own second triple q (A: v, B: lambda_r); the instruction stream is the same for both.
+//   kp = slope of the lane's first triple:   A: r' = v                          B: lambda_v' = 2w J lambda_v - lambda_r
+//        written as sg q + kap J L with per-lane (sg, kap) = (1, 0) / (-1, 2w): exact in both lanes;
+//   kq = slope of the second triple:         A: v' (gravity, Coriolis, thrust)  B: lambda_r' = -(d a / d r)^T lambda_v
+//        both evaluated, one kept.
+// Same arithmetic per component as rhs12_base_parts (same by-products in bp).
+template <int PM>
+__device__ __forceinline__ void rhs12_base_half(const double (&R)[3], const double (&L)[3], const double (&q)[3], const bool is_a,
+                                                const double sg, const double kap, const TrajParams& tp, double (&kp)[3],
+                                                double (&kq)[3], BaseParts12& bp) {
+  const double MU = tp.MU;
+  const double x = R[0], yy = R[1], z = R[2];
+  const double w2 = 2.0 * tp.omega;
+  const double a = x + MU, b = a - 1.0;
+  const double yz2 = __builtin_fma(yy, yy, z * z);
+  const double d1 = __builtin_fma(a, a, yz2), d2 = __builtin_fma(b, b, yz2);
+  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
+  const double i1s = i1 * i1, i2s = i2 * i2;
+  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
+  const double cs = c1 + c2, omc = 1.0 - cs;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double lx = L[0], ly = L[1], lz = L[2];
+  const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
+  const double inv_n = inv_norm_guarded(n2);
+  const double n = n2 * inv_n;
+  double m, ua, ub;
+  if constexpr (PM == PM_P1) {
+    const double zz = fmin(fmax((1.0 - n) * tp.inv_rho, -700.0), 690.0);
+    const double e = exp_mid(zz);
+    const double qq = rcp_nr(1.0 + e);
+    m = tp.accel_limit * qq;
+    ua = m * inv_n;
+    ub = __builtin_fma(-(tp.accel_limit * tp.inv_rho) * (e * qq), qq, ua);
+  } else {
+    double un;
+    bool tlim;
+    control_dispatch<PM, true, true>(tp, tp.accel_limit, n, inv_n, m, ua, ub, un, tlim);
+  }
+  const double yzl = __builtin_fma(yy, ly, z * lz);
+  const double s1 = __builtin_fma(a, lx, yzl), s2 = __builtin_fma(b, lx, yzl);
+  const double t1 = e1 * s1, t2 = e2 * s2;
+  const double es = t1 + t2;
+  const double tA = __builtin_fma(t1, a, t2 * b);
+  kp[0] = __builtin_fma(kap, ly, sg * q[0]);
+  kp[1] = __builtin_fma(-kap, lx, sg * q[1]);
+  kp[2] = sg * q[2];
+  const double ax = __builtin_fma(-ua, lx, __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(w2, q[1], x))));
+  const double ay = __builtin_fma(-ua, ly, __builtin_fma(-cs, yy, __builtin_fma(-w2, q[0], yy)));
+  const double az = __builtin_fma(-ua, lz, -cs * z);
+  const double gx = __builtin_fma(-omc, lx, -tA);
+  const double gy = __builtin_fma(-omc, ly, -es * yy);
+  const double gz = __builtin_fma(cs, lz, -es * z);
+  kq[0] = is_a ? ax : gx; kq[1] = is_a ? ay : gy; kq[2] = is_a ? az : gz;
+  bp.c1 = c1; bp.c2 = c2; bp.i1s = i1s; bp.i2s = i2s; bp.ua = ua; bp.ub = ub; bp.inv_n = inv_n;
+}
+
+// The two halves of coef12_from_parts / var_col12 for a column split over two lanes in different waves (cooperative kernel):
+// the TOP lane owns (a, b) = (delta r, delta v) and needs G and U, the BOTTOM lane owns (d, g) = (delta lambda_v, delta
+// lambda_r) and needs G and H; each receives the other's first triple.  Same arithmetic per entry as the one-piece forms.
+struct CoefG12 { double Gxx, Gyy, Gzz, Gxy, Gxz, Gyz; };
+__device__ __forceinline__ void coefG12_from_parts(const double x, const double yy, const double z, const BaseParts12& bp, const double MU,
+                                                   CoefG12& g, double& st, double& ee, double& e1, double& e2, double& a, double& b) {
+  a = x + MU; b = a - 1.0;
+  const double c1 = bp.c1, c2 = bp.c2;
+  const double cs = c1 + c2;
+  e1 = 3.0 * c1 * bp.i1s; e2 = 3.0 * c2 * bp.i2s;
+  ee = e1 + e2;
+  const double sa = e1 * a, tb = e2 * b;
+  st = sa + tb;
+  g.Gxx = __builtin_fma(sa, a, __builtin_fma(tb, b, 1.0 - cs));
+  g.Gyy = __builtin_fma(ee * yy, yy, 1.0 - cs);
+  g.Gzz = __builtin_fma(ee * z, z, -cs);
+  g.Gxy = st * yy; g.Gxz = st * z; g.Gyz = ee * yy * z;
+}
+// top half: (a', b') from own (a, b) and the received d
+__device__ __forceinline__ void var_col12_top(const double x, const double yy, const double z, const double lx0, const double ly0,
+                                              const double lz0, const BaseParts12& bp, const double MU, const double w2,
+                                              const double (&w)[6], const double (&d)[3], double (&dw)[6]) {
+  CoefG12 g; double st, ee, e1, e2, a, b;
+  coefG12_from_parts(x, yy, z, bp, MU, g, st, ee, e1, e2, a, b);
+  const double lx = lx0 * bp.inv_n, ly = ly0 * bp.inv_n, lz = lz0 * bp.inv_n;
+  const double ax = w[0], ay = w[1], az = w[2];
+  const double dx = d[0], dyv = d[1], dz = d[2];
+  dw[0] = w[3]; dw[1] = w[4]; dw[2] = w[5];
+  const double ld = __builtin_fma(lx, dx, __builtin_fma(ly, dyv, lz * dz));
+  const double tl = bp.ub * ld;
+  dw[3] = __builtin_fma(g.Gxx, ax, __builtin_fma(g.Gxy, ay, __builtin_fma(g.Gxz, az,
+          __builtin_fma(w2, w[4], __builtin_fma(-bp.ua, dx, tl * lx)))));
+  dw[4] = __builtin_fma(g.Gxy, ax, __builtin_fma(g.Gyy, ay, __builtin_fma(g.Gyz, az,
+          __builtin_fma(-w2, w[3], __builtin_fma(-bp.ua, dyv, tl * ly)))));
+  dw[5] = __builtin_fma(g.Gxz, ax, __builtin_fma(g.Gyz, ay, __builtin_fma(g.Gzz, az,
+          __builtin_fma(-bp.ua, dz, tl * lz))));
+}
+// bottom half: own w = (d, g) = (delta lambda_v, delta lambda_r), received a = delta r; returns (d', g')
+__device__ __forceinline__ void var_col12_bottom(const double x, const double yy, const double z, const double lx0, const double ly0,
+                                                 const double lz0, const BaseParts12& bp, const double MU, const double w2,
+                                                 const double (&w)[6], const double (&av)[3], double (&dw)[6]) {
+  CoefG12 g; double st, ee, e1, e2, a, b;
+  coefG12_from_parts(x, yy, z, bp, MU, g, st, ee, e1, e2, a, b);
+  const double yzl = __builtin_fma(yy, ly0, z * lz0);
+  const double s1 = __builtin_fma(a, lx0, yzl), s2 = __builtin_fma(b, lx0, yzl);
+  const double q1 = 5.0 * e1 * bp.i1s * s1, q2 = 5.0 * e2 * bp.i2s * s2;
+  const double es = __builtin_fma(e1, s1, e2 * s2);
+  const double qq = q1 + q2;
+  const double qa = __builtin_fma(q1, a, q2 * b);
+  const double Hxx = es + 2.0 * st * lx0 - __builtin_fma(q1 * a, a, q2 * b * b);
+  const double Hyy = es + 2.0 * ee * yy * ly0 - qq * yy * yy;
+  const double Hzz = es + 2.0 * ee * z * lz0 - qq * z * z;
+  const double Hxy = __builtin_fma(st, ly0, ee * yy * lx0) - qa * yy;
+  const double Hxz = __builtin_fma(st, lz0, ee * z * lx0) - qa * z;
+  const double Hyz = ee * __builtin_fma(yy, lz0, z * ly0) - qq * yy * z;
+  const double ax = av[0], ay = av[1], az = av[2];
+  const double dx = w[0], dyv = w[1], dz = w[2];
+  dw[0] = __builtin_fma(w2, dyv, -w[3]);
+  dw[1] = __builtin_fma(-w2, dx, -w[4]);
+  dw[2] = -w[5];
+  dw[3] = -__builtin_fma(Hxx, ax, __builtin_fma(Hxy, ay, __builtin_fma(Hxz, az,
+           __builtin_fma(g.Gxx, dx, __builtin_fma(g.Gxy, dyv, g.Gxz * dz)))));
+  dw[4] = -__builtin_fma(Hxy, ax, __builtin_fma(Hyy, ay, __builtin_fma(Hyz, az,
+           __builtin_fma(g.Gxy, dx, __builtin_fma(g.Gyy, dyv, g.Gyz * dz)))));
+  dw[5] = -__builtin_fma(Hxz, ax, __builtin_fma(Hyz, ay, __builtin_fma(Hzz, az,
+           __builtin_fma(g.Gxz, dx, __builtin_fma(g.Gyz, dyv, g.Gzz * dz)))));
+}
+
 // G, H, U of the 12-dim system from the base argument's position r, lambda_v and the base lane's by-products: the
 // VAR block of rhs12 without its reciprocal square roots and control law.
 __device__ __forceinline__ void coef12_from_parts(const double x, const double yy, const double z, const double lx0, const double ly0,

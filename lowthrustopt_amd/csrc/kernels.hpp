@@ -58,6 +58,8 @@ hipError_t launch_indirect14_defect(int pm, int method, const IndirectArgs& a, h
 hipError_t launch_indirect14_stm(int pm, int method, int cols_per_lane, const IndirectArgs& a, hipStream_t st);
 // wave-specialised STM kernel (kernels_indirect_coop.hip): base wave + column waves per 16 segments
 hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const IndirectArgs& a, hipStream_t st);
+// the same with every 12-component state split over two lanes (kernels_indirect_coop2.hip): 12-dim, DOP853 adaptive only
+hipError_t launch_indirect_stm_coop2(int pm, const IndirectArgs& a, hipStream_t st);
 // three-role pipeline (kernels_indirect_pipe.hip): base wave, coefficient wave and two column waves per 16 segments,
 // skewed by one RK4 step; fixed-step RK4 only
 hipError_t launch_indirect_stm_pipe(int ndim, int pm, const IndirectArgs& a, hipStream_t st);

@@ -1,0 +1,388 @@
+// kernels_indirect_coop2.hip -- the reference's integrator setting (adaptive order 8, rtol = atol = 1e-13) with the STM by
+// variational equations, 12-dim system (src/multiShoot_CRTBP_indirect.jl:79,107-110,121): the cooperative kernel with every
+// 12-component state SPLIT OVER TWO LANES.
+//
+// Why: a DOP853 lane of kernels_indirect_coop.hip keeps ten live slopes of 12 components (240 registers) next to its state,
+// argument and coefficients; that does not fit the 256 registers a VALU instruction can address, and 18 % of the issue slots
+// of BOTH roles were v_accvgpr_read / v_accvgpr_write moves (1 070 of 5 900 instructions per trial step).  With six components
+// per lane the slopes take 120 registers, the tableau arithmetic per lane halves, and nothing spills.
+//
+// One workgroup = 16 segments = 8 wavefronts (wave i and wave i + 4 share a SIMD):
+//   waves 0-2  TOP halves of the 12 STM columns: lane = (segment, column), owns (a, b) = (delta r, delta v); needs G and U.
+//   waves 4-6  BOTTOM halves: owns (d, g) = (delta lambda_v, delta lambda_r); needs G and H.  A top and a bottom wave share a
+//              SIMD (123 + 159 instructions per stage between them).
+//   wave 3     base wave, alone on its SIMD (wave 7 leaves at once).  Two lanes per segment in neighbouring 4-lane banks:
+//              lane A owns (r, v), lane B owns (lambda_v, lambda_r).  The three doubles each needs from the other (r, lambda_v)
+//              cross over in v_mov_b32_dpp row_shl:4 / row_shr:4 with a bank mask, so both lanes hold R = r and L = lambda_v
+//              and run ONE instruction stream (rhs12_base_half: per-lane constants select the first triple's slope, a
+//              v_cndmask the second's).
+// Per RK stage one __syncthreads(): before it the base lanes evaluate the stage and publish their argument (r, lambda_v) and
+// by-products (13 doubles, double-buffered), and the column halves -- whose stage argument needs only their own earlier
+// slopes -- publish the triple their partner needs; after it the column halves assemble their coefficients from the parts
+// (wave-uniform code per half: var_col12_top / var_col12_bottom) while the base lanes are already in the next stage.
+//
+// Step control as in kernels_indirect_coop.hip: one common step sequence per segment, the error norm over the base state AND
+// all 144 column components (what ForwardDiff duals see inside the adaptive solver), partial sums of the 26 roles of a
+// segment through LDS, identical arithmetic in every lane of the segment => identical decision, no broadcast.
+// Every loop is bounded (max_steps trial steps), every wavefront executes the same barriers, out-of-range lanes shadow a valid
+// segment without storing: the grid always drains.
+#include "kernels.hpp"
+#include "rk.hpp"
+
+namespace lto {
+
+constexpr int C2_SEG = 16;      // segments per workgroup
+constexpr int C2_ROLES = 26;    // 12 top halves, 12 bottom halves, base A, base B
+constexpr int C2_PAD = 28;      // row pitch of the partial-sum table (16-byte aligned rows)
+
+enum C2Role : int { C2_TOP = 0, C2_BOTTOM = 1, C2_BASE = 2 };
+
+struct C2Shared {
+  double pub[2][13][C2_SEG];                 // base argument (r, lambda_v) + by-products of the stage, double-buffered
+  double xch[2][2][12][3][C2_SEG];           // [buffer][half that wrote][column][j][segment]: first triple of the stage argument
+  alignas(16) double part[2][3][C2_SEG][C2_PAD];  // partial norms [trial parity][which][segment][role]
+  double scale[12][C2_SEG];                  // 1 / (atol + rtol |base value|) of global row r
+};
+
+// src's value from the lane 4 below (CTRL = row_shr:4) or 4 above (row_shl:4) into the lanes of the banks in BANK; the other
+// lanes keep old.
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_bank_merge(const double old, const double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANK, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Probe build (make probe): ticks every role waits at the stage barriers and the ticks of its trial loop, per workgroup,
+// into rows 16-19 (base), 20-21 (top wave 0), 22-23 (bottom wave 0) of a 24-row defect buffer (tools/probe_coop2.py).
+#ifdef PIPE_PROBE
+#define C2_SYNC() do { const long long c2_t = clock64(); __syncthreads(); c2_wait += clock64() - c2_t; } while (0)
+#else
+#define C2_SYNC() __syncthreads()
+#endif
+
+template <int PM, int ROLE>
+__device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, const int lane, const int cwave) {
+  constexpr bool BASE = (ROLE == C2_BASE);
+  constexpr int NS = 12;
+  // ---- who is this lane
+  int seg, col = 0;
+  bool is_a = true, shadow = false;
+  if (BASE) {
+    // rows of 16 lanes = banks A B A B of four segments each; rows 2, 3 repeat rows 0, 1 (store nothing)
+    seg = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + (lane & 3);
+    is_a = ((lane >> 2) & 1) == 0;
+    shadow = lane >= 32;
+  } else {
+    seg = lane & (C2_SEG - 1);
+    col = cwave * 4 + (lane >> 4);
+  }
+  const bool natural = BASE ? is_a : (ROLE == C2_TOP);      // own rows are global rows 0..5; else (9, 10, 11, 6, 7, 8)
+  int grow[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) grow[j] = natural ? j : (j < 3 ? 9 + j : 3 + j);
+  const int role = BASE ? (is_a ? 24 : 25) : (ROLE == C2_TOP ? col : 12 + col);
+
+  const int s_raw = blockIdx.x * C2_SEG + seg;
+  const int s_lin = s_raw < a.S ? s_raw : a.S - 1;             // shadow lanes repeat the last segment
+  const int s = a.order ? a.order[s_lin] : s_lin;              // balanced order (lto_indirect_plan_rebalance)
+  const bool in_range = (s_raw < a.S) && !shadow;
+  const int traj = s / a.seg_per_traj;
+  const int i = s - traj * a.seg_per_traj;
+  const long node = (long)traj * a.n_nodes + i;
+  const long tg = (long)traj * a.t_stride + i;
+  const double span = a.t[tg + 1] - a.t[tg];
+  const TrajParams tp = a.tp[(long)traj * a.tp_stride];
+  const double w2 = 2.0 * tp.omega;
+  const bool mine = !a.class_filter || p_class(tp.p) == PM;
+  if (!__syncthreads_or(mine)) return;         // workgroup-uniform (wave 7 voted 0 and left)
+  const double sg = is_a ? 1.0 : -1.0, kap = is_a ? 0.0 : w2;   // base lanes: slope of the first triple = sg q + kap J L
+
+  // ---- state of this lane: six rows of the base state or of one STM column
+  double y[6], K[13][6];
+  if (BASE) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) y[j] = a.X[grow[j] * a.ldx + node];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) y[j] = (grow[j] == col) ? 1.0 : 0.0;
+  }
+
+#ifdef PIPE_PROBE
+  long long c2_wait = 0;
+#endif
+  // slope of the stage argument `arg` (own six rows) into `out`.  Called by ALL threads: one barrier inside.  `overlap` is work
+  // that needs neither this stage's slope nor LDS (the next argument's sum over the older slopes): the base lanes run it
+  // between their LDS stores and the barrier, the column lanes between issuing their LDS loads and the first use.
+  auto slope = [&](const double (&arg)[6], double (&out)[6], const int buf, auto&& overlap) {
+    if constexpr (BASE) {
+      double R[3], L[3], q[3], kp[3], kq[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        R[j] = dpp_bank_merge<0x114, 0xA>(arg[j], arg[j]);      // B lanes take r from their A lane (row_shr:4)
+        L[j] = dpp_bank_merge<0x104, 0x5>(arg[j], arg[j]);      // A lanes take lambda_v from their B lane (row_shl:4)
+        q[j] = arg[3 + j];
+      }
+      BaseParts12 bp;
+      rhs12_base_half<PM>(R, L, q, is_a, sg, kap, tp, kp, kq, bp);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { out[j] = kp[j]; out[3 + j] = kq[j]; }
+      if (is_a && !shadow) {
+        double (&p)[13][C2_SEG] = sh.pub[buf];
+        p[0][seg] = R[0]; p[1][seg] = R[1]; p[2][seg] = R[2];
+        p[3][seg] = L[0]; p[4][seg] = L[1]; p[5][seg] = L[2];
+        p[6][seg] = bp.c1; p[7][seg] = bp.c2; p[8][seg] = bp.i1s; p[9][seg] = bp.i2s;
+        p[10][seg] = bp.ua; p[11][seg] = bp.ub; p[12][seg] = bp.inv_n;
+      }
+      overlap();
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sh.xch[buf][ROLE][col][j][seg] = arg[j];
+    }
+    C2_SYNC();
+    if constexpr (!BASE) {
+      const double (&p)[13][C2_SEG] = sh.pub[buf];
+      double v[13], other[3];
+#pragma unroll
+      for (int e = 0; e < 13; ++e) v[e] = p[e][seg];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) other[j] = sh.xch[buf][1 - ROLE][col][j][seg];
+      overlap();
+      BaseParts12 bp;
+      bp.c1 = v[6]; bp.c2 = v[7]; bp.i1s = v[8]; bp.i2s = v[9]; bp.ua = v[10]; bp.ub = v[11]; bp.inv_n = v[12];
+      if constexpr (ROLE == C2_TOP) var_col12_top(v[0], v[1], v[2], v[3], v[4], v[5], bp, tp.MU, w2, arg, other, out);
+      else var_col12_bottom(v[0], v[1], v[2], v[3], v[4], v[5], bp, tp.MU, w2, arg, other, out);
+    }
+  };
+  // sum over all roles of partial `which` for this lane's segment (fixed order => identical in every lane)
+  auto total = [&](const int parity, const int which) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < C2_ROLES; ++r) t += sh.part[parity][which][seg][r];
+    return t;
+  };
+  auto nothing = [] {};
+
+  const double rtol = a.rtol, atol = a.atol;
+  double h_abs = 0.0, t = 0.0;
+  double rejected = 0.0;
+  int nacc = 0, nrej = 0;
+  int buf = 0;
+  int done = !(span > 0.0) || !mine;
+  constexpr double NCOMP = 156.0;              // 12 + 144 components
+
+  // ---- Hairer's initial step over all components.  Row r of every column is scaled with the BASE value of row r (a dual
+  // number's partials share the scale of its value), published by the base lanes.
+  {
+    if (BASE && !shadow) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
+    }
+    slope(y, K[0], buf, nothing); buf ^= 1;
+    double isc0[6];
+    double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double isc = sh.scale[grow[j]][seg];
+      isc0[j] = isc;
+      p0 = __builtin_fma(y[j] * isc, y[j] * isc, p0);
+      p1 = __builtin_fma(K[0][j] * isc, K[0][j] * isc, p1);
+    }
+    if (!shadow) { sh.part[1][0][seg][role] = p0; sh.part[1][1][seg][role] = p1; }
+    __syncthreads();
+    const double d0 = sqrt(total(1, 0) / NCOMP), d1 = sqrt(total(1, 1) / NCOMP);
+    const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    double arg[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) arg[j] = __builtin_fma(h0, K[0][j], y[j]);
+    slope(arg, K[1], buf, nothing); buf ^= 1;   // the barrier inside also separates the reads above from the writes below
+    double p2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double df = (K[1][j] - K[0][j]) * isc0[j];
+      p2 = __builtin_fma(df, df, p2);
+    }
+    if (!shadow) sh.part[1][2][seg][role] = p2;
+    __syncthreads();
+    const double d2 = sqrt(total(1, 2) / NCOMP) / h0;
+    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : cbrt(cbrt(0.01 / fmax(d1, d2)));
+    h_abs = fmin(fmin(100.0 * h0, h1), span);
+  }
+
+#ifdef PIPE_PROBE
+  const long long c2_t0 = clock64();
+  int c2_trials = 0;
+#endif
+  for (int trial = 0; trial < a.max_steps; ++trial) {
+#ifdef PIPE_PROBE
+    ++c2_trials;
+#endif
+    // every lane of a segment holds identical (t, h_abs, done): they are updated from identical data below
+    double h = h_abs;
+    double last = 0.0;
+    if (t + h >= span) { h = span - t; last = 1.0; }
+    // Argument st (st = 1..11: stage st, weights DP8_A[st][.]; st = 12: the new state, weights DP8_B) is y + h (older + w K[st-1])
+    // with older = the sum over the slopes before the newest one, formed one stage earlier in the shadow of that stage's LDS
+    // traffic (same summation order as the one-piece loop: bit-identical arguments).
+    double older[6], yn[6], a5[6], a3[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) older[j] = 0.0;
+#pragma unroll
+    for (int st = 1; st <= NS; ++st) {       // enters with K[0] = f(y) (FSAL)
+      double arg[6], next[6];
+      const double wn = (st < NS) ? DP8_A[st < NS ? st : 0][st - 1] : DP8_B[st - 1];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double acc = (wn != 0.0) ? __builtin_fma(wn, K[st - 1][j], older[j]) : older[j];
+        arg[j] = __builtin_fma(h, acc, y[j]);
+      }
+      if (st < NS) {
+        slope(arg, K[st], buf, [&] {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < st; ++k) {
+              const double w = (st + 1 < NS) ? DP8_A[st + 1 < NS ? st + 1 : 0][k] : DP8_B[k];
+              if (w != 0.0) acc = __builtin_fma(w, K[k][j], acc);
+            }
+            next[j] = acc;
+          }
+        });
+#pragma unroll
+        for (int j = 0; j < 6; ++j) older[j] = next[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) yn[j] = arg[j];
+        if (BASE && !shadow) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
+        }
+        slope(yn, K[12], buf, [&] {          // FSAL slope; in its shadow: the error sums over the twelve older slopes
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            double s5 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+              if (DP8_E5[k] != 0.0) s5 = __builtin_fma(DP8_E5[k], K[k][j], s5);
+              if (DP8_E3[k] != 0.0) s3 = __builtin_fma(DP8_E3[k], K[k][j], s3);
+            }
+            a5[j] = s5; a3[j] = s3;
+          }
+        });
+      }
+      buf ^= 1;
+    }
+    const int par = trial & 1;
+    double e5 = 0.0, e3 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double s5 = a5[j], s3 = a3[j];
+      if (DP8_E5[12] != 0.0) s5 = __builtin_fma(DP8_E5[12], K[12][j], s5);
+      if (DP8_E3[12] != 0.0) s3 = __builtin_fma(DP8_E3[12], K[12][j], s3);
+      const double isc = sh.scale[grow[j]][seg];
+      s5 *= isc; s3 *= isc;
+      e5 = __builtin_fma(s5, s5, e5);
+      e3 = __builtin_fma(s3, s3, e3);
+    }
+    if (!shadow) { sh.part[par][0][seg][role] = e5; sh.part[par][1][seg][role] = e3; }
+    __syncthreads();
+    const double E5 = total(par, 0), E3 = total(par, 1);
+    const double err = (E5 == 0.0 && E3 == 0.0) ? 0.0 : fabs(h) * E5 / sqrt((E5 + 0.01 * E3) * NCOMP);
+    double accept, bad = 0.0;
+    if (err < 1.0) {
+      double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 / sqrt(sqrt(sqrt(err))));
+      if (rejected != 0.0) factor = fmin(1.0, factor);
+      h_abs = h * factor;
+      accept = 1.0;
+    } else {
+      h_abs = h * fmax(0.2, 0.9 / sqrt(sqrt(sqrt(err))));
+      accept = 0.0;
+      if (err != err) bad = err;           // a NaN never recovers: poison the segment and stop (below)
+    }
+    // (no barrier here: the next trial writes the partial sums of the other parity)
+    if (!done) {
+      if (bad != 0.0) {                    // NaN in the step: NaN results (status_flag 2 upstream), no max_steps stall
+#pragma unroll
+        for (int j = 0; j < 6; ++j) y[j] = bad;
+        t = span;
+      } else if (accept != 0.0) {
+        t = (last != 0.0) ? span : t + h;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
+        ++nacc;
+        rejected = 0.0;
+      } else {
+        ++nrej;
+        rejected = 1.0;
+      }
+      if (!(t < span)) done = 1;
+    }
+    if (!__syncthreads_or(!done)) break;   // workgroup-uniform exit: all 16 segments done
+  }
+#ifdef PIPE_PROBE
+  if (a.defect && (lane & 15) == 0 && (BASE ? lane == 0 : (cwave == 0 && lane == 0))) {
+    const int r0 = BASE ? 16 : (ROLE == C2_TOP ? 20 : 22);
+    const long at = (long)blockIdx.x * C2_SEG;
+    a.defect[(r0 + 0) * a.ldd + at] = (double)c2_wait;
+    a.defect[(r0 + 1) * a.ldd + at] = (double)(clock64() - c2_t0);
+    if (BASE) a.defect[18 * a.ldd + at] = (double)c2_trials;
+  }
+#endif
+  // A segment that did not reach t1 (max_steps trial steps used up, or a decreasing time grid: the controller integrates
+  // forward only) has no result: NaN, which the driver reports as status_flag 2 (indirect.jl:339-341).
+  if (mine && (t < span || span < 0.0)) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) y[j] = __builtin_nan("");
+  }
+
+  if (in_range && mine) {
+    if (BASE) {
+      if (a.defect) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a.defect[grow[j] * a.ldd + s] = y[j] - a.X[grow[j] * a.ldx + node + 1];
+      }
+      if (is_a) {
+        if (a.errors) a.errors[s] = 0.0;
+        if (a.nacc) a.nacc[s] = nacc;
+        if (a.nrej) a.nrej[s] = nrej;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) a.Phi[(long)(col * 12 + grow[j]) * a.ldp + s] = y[j];
+    }
+  }
+}
+
+template <int PM>
+__global__ __launch_bounds__(512) void k_indirect_coop2(const IndirectArgs a) {
+  __shared__ C2Shared sh;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (wave == 7) { (void)__syncthreads_or(0); return; }   // shares the base wave's SIMD: votes and leaves before the stage barriers
+  if (wave == 3) coop2_run<PM, C2_BASE>(a, sh, lane, 0);
+  else if (wave < 3) coop2_run<PM, C2_TOP>(a, sh, lane, wave);
+  else coop2_run<PM, C2_BOTTOM>(a, sh, lane, wave - 4);
+}
+
+template <int PM>
+static hipError_t launch_coop2_one(const IndirectArgs& a, hipStream_t st) {
+  dim3 grid((a.S + C2_SEG - 1) / C2_SEG);
+  hipLaunchKernelGGL((k_indirect_coop2<PM>), grid, dim3(512), 0, st, a);
+  return hipGetLastError();
+}
+
+// 12-dim system, DOP853 adaptive only.
+hipError_t launch_indirect_stm_coop2(int pm, const IndirectArgs& a0, hipStream_t st) {
+  if (a0.S <= 0) return hipSuccess;
+  IndirectArgs a = a0;
+  a.class_filter = single_class(pm) ? 0 : 1;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_coop2_one<PM_P0>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_coop2_one<PM_P1>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_coop2_one<PM_P2>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_coop2_one<PM_PGEN>(a, st);
+  return e;
+}
+
+}  // namespace lto

@@ -220,9 +220,8 @@ int lto_create(lto_ctx** out, int device_id) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LTO_ENODEVICE;
   if (device_id < 0 || device_id >= n) return LTO_EINVAL;
-  lto_ctx* c = new (std::nothrow) lto_ctx();
+  lto_ctx* c = new (std::nothrow) lto_ctx();   // value-initialised: every scalar member zero, the vector empty
   if (!c) return LTO_EHIP;
-  std::memset(c, 0, sizeof *c);
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -394,8 +393,10 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
 int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
   if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE && kernel != LTO_KERNEL_PIPE6 &&
-      kernel != LTO_KERNEL_PIPE8)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE, _PIPE6 or _PIPE8");
+      kernel != LTO_KERNEL_PIPE8 && kernel != LTO_KERNEL_COOP2)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE, _PIPE6, _PIPE8 or _COOP2");
+  if (kernel == LTO_KERNEL_COOP2 && (p->integ.method != LTO_DOP853_ADAPTIVE || p->ndim != 12))
+    return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_COOP2 is built for 12-dim DOP853_ADAPTIVE plans");
   if ((kernel == LTO_KERNEL_PIPE || kernel == LTO_KERNEL_PIPE6 || kernel == LTO_KERNEL_PIPE8) && p->integ.method != LTO_RK4)
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_PIPE is built for fixed-step RK4 plans");
   p->kernel = kernel;
@@ -474,11 +475,12 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   // against 1.29 ms four-wave, 1.59 ms per-lane); beyond that the four-wave form, which fits two workgroups per CU
   // (262 144 segments 14-dim: 4.8 ms against 5.0 ms eight-wave, 6.3 ms per-lane).  12-dim above 4 096 segments: four-wave
   // form up to ~12 000 segments, then the per-lane kernel with 3 columns per lane.  13-stage methods -> wave-specialised
-  // kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms), whose 12/14-component
-  // lanes keep all slopes in registers.
+  // kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms); for the reference's setting
+  // (12-dim, DOP853) its form with six components per lane, which keeps all slopes in addressable registers.
   int kern = p->kernel;
   if (kern == LTO_KERNEL_AUTO) {
-    if (p->integ.method != LTO_RK4) kern = LTO_KERNEL_COOP;
+    if (p->integ.method != LTO_RK4)   // 12-dim DOP853: the two-lanes-per-state form (0.233 against 0.260 ms at 4 096 segments)
+      kern = (p->integ.method == LTO_DOP853_ADAPTIVE && p->ndim == 12) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
     else if (p->integ.steps < 6) kern = LTO_KERNEL_PER_LANE;   // fill and drain phases outweigh the shorter phase
     else if (p->S <= 4096) kern = LTO_KERNEL_PIPE8;
     else if (p->ndim == 14) kern = (p->S <= 131072) ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PIPE;
@@ -487,6 +489,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   p->last_kernel = kern;
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
+  else if (kern == LTO_KERNEL_COOP2) e = launch_indirect_stm_coop2(p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE) e = launch_indirect_stm_pipe(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE6) e = launch_indirect_stm_pipe6(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);

@@ -26,7 +26,41 @@ template <int PM> static void parts12(const double (&y)[12], const TrajParams& t
   VarCoef12 w; coef12_from_parts(y[0], y[1], y[2], y[9], y[10], y[11], bp, tp.MU, w);
   std::memcpy(vc_b, &w, sizeof w);
 }
+// two-lanes-per-state forms of the cooperative kernel: the base slopes assembled from lane A (r, v) and lane B (lambda_v,
+// lambda_r) of rhs12_base_half, the column slopes from var_col12_top / var_col12_bottom, against the one-piece functions
+template <int PM> static void halves12(const double (&y)[12], const double (&c)[12], const TrajParams& tp, double* dy_a, double* dc_a,
+                                       double* dy_b, double* dc_b, double* parts_ab) {
+  double d[12], dc[12]; VarCoef12 v; rhs12<PM, true>(y, tp, d, v);
+  const double w2 = 2.0 * tp.omega;
+  var_col12(v, w2, c, dc);
+  for (int i = 0; i < 12; ++i) { dy_a[i] = d[i]; dc_a[i] = dc[i]; }
+  const double R[3] = {y[0], y[1], y[2]}, L[3] = {y[9], y[10], y[11]};
+  const double qa[3] = {y[3], y[4], y[5]}, qb[3] = {y[6], y[7], y[8]};
+  double kp[3], kq[3]; BaseParts12 bpa, bpb;
+  rhs12_base_half<PM>(R, L, qa, true, 1.0, 0.0, tp, kp, kq, bpa);          // lane A: (r', v')
+  for (int j = 0; j < 3; ++j) { dy_b[j] = kp[j]; dy_b[3 + j] = kq[j]; }
+  rhs12_base_half<PM>(R, L, qb, false, -1.0, w2, tp, kp, kq, bpb);         // lane B: (lambda_v', lambda_r')
+  for (int j = 0; j < 3; ++j) { dy_b[9 + j] = kp[j]; dy_b[6 + j] = kq[j]; }
+  std::memcpy(parts_ab, &bpa, sizeof bpa); std::memcpy(parts_ab + 7, &bpb, sizeof bpb);
+  const double wt[6] = {c[0], c[1], c[2], c[3], c[4], c[5]}, wb[6] = {c[9], c[10], c[11], c[6], c[7], c[8]};
+  const double dd[3] = {c[9], c[10], c[11]}, aa[3] = {c[0], c[1], c[2]};
+  double ot[6], ob[6];
+  var_col12_top(y[0], y[1], y[2], y[9], y[10], y[11], bpa, tp.MU, w2, wt, dd, ot);
+  var_col12_bottom(y[0], y[1], y[2], y[9], y[10], y[11], bpa, tp.MU, w2, wb, aa, ob);
+  for (int j = 0; j < 6; ++j) dc_b[j] = ot[j];
+  for (int j = 0; j < 3; ++j) { dc_b[9 + j] = ob[j]; dc_b[6 + j] = ob[3 + j]; }
+}
 extern "C" {
+void chk_halves12(const double* y, const double* col, const double* tpv, int pm, double* dy_a, double* dc_a, double* dy_b, double* dc_b,
+                  double* parts_ab) {
+  TrajParams tp; std::memcpy(&tp, tpv, sizeof tp);
+  double yy[12], cc[12];
+  for (int i = 0; i < 12; ++i) { yy[i] = y[i]; cc[i] = col[i]; }
+  if (pm == PM_P1) halves12<PM_P1>(yy, cc, tp, dy_a, dc_a, dy_b, dc_b, parts_ab);
+  else if (pm == PM_P2) halves12<PM_P2>(yy, cc, tp, dy_a, dc_a, dy_b, dc_b, parts_ab);
+  else if (pm == PM_P0) halves12<PM_P0>(yy, cc, tp, dy_a, dc_a, dy_b, dc_b, parts_ab);
+  else halves12<PM_PGEN>(yy, cc, tp, dy_a, dc_a, dy_b, dc_b, parts_ab);
+}
 // F*col for the 14-dim system via device formulas (host-compiled)
 void chk_rhs14(const double* y, const double* tpv, int pm, double* dy, const double* col, double* dcol, double* dy_f, double* dcol_f) {
   TrajParams tp; std::memcpy(&tp, tpv, sizeof tp);

@@ -123,3 +123,22 @@ def test_by_products_path_of_the_cooperative_kernel(chk):
             assert np.all(np.isfinite(vb)) and np.all(np.isfinite(db))
             assert np.abs(da - db).max() <= 5e-14 * max(1.0, np.abs(da).max())
             assert np.abs(va - vb).max() <= 1e-13 * max(1.0, np.abs(va).max())
+
+
+def test_two_lanes_per_state_forms_of_the_cooperative_kernel(chk):
+    """rhs12_base_half evaluated as lane A (r, v) and as lane B (lambda_v, lambda_r) assembles the slopes of the one-piece
+    rhs12 with the same by-products in both lanes, and var_col12_top / var_col12_bottom (fed the other half's first triple)
+    assemble F * column of var_col12 -- every control-law class, both time directions, rho down to 1e-4."""
+    rng = np.random.default_rng(6)
+    H1 = synth.halo_orbits()[0]
+    for td in (1.0, -1.0):
+        for p, rho, thr, lam, pm in CASES:
+            y = np.concatenate([H1[:, rng.integers(0, 99)], lam * rng.standard_normal(6)])
+            col = rng.standard_normal(12)
+            tp = tp_vec(12, thr, 1000.0, td, p, rho)
+            da = np.zeros(12); ca = np.zeros(12); db = np.zeros(12); cb = np.zeros(12); parts = np.zeros(14)
+            chk.chk_halves12(P(y), P(col), P(tp), pm, P(da), P(ca), P(db), P(cb), P(parts))
+            assert np.all(np.isfinite(db)) and np.all(np.isfinite(cb))
+            assert np.array_equal(parts[:7], parts[7:])                  # both lanes publish the same by-products
+            assert np.abs(da - db).max() <= 5e-14 * max(1.0, np.abs(da).max())
+            assert np.abs(ca - cb).max() <= 1e-13 * max(1.0, np.abs(ca).max())
