@@ -53,6 +53,14 @@ __device__ __forceinline__ double dpp_bank_merge(const double old, const double 
   return __hiloint2double(hi, lo);
 }
 
+// A tableau coefficient as a scalar-register operand materialised where it is used.  Left to itself the compiler hoists the ~75
+// 64-bit literals of the trial loop out of it, runs out of scalar registers and spills them to VGPR lanes (100 v_readlane /
+// v_writelane per trial step in the bottom role); an asm statement cannot be hoisted.
+__device__ __forceinline__ double here(double c) {
+  asm volatile("" : "+s"(c));
+  return c;
+}
+
 // Probe build (make probe): ticks every role waits at the stage barriers and the ticks of its trial loop, per workgroup,
 // into rows 16-19 (base), 20-21 (top wave 0), 22-23 (bottom wave 0) of a 24-row defect buffer (tools/probe_coop2.py).
 #ifdef PIPE_PROBE
@@ -230,23 +238,25 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
 #pragma unroll
     for (int st = 1; st <= NS; ++st) {       // enters with K[0] = f(y) (FSAL)
       double arg[6], next[6];
-      const double wn = (st < NS) ? DP8_A[st < NS ? st : 0][st - 1] : DP8_B[st - 1];
+      const double wn_c = (st < NS) ? DP8_A[st < NS ? st : 0][st - 1] : DP8_B[st - 1];
+      const double wn = (wn_c != 0.0) ? here(wn_c) : 0.0;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const double acc = (wn != 0.0) ? __builtin_fma(wn, K[st - 1][j], older[j]) : older[j];
+        const double acc = (wn_c != 0.0) ? __builtin_fma(wn, K[st - 1][j], older[j]) : older[j];
         arg[j] = __builtin_fma(h, acc, y[j]);
       }
       if (st < NS) {
         slope(arg, K[st], buf, [&] {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            double acc = 0.0;
+          for (int j = 0; j < 6; ++j) next[j] = 0.0;
 #pragma unroll
-            for (int k = 0; k < st; ++k) {
-              const double w = (st + 1 < NS) ? DP8_A[st + 1 < NS ? st + 1 : 0][k] : DP8_B[k];
-              if (w != 0.0) acc = __builtin_fma(w, K[k][j], acc);
+          for (int k = 0; k < st; ++k) {
+            const double w_c = (st + 1 < NS) ? DP8_A[st + 1 < NS ? st + 1 : 0][k] : DP8_B[k];
+            if (w_c != 0.0) {
+              const double w = here(w_c);
+#pragma unroll
+              for (int j = 0; j < 6; ++j) next[j] = __builtin_fma(w, K[k][j], next[j]);
             }
-            next[j] = acc;
           }
         });
 #pragma unroll
@@ -260,14 +270,19 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
         }
         slope(yn, K[12], buf, [&] {          // FSAL slope; in its shadow: the error sums over the twelve older slopes
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            double s5 = 0.0, s3 = 0.0;
+          for (int j = 0; j < 6; ++j) { a5[j] = 0.0; a3[j] = 0.0; }
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {
-              if (DP8_E5[k] != 0.0) s5 = __builtin_fma(DP8_E5[k], K[k][j], s5);
-              if (DP8_E3[k] != 0.0) s3 = __builtin_fma(DP8_E3[k], K[k][j], s3);
+          for (int k = 0; k < 12; ++k) {
+            if (DP8_E5[k] != 0.0) {
+              const double w = here(DP8_E5[k]);
+#pragma unroll
+              for (int j = 0; j < 6; ++j) a5[j] = __builtin_fma(w, K[k][j], a5[j]);
             }
-            a5[j] = s5; a3[j] = s3;
+            if (DP8_E3[k] != 0.0) {
+              const double w = here(DP8_E3[k]);
+#pragma unroll
+              for (int j = 0; j < 6; ++j) a3[j] = __builtin_fma(w, K[k][j], a3[j]);
+            }
           }
         });
       }
