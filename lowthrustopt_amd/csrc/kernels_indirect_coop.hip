@@ -165,15 +165,18 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
     for (int step = 0; step < a.steps; ++step) {
 #pragma unroll
       for (int st = 0; st < NS; ++st) {
-        double arg[ND];
+        double arg[ND], acc[ND];
 #pragma unroll
-        for (int c = 0; c < ND; ++c) {
-          double acc = 0.0;
+        for (int c = 0; c < ND; ++c) acc[c] = 0.0;
 #pragma unroll
-          for (int k = 0; k < st; ++k)
-            if (tabA<METHOD>(st, k) != 0.0) acc = __builtin_fma(tabA<METHOD>(st, k), K[k][c], acc);
-          arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc, y[c]);
-        }
+        for (int k = 0; k < st; ++k)
+          if (tabA<METHOD>(st, k) != 0.0) {
+            const double w = coef_here(tabA<METHOD>(st, k));
+#pragma unroll
+            for (int c = 0; c < ND; ++c) acc[c] = __builtin_fma(w, K[k][c], acc[c]);
+          }
+#pragma unroll
+        for (int c = 0; c < ND; ++c) arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc[c], y[c]);
         slope(arg, K[st], buf);
         buf ^= 1;
       }
@@ -249,15 +252,18 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
       const int st0 = DOP ? 1 : 0;            // DOP853 enters with K[0] = f(y) (FSAL)
 #pragma unroll
       for (int st = st0; st < NS; ++st) {
-        double arg[ND];
+        double arg[ND], acc[ND];
 #pragma unroll
-        for (int c = 0; c < ND; ++c) {
-          double acc = 0.0;
+        for (int c = 0; c < ND; ++c) acc[c] = 0.0;
 #pragma unroll
-          for (int k = 0; k < st; ++k)
-            if (tabA<METHOD>(st, k) != 0.0) acc = __builtin_fma(tabA<METHOD>(st, k), K[k][c], acc);
-          arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc, y[c]);
-        }
+        for (int k = 0; k < st; ++k)
+          if (tabA<METHOD>(st, k) != 0.0) {
+            const double w = coef_here(tabA<METHOD>(st, k));
+#pragma unroll
+            for (int c = 0; c < ND; ++c) acc[c] = __builtin_fma(w, K[k][c], acc[c]);
+          }
+#pragma unroll
+        for (int c = 0; c < ND; ++c) arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc[c], y[c]);
         slope(arg, K[st], buf);
         buf ^= 1;
       }

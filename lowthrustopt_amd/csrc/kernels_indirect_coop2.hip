@@ -53,14 +53,6 @@ __device__ __forceinline__ double dpp_bank_merge(const double old, const double 
   return __hiloint2double(hi, lo);
 }
 
-// A tableau coefficient as a scalar-register operand materialised where it is used.  Left to itself the compiler hoists the ~75
-// 64-bit literals of the trial loop out of it, runs out of scalar registers and spills them to VGPR lanes (100 v_readlane /
-// v_writelane per trial step in the bottom role); an asm statement cannot be hoisted.
-__device__ __forceinline__ double here(double c) {
-  asm volatile("" : "+s"(c));
-  return c;
-}
-
 // Probe build (make probe): ticks every role waits at the stage barriers and the ticks of its trial loop, per workgroup,
 // into rows 16-19 (base), 20-21 (top wave 0), 22-23 (bottom wave 0) of a 24-row defect buffer (tools/probe_coop2.py).
 #ifdef PIPE_PROBE
@@ -239,7 +231,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     for (int st = 1; st <= NS; ++st) {       // enters with K[0] = f(y) (FSAL)
       double arg[6], next[6];
       const double wn_c = (st < NS) ? DP8_A[st < NS ? st : 0][st - 1] : DP8_B[st - 1];
-      const double wn = (wn_c != 0.0) ? here(wn_c) : 0.0;
+      const double wn = (wn_c != 0.0) ? coef_here(wn_c) : 0.0;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const double acc = (wn_c != 0.0) ? __builtin_fma(wn, K[st - 1][j], older[j]) : older[j];
@@ -253,7 +245,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
           for (int k = 0; k < st; ++k) {
             const double w_c = (st + 1 < NS) ? DP8_A[st + 1 < NS ? st + 1 : 0][k] : DP8_B[k];
             if (w_c != 0.0) {
-              const double w = here(w_c);
+              const double w = coef_here(w_c);
 #pragma unroll
               for (int j = 0; j < 6; ++j) next[j] = __builtin_fma(w, K[k][j], next[j]);
             }
@@ -274,12 +266,12 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
 #pragma unroll
           for (int k = 0; k < 12; ++k) {
             if (DP8_E5[k] != 0.0) {
-              const double w = here(DP8_E5[k]);
+              const double w = coef_here(DP8_E5[k]);
 #pragma unroll
               for (int j = 0; j < 6; ++j) a5[j] = __builtin_fma(w, K[k][j], a5[j]);
             }
             if (DP8_E3[k] != 0.0) {
-              const double w = here(DP8_E3[k]);
+              const double w = coef_here(DP8_E3[k]);
 #pragma unroll
               for (int j = 0; j < 6; ++j) a3[j] = __builtin_fma(w, K[k][j], a3[j]);
             }

@@ -15,6 +15,14 @@
 
 namespace lto {
 
+// A tableau coefficient as a scalar-register operand materialised where it is used.  Left to itself the compiler hoists the
+// 64-bit literals of an unrolled 13-stage loop out of it, runs out of scalar registers and spills them to VGPR lanes
+// (v_readlane / v_writelane inside the loop); an asm statement cannot be hoisted.
+__device__ __forceinline__ double coef_here(double c) {
+  asm volatile("" : "+s"(c));
+  return c;
+}
+
 // ------------------------------------------------------------------------------------ RK4
 // One classical RK4 step, y <- y + h/6 (k1 + 2 k2 + 2 k3 + k4).
 template <class Sys>
