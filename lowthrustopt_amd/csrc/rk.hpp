@@ -119,24 +119,33 @@ __device__ __forceinline__ double dop853_try(const Sys& sys, const double h, con
   constexpr int NS = DP8_NSTAGES;
 #pragma unroll
   for (int s = 1; s < NS; ++s) {
-    double yt[D];
+    double yt[D], a[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      double a = 0.0;
+    for (int i = 0; i < D; ++i) a[i] = 0.0;
 #pragma unroll
-      for (int k = 0; k < s; ++k)
-        if (DP8_A[s][k] != 0.0) a = __builtin_fma(DP8_A[s][k], K[k][i], a);
-      yt[i] = __builtin_fma(h, a, y[i]);
-    }
+    for (int k = 0; k < s; ++k)
+      if (DP8_A[s][k] != 0.0) {
+        const double w = coef_here(DP8_A[s][k]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) a[i] = __builtin_fma(w, K[k][i], a[i]);
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i) yt[i] = __builtin_fma(h, a[i], y[i]);
     sys.rhs(yt, K[s]);
   }
+  {
+    double a[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    double a = 0.0;
+    for (int i = 0; i < D; ++i) a[i] = 0.0;
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (DP8_B[k] != 0.0) a = __builtin_fma(DP8_B[k], K[k][i], a);
-    ynew[i] = __builtin_fma(h, a, y[i]);
+      if (DP8_B[k] != 0.0) {
+        const double w = coef_here(DP8_B[k]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) a[i] = __builtin_fma(w, K[k][i], a[i]);
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i) ynew[i] = __builtin_fma(h, a[i], y[i]);
   }
   sys.rhs(ynew, K[NS]);
   double e5 = 0.0, e3 = 0.0;
