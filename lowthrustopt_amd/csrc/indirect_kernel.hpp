@@ -32,6 +32,11 @@ struct SysIndirect {
       rhs14_fused1<PM>(y, tp, w2, k);
       return;
     }
+    if constexpr (COLS == 0) {     // defect-only sweeps: the lean base RHS of the pipeline kernels (no selects, short exp)
+      if constexpr (ND == 12) rhs12_base<PM>(y, tp, k);
+      else rhs14_base<PM, true>(y, tp, k);
+      return;
+    }
     double yb[ND], kb[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) yb[i] = y[i];
