@@ -250,15 +250,19 @@ def leg_host_api(lto, ctx, XC, T, prm, integ, ndim, S, calls=30):
 
     def per_call(fn):
         fn(); fn()
-        ts = []
+        ts, inside = [], []
         for _ in range(calls):
             t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
-        return float(np.median(ts)) * 1e3
-    ms_page = per_call(lambda: lto.indirect_stm(X, t, prm, integ, ctx=ctx, out=out_page))
-    ms_pin = per_call(lambda: lto.indirect_stm(X_pin, t_pin, prm, integ, ctx=ctx, out=out_pin))
+            inside.append(ctx.last_call_ms())
+        return float(np.median(ts)) * 1e3, float(np.median(inside))
+    ms_page, in_page = per_call(lambda: lto.indirect_stm(X, t, prm, integ, ctx=ctx, out=out_page))
+    ms_pin, in_pin = per_call(lambda: lto.indirect_stm(X_pin, t_pin, prm, integ, ctx=ctx, out=out_pin))
     assert np.array_equal(out_page[0], out_pin[0])
     return {"entry_point": "lto_indirect_jacobian (Phi + defect), %d-dim, %d segments, through ctypes" % (ndim, S),
             "ms_per_call_pageable": ms_page, "ms_per_call_page_locked": ms_pin, "calls": calls, "statistic": "median",
+            "ms_in_library_pageable": in_page, "ms_in_library_page_locked": in_pin,
+            "in_library": "entry to return of the C function (lto_last_call_ms): what a C or Julia caller waits for; the "
+                          "difference to ms_per_call is the Python binding",
             "segments_per_s_page_locked": S / (ms_pin * 1e-3), "bytes_out": 8 * (ndim * ndim + ndim) * S, "bytes_in": 8 * (ndim + 1) * n,
             "note": "PCIe-inclusive host-buffer path (what a Julia ccall takes); `value` is the device-resident rate"}
 

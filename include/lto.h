@@ -96,6 +96,9 @@ int lto_ctx_device(const lto_ctx* ctx); /* HIP ordinal the context was created o
  * lto_last_kernel_ms blocks on the stop event and returns that kernel's duration. */
 int lto_set_timing(lto_ctx* ctx, int enabled);
 double lto_last_kernel_ms(lto_ctx* ctx);
+/* Wall time [ms] of the last host-pointer call on this context (lto_indirect_defect, lto_indirect_jacobian, lto_direct_*),
+ * from entry to return as measured inside the library: what a C or Julia caller waits for, without a binding's overhead. */
+double lto_last_call_ms(const lto_ctx* ctx);
 
 /* --------------------------------------------------------- host-pointer API (what Julia ccalls)
  * Each call: plan looked up in the context's cache by (shape, integrator, parameter values) -> H2D ->

@@ -15,7 +15,7 @@ using SparseArrays, LinearAlgebra, Libdl
 
 export LtoIndirectPlan, LtoDirectPlan, LtoComm, pinned_array, pack_soa!, unpack_soa!, defect_norms!, indirect_defect_dev!,
        indirect_jacobian_dev!, newton_solve_dev!, axpy_dev!, direct_defect_dev!, direct_jacobian_dev!, rebalance!, set_kernel!,
-       comm_unique_id, allgather_dev!, allreduce_dev!, ctx_stream
+       comm_unique_id, allgather_dev!, allreduce_dev!, ctx_stream, last_call_ms
 export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, indirect_solve, indirect_solve_batch, densify,
        direct_defectCalc, direct_jacobianCalc, direct_midpoints, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
 
@@ -294,6 +294,8 @@ devptr(::Nothing) = C_NULL
 
 "hipStream_t owned by the context (non-blocking); pass it as `stream` to keep library work off the default stream."
 ctx_stream(ctx::LtoContext) = ccall((:lto_ctx_stream, liblto), Ptr{Cvoid}, (Ptr{Cvoid},), ctx.handle)
+"Wall time [ms] of the last host-pointer call on `ctx`, entry to return, as measured inside the library."
+last_call_ms(ctx::LtoContext) = ccall((:lto_last_call_ms, liblto), Cdouble, (Ptr{Cvoid},), ctx.handle)
 
 """`Array{Float64}` of the given size in page-locked host memory (lto_host_alloc): the GPU reads and writes such arrays (and
 contiguous views into them) in place during a host-pointer call -- no copy is queued (Jacobian call at 4 096 segments: 0.215 ms

@@ -48,6 +48,7 @@ SIGNATURES = {
     "lto_ctx_device": (C.c_int, [_vp]),
     "lto_set_timing": (C.c_int, [_vp, C.c_int]),
     "lto_last_kernel_ms": (C.c_double, [_vp]),
+    "lto_last_call_ms": (C.c_double, [_vp]),
     "lto_indirect_defect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,
                                       C.POINTER(LtoIntegrator), _vp, _vp]),
     "lto_indirect_jacobian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(LtoParams), C.c_int,

@@ -57,6 +57,7 @@ struct lto_ctx {
   // copy-engine operation (about 10 us of latency each) is queued.
   struct Pinned { char* host; char* dev; size_t bytes; };
   std::vector<Pinned> pinned;
+  double last_call_ms;     // wall time of the last host-pointer call, entry to return (lto_last_call_ms)
   char err[512];
 };
 
@@ -274,6 +275,16 @@ double lto_last_kernel_ms(lto_ctx* c) {
   if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
   return (double)ms;
 }
+
+double lto_last_call_ms(const lto_ctx* c) { return c ? c->last_call_ms : -1.0; }
+
+// entry-to-return wall time of a host-pointer call, kept in the context
+struct CallTimer {
+  lto_ctx* c;
+  std::chrono::steady_clock::time_point t0;
+  explicit CallTimer(lto_ctx* ctx) : c(ctx), t0(std::chrono::steady_clock::now()) {}
+  ~CallTimer() { if (c) c->last_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 /* ------------------------------------------------------------------------------ indirect plans */
 
@@ -1133,6 +1144,7 @@ int lto_host_free(lto_ctx* c, void* ptr) {
 
 int lto_indirect_defect(lto_ctx* c, int ndim, int n_nodes, int n_batch, const double* XC, const double* t, int n_tgrids,
                         const lto_params* prm, int n_prm, const lto_integrator* integ, double* defect, double* errors) {
+  CallTimer call_timer(c);
   if (!c) return LTO_ENULL;
   if (!XC || !t || !defect) return set_err(c, LTO_ENULL, "XC, t or defect is NULL");
   if (n_tgrids != 1 && n_tgrids != n_batch) return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
@@ -1171,6 +1183,7 @@ int lto_indirect_defect(lto_ctx* c, int ndim, int n_nodes, int n_batch, const do
 
 int lto_indirect_jacobian(lto_ctx* c, int ndim, int n_nodes, int n_batch, const double* XC, const double* t, int n_tgrids,
                           const lto_params* prm, int n_prm, const lto_integrator* integ, double* Phi, double* defect) {
+  CallTimer call_timer(c);
   if (!c) return LTO_ENULL;
   if (!XC || !t || !Phi) return set_err(c, LTO_ENULL, "XC, t or Phi is NULL");
   if (n_tgrids != 1 && n_tgrids != n_batch) return set_err(c, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
@@ -1293,6 +1306,7 @@ int lto_indirect_densify(lto_ctx* c, int ndim, int n_nodes, const double* XC, co
 static int direct_host(lto_ctx* c, int nstate, int n_nodes, int n_batch, const double* X, const double* U, const double* t,
                        int n_tgrids, int nsteps, const lto_direct_params* prm, double* Jac_temp, double* ddefect_dtf,
                        double* defect, double* errors, bool want_jac, double* x_mid = nullptr) {
+  CallTimer call_timer(c);
   lto_direct_plan* p = nullptr;
   int rc = direct_plan_build(c, nstate, n_nodes, n_batch, nsteps, prm, &p);
   if (rc) return rc;

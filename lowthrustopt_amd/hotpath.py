@@ -108,6 +108,10 @@ class Context:
     def last_kernel_ms(self):
         return float(self.lib.lto_last_kernel_ms(self.handle))
 
+    def last_call_ms(self):
+        """Wall time of the last host-pointer call as measured inside the library (entry to return)."""
+        return float(self.lib.lto_last_call_ms(self.handle))
+
 
 class Group:
     """Several GPUs behind this one process (lto_group_*): pass as `ctx=` to indirect_defectCalc, indirect_stm,
