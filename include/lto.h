@@ -242,7 +242,9 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 #define LTO_KERNEL_PIPE8 5
 /* ndim = 12, DOP853_ADAPTIVE plans only: the cooperative kernel with every 12-component state split over two lanes (top /
  * bottom halves of a column in different waves, the two halves of the base state in neighbouring DPP banks): six components
- * per lane keep all slopes of the 13-stage method in addressable registers.  Other plans: LTO_EINVAL. */
+ * per lane keep all slopes of the 13-stage method in addressable registers.  Other plans: LTO_EINVAL.  The defect-only
+ * sweep of such a plan has the same two forms (one lane per segment / two lanes per segment; AUTO: two lanes up to 262 144
+ * segments); LTO_KERNEL_PER_LANE and LTO_KERNEL_COOP2 select them explicitly. */
 #define LTO_KERNEL_COOP2 6
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */

@@ -60,6 +60,8 @@ hipError_t launch_indirect14_stm(int pm, int method, int cols_per_lane, const In
 hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const IndirectArgs& a, hipStream_t st);
 // the same with every 12-component state split over two lanes (kernels_indirect_coop2.hip): 12-dim, DOP853 adaptive only
 hipError_t launch_indirect_stm_coop2(int pm, const IndirectArgs& a, hipStream_t st);
+// defect-only sweep with two lanes per segment (kernels_indirect_defect2.hip): 12-dim, DOP853 adaptive only
+hipError_t launch_indirect_defect2(int pm, const IndirectArgs& a, hipStream_t st);
 // three-role pipeline (kernels_indirect_pipe.hip): base wave, coefficient wave and two column waves per 16 segments,
 // skewed by one RK4 step; fixed-step RK4 only
 hipError_t launch_indirect_stm_pipe(int ndim, int pm, const IndirectArgs& a, hipStream_t st);

@@ -28,6 +28,7 @@
 // segment without storing: the grid always drains.
 #include "kernels.hpp"
 #include "rk.hpp"
+#include "halves.hpp"
 
 namespace lto {
 
@@ -43,15 +44,6 @@ struct C2Shared {
   alignas(16) double part[2][3][C2_SEG][C2_PAD];  // partial norms [trial parity][which][segment][role]
   double scale[12][C2_SEG];                  // 1 / (atol + rtol |base value|) of global row r
 };
-
-// src's value from the lane 4 below (CTRL = row_shr:4) or 4 above (row_shl:4) into the lanes of the banks in BANK; the other
-// lanes keep old.
-template <int CTRL, int BANK>
-__device__ __forceinline__ double dpp_bank_merge(const double old, const double src) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANK, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANK, false);
-  return __hiloint2double(hi, lo);
-}
 
 // Probe build (make probe): ticks every role waits at the stage barriers and the ticks of its trial loop, per workgroup,
 // into rows 16-19 (base), 20-21 (top wave 0), 22-23 (bottom wave 0) of a 24-row defect buffer (tools/probe_coop2.py).
@@ -119,8 +111,8 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       double R[3], L[3], q[3], kp[3], kq[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        R[j] = dpp_bank_merge<0x114, 0xA>(arg[j], arg[j]);      // B lanes take r from their A lane (row_shr:4)
-        L[j] = dpp_bank_merge<0x104, 0x5>(arg[j], arg[j]);      // A lanes take lambda_v from their B lane (row_shl:4)
+        R[j] = from_lane_a(arg[j]);      // B lanes take r from their A lane (row_shr:4)
+        L[j] = from_lane_b(arg[j]);      // A lanes take lambda_v from their B lane (row_shl:4)
         q[j] = arg[3 + j];
       }
       BaseParts12 bp;

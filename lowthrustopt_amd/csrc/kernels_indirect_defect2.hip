@@ -1,0 +1,201 @@
+// kernels_indirect_defect2.hip -- defect-only sweep with the reference's integrator setting (adaptive order 8, rtol = atol =
+// 1e-13; src/multiShoot_CRTBP_indirect.jl:63-90, :79) on the 12-dim system, TWO LANES PER SEGMENT.
+//
+// The one-lane kernel (k_indirect<12, PM, M_DOP853_ADAPTIVE, 0>) keeps ten live slopes of 12 components: 240 of the 256
+// registers a VALU instruction can address, so state, argument and temporaries overflow into AGPRs (620 v_accvgpr moves per
+// trial step), and a sweep lasts as long as its slowest segment's instruction stream (C5: 69 trial steps against a mean of
+// 8.5).  Here lane A owns (r, v) and lane B -- four lanes up, the next DPP bank -- owns (lambda_v, lambda_r): six components
+// and 13 x 6 slopes per lane, the tableau arithmetic per lane halves, nothing spills.  Both lanes hold r and lambda_v (three
+// doubles each cross over by v_mov_b32_dpp) and run one instruction stream (rhs12_base_half); error norms are pair sums
+// formed in the same order in both lanes, so both take the same decisions and the pair's control flow never diverges.
+// Twice the wavefronts: chosen while the chip holds them at two per SIMD (launcher below).
+#include "kernels.hpp"
+#include "rk.hpp"
+#include "halves.hpp"
+
+namespace lto {
+
+template <int PM>
+__global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
+  const int lane = threadIdx.x;
+  const bool is_a = ((lane >> 2) & 1) == 0;
+  const int sl = blockIdx.x * 32 + (lane >> 3) * 4 + (lane & 3);       // 32 segments per wavefront
+  if (sl >= a.S) return;                                               // both lanes of a pair leave together
+  const int s = a.order ? a.order[sl] : sl;
+  const int traj = s / a.seg_per_traj;
+  const int i = s - traj * a.seg_per_traj;
+  const long node = (long)traj * a.n_nodes + i;
+  const long tg = (long)traj * a.t_stride + i;
+  const double span = a.t[tg + 1] - a.t[tg];
+  const TrajParams tp = a.tp[(long)traj * a.tp_stride];
+  if (a.class_filter && p_class(tp.p) != PM) return;                   // mixed-class batch: another launch owns this trajectory
+  const double w2 = 2.0 * tp.omega;
+  const double sg = is_a ? 1.0 : -1.0, kap = is_a ? 0.0 : w2;
+  int grow[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) grow[j] = is_a ? j : (j < 3 ? 9 + j : 3 + j);
+
+  double y[6], K[13][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) y[j] = a.X[grow[j] * a.ldx + node];
+
+  auto rhs = [&](const double (&arg)[6], double (&out)[6]) {
+    double R[3], L[3], q[3], kp[3], kq[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { R[j] = from_lane_a(arg[j]); L[j] = from_lane_b(arg[j]); q[j] = arg[3 + j]; }
+    BaseParts12 bp;
+    rhs12_base_half<PM>(R, L, q, is_a, sg, kap, tp, kp, kq, bp);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { out[j] = kp[j]; out[3 + j] = kq[j]; }
+  };
+
+  const double rtol = a.rtol, atol = a.atol;
+  int nacc = 0, nrej = 0;
+  double t = 0.0;
+  if (span > 0.0) {
+    rhs(y, K[0]);
+    double h_abs;
+    {   // Hairer's initial step over the 12 components
+      double isc[6], p0 = 0.0, p1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        isc[j] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
+        p0 = __builtin_fma(y[j] * isc[j], y[j] * isc[j], p0);
+        p1 = __builtin_fma(K[0][j] * isc[j], K[0][j] * isc[j], p1);
+      }
+      const double d0 = sqrt(pair_sum(p0) / 12.0), d1 = sqrt(pair_sum(p1) / 12.0);
+      const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+      double yt[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) yt[j] = __builtin_fma(h0, K[0][j], y[j]);
+      rhs(yt, K[1]);
+      double p2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double df = (K[1][j] - K[0][j]) * isc[j];
+        p2 = __builtin_fma(df, df, p2);
+      }
+      const double d2 = sqrt(pair_sum(p2) / 12.0) / h0;
+      const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : cbrt(cbrt(0.01 / fmax(d1, d2)));
+      h_abs = fmin(fmin(100.0 * h0, h1), span);
+    }
+    double rejected = 0.0;       // per-lane flags as doubles (DESIGN.md "Compiler hazards")
+    while (t < span && nacc + nrej < a.max_steps) {
+      double h = h_abs;
+      double last = 0.0;
+      if (t + h >= span) { h = span - t; last = 1.0; }
+#pragma unroll
+      for (int st = 1; st < 12; ++st) {
+        double arg[6], acc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < st; ++k)
+          if (DP8_A[st][k] != 0.0) {
+            const double w = coef_here(DP8_A[st][k]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[j] = __builtin_fma(w, K[k][j], acc[j]);
+          }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) arg[j] = __builtin_fma(h, acc[j], y[j]);
+        rhs(arg, K[st]);
+      }
+      double yn[6], acc[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[j] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 12; ++k)
+        if (DP8_B[k] != 0.0) {
+          const double w = coef_here(DP8_B[k]);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc[j] = __builtin_fma(w, K[k][j], acc[j]);
+        }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) yn[j] = __builtin_fma(h, acc[j], y[j]);
+      rhs(yn, K[12]);
+      double a5[6], a3[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { a5[j] = 0.0; a3[j] = 0.0; }
+#pragma unroll
+      for (int k = 0; k <= 12; ++k) {
+        if (DP8_E5[k] != 0.0) {
+          const double w = coef_here(DP8_E5[k]);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) a5[j] = __builtin_fma(w, K[k][j], a5[j]);
+        }
+        if (DP8_E3[k] != 0.0) {
+          const double w = coef_here(DP8_E3[k]);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) a3[j] = __builtin_fma(w, K[k][j], a3[j]);
+        }
+      }
+      double e5 = 0.0, e3 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double isc = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
+        const double s5 = a5[j] * isc, s3 = a3[j] * isc;
+        e5 = __builtin_fma(s5, s5, e5);
+        e3 = __builtin_fma(s3, s3, e3);
+      }
+      const double E5 = pair_sum(e5), E3 = pair_sum(e3);
+      const double err = (E5 == 0.0 && E3 == 0.0) ? 0.0 : fabs(h) * E5 / sqrt((E5 + 0.01 * E3) * 12.0);
+      if (err < 1.0) {
+        double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 / sqrt(sqrt(sqrt(err))));
+        if (rejected != 0.0) factor = fmin(1.0, factor);
+        h_abs = h * factor;
+        t = (last != 0.0) ? span : t + h;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
+        ++nacc;
+        rejected = 0.0;
+      } else {
+        h_abs = h * fmax(0.2, 0.9 / sqrt(sqrt(sqrt(err))));
+        rejected = 1.0;
+        ++nrej;
+        if (err != err) {                     // a NaN never recovers: poison and stop instead of max_steps retries
+#pragma unroll
+          for (int j = 0; j < 6; ++j) y[j] = err;
+          t = span;
+        }
+      }
+    }
+    if (t < span) {                           // max_steps trial steps used up before t1: no result
+#pragma unroll
+      for (int j = 0; j < 6; ++j) y[j] = __builtin_nan("");
+    }
+  } else if (span != 0.0) {                   // decreasing grid (forward integration only) or NaN span: no result
+#pragma unroll
+    for (int j = 0; j < 6; ++j) y[j] = __builtin_nan("");
+  }
+
+  if (a.defect) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) a.defect[grow[j] * a.ldd + s] = y[j] - a.X[grow[j] * a.ldx + node + 1];
+  }
+  if (is_a) {
+    if (a.errors) a.errors[s] = 0.0;
+    if (a.nacc) a.nacc[s] = nacc;
+    if (a.nrej) a.nrej[s] = nrej;
+  }
+}
+
+template <int PM>
+static hipError_t launch_defect2_one(const IndirectArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((k_indirect_defect2<PM>), dim3((a.S + 31) / 32), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// 12-dim system, DOP853 adaptive, defect only.
+hipError_t launch_indirect_defect2(int pm, const IndirectArgs& a0, hipStream_t st) {
+  if (a0.S <= 0) return hipSuccess;
+  IndirectArgs a = a0;
+  a.class_filter = single_class(pm) ? 0 : 1;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_defect2_one<PM_P0>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_defect2_one<PM_P1>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_defect2_one<PM_P2>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_defect2_one<PM_PGEN>(a, st);
+  return e;
+}
+
+}  // namespace lto

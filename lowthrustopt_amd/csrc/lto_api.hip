@@ -457,8 +457,14 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  hipError_t e = (p->ndim == 12) ? launch_indirect_defect(p->pm, p->integ.method, a, st)
-                                 : launch_indirect14_defect(p->pm, p->integ.method, a, st);
+  // The reference's setting (12-dim, DOP853): two lanes per segment (tools/probe_defect2.py: 29 segments 99 -> 73 us, 4 096:
+  // 119 -> 88 us, 65 536 ordered: 0.43 -> 0.32 ms, 262 144: 0.44 -> 0.38 ms; 524 288: 0.60 -> 0.73 ms, so one lane beyond);
+  // LTO_KERNEL_PER_LANE / LTO_KERNEL_COOP2 on the plan force one form.
+  const bool two_lane = p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE &&
+                        (p->kernel == LTO_KERNEL_COOP2 || (p->kernel == LTO_KERNEL_AUTO && p->S <= 262144));
+  hipError_t e = two_lane          ? launch_indirect_defect2(p->pm, a, st)
+                 : (p->ndim == 12) ? launch_indirect_defect(p->pm, p->integ.method, a, st)
+                                   : launch_indirect14_defect(p->pm, p->integ.method, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_defect", e);
   p->swept = 1;

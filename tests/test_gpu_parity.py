@@ -253,6 +253,49 @@ def test_indirect_mixed_control_law_classes(gpu_ctx, ndim, mname, kernel):
         assert np.array_equal(d[:, sl], d1) and np.array_equal(d0[:, sl], d01)
 
 
+@pytest.mark.parametrize("pcase", list(P_CASES))
+def test_indirect_defect_two_lanes_per_segment(gpu_ctx, oracle, pcase):
+    """Defect-only sweep with the reference's integrator setting (12-dim, DOP853 @ 1e-13): the form with two lanes per segment
+    (lane A: r, v; lane B: lambda_v, lambda_r; what AUTO runs up to 262 144 segments) and the one-lane form, forced through
+    the plan's kernel knob, both against the oracle; ragged segment count (pairs in the last wavefront missing), counters
+    from the A lane, a zero-length and a decreasing segment in the same wavefront."""
+    import torch
+    p, rho, thr, lam = P_CASES[pcase]
+    n = 75
+    XC, T = synth.indirect_problem(n, seed=17, lam_sigma=lam)
+    XC, t = XC[:, :, 0], T[:, 0].copy()
+    prm_l = [MU, DU, TU, thr, 1000.0, 1.0, p, rho]
+    S = n - 1
+    d_o, e_o, rc = oracle.indirect_defect(XC, t, prm_l, lto.DOP853_ADAPTIVE, 0)
+    assert rc == 0
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    res = {}
+    for name, kern in (("one", lto.IndirectPlan.KERNEL_PER_LANE), ("two", lto.IndirectPlan.KERNEL_COOP2), ("auto", lto.IndirectPlan.KERNEL_AUTO)):
+        plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator())
+        plan.set_kernel(kern)
+        td = torch.from_numpy(np.ascontiguousarray(t)).cuda()
+        d = torch.full((12, S), 7.0, dtype=torch.float64, device="cuda")
+        plan.defect(X, n, td, 1, d, S)
+        torch.cuda.synchronize()
+        acc, rej = plan.step_counts()
+        res[name] = (d.cpu().numpy(), acc, rej)
+        assert rel_l2(res[name][0], d_o, XC[:, 1:]) < 1e-10
+        assert acc.min() >= 1 and (acc + rej).max() < 400
+        # degenerate segments next to ordinary ones: zero span -> identity (defect = x_i - x_{i+1}), negative span -> NaN
+        t2 = t.copy(); t2[11] = t2[10]; t2[41] = t2[40] - 0.01
+        td2 = torch.from_numpy(t2).cuda()
+        d2 = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        plan.defect(X, n, td2, 1, d2, S)
+        torch.cuda.synchronize()
+        d2 = d2.cpu().numpy()
+        assert np.array_equal(d2[:, 10], XC[:, 10] - XC[:, 11]) and np.all(np.isnan(d2[:, 40]))
+        keep = [i for i in range(S) if i not in (9, 10, 11, 39, 40, 41)]
+        assert np.array_equal(d2[:, keep], res[name][0][:, keep])
+        plan.close()
+    assert np.array_equal(res["auto"][0], res["two"][0])
+    assert np.abs(res["one"][0] - res["two"][0]).max() < 1e-11
+
+
 def test_indirect_backward_time_direction(gpu_ctx, oracle):
     XC, T = synth.indirect_problem(12, seed=8)
     XC, t = XC[:, :, 0], T[:, 0]
