@@ -83,7 +83,7 @@ int lto_create(lto_ctx** out, int device_id);
 void lto_destroy(lto_ctx* ctx);
 /* Page-locked host memory for the arrays of the host-pointer API.  An operand that lies inside a block from here (the
  * whole block or any contiguous part of it) is read / written by the GPU in place: the layout kernels of the call are the
- * transfer and no copy operation is queued (Jacobian call at 4 096 segments: 0.215 ms, of which 0.09 ms are the 4.7 MB of
+ * transfer and no copy operation is queued (Jacobian call at 4 096 segments: 0.20 ms, of which 0.09 ms are the 4.7 MB of
  * Phi crossing the link).  Other buffers work too: pageable ones are staged by the HIP runtime (0.31 ms for the same call).
  * Julia: unsafe_wrap the pointer as an Array and free it in a finalizer (julia/LowThrustOptHIP.jl: pinned_array). */
 int lto_host_alloc(lto_ctx* ctx, size_t bytes, void** out);

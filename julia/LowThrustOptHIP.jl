@@ -298,8 +298,8 @@ ctx_stream(ctx::LtoContext) = ccall((:lto_ctx_stream, liblto), Ptr{Cvoid}, (Ptr{
 last_call_ms(ctx::LtoContext) = ccall((:lto_last_call_ms, liblto), Cdouble, (Ptr{Cvoid},), ctx.handle)
 
 """`Array{Float64}` of the given size in page-locked host memory (lto_host_alloc): the GPU reads and writes such arrays (and
-contiguous views into them) in place during a host-pointer call -- no copy is queued (Jacobian call at 4 096 segments: 0.215 ms
-instead of 0.31 ms with ordinary arrays).  Freed by a finalizer."""
+contiguous views into them) in place during a host-pointer call -- no copy is queued (Jacobian call at 4 096 segments: 0.20 ms
+instead of 0.29 ms with ordinary arrays).  Freed by a finalizer."""
 function pinned_array(ctx::LtoContext, dims::Integer...)
     p = Ref{Ptr{Cvoid}}(C_NULL)
     check(ctx, ccall((:lto_host_alloc, liblto), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, 8 * prod(dims), p))

@@ -18,8 +18,8 @@ python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/nul
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_c5.json"; last "$OUT/bench_c5.json"
 python bench.py --workload c5_stm --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null > "$OUT/bench_c5_stm.json"; last "$OUT/bench_c5_stm.json"
 # kernel traces + stats.  The device ramps its clocks over the first ~300 contract launches (91 -> 79 us per launch): the c2
-# and c3 traces time enough steps for the average over ALL launches of the trace to be the ramped duration.
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2" -- python bench.py --steps 2000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2.log" 2>&1
+# and c3 traces time enough steps (4 000 / 2 000) for the average over ALL launches of the trace to be the ramped duration.
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2" -- python bench.py --steps 4000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c3" -- python bench.py --workload c3 --steps 2000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c3.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c4" -- python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/prof_c4.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_dop853" -- python bench.py --ndim 12 --method dop853 --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2_dop853.log" 2>&1
