@@ -227,7 +227,8 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
  * pipeline kernels (eight-wave form up to 4 096 segments and, for ndim = 14, up to ~130 000; four-wave form beyond: at
  * every size for ndim = 14, up to ~12 000 segments for ndim = 12) and otherwise the per-lane kernel (each lane re-integrates the base state with 1-3
  * columns); for the 13-stage integrators the wave-specialised kernel (base wave + column waves per 16 segments,
- * coefficients handed over through LDS at every RK stage). */
+ * coefficients handed over through LDS at every RK stage) -- for ndim = 12 with DOP853_ADAPTIVE, the reference's setting,
+ * its form with two lanes per state (LTO_KERNEL_COOP2). */
 #define LTO_KERNEL_AUTO 0
 #define LTO_KERNEL_PER_LANE 1
 #define LTO_KERNEL_COOP 2
