@@ -224,8 +224,9 @@ int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
 int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 
 /* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4 with >= 6 steps per segment, the three-role
- * pipeline kernels (eight-wave form up to 4 096 segments and, for ndim = 14, up to ~130 000; four-wave form beyond: at
- * every size for ndim = 14, up to ~12 000 segments for ndim = 12) and otherwise the per-lane kernel (each lane re-integrates the base state with 1-3
+ * pipeline kernels (eight-wave form up to 4 096 segments and, for ndim = 14, up to ~24 000; four-wave form for ndim = 12 up to
+ * ~12 000 segments; the 48-segment form for large batches: ndim = 14 from 24 576, ndim = 12 from 32 768 segments) and otherwise
+ * the per-lane kernel (each lane re-integrates the base state with 1-3
  * columns); for the 13-stage integrators the wave-specialised kernel (base wave + column waves per 16 segments,
  * coefficients handed over through LDS at every RK stage) -- for ndim = 12 with DOP853_ADAPTIVE, the reference's setting,
  * its form with two lanes per state (LTO_KERNEL_COOP2). */
@@ -247,6 +248,9 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
  * sweep of such a plan has the same two forms (one lane per segment / two lanes per segment; AUTO: two lanes up to 262 144
  * segments); LTO_KERNEL_PER_LANE and LTO_KERNEL_COOP2 select them explicitly. */
 #define LTO_KERNEL_COOP2 6
+/* RK4 plans only: the pipeline for large batches -- 48 segments and 16 wavefronts per workgroup, the base wave's lanes are 48
+ * different segments, twelve column waves with one segment per DPP row. */
+#define LTO_KERNEL_PIPE48 7
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* plan);

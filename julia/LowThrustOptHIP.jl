@@ -355,7 +355,7 @@ axpy_dev!(ctx::LtoContext, stream, x, d, alpha::Real, y, count::Integer) =
 
 "Order the lanes of the following adaptive sweeps by the last sweep's step counts (results unchanged)."
 rebalance!(pl::LtoIndirectPlan, stream) = check(pl.ctx, ccall((:lto_indirect_plan_rebalance, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), pl.handle, devptr(stream)))
-"LTO_KERNEL_*: 0 auto, 1 per-lane, 2 cooperative, 3 / 4 / 5 pipeline forms (RK4 plans), 6 cooperative with two lanes per state (12-dim DOP853 plans)."
+"LTO_KERNEL_*: 0 auto, 1 per-lane, 2 cooperative, 3 / 4 / 5 pipeline forms (RK4 plans), 6 cooperative with two lanes per state (12-dim DOP853 plans), 7 pipeline for large batches (RK4 plans)."
 set_kernel!(pl::LtoIndirectPlan, kernel::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_kernel, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, kernel))
 
 "Julia column-major [ndim x count] on the device -> SoA [ndim][ld] (and back)."

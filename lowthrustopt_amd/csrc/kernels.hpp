@@ -69,6 +69,8 @@ hipError_t launch_indirect_stm_pipe(int ndim, int pm, const IndirectArgs& a, hip
 hipError_t launch_indirect_stm_pipe6(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 // eight-wave form (kernels_indirect_pipe8.hip): two RK4 steps per phase, a fourth of the column work alternates between two SIMDs
 hipError_t launch_indirect_stm_pipe8(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
+// large batches (kernels_indirect_pipe48.hip): 48 segments and 16 waves per workgroup, base lane = segment, DPP column rows
+hipError_t launch_indirect_stm_pipe48(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian_coop(int nstate, const DirectArgs& a, hipStream_t st);

@@ -1,0 +1,187 @@
+// kernels_indirect_pipe48.hip -- the three-role RK4 pipeline for LARGE batches: 48 segments and 16 wavefronts per workgroup.
+//
+// The pipeline kernels of kernels_indirect_pipe.hip / _pipe8.hip are built for the latency regime (4 096 segments = one
+// workgroup of 16 segments per CU): their base wave integrates 16 segments in 64 lanes.  Once the chip is full many times over
+// (BASELINE configs[3]: 256 x 1 024 segments) only the number of instructions issued per segment counts, and there the per-lane
+// kernel (every lane re-integrates the base state with three columns; 384 live registers, a fifth of its instructions AGPR
+// moves) was level with them.  This form keeps the three roles and the one-step skew but fills the wavefronts:
+//   wave 0       base: lane = segment (48 of 64 lanes), publishes the stage arguments stage by stage (no lane groups to
+//                remember them in -- 12 stores per step more on a stream that is no longer the critical one)
+//   waves 1-3    coefficients: lane = (segment, RK stage), 16 segments per wave, one step behind
+//   waves 4-15   columns: DPP row = segment (12 or 14 column lanes + spare lanes), four segments per wave, two steps behind;
+//                coefficients broadcast inside v_fmac_f64_dpp (col_dpp_step, pipe_common.hpp)
+// Wave w runs on SIMD w mod 4: every SIMD carries one base / coefficient wave and three column waves (~1 350-1 500
+// instructions per step).  Hand-overs double-buffered per step in LDS (12-dim: 18 + 101 KB; one workgroup per CU), one
+// __syncthreads() per step, steps + 2 phases, every wave executes the same barriers, nothing spins.
+// Instructions issued per segment and RK4 step: 541 / 48 + 3 x 400 / 48 + 12 x 310 / 48 = 114 against 184 in the per-lane kernel.
+#include "pipe_common.hpp"
+
+namespace lto {
+
+constexpr int P48_SEG = 48;
+
+template <int ND, int PM> struct Pipe48 {
+  using Arg = PipeArg<ND, PM>;
+  static constexpr int NI = Arg::N;
+  static constexpr int NC = sizeof(typename PipeCoef<ND>::type) / sizeof(double);
+  static constexpr int SD = P48_SEG * CoefBySegment::LD;           // doubles of one stage's coefficient records
+  static constexpr int INT_DOUBLES = 2 * 4 * NI * P48_SEG;         // [step parity][stage][value][segment]
+  static constexpr int COEF_DOUBLES = 2 * 4 * SD;                  // [step parity][stage][segment record]
+};
+
+template <int ND, int PM>
+__device__ __forceinline__ void pipe48_role_base(const IndirectArgs& a, const PipeLane& L, const int seg, const bool live, double* s_int) {
+  using P = Pipe48<ND, PM>;
+  constexpr int NI = P::NI;
+  const int steps = a.steps;
+  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
+  auto rhs = [&](const double (&y)[ND], double (&k)[ND]) {
+    if constexpr (ND == 12) rhs12_base<PM>(y, L.tp, k);
+    else rhs14_base<PM>(y, L.tp, k);
+  };
+  double y[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + L.node];
+  for (int p = 0; p < steps + 2; ++p) {
+    if (p < steps) {
+      double k[ND], yt[ND], acc[ND];
+      double* slab = s_int + ((p & 1) * 4 * NI) * P48_SEG + seg;
+      auto publish = [&](const int stage, const double (&arg)[ND]) {
+        if (live) {
+#pragma unroll
+          for (int e = 0; e < NI; ++e) slab[(stage * NI + e) * P48_SEG] = arg[P::Arg::idx[e]];
+        }
+      };
+      publish(0, y);
+      rhs(y, k);
+#pragma unroll
+      for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
+      publish(1, yt);
+      rhs(yt, k);
+#pragma unroll
+      for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
+      publish(2, yt);
+      rhs(yt, k);
+#pragma unroll
+      for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
+      publish(3, yt);
+      rhs(yt, k);
+#pragma unroll
+      for (int c = 0; c < ND; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
+    }
+    __syncthreads();
+  }
+  if (L.in_range && live) {
+    if (a.defect) {
+#pragma unroll
+      for (int c = 0; c < ND; ++c) a.defect[c * a.ldd + L.s] = y[c] - a.X[c * a.ldx + L.node + 1];
+    }
+    if (a.errors) a.errors[L.s] = 0.0;
+    if (a.nacc) a.nacc[L.s] = steps;
+    if (a.nrej) a.nrej[L.s] = 0;
+  }
+}
+
+// lane = (segment, RK stage): the four stages of step p - 1 are built side by side in phase p; every coefficient except the
+// unit vector lhat (entries 14..16) is stored times the stage's RK4 argument weight (h/2, h/2, h, h/2: col_dpp_step).
+template <int ND, int PM>
+__device__ __forceinline__ void pipe48_role_coef(const IndirectArgs& a, const PipeLane& L, const int seg, const int stage,
+                                                 const double* s_int, double* s_coef) {
+  using P = Pipe48<ND, PM>;
+  using Coef = typename PipeCoef<ND>::type;
+  constexpr int NI = P::NI, NC = P::NC;
+  const int steps = a.steps;
+  const double as = (stage == 2) ? L.h : 0.5 * L.h;
+  for (int p = 0; p < steps + 2; ++p) {
+    if (p >= 1 && p <= steps) {
+      const int buf = (p - 1) & 1;
+      double arg[ND], dead[ND];
+#pragma unroll
+      for (int c = 0; c < ND; ++c) arg[c] = 0.0;
+      const double* src = s_int + ((buf * 4 + stage) * NI) * P48_SEG + seg;
+#pragma unroll
+      for (int e = 0; e < NI; ++e) arg[P::Arg::idx[e]] = src[e * P48_SEG];
+      Coef vc;
+      if constexpr (ND == 12) rhs12<PM, true>(arg, L.tp, dead, vc);
+      else rhs14<PM, true>(arg, L.tp, dead, vc);
+      const double* o = reinterpret_cast<const double*>(&vc);
+      double* dst = s_coef + (buf * 4 + stage) * P::SD;
+#pragma unroll
+      for (int e = 0; e < NC; ++e) dst[CoefBySegment::at<ND>(e, seg)] = (e < 14 || e > 16) ? o[e] * as : o[e];
+    }
+    __syncthreads();
+  }
+}
+
+// lane = (row = segment, column); one RK4 step = col_dpp_step
+template <int ND>
+__device__ __forceinline__ void pipe48_role_columns(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
+                                                    const double* s_coef) {
+  constexpr int SD = P48_SEG * CoefBySegment::LD;
+  const int steps = a.steps;
+  const ColStepConst k(L.h, L.w2);
+  double y[ND];
+#pragma unroll
+  for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
+  for (int p = 0; p < steps + 2; ++p) {
+    if (p >= 2 && col < ND)                    // the spare lanes of a row stay switched off: they are never DPP sources
+      col_dpp_step<ND, SD>(s_coef + ((p & 1) * 4) * SD + CoefBySegment::lane_base(col, seg), k, p - 2, y);
+    __syncthreads();
+  }
+  if (L.in_range && col < ND) {
+#pragma unroll
+    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = y[r] * a.stm_scale;
+  }
+}
+
+template <int ND, int PM>
+__global__ __launch_bounds__(1024) void k_indirect_pipe48(const IndirectArgs a) {
+  using P = Pipe48<ND, PM>;
+  __shared__ double s_int[P::INT_DOUBLES];
+  __shared__ double s_coef[P::COEF_DOUBLES];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  // wave 0: base (lane = segment, lanes 48..63 shadow segment 47); waves 1-3: coefficients of segments 16 (w - 1) ..;
+  // waves 4-15: columns of segments 4 (w - 4) .. + 3
+  const int seg = (wave == 0) ? (lane < P48_SEG ? lane : P48_SEG - 1)
+                : (wave < 4)  ? (wave - 1) * 16 + (lane & 15)
+                              : (wave - 4) * 4 + (lane >> 4);
+  const PipeLane L = pipe_lane<PM, P48_SEG>(a, seg);
+  if (!__syncthreads_or(L.mine)) return;         // workgroup-uniform
+  // Every wave shares its SIMD with three others and all meet at one barrier per step: the two roles with the long dependent
+  // streams and the fewest instructions (base 565, coefficients ~400 per step) issue first, or the step would last four times
+  // the base wave's stream.
+  if (wave == 0) { __builtin_amdgcn_s_setprio(3); pipe48_role_base<ND, PM>(a, L, seg, lane < P48_SEG, s_int); }
+  else if (wave < 4) { __builtin_amdgcn_s_setprio(2); pipe48_role_coef<ND, PM>(a, L, seg, lane >> 4, s_int, s_coef); }
+  else pipe48_role_columns<ND>(a, L, seg, lane & 15, s_coef);
+}
+
+template <int ND, int PM>
+static hipError_t launch_pipe48_one(const IndirectArgs& a, hipStream_t st) {
+  dim3 grid((a.S + P48_SEG - 1) / P48_SEG);
+  hipLaunchKernelGGL((k_indirect_pipe48<ND, PM>), grid, dim3(1024), 0, st, a);
+  return hipGetLastError();
+}
+
+template <int ND>
+static hipError_t launch_pipe48_pm(int pm, const IndirectArgs& a0, hipStream_t st) {
+  IndirectArgs a = a0;
+  a.class_filter = single_class(pm) ? 0 : 1;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_pipe48_one<ND, PM_P0>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_pipe48_one<ND, PM_P1>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_pipe48_one<ND, PM_P2>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_pipe48_one<ND, PM_PGEN>(a, st);
+  return e;
+}
+
+// RK4 only; steps >= 1.
+hipError_t launch_indirect_stm_pipe48(int ndim, int pm, const IndirectArgs& a, hipStream_t st) {
+  if (a.S <= 0) return hipSuccess;
+  if (a.steps < 1) return hipErrorInvalidValue;
+  if (ndim == 12) return launch_pipe48_pm<12>(pm, a, st);
+  if (ndim == 14) return launch_pipe48_pm<14>(pm, a, st);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace lto

@@ -404,11 +404,12 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
 int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
   if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE && kernel != LTO_KERNEL_PIPE6 &&
-      kernel != LTO_KERNEL_PIPE8 && kernel != LTO_KERNEL_COOP2)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE, _PIPE6, _PIPE8 or _COOP2");
+      kernel != LTO_KERNEL_PIPE8 && kernel != LTO_KERNEL_COOP2 && kernel != LTO_KERNEL_PIPE48)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE, _PIPE6, _PIPE8, _COOP2 or _PIPE48");
   if (kernel == LTO_KERNEL_COOP2 && (p->integ.method != LTO_DOP853_ADAPTIVE || p->ndim != 12))
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_COOP2 is built for 12-dim DOP853_ADAPTIVE plans");
-  if ((kernel == LTO_KERNEL_PIPE || kernel == LTO_KERNEL_PIPE6 || kernel == LTO_KERNEL_PIPE8) && p->integ.method != LTO_RK4)
+  if ((kernel == LTO_KERNEL_PIPE || kernel == LTO_KERNEL_PIPE6 || kernel == LTO_KERNEL_PIPE8 || kernel == LTO_KERNEL_PIPE48) &&
+      p->integ.method != LTO_RK4)
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_PIPE is built for fixed-step RK4 plans");
   p->kernel = kernel;
   return LTO_OK;
@@ -488,10 +489,11 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   // Kernel choice (DESIGN.md "Kernels", measured on MI355X, tools/probe_kernels.py).  RK4: the three-role pipeline
   // kernels -- the eight-wave form (two steps per phase, a fourth of the column work alternating between two SIMDs) up
   // to one workgroup per CU (4 096 segments, 14-dim: 81 us against 89 us six-wave, 104 us four-wave, 174 us per-lane,
-  // 243 us cooperative; 12-dim: 78 / 80 / 87 / 134 / 142 us) and, for 14-dim, on to ~130 000 segments (65 536: 1.27 ms
-  // against 1.29 ms four-wave, 1.59 ms per-lane); beyond that the four-wave form, which fits two workgroups per CU
-  // (262 144 segments 14-dim: 4.8 ms against 5.0 ms eight-wave, 6.3 ms per-lane).  12-dim above 4 096 segments: four-wave
-  // form up to ~12 000 segments, then the per-lane kernel with 3 columns per lane.  13-stage methods -> wave-specialised
+  // 243 us cooperative; 12-dim: 78 / 80 / 87 / 134 / 142 us) and, for 14-dim, on to ~24 000 segments; 12-dim above 4 096
+  // segments: four-wave form up to ~12 000 segments, then the per-lane kernel with 3 columns per lane.  Large batches (14-dim
+  // from 24 576, 12-dim from 32 768 segments): the 48-segment, 16-wave form, which fills its wavefronts (262 144 segments:
+  // 14-dim 4.17 ms against 4.85 four-wave, 4.95 eight-wave, 6.3 per-lane; 12-dim 3.55 ms against 3.86 per-lane, 4.06
+  // four-wave; 49 152: 0.76 / 0.93 ms and 0.65 / 0.74 ms).  13-stage methods -> wave-specialised
   // kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms); for the reference's setting
   // (12-dim, DOP853) its form with six components per lane, which keeps all slopes in addressable registers.
   int kern = p->kernel;
@@ -500,8 +502,8 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
       kern = (p->integ.method == LTO_DOP853_ADAPTIVE && p->ndim == 12) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
     else if (p->integ.steps < 6) kern = LTO_KERNEL_PER_LANE;   // fill and drain phases outweigh the shorter phase
     else if (p->S <= 4096) kern = LTO_KERNEL_PIPE8;
-    else if (p->ndim == 14) kern = (p->S <= 131072) ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PIPE;
-    else kern = (p->S <= 12288) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
+    else if (p->ndim == 14) kern = (p->S < 24576) ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PIPE48;
+    else kern = (p->S <= 12288) ? LTO_KERNEL_PIPE : (p->S < 32768 ? LTO_KERNEL_PER_LANE : LTO_KERNEL_PIPE48);
   }
   p->last_kernel = kern;
   hipError_t e;
@@ -510,6 +512,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   else if (kern == LTO_KERNEL_PIPE) e = launch_indirect_stm_pipe(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE6) e = launch_indirect_stm_pipe6(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);
+  else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, st);
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);

@@ -54,10 +54,10 @@ struct PipeLane {
   TrajParams tp;
 };
 
-template <int PM>
+template <int PM, int SEGS = PIPE_SEG>
 __device__ __forceinline__ PipeLane pipe_lane(const IndirectArgs& a, const int seg) {
   PipeLane L;
-  const int s_raw = blockIdx.x * PIPE_SEG + seg;
+  const int s_raw = blockIdx.x * SEGS + seg;
   const int s_lin = s_raw < a.S ? s_raw : a.S - 1;             // shadow lanes repeat the last segment
   L.s = a.order ? a.order[s_lin] : s_lin;
   const int traj = L.s / a.seg_per_traj;

@@ -32,7 +32,7 @@ def make_case(seed):
     kernel = int(rng.integers(0, 3))
     cols = int(rng.integers(0, 4))
     if method == lto.RK4:        # the pipeline kernels exist for fixed-step RK4 only (own generator: the other draws stay put)
-        kernel = int(np.random.default_rng(7000 + seed).choice([kernel, 3, 4, 5]))
+        kernel = int(np.random.default_rng(7000 + seed).choice([kernel, 3, 4, 5, 7]))
     XC, T = synth.indirect_problem(n, n_batch=B, seed=seed, dt_range=(lo, hi), lam_sigma=lam)
     if ndim == 14:
         X = np.zeros((14, n, B), order="F")

@@ -38,12 +38,12 @@ METHODS = {
 
 
 # STM kernel families x integrators: the three-role pipeline kernel is built for fixed-step RK4 only
-KERNEL_METHODS = [(k, m) for k in ("per_lane", "coop") for m in METHODS] + [("pipe", "rk4x64"), ("pipe6", "rk4x64"), ("pipe8", "rk4x64"), ("coop2", "dop853_adaptive")]
+KERNEL_METHODS = [(k, m) for k in ("per_lane", "coop") for m in METHODS] + [("pipe", "rk4x64"), ("pipe6", "rk4x64"), ("pipe8", "rk4x64"), ("pipe48", "rk4x64"), ("coop2", "dop853_adaptive")]
 
 
 def pick_kernel(plan, kernel):
     plan.set_kernel({"per_lane": plan.KERNEL_PER_LANE, "coop": plan.KERNEL_COOP, "pipe": plan.KERNEL_PIPE, "pipe6": plan.KERNEL_PIPE6,
-                     "pipe8": plan.KERNEL_PIPE8, "coop2": plan.KERNEL_COOP2}[kernel])
+                     "pipe8": plan.KERNEL_PIPE8, "coop2": plan.KERNEL_COOP2, "pipe48": plan.KERNEL_PIPE48}[kernel])
 
 
 def rel_l2(d_gpu, d_ref, x1):
@@ -1228,11 +1228,12 @@ def test_indirect_pipeline_kernel_is_rk4_only(gpu_ctx):
 def test_indirect_auto_kernel_choice(gpu_ctx):
     """What LTO_KERNEL_AUTO resolves to (lto_indirect_plan_last_kernel): RK4 with >= 6 steps -> pipeline kernels (eight-wave
     form up to 4 096 segments and for 14-dim beyond, four-wave for 12-dim beyond; 12-dim falls back to the per-lane kernel above
-    12 288 segments), RK4 with
+    12 288 segments and to the 48-segment pipeline from 32 768; 14-dim: 48-segment pipeline from 24 576), RK4 with
     fewer steps -> per-lane, 13-stage integrators -> cooperative (12-dim DOP853, the reference's setting: its two-lanes-per-state form)."""
     import torch
     cases = [(12, 30, lto.RK4, 64, "pipeline8"), (14, 4097, lto.RK4, 64, "pipeline8"), (14, 8193, lto.RK4, 64, "pipeline8"),
              (12, 8193, lto.RK4, 64, "pipeline"), (12, 16385, lto.RK4, 8, "per-lane"), (14, 30, lto.RK4, 2, "per-lane"),
+             (12, 32769, lto.RK4, 8, "pipeline48"), (14, 24577, lto.RK4, 6, "pipeline48"),
              (12, 30, lto.DOP853_ADAPTIVE, 0, "cooperative2"), (14, 30, lto.DOP853_ADAPTIVE, 0, "cooperative"),
              (12, 30, lto.RKF78_ADAPTIVE, 0, "cooperative"), (14, 30, lto.RKF78_FIXED, 4, "cooperative")]
     for ndim, n, method, steps, want in cases:
