@@ -1188,7 +1188,7 @@ def test_indirect_pipeline_kernel_equals_per_lane_at_full_size(gpu_ctx, ndim, st
 @pytest.mark.parametrize("steps", [255, 256, 257, 600])
 def test_indirect_pipeline_column_rescaling_at_many_steps(gpu_ctx, oracle, ndim, steps):
     """The DPP column lanes carry 3^k Phi and multiply by 3^-256 every 256 steps (pipe_common.hpp): step counts around and
-    beyond that period, six- and eight-wave forms, against the oracle's dual-number STM of the same discrete map."""
+    beyond that period, six-, eight- and sixteen-wave forms, against the oracle's dual-number STM of the same discrete map."""
     import torch
     n = 20
     XC, T = synth.indirect_problem(n, seed=17)
@@ -1205,7 +1205,7 @@ def test_indirect_pipeline_column_rescaling_at_many_steps(gpu_ctx, oracle, ndim,
     S = n - 1
     Xd = torch.from_numpy(synth.to_soa_nodes(np.asfortranarray(X)[:, :, None])).cuda()
     td = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
-    for kernel in ("pipe6", "pipe8"):
+    for kernel in ("pipe6", "pipe8", "pipe48"):
         plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(lto.RK4, steps=steps), ndim=ndim)
         pick_kernel(plan, kernel)
         Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
