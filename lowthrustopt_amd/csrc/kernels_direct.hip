@@ -344,8 +344,19 @@ __global__ __launch_bounds__(384) void k_direct_jacobian_coop(const DirectArgs a
 // One barrier per step (half_steps + 1 phases), coefficient slabs double-buffered (93 / 133 KB of LDS: one workgroup per CU,
 // three waves per SIMD).  Per arc and stage ~9.3 wave-instructions against ~17.6 in the per-lane kernel.  Same tableau, step
 // grid, arithmetic per column and output layout as k_direct_jacobian.
+// Wave w of a workgroup runs on SIMD w mod 4 (tools/micro/sync_probe.hip).  Twelve wavefronts are launched so that the column
+// waves sit three to a SIMD (~2 150 instructions per step) and the base wave (~1 300, the longest dependent stream) has
+// SIMD 0 to itself (NS = 6: waves 4 and 8 leave at once) or shares it with one column wave (NS = 7: ten columns, wave 8
+// leaves).  With ten waves in launch order SIMD 0 carried the base wave AND two column waves: 2 700 instructions per step
+// against 1 400-2 150 on the others, and the step barrier waited for it (95.5 -> 79.7 us at 16 384 segments).
 template <int NS>
-__global__ __launch_bounds__(64 * (NS + 4)) void k_direct_jacobian_pipe(const DirectArgs a) {
+__device__ __forceinline__ int direct_pipe_column_of_wave(const int w) {   // -1: leaves at once
+  if (NS == 6) return (w & 3) == 0 ? -1 : (w & 3) - 1 + 3 * (w >> 2);       // waves 1 2 3 | 5 6 7 | 9 10 11 -> columns 0..8
+  return (w == 8) ? -1 : (w < 8 ? w - 1 : w - 2);                           // waves 1..7, 9..11 -> columns 0..9
+}
+
+template <int NS>
+__global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a) {
   constexpr int ARCS = 64;
   constexpr int NC = (NS == 7) ? 10 : 7;       // doubles handed over per (arc, stage)
   __shared__ double s_coef[2][13][NC][ARCS];
@@ -353,7 +364,9 @@ __global__ __launch_bounds__(64 * (NS + 4)) void k_direct_jacobian_pipe(const Di
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), arc = threadIdx.x & 63;
   const bool is_base = (wave == 0);
-  const int j = is_base ? 0 : wave - 1;        // sensitivity column of this wave
+  const int jw = is_base ? 0 : direct_pipe_column_of_wave<NS>(wave);
+  if (jw < 0) return;                          // before any barrier: the hardware barrier counts the waves still alive
+  const int j = jw;                            // sensitivity column of this wave
   const int seg = arc >> 1, dir = arc & 1;     // forward / backward half-arcs of a segment are lane neighbours
   const int s_raw = blockIdx.x * (ARCS / 2) + seg;
   const int s = s_raw < a.S ? s_raw : a.S - 1; // shadow lanes repeat the last segment, store nothing
@@ -484,8 +497,8 @@ __global__ __launch_bounds__(64 * (NS + 4)) void k_direct_jacobian_pipe(const Di
 hipError_t launch_direct_jacobian_pipe(int nstate, const DirectArgs& a, hipStream_t st) {
   if (a.S <= 0) return hipSuccess;
   dim3 grid((a.S + 31) / 32);
-  if (nstate == 6) hipLaunchKernelGGL((k_direct_jacobian_pipe<6>), grid, dim3(64 * 10), 0, st, a);
-  else if (nstate == 7) hipLaunchKernelGGL((k_direct_jacobian_pipe<7>), grid, dim3(64 * 11), 0, st, a);
+  if (nstate == 6) hipLaunchKernelGGL((k_direct_jacobian_pipe<6>), grid, dim3(768), 0, st, a);
+  else if (nstate == 7) hipLaunchKernelGGL((k_direct_jacobian_pipe<7>), grid, dim3(768), 0, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
