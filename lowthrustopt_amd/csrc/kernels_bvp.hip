@@ -316,9 +316,79 @@ __device__ __forceinline__ void bvp_backsub_pair(const BvpArgs& a, int level, in
   }
 }
 
+// The same with SIXTEEN lanes per pair (lane r = row r of the unknown): the record's matrices are read as rows of NU
+// consecutive doubles instead of one 6 KB record per lane (4 096 segments: a level took 15 us with one lane per pair, the
+// loads of 64 lanes going to 64 different records).  Lane r forms s_r = g_r - (Ca d_left + Cb d_right)_r, then the triangular
+// solve runs column by column: lane k divides, broadcasts x_k inside the 16-lane group, the lanes above it update their s.
+template <int NU>
+__device__ __forceinline__ void bvp_backsub_pair16(const BvpArgs& a, int level, int M, const int j, const int b, const int r) {
+  using D = BvpDims<NU>;
+  if (j >= M / 2) return;               // uniform for the 16 lanes of a pair
+  const int mid = (2 * j + 1) << level, left = (2 * j) << level;
+  int right = (2 * j + 2) << level;
+  if (right > a.n_nodes - 1) right = a.n_nodes - 1;
+  const double* rec = a.rec + ((long)b * a.n_nodes + mid) * D::REC;
+  const long nb = (long)b * a.n_nodes;
+  constexpr int off = 12 - NU;
+  const int rr = r < NU ? r : NU - 1;   // lanes NU..15 shadow the last row (no stores)
+  double s = rec[D::REC_G + rr];
+#pragma unroll
+  for (int c = 0; c < NU; ++c) {
+    const double dl = a.delta[(long)(off + c) * a.ldx + nb + left], dr = a.delta[(long)(off + c) * a.ldx + nb + right];
+    s -= rec[D::REC_CA + c * NU + rr] * dl + rec[D::REC_CB + c * NU + rr] * dr;
+  }
+  double x = 0.0;
+#pragma unroll
+  for (int k = NU - 1; k >= 0; --k) {
+    const double xk = __shfl(s / rec[D::REC_R + k * NU + k], k, 16);      // lane k of the group holds the finished s_k
+    if (rr == k) x = xk;
+    s = __builtin_fma(-rec[D::REC_R + k * NU + (rr < k ? rr : 0)], (rr < k) ? xk : 0.0, s);
+  }
+  if (r < NU) a.delta[(long)(off + r) * a.ldx + nb + mid] = x;
+  if (NU == 6 && r < 6) a.delta[(long)r * a.ldx + nb + mid] = 0.0;       // states are not updated
+}
+
+// one level: 16 lanes per pair, four pairs per wavefront
 template <int NU>
 __global__ __launch_bounds__(64) void k_bvp_backsub(BvpArgs a, int level, int M) {
-  bvp_backsub_pair<NU>(a, level, M, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
+  bvp_backsub_pair16<NU>(a, level, M, blockIdx.x * 4 + (threadIdx.x >> 4), blockIdx.y, threadIdx.x & 15);
+}
+
+// Two levels of the reduction in one launch (a level is ~15 us of launch + latency whatever its size, and 4 096 segments
+// are twelve levels).  Workgroup g: its two wavefronts reduce the pairs 2g and 2g + 1 of `level` (cur -> nxt), then --
+// block-scope barrier: both rows were written by this workgroup -- wavefront 0 reduces pair g of level + 1 (nxt -> out).
+// `out` is a third buffer: other workgroups may still be reading cur.
+template <int NU>
+__global__ __launch_bounds__(128) void k_bvp_reduce2(BvpArgs a, int level, int M, const double* __restrict__ cur, double* nxt, double* out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = blockIdx.x, b = blockIdx.y;
+  const int M1 = M / 2 + (M & 1);
+  const int j = 2 * g + wave;
+  if (j < M1) bvp_reduce_pair<NU>(a, level, M, cur, nxt, j, b, lane);
+  __syncthreads();
+  if (wave == 0 && g < M1 / 2 + (M1 & 1)) bvp_reduce_pair<NU>(a, level + 1, M1, nxt, out, g, b, lane);
+}
+// the same for a new right-hand side: one lane does the pairs 2g, 2g + 1 of `level` and then pair g of level + 1
+template <int NU>
+__global__ __launch_bounds__(64) void k_bvp_reduce_rhs2(BvpArgs a, int level, int M, const double* __restrict__ cur, double* nxt, double* out) {
+  const int g = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  const int M1 = M / 2 + (M & 1);
+  if (g >= M1 / 2 + (M1 & 1)) return;
+  bvp_reduce_rhs_pair<NU>(a, level, M, cur, nxt, 2 * g, b);
+  bvp_reduce_rhs_pair<NU>(a, level, M, cur, nxt, 2 * g + 1, b);
+  __threadfence_block();               // this lane reads back what it has just written
+  bvp_reduce_rhs_pair<NU>(a, level + 1, M1, nxt, out, g, b);
+}
+// Two levels of the back-substitution: the 16-lane group that forms the unknown of pair g at level + 1 then forms those of the
+// pairs 2g and 2g + 1 of `level`, whose outer unknowns are that one and unknowns of earlier launches.
+template <int NU>
+__global__ __launch_bounds__(64) void k_bvp_backsub2(BvpArgs a, int level, int M) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 4), r = threadIdx.x & 15, b = blockIdx.y;
+  const int M1 = M / 2 + (M & 1);
+  if (g >= M1 / 2 + (M1 & 1)) return;  // uniform for the 16 lanes of a group
+  bvp_backsub_pair16<NU>(a, level + 1, M1, g, b, r);
+  __threadfence_block();               // the group reads back the unknown it has just stored
+  bvp_backsub_pair16<NU>(a, level, M, 2 * g, b, r);
+  bvp_backsub_pair16<NU>(a, level, M, 2 * g + 1, b, r);
 }
 
 // Tail of the reduction in ONE launch: once a level has at most 16 block rows (8 pairs = 8 wavefronts, 2 per SIMD: the full register budget) the
@@ -345,7 +415,7 @@ __global__ __launch_bounds__(512) void k_bvp_tail(BvpArgs a, int level0, int M0,
   if (wave == 0) bvp_final_one<NU>(a, cur, b, lane);
   __syncthreads();
   for (int l = level - 1; l >= level0; --l) {
-    bvp_backsub_pair<NU>(a, l, Ms[l - level0], tid, b);
+    bvp_backsub_pair16<NU>(a, l, Ms[l - level0], tid >> 4, b, tid & 15);     // at most 8 pairs: 32 groups of 16 lanes
     __syncthreads();
   }
 }
@@ -359,7 +429,8 @@ __global__ __launch_bounds__(256) void k_axpy(const double* __restrict__ x, cons
 
 size_t bvp_workspace_doubles(int n_nodes, int n_batch) {
   // sized for the larger (NU = 12) variant; the adjoints-only variant uses a prefix of the same workspace
-  return (size_t)2 * (n_nodes - 1) * n_batch * BvpDims<12>::ROW + (size_t)n_nodes * n_batch * BvpDims<12>::REC;
+  // three buffers of block rows (a two-level launch reads one and writes the other two; same per-trajectory pitch), the records
+  return (size_t)3 * (n_nodes - 1) * n_batch * BvpDims<12>::ROW + (size_t)n_nodes * n_batch * BvpDims<12>::REC;
 }
 
 template <int NU>
@@ -369,7 +440,8 @@ static hipError_t bvp_solve_impl(const double* Phi, long ldp, const double* defe
   BvpArgs a;
   a.n_nodes = n_nodes; a.n_batch = n_batch; a.S_traj = n_nodes - 1;
   const size_t rows_sz = (size_t)a.S_traj * n_batch * D::ROW;
-  a.rows0 = workspace; a.rows1 = workspace + rows_sz; a.rec = workspace + 2 * rows_sz;
+  a.rows0 = workspace; a.rows1 = workspace + rows_sz; a.rec = workspace + 3 * rows_sz;
+  double* rows2 = workspace + 2 * rows_sz;
   a.delta = delta; a.ldx = ldx;
   const long S_total = (long)a.S_traj * n_batch;
   if (Phi) {
@@ -381,22 +453,39 @@ static hipError_t bvp_solve_impl(const double* Phi, long ldp, const double* defe
   }
   double* cur = a.rows0;
   double* nxt = a.rows1;
+  double* spare = rows2;
   int M = a.S_traj, level = 0;
   int Ms[40];
   while (M > BVP_TAIL_MAX) {
-    Ms[level] = M;
-    const int npairs = M / 2, carry = M & 1;
-    if (Phi) hipLaunchKernelGGL((k_bvp_reduce<NU>), dim3(npairs + carry, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
-    else hipLaunchKernelGGL((k_bvp_reduce_rhs<NU>), dim3((npairs + carry + 63) / 64, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
-    double* t = cur; cur = nxt; nxt = t;
-    M = npairs + carry;
-    ++level;
+    const int M1 = M / 2 + (M & 1);
+    if (M1 > BVP_TAIL_MAX) {           // two levels in one launch: cur -> nxt -> spare
+      const int M2 = M1 / 2 + (M1 & 1);
+      Ms[level] = M; Ms[level + 1] = M1;
+      if (Phi) hipLaunchKernelGGL((k_bvp_reduce2<NU>), dim3(M2, n_batch), dim3(128), 0, st, a, level, M, cur, nxt, spare);
+      else hipLaunchKernelGGL((k_bvp_reduce_rhs2<NU>), dim3((M2 + 63) / 64, n_batch), dim3(64), 0, st, a, level, M, cur, nxt, spare);
+      double* t = cur; cur = spare; spare = t;
+      M = M2;
+      level += 2;
+    } else {
+      Ms[level] = M;
+      if (Phi) hipLaunchKernelGGL((k_bvp_reduce<NU>), dim3(M1, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
+      else hipLaunchKernelGGL((k_bvp_reduce_rhs<NU>), dim3((M1 + 63) / 64, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
+      double* t = cur; cur = nxt; nxt = t;
+      M = M1;
+      ++level;
+    }
   }
-  // remaining levels (M <= 32), final solve and their back-substitution in one launch per trajectory
+  // remaining levels, final solve and their back-substitution in one launch per trajectory
   hipLaunchKernelGGL((k_bvp_tail<NU>), dim3(n_batch), dim3(512), 0, st, a, level, M, cur, nxt, Phi ? 1 : 0);
-  for (int l = level - 1; l >= 0; --l) {
-    const int npairs = Ms[l] / 2;
-    hipLaunchKernelGGL((k_bvp_backsub<NU>), dim3((npairs + 63) / 64, n_batch), dim3(64), 0, st, a, l, Ms[l]);
+  int l = level - 1;
+  for (; l >= 1; l -= 2) {             // levels l and l - 1 in one launch
+    const int M1 = Ms[l];
+    const int groups = M1 / 2 + (M1 & 1);
+    hipLaunchKernelGGL((k_bvp_backsub2<NU>), dim3((groups + 3) / 4, n_batch), dim3(64), 0, st, a, l - 1, Ms[l - 1]);
+  }
+  if (l == 0) {
+    const int npairs = Ms[0] / 2;
+    hipLaunchKernelGGL((k_bvp_backsub<NU>), dim3((npairs + 3) / 4, n_batch), dim3(64), 0, st, a, 0, Ms[0]);
   }
   return hipGetLastError();
 }
