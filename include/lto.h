@@ -17,8 +17,10 @@
  *   - Return value: 0 = ok; < 0 = API misuse; > 0 = runtime failure (see LTO_E*).  Non-finite
  *     results are not errors: NaN/Inf propagate into the outputs so the caller's driver reproduces the
  *     reference's status_flag = 2 path (src/multiShoot_CRTBP_indirect.jl:339-341).
- *   - The library never throws across the ABI, installs no signal handlers and keeps no host pointer
- *     after a call returns.  One thread per context at a time; distinct contexts are independent.
+ *   - The library never throws across the ABI (it is built without exception support: running out of host
+ *     memory or of threads inside a call ends the process instead), installs no signal handlers and keeps
+ *     no host pointer after a call returns.  One thread per context at a time; distinct contexts are
+ *     independent.
  */
 #ifndef LTO_H
 #define LTO_H
