@@ -226,9 +226,9 @@ int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
 int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 
 /* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4 with >= 6 steps per segment, the three-role
- * pipeline kernels (eight-wave form up to 4 096 segments and, for ndim = 14, up to ~24 000; four-wave form for ndim = 12 up to
- * ~12 000 segments; the 48-segment form for large batches: ndim = 14 from 24 576, ndim = 12 from 32 768 segments) and otherwise
- * the per-lane kernel (each lane re-integrates the base state with 1-3
+ * pipeline kernels (eight-wave form up to 4 096 segments; above that, whichever of eight-wave (ndim = 14) / four-wave
+ * (ndim = 12) form, 48-segment form and per-lane kernel needs the cheapest rounds for the segment count -- from ~30 000
+ * segments on always the 48-segment form) and otherwise the per-lane kernel (each lane re-integrates the base state with 1-3
  * columns); for the 13-stage integrators the wave-specialised kernel (base wave + column waves per 16 segments,
  * coefficients handed over through LDS at every RK stage) -- for ndim = 12 with DOP853_ADAPTIVE, the reference's setting,
  * its form with two lanes per state (LTO_KERNEL_COOP2). */

@@ -489,11 +489,11 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   // Kernel choice (DESIGN.md "Kernels", measured on MI355X, tools/probe_kernels.py).  RK4: the three-role pipeline
   // kernels -- the eight-wave form (two steps per phase, a fourth of the column work alternating between two SIMDs) up
   // to one workgroup per CU (4 096 segments, 14-dim: 81 us against 89 us six-wave, 104 us four-wave, 174 us per-lane,
-  // 243 us cooperative; 12-dim: 78 / 80 / 87 / 134 / 142 us) and, for 14-dim, on to ~24 000 segments; 12-dim above 4 096
-  // segments: four-wave form up to ~12 000 segments, then the per-lane kernel with 3 columns per lane.  Large batches (14-dim
-  // from 24 576, 12-dim from 32 768 segments): the 48-segment, 16-wave form, which fills its wavefronts (262 144 segments:
-  // 14-dim 4.17 ms against 4.85 four-wave, 4.95 eight-wave, 6.3 per-lane; 12-dim 3.55 ms against 3.86 per-lane, 4.06
-  // four-wave; 49 152: 0.76 / 0.93 ms and 0.65 / 0.74 ms).  13-stage methods -> wave-specialised
+  // 243 us cooperative; 12-dim: 78 / 80 / 87 / 134 / 142 us).  Above that: eight-wave (14-dim) / four-wave (12-dim) form in
+  // rounds of 4 096 segments, the per-lane kernel with 3 columns per lane (12-dim) in rounds of 16 384, or the 48-segment,
+  // 16-wave form, which fills its wavefronts, in rounds of 12 288 -- whichever is cheapest for the segment count (262 144
+  // segments: 14-dim 4.17 ms against 4.85 four-wave, 4.95 eight-wave, 6.3 per-lane; 12-dim 3.55 ms against 3.86 per-lane,
+  // 4.06 four-wave; 12 288: 0.19 / 0.23 ms and 0.16 / 0.21 ms; 16 384: 0.31 ms eight-wave and 0.25 ms per-lane win).  13-stage methods -> wave-specialised
   // kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms); for the reference's setting
   // (12-dim, DOP853) its form with six components per lane, which keeps all slopes in addressable registers.
   int kern = p->kernel;
@@ -502,8 +502,19 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
       kern = (p->integ.method == LTO_DOP853_ADAPTIVE && p->ndim == 12) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
     else if (p->integ.steps < 6) kern = LTO_KERNEL_PER_LANE;   // fill and drain phases outweigh the shorter phase
     else if (p->S <= 4096) kern = LTO_KERNEL_PIPE8;
-    else if (p->ndim == 14) kern = (p->S < 24576) ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PIPE48;
-    else kern = (p->S <= 12288) ? LTO_KERNEL_PIPE : (p->S < 32768 ? LTO_KERNEL_PER_LANE : LTO_KERNEL_PIPE48);
+    else {
+      // Above one workgroup per CU every family runs in rounds of the segments the chip holds at once, and a partly filled
+      // round costs a whole one: the family with the cheapest rounds for THIS segment count wins (us per round at 64 steps,
+      // tools/probe_kernels.py; the ratios do not depend on the step count).
+      const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };
+      if (p->ndim == 14) {
+        const double t8 = rounds(4096) * 78.0, t48 = rounds(12288) * 190.0;
+        kern = (t48 < t8) ? LTO_KERNEL_PIPE48 : LTO_KERNEL_PIPE8;
+      } else {
+        const double t4 = rounds(4096) * 69.0, t48 = rounds(12288) * 163.0, tl = rounds(16384) * 249.0;
+        kern = (t48 <= t4 && t48 <= tl) ? LTO_KERNEL_PIPE48 : (t4 <= tl ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE);
+      }
+    }
   }
   p->last_kernel = kern;
   hipError_t e;

@@ -1227,12 +1227,14 @@ def test_indirect_pipeline_kernel_is_rk4_only(gpu_ctx):
 
 def test_indirect_auto_kernel_choice(gpu_ctx):
     """What LTO_KERNEL_AUTO resolves to (lto_indirect_plan_last_kernel): RK4 with >= 6 steps -> pipeline kernels (eight-wave
-    form up to 4 096 segments and for 14-dim beyond, four-wave for 12-dim beyond; 12-dim falls back to the per-lane kernel above
-    12 288 segments and to the 48-segment pipeline from 32 768; 14-dim: 48-segment pipeline from 24 576), RK4 with
-    fewer steps -> per-lane, 13-stage integrators -> cooperative (12-dim DOP853, the reference's setting: its two-lanes-per-state form)."""
+    form up to 4 096 segments; above that the family whose rounds are cheapest for the segment count: eight-wave / four-wave
+    form in rounds of 4 096, the 48-segment form in rounds of 12 288, the per-lane kernel (12-dim) in rounds of 16 384), RK4
+    with fewer steps -> per-lane, 13-stage integrators -> cooperative (12-dim DOP853, the reference's setting: its
+    two-lanes-per-state form)."""
     import torch
     cases = [(12, 30, lto.RK4, 64, "pipeline8"), (14, 4097, lto.RK4, 64, "pipeline8"), (14, 8193, lto.RK4, 64, "pipeline8"),
-             (12, 8193, lto.RK4, 64, "pipeline"), (12, 16385, lto.RK4, 8, "per-lane"), (14, 30, lto.RK4, 2, "per-lane"),
+             (12, 8193, lto.RK4, 64, "pipeline"), (12, 12289, lto.RK4, 8, "pipeline48"), (12, 16385, lto.RK4, 8, "per-lane"),
+             (14, 30, lto.RK4, 2, "per-lane"), (14, 12289, lto.RK4, 6, "pipeline48"), (14, 16385, lto.RK4, 6, "pipeline8"),
              (12, 32769, lto.RK4, 8, "pipeline48"), (14, 24577, lto.RK4, 6, "pipeline48"),
              (12, 30, lto.DOP853_ADAPTIVE, 0, "cooperative2"), (14, 30, lto.DOP853_ADAPTIVE, 0, "cooperative"),
              (12, 30, lto.RKF78_ADAPTIVE, 0, "cooperative"), (14, 30, lto.RKF78_FIXED, 4, "cooperative")]
