@@ -2,6 +2,8 @@
 thrust, segment lengths, time direction, kernel family, columns per lane) against the oracle.  Complements the
 structured cases of test_gpu_parity.py: kernels that are miscompiled or mis-dispatched only for some template
 combination show up here (see DESIGN.md "Compiler hazards")."""
+import os
+
 import numpy as np
 import pytest
 
@@ -45,7 +47,7 @@ def make_case(seed):
                 cols=cols)
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LTO_FUZZ_SEEDS", "96"))))
 def test_indirect_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
     import torch
     c = make_case(seed)
@@ -74,6 +76,14 @@ def test_indirect_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
     tol_d = 1e-10
     tol_P = 1e-7 if c["adaptive"] else 1e-10
     for b in range(B):
+        tol_d, tol_P = 1e-10, (1e-7 if c["adaptive"] else 1e-10)
+        if c["method"] == lto.RKF78_ADAPTIVE and c["prm_l"][b][6] > 1.0:
+            # ode78 (error control on the base state's infinity norm only, ode.jl:492-497) across the clamp of the p > 1 law:
+            # two implementations whose step sizes differ in the last bit land on different sides of the kink and agree to the
+            # method's TRUE error there, not to round-off (seeds 149, 239, 2982 of an extended run; cf. the rho = 1e-4 case of
+            # test_indirect_defect_vs_oracle); the STM, which ode78 does not control at all, only to ~1e-3 (seed 1388).  DOP853,
+            # the setting the indirect path uses, holds the tight bars.
+            tol_d, tol_P = 1e-6, 1e-2
         Xb, tb, sl = c["X"][:, :, b], c["T"][:, b], slice(b * S, (b + 1) * S)
         if ndim == 12:
             P_o, d_o, rc = oracle.indirect_jacobian(Xb, tb, c["prm_l"][b], c["method"], c["steps"])
@@ -88,7 +98,7 @@ def test_indirect_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
         assert np.abs(Pn[:, :, sl] - P_o).max() < tol_P * np.abs(P_o).max(), what
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LTO_FUZZ_SEEDS_DIRECT", "32"))))
 def test_direct_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
     """Direct transcription: random state size, node count, batch, steps per half segment, Isp, thrust scale (incl.
     zero-control nodes), segment lengths and Jacobian kernel family against the oracle: defect, RKF7(8) error estimate,
@@ -101,6 +111,7 @@ def test_direct_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
     nsteps = int(rng.integers(2, 13))
     Isp = float(rng.choice([300.0, 2000.0, 3000.0]))
     kern = int(rng.integers(0, 3))
+    kern = int(np.random.default_rng(9000 + seed).choice([kern, 3]))   # + the pipelined kernel (own generator: the other draws stay put)
     X, U, T = synth.direct_problem(n, n_batch=B, seed=seed, nstate=nstate, dt_seg=10.0 ** rng.uniform(-2.5, -0.4),
                                    thrust_sigma=float(rng.choice([0.0, 0.03, 1.0])))
     if n > 3:
@@ -129,9 +140,10 @@ def test_direct_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
         Xb, Ub, tb, sl = X[:, :, b], U[:, :, b], T[:, b], slice(b * S, (b + 1) * S)
         d_o, e_o = oracle.direct_defect(Xb, Ub, tb, nsteps, MU, DU, TU, Isp)
         Jd, dh, dd = oracle.direct_jacobian_dual(Xb, Ub, tb, nsteps, MU, DU, TU, Isp)
-        assert np.abs(dg[:, sl] - d_o).max() < 1e-12 and np.abs(d0g[:, sl] - d_o).max() < 1e-12, what
+        tol = 1e-12 * max(1.0, np.abs(Xb).max() * 1e-2)      # the mass row (~1e3 kg) carries round-off of its own size
+        assert np.abs(dg[:, sl] - d_o).max() < tol and np.abs(d0g[:, sl] - d_o).max() < tol, what
         # the estimate is a difference of nearly equal slopes: round-off level noise differs between kernels
-        assert np.abs(eg[sl] - e_o).max() < 1e-3 * e_o.max() + 1e-17 and np.abs(e0g[sl] - e_o).max() < 1e-3 * e_o.max() + 1e-17, what
+        assert np.abs(eg[sl] - e_o).max() < 1e-3 * e_o.max() + 1e-16 and np.abs(e0g[sl] - e_o).max() < 1e-3 * e_o.max() + 1e-16, what
         assert np.abs(Jg[:, :, sl] - Jd).max() < 1e-10 * max(1.0, np.abs(Jd).max()), what
         dtf_exact = dh * (np.diff(tb) / (tb[-1] - tb[0]))[None, :]
         # the tf partial is the continuous formula (f_f - R f_b) h/(tf - t0); against the derivative of the discrete
