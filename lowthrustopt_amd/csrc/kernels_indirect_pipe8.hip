@@ -165,6 +165,179 @@ __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const Pip
   }
 }
 
+// ------------------------------------------------------------------------------------- base role, paired stages (round 3)
+// The chain of the role above is one RK4 stage after the other: ~135 instructions each, of which ~85 are the "expensive"
+// part -- three reciprocal square roots, the logistic, the gravity coefficients -- and all four 16-lane rows of the wave
+// compute the same thing.  But in RK4 on this system the position and lambda_v arguments of stage 2 do not depend on the
+// expensive part of stage 1 (r_2 = r + h/2 v, lambda_v,2 = lambda_v + h/2 (2 w J lambda_v - lambda_r)), nor stage 4's on
+// stage 3's (r_4 = r + h Y3_v, Y3_v from stage 2).  So a segment is four neighbouring lanes (a DPP quad), lanes 0 / 2 ("A")
+// evaluate the expensive part of stages 1 and 3, lanes 1 / 3 ("B") of stages 2 and 4, at the same time with the same
+// instructions: TWO expensive evaluations per step on the chain instead of four.  Each lane turns its evaluation into the
+// pieces of its stage's slope that depend on it (base_stage_own: three components of v_dot without the Coriolis term, three
+// of lambda_r_dot; for ND = 14 the thrust is kept apart as two scalars because it needs the stage's mass, which depends on
+// the other lane's stage), the pair exchanges them by v_mov_b32_dpp quad_perm (two per double and direction; 64-bit DPP has
+// row_newbcast only), and everything that is cheap -- Coriolis and identity rows, the stage arguments, the RK4 sums -- is
+// computed by every lane of the quad redundantly, so after the exchange all four lanes hold the same bits again.
+// Each lane publishes the argument of its own stage before evaluating it (the old role's `remember` moves are gone); the
+// stage masses of ND = 14 follow once they exist.  Lanes 2 / 3 of a quad duplicate lanes 0 / 1 (same addresses, same
+// values).  ND = 14 with lambda_m on the chain (unclamped p > 1 laws: the law itself depends on the stage's lambda_m and
+// mass) keeps the one-stage-at-a-time role above.
+template <int CTRL>
+__device__ __forceinline__ double quad_from(const double x) {      // CTRL = quad_perm code
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_a(const double x) { return quad_from<0xA0>(x); }   // quad_perm:[0,0,2,2]
+__device__ __forceinline__ double from_b(const double x) { return quad_from<0xF5>(x); }   // quad_perm:[1,1,3,3]
+
+template <int ND, int PM>
+__device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, const PipeLane& L, const int seg, const int q,
+                                                       double* s_int, Pipe8Flags* fl) {
+  using P = Pipe8<ND, PM>;
+  static_assert(ND == 12 || P::LM_OFF, "lambda_m on the chain: the stages do not pair");
+  constexpr int NI = P::NI, NB = P::NB;
+  constexpr bool M14 = (ND == 14);
+  constexpr int V = 3, MI = 6, LR = M14 ? 7 : 6, LV = LR + 3;      // first row of v, mass row, first rows of lambda_r, lambda_v
+  constexpr int EL = M14 ? 4 : 3;                                   // published value index of lambda_v,x (PipeArg::idx)
+  constexpr int SLAB = NI * PIPE_SEG;
+  const int steps = a.steps;
+  const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0), w2 = L.w2;
+  const bool is_b = (q & 1) != 0;
+  const double gA = is_b ? h2 : 0.0;                 // round 1, own stage argument (rows r, lambda_v): y + gA k1
+  const double al = is_b ? 0.0 : h2, be = is_b ? h : 0.0;   // round 2: y + al k2 + be k3
+  const int own = is_b ? SLAB : 0;                   // own stage's slab relative to the round's first
+  const double kt = L.tp.kappa_td;
+  double y[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + L.node];
+  double inv_m = 0.0;
+  if constexpr (M14) inv_m = rcp_nr(y[MI]);
+  P8_WAIT_DECL;
+  // one barrier per phase of two steps (after every odd step and after the last one), then the drain phase: npairs + 1 in all
+  for (int step = 0; step < steps; ++step) {
+    if (PIPE_ROLE_ON(a, 1)) {
+      {
+        double* slab = s_int + ((step & 3) * 4) * SLAB + seg;     // stage s of this step: slab + s * SLAB
+        auto publish = [&](double* d, const double (&pr)[3], const double (&pl)[3]) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { d[i * PIPE_SEG] = pr[i]; d[(EL + i) * PIPE_SEG] = pl[i]; }
+        };
+        StageOwn o;
+        double pr[3], pl[3];
+        // ------------------------------------------------------------ round 1: stages 1 (A lanes) and 2 (B lanes)
+        const double kl1[3] = {__builtin_fma(w2, y[LV + 1], -y[LR]), __builtin_fma(-w2, y[LV], -y[LR + 1]), -y[LR + 2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { pr[i] = __builtin_fma(gA, y[V + i], y[i]); pl[i] = __builtin_fma(gA, kl1[i], y[LV + i]); }
+        publish(slab + own, pr, pl);
+        base_stage_own<ND, PM>(pr[0], pr[1], pr[2], pl[0], pl[1], pl[2], L.tp, o);
+        double a1[3], a2[3], g1[3], g2[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a1[i] = from_a(o.av[i]); a2[i] = from_b(o.av[i]); g1[i] = from_a(o.gl[i]); g2[i] = from_b(o.gl[i]); }
+        double kv1[3], kv2[3], km1 = 0.0, km2 = 0.0, y3m = 0.0, gf2 = 0.0;
+        if constexpr (M14) {
+          const double u1 = from_a(o.gf) * inv_m;
+          gf2 = from_b(o.gf);
+          km1 = -kt * from_a(o.sc); km2 = -kt * from_b(o.sc);
+          kv1[0] = __builtin_fma(w2, y[V + 1], __builtin_fma(-u1, y[LV], a1[0]));
+          kv1[1] = __builtin_fma(-w2, y[V], __builtin_fma(-u1, y[LV + 1], a1[1]));
+          kv1[2] = __builtin_fma(-u1, y[LV + 2], a1[2]);
+        } else {
+          kv1[0] = __builtin_fma(w2, y[V + 1], a1[0]); kv1[1] = __builtin_fma(-w2, y[V], a1[1]); kv1[2] = a1[2];
+        }
+        double y2v[3], y2g[3], y2l[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          y2v[i] = __builtin_fma(h2, kv1[i], y[V + i]); y2g[i] = __builtin_fma(h2, g1[i], y[LR + i]); y2l[i] = __builtin_fma(h2, kl1[i], y[LV + i]);
+        }
+        if constexpr (M14) {
+          const double y2m = __builtin_fma(h2, km1, y[MI]);
+          slab[3 * PIPE_SEG] = y[MI]; slab[SLAB + 3 * PIPE_SEG] = y2m;
+          const double u2 = gf2 * rcp_nr(y2m);
+          kv2[0] = __builtin_fma(w2, y2v[1], __builtin_fma(-u2, y2l[0], a2[0]));
+          kv2[1] = __builtin_fma(-w2, y2v[0], __builtin_fma(-u2, y2l[1], a2[1]));
+          kv2[2] = __builtin_fma(-u2, y2l[2], a2[2]);
+          y3m = __builtin_fma(h2, km2, y[MI]);
+        } else {
+          kv2[0] = __builtin_fma(w2, y2v[1], a2[0]); kv2[1] = __builtin_fma(-w2, y2v[0], a2[1]); kv2[2] = a2[2];
+        }
+        const double kl2[3] = {__builtin_fma(w2, y2l[1], -y2g[0]), __builtin_fma(-w2, y2l[0], -y2g[1]), -y2g[2]};
+        double y3v[3], y3g[3], y3l[3], ar[3], avv[3], ag[3], alv[3], am = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          y3v[i] = __builtin_fma(h2, kv2[i], y[V + i]); y3g[i] = __builtin_fma(h2, g2[i], y[LR + i]); y3l[i] = __builtin_fma(h2, kl2[i], y[LV + i]);
+          ar[i] = __builtin_fma(h3, y2v[i], __builtin_fma(h6, y[V + i], y[i]));
+          avv[i] = __builtin_fma(h3, kv2[i], __builtin_fma(h6, kv1[i], y[V + i]));
+          ag[i] = __builtin_fma(h3, g2[i], __builtin_fma(h6, g1[i], y[LR + i]));
+          alv[i] = __builtin_fma(h3, kl2[i], __builtin_fma(h6, kl1[i], y[LV + i]));
+        }
+        if constexpr (M14) am = __builtin_fma(h3, km2, __builtin_fma(h6, km1, y[MI]));
+        // ------------------------------------------------------------ round 2: stages 3 (A lanes) and 4 (B lanes)
+        const double kl3[3] = {__builtin_fma(w2, y3l[1], -y3g[0]), __builtin_fma(-w2, y3l[0], -y3g[1]), -y3g[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          pr[i] = __builtin_fma(be, y3v[i], __builtin_fma(al, y2v[i], y[i]));        // A: r + h/2 k2_r, B: r + h k3_r
+          pl[i] = __builtin_fma(be, kl3[i], __builtin_fma(al, kl2[i], y[LV + i]));
+        }
+        publish(slab + 2 * SLAB + own, pr, pl);
+        base_stage_own<ND, PM>(pr[0], pr[1], pr[2], pl[0], pl[1], pl[2], L.tp, o);
+        double a3[3], a4[3], g3[3], g4[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a3[i] = from_a(o.av[i]); a4[i] = from_b(o.av[i]); g3[i] = from_a(o.gl[i]); g4[i] = from_b(o.gl[i]); }
+        double kv3[3], kv4[3], km3 = 0.0, km4 = 0.0, gf4 = 0.0;
+        if constexpr (M14) {
+          const double u3 = from_a(o.gf) * rcp_nr(y3m);
+          gf4 = from_b(o.gf);
+          km3 = -kt * from_a(o.sc); km4 = -kt * from_b(o.sc);
+          kv3[0] = __builtin_fma(w2, y3v[1], __builtin_fma(-u3, y3l[0], a3[0]));
+          kv3[1] = __builtin_fma(-w2, y3v[0], __builtin_fma(-u3, y3l[1], a3[1]));
+          kv3[2] = __builtin_fma(-u3, y3l[2], a3[2]);
+        } else {
+          kv3[0] = __builtin_fma(w2, y3v[1], a3[0]); kv3[1] = __builtin_fma(-w2, y3v[0], a3[1]); kv3[2] = a3[2];
+        }
+        double y4v[3], y4g[3], y4l[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          y4v[i] = __builtin_fma(h, kv3[i], y[V + i]); y4g[i] = __builtin_fma(h, g3[i], y[LR + i]); y4l[i] = __builtin_fma(h, kl3[i], y[LV + i]);
+        }
+        if constexpr (M14) {
+          const double y4m = __builtin_fma(h, km3, y[MI]);
+          slab[2 * SLAB + 3 * PIPE_SEG] = y3m; slab[3 * SLAB + 3 * PIPE_SEG] = y4m;
+          const double u4 = gf4 * rcp_nr(y4m);
+          kv4[0] = __builtin_fma(w2, y4v[1], __builtin_fma(-u4, y4l[0], a4[0]));
+          kv4[1] = __builtin_fma(-w2, y4v[0], __builtin_fma(-u4, y4l[1], a4[1]));
+          kv4[2] = __builtin_fma(-u4, y4l[2], a4[2]);
+        } else {
+          kv4[0] = __builtin_fma(w2, y4v[1], a4[0]); kv4[1] = __builtin_fma(-w2, y4v[0], a4[1]); kv4[2] = a4[2];
+        }
+        const double kl4[3] = {__builtin_fma(w2, y4l[1], -y4g[0]), __builtin_fma(-w2, y4l[0], -y4g[1]), -y4g[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          y[i] = __builtin_fma(h6, y4v[i], __builtin_fma(h3, y3v[i], ar[i]));
+          y[V + i] = __builtin_fma(h6, kv4[i], __builtin_fma(h3, kv3[i], avv[i]));
+          y[LR + i] = __builtin_fma(h6, g4[i], __builtin_fma(h3, g3[i], ag[i]));
+          y[LV + i] = __builtin_fma(h6, kl4[i], __builtin_fma(h3, kl3[i], alv[i]));
+        }
+        if constexpr (M14) { y[MI] = __builtin_fma(h6, km4, __builtin_fma(h3, km3, am)); inv_m = rcp_nr(y[MI]); }
+        if (!(step & 1)) p8_signal(&fl->base_steps, step + 1);   // the phase's first step: the coefficient wave is waiting for it
+      }
+    }
+    if ((step & 1) || step == steps - 1) P8_SYNC();
+  }
+  P8_SYNC();
+  P8_WAIT_REPORT(a);
+  if (L.in_range && q == 0) {
+    const bool fail = fl->fail != 0;
+    if (a.defect) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) a.defect[c * a.ldd + L.s] = fail ? __builtin_nan("") : y[c] - a.X[c * a.ldx + L.node + 1];
+    }
+    if (a.errors) a.errors[L.s] = 0.0;
+    if (a.nacc) a.nacc[L.s] = steps;
+    if (a.nrej) a.nrej[L.s] = 0;
+  }
+}
+
 // --------------------------------------------------------------------------------------------------- coefficient role
 // lane = (segment, RK stage); phase p: step 2p - 1, then step 2p as soon as the base wave has published it.
 template <int ND, int PM>
@@ -339,7 +512,8 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   // waves 0, 1, 7: column waves 0, 1, 2; waves 4, 5: the alternating column job 3; wave 2 base, wave 3 coefficients
   const bool col_wave = (wave != 2 && wave != 3);
   const int cw = (wave == 7) ? 2 : (wave >= 4) ? 3 : wave;
-  const int seg = col_wave ? cw * 4 + (lane >> 4) : (lane & (PIPE_SEG - 1));
+  constexpr bool PAIRED = (ND == 12) || P::LM_OFF;   // base role with paired stages: a segment is a DPP quad of the base wave
+  const int seg = col_wave ? cw * 4 + (lane >> 4) : (PAIRED && wave == 2) ? (lane >> 2) : (lane & (PIPE_SEG - 1));
   const PipeLane L = pipe_lane<PM>(a, seg);
   if (threadIdx.x == 0) { s_fl.base_steps = 0; s_fl.coef_steps = 0; s_fl.hand = 0; s_fl.fail = 0; }
   if (!__syncthreads_or(L.mine)) return;         // workgroup-uniform
@@ -347,7 +521,10 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
 #ifdef PIPE_PROBE
   if (threadIdx.x == 128 && a.defect) a.defect[19 * a.ldd + blockIdx.x * PIPE_SEG] = (double)(wall_clock64() - s_probe_t0);   // prologue: entry -> roles start (100 MHz ticks)
 #endif
-  if (wave == 2) pipe8_role_base<ND, PM>(a, L, seg, lane >> 4, s_int, &s_fl);
+  if (wave == 2) {
+    if constexpr (PAIRED) pipe8_role_base_paired<ND, PM>(a, L, seg, lane & 3, s_int, &s_fl);
+    else pipe8_role_base<ND, PM>(a, L, seg, lane >> 4, s_int, &s_fl);
+  }
   else if (wave == 3) pipe8_role_coef<ND, PM>(a, L, seg, lane >> 4, s_int, s_coef, s_lm, &s_fl);
   else if (wave == 4) pipe8_role_columns_alt<ND, PM, false>(a, L, seg, lane & 15, s_coef, s_hand, &s_fl);
   else if (wave == 5) pipe8_role_columns_alt<ND, PM, true>(a, L, seg, lane & 15, s_coef, s_hand, &s_fl);
