@@ -183,21 +183,34 @@ def dop853_flops(trial_steps, f_rhs, dim):
     return trial_steps * (12 * f_rhs + 148 * dim)
 
 
-def roofline(wl, ndim, S, kern_ms, work=None, samples=None, burst_n=N_BURST):
+def pmc_key(wl, ndim, method=None):
+    """Name of the stored counter profile of a workload: profiles/pmc_<key>.json (tools/gpu_round.sh, tools/summarize_profile.py)."""
+    key = wl
+    if wl in ("c2", "c2_defect", "hbm") and ndim == 12:
+        key += "_ndim12"
+    if method:
+        key += "_" + method
+    return key
+
+
+def roofline(wl, ndim, S, kern_ms, work=None, samples=None, burst_n=N_BURST, method=None):
     flops, nbytes = work if work is not None else WORK[(wl, ndim)]
     dur = kern_ms * 1e-3
     ach_tf = flops * S / dur / 1e12
     ach_gb = nbytes * S / dur / 1e9
     traffic, traffic_from = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_%s%s.json" % (wl, "" if ndim == 14 or wl in ("c3", "c4", "c5_stm") else "_ndim12"))
+    pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % pmc_key(wl, ndim, method))
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             traffic = rec.get("hbm_bytes_per_launch")
             traffic_from = "stored rocprofv3 --pmc profile of this command (FETCH_SIZE x 2 + WRITE_SIZE, separate passes): profiles/%s, %s" % (
                 os.path.basename(pmc), rec.get("source", "?"))
-        except Exception:
-            traffic = None
+        except Exception as ex:      # noqa: BLE001
+            traffic, traffic_from = None, "profiles/%s unreadable: %s" % (os.path.basename(pmc), ex)
+    else:
+        traffic_from = ("null: no counter profile of this workload is stored (profiles/%s; tools/gpu_round.sh collects FETCH_SIZE / WRITE_SIZE "
+                        "in separate --pmc passes)" % os.path.basename(pmc))
     return {
         # schema value "mfma" = the compute roof: the dense FP64 matrix peak of MI355X (78.6 TFLOP/s) is numerically the
         # FP64 vector peak, and the vector pipe is what this kernel runs on (compute_pipe); the HBM roof is in "hbm"
@@ -215,12 +228,17 @@ def roofline(wl, ndim, S, kern_ms, work=None, samples=None, burst_n=N_BURST):
     }
 
 
-def parity_vs_oracle(ndim, XC, T, defect, Phi, S):
-    """Defect / STM of the benchmark's own last sweep against the oracle (checker) on a 256-segment sample."""
+def parity_vs_oracle(ndim, XC, T, defect, Phi, S, adaptive=False):
+    """Defect / STM of the benchmark's own last sweep against the oracle (checker) on a 256-segment sample (adaptive: 64
+    segments against the oracle's converged dual-number flow at the same tolerances)."""
     from oracle import oracle as O
     import lowthrustopt_amd as lto
-    ns = min(256, S)
-    if ndim == 14:
+    ns = min(64 if adaptive else 256, S)
+    if adaptive:
+        prm_o = [lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+        Phi_o, d_o, rc = O.indirect_jacobian(XC[:, :ns + 1, 0], T[:ns + 1, 0], prm_o, O.DOP853_ADAPTIVE, 0)
+        against = "CPU oracle, adaptive order 8 @ 1e-13 on dual numbers (the converged flow; step sequences may differ)"
+    elif ndim == 14:
         prm_o = [lto.MU, lto.DU, lto.TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
         Phi_o, d_o, rc = O.indirect14(XC[:, :ns + 1, 0], T[:ns + 1, 0], prm_o, O.RK4, 64)
         against = ("CPU oracle of the same 14-dim model, same RK4 x 64 discrete map, dual-number STM (build extension: the "
@@ -267,16 +285,19 @@ def leg_host_api(lto, ctx, XC, T, prm, integ, ndim, S, calls=30):
             "note": "PCIe-inclusive host-buffer path (what a Julia ccall takes); `value` is the device-resident rate"}
 
 
-def leg_12dim(lto, synth, ctx, st, torch, a):
-    """C2 on the reference's own 12-dim system: same segments, integrator, step count and timing method.  Returns the
-    result object and a closure that adds the oracle parity figures (run after all GPU timing is done)."""
+def leg_12dim(lto, synth, ctx, st, torch, a, reference_integrator=False):
+    """C2 on the reference's own 12-dim system: same segments and timing method.  Default: the contract's integrator (RK4 x 64).
+    reference_integrator: the setting multiShoot_CRTBP_indirect really runs (adaptive order 8, reltol = abstol = 1e-13,
+    indirect.jl:79,110 -- DOP853 stands in for Vern8), defect + STM, roofline flops from the sweep's own step
+    counts.  Returns the result object and a closure that adds the oracle parity figures (run after all GPU timing is done)."""
     S = 4096
     n = S + 1
     XC, T = synth.indirect_problem(n, seed=0)
     X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
     t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
     prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
-    plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=64))
+    integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13) if reference_integrator else lto.integrator(lto.RK4, steps=64)
+    plan = lto.IndirectPlan(ctx, n, 1, prm, integ)
     defect = torch.zeros(12, S, dtype=torch.float64, device="cuda")
     Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
     for _ in range(a.warmup):
@@ -288,13 +309,40 @@ def leg_12dim(lto, synth, ctx, st, torch, a):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     kern_ms, burst_n, samples = sample_launches(torch, lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st))
-    out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
-           "workload": "C2 on the reference's CRTBP_stateCostate_deriv! system: 12-dim state+costate + 12x12 STM, 4 096 "
-                       "segments, RK4 x 64, fp64", "stm_kernel": plan.last_kernel(), "roofline": roofline("c2", 12, S, kern_ms, samples=samples, burst_n=burst_n)}
+    if reference_integrator:
+        acc, rej = plan.step_counts(stream=st)
+        trial = float((acc + rej).sum())
+        roof = roofline("c2", 12, S, kern_ms, work=(dop853_flops(trial, 1070, 156) / S, 1456), samples=samples, burst_n=burst_n, method="dop853")
+        roof["flops_from"] = ("measured step counts of this sweep: %.2f accepted + %.2f rejected trial steps per segment (max %d) x (12 x 1070 + 148 x 156)"
+                              % (acc.mean(), rej.mean(), int((acc + rej).max())))
+        # the defect-only sweep of the same setting: what the line search runs 20 times per Newton iteration (indirect.jl:221-246)
+        for _ in range(a.warmup):
+            plan.defect(X, n, t, 1, defect, S, stream=st)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(a.steps):
+            plan.defect(X, n, t, 1, defect, S, stream=st)
+        torch.cuda.synchronize()
+        el_d = time.perf_counter() - t1
+        plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)     # leave the STM sweep's outputs for the parity check
+        torch.cuda.synchronize()
+        out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
+               "workload": "C2 segments on the reference's 12-dim system with the reference's integrator setting: adaptive order 8 (DOP853 for "
+                           "Vern8), reltol = abstol = 1e-13, defect + 12x12 STM (what jacobianCalc, indirect.jl:93-146, runs)",
+               "stm_kernel": plan.last_kernel(), "roofline": roof,
+               "defect_only": {"ms_per_step": el_d / a.steps * 1e3, "value": S * a.steps / el_d,
+                               "workload": "defectCalc (indirect.jl:63-90) with the same setting"}}
+    else:
+        out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
+               "workload": "C2 on the reference's CRTBP_stateCostate_deriv! system: 12-dim state+costate + 12x12 STM, 4 096 "
+                           "segments, RK4 x 64, fp64", "stm_kernel": plan.last_kernel(), "roofline": roofline("c2", 12, S, kern_ms, samples=samples, burst_n=burst_n)}
     plan.close()
 
     def add_parity():
-        out["parity"] = parity_vs_oracle(12, XC, T, defect, Phi, S)
+        if not reference_integrator:
+            out["parity"] = parity_vs_oracle(12, XC, T, defect, Phi, S)
+        else:
+            out["parity"] = parity_vs_oracle(12, XC, T, defect, Phi, S, adaptive=True)
     return out, add_parity
 
 
@@ -416,18 +464,59 @@ def main():
     # The collective of the product: the library's own RCCL all-gather (lto_comm_allgather_dev; communicator created from an
     # id that rank 0 makes and torch.distributed hands round).  If any rank cannot set it up, every rank falls back to
     # torch.distributed's all_gather_into_tensor (also RCCL) and the JSON line says so.
-    native, native_note = None, None
+    native, native_note, transport = None, None, "torch.distributed"
     if use_coll:
-        try:
-            box = [lto.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, device=dev)
-            native = lto.Comm(ctx, world, rank, box[0])
-        except Exception as ex:      # noqa: BLE001 -- any failure means "use the torch path"
-            native, native_note = None, "%s: %s" % (type(ex).__name__, ex)
-        ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and native is not None:
-            native.close(); native = None; native_note = "another rank could not create its communicator"
+        # Transport of the library's collective, in order of preference (LTO_BENCH_TRANSPORT = windows | rccl | torch):
+        #   windows  lto_comm_window_*: every rank pushes its slab into IPC-mapped receive windows with device copies and raises a
+        #            flag; no RCCL kernel, so no compute unit is taken from the sweep that holds a workgroup on every CU
+        #   rccl     lto_comm_create + ncclAllGather
+        #   torch    torch.distributed.all_gather_into_tensor (also RCCL)
+        # A transport is used only if EVERY rank set it up AND a test gather of rank-stamped slabs came back right everywhere.
+        want = os.environ.get("LTO_BENCH_TRANSPORT", "windows")
+        notes = []
+
+        def agreed(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def gather_works(comm):
+            cnt = gather_rows * S
+            try:
+                src = torch.full((cnt,), float(rank + 1), **f64)
+                dst = torch.zeros(world, cnt, **f64)
+                for _ in range(3):             # both window halves, and a reuse
+                    comm.allgather(src, dst, cnt, stream=C_void_p(torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                return bool(all(torch.all(dst[r] == float(r + 1)) for r in range(world)))
+            except Exception as ex:            # noqa: BLE001
+                notes.append("test gather: %s" % ex)
+                return False
+
+        for kind in (["windows", "rccl"] if want == "windows" else ["rccl"] if want == "rccl" else []):
+            cand = None
+            try:
+                if kind == "windows":
+                    def exchange(blob):
+                        got = [None] * world
+                        dist.all_gather_object(got, blob)
+                        return got
+                    cand = lto.Comm.windows(ctx, world, rank, gather_rows * S, exchange)
+                else:
+                    box = [lto.Comm.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0, device=dev)
+                    cand = lto.Comm(ctx, world, rank, box[0])
+            except Exception as ex:      # noqa: BLE001 -- any failure means "try the next transport"
+                notes.append("%s: %s: %s" % (kind, type(ex).__name__, ex))
+            ok = agreed(cand is not None) and agreed(gather_works(cand))
+            if ok:
+                native, transport = cand, kind
+                break
+            if cand is not None:
+                dist.barrier()
+                cand.close()
+            notes.append("%s not usable on every rank" % kind)
+        native_note = "; ".join(notes) if notes else None
     # N > 1: the defect slab of step k is all-gathered (RCCL) on a side stream while step k+1 propagates: two defect /
     # gather buffers alternate, events order producer -> collective -> buffer reuse.  All collectives complete before
     # the closing barrier + synchronize, so every one of the K steps is fully inside the timed region.
@@ -445,39 +534,34 @@ def main():
     def gather(b):
         with torch.cuda.stream(comm_stream):
             if native is not None:
-                native.allgather(dbufs[b], gathered[b], gather_rows * S, stream=C_void_p(comm_stream.cuda_stream))   # RCCL over xGMI
+                native.allgather(dbufs[b], gathered[b], gather_rows * S, stream=C_void_p(comm_stream.cuda_stream))
             else:
                 dist.all_gather_into_tensor(gathered[b], dbufs[b])
-            ev_done[b].record(comm_stream)
+            if not serial_coll:
+                ev_done[b].record(comm_stream)
 
-    def step(k):
+    def step(k, check_free):
         b = k % len(dbufs)
-        if use_coll and k >= len(dbufs):
+        if use_coll and not serial_coll and check_free:
             main.wait_event(ev_done[b])                # buffer b is free again
         sweep(dbufs[b])
         if use_coll:
-            ev_ready[b].record(main)
-            comm_stream.wait_event(ev_ready[b])
+            if not serial_coll:                        # same stream: its order is the dependency, no event needed
+                ev_ready[b].record(main)
+                comm_stream.wait_event(ev_ready[b])
             gather(b)
 
     def timed_leg():
         """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize."""
         for k in range(a.warmup):
-            step(k)
+            step(k, k >= len(dbufs))
         if use_coll:
             comm_stream.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(a.steps):
-            b = k % len(dbufs)
-            if use_coll and (k >= len(dbufs) or a.warmup >= len(dbufs)):
-                main.wait_event(ev_done[b])
-            sweep(dbufs[b])
-            if use_coll:
-                ev_ready[b].record(main)
-                comm_stream.wait_event(ev_ready[b])
-                gather(b)
+            step(k, k >= len(dbufs) or a.warmup >= len(dbufs))
         if use_coll:
             comm_stream.synchronize()
             dist.barrier()
@@ -501,15 +585,16 @@ def main():
                 sweep(dbufs[0])
             torch.cuda.synchronize()
 
-    ref12 = None
+    ref12 = refint = None
     if rank == 0 and world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
         # the reference's own system (12-dim, constant mass): the sweep reference parity is claimed for, same run, timed
         # the same way (W warm-up + K timed steps) BEFORE the contract leg
         ref12 = leg_12dim(lto, synth, ctx, st, torch, a)
+        refint = leg_12dim(lto, synth, ctx, st, torch, a, reference_integrator=True)
 
     if c5 and a.warmup > 0 and not a.no_rebalance:
         for k in range(a.warmup):
-            step(k)
+            step(k, k >= len(dbufs))
         plan.rebalance(stream=st)                      # lanes ordered by the warm-up sweep's step counts (on device)
         rebalanced = True
     elapsed = timed_leg()
@@ -537,7 +622,11 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
                        "collective": ("none" if not use_coll else
-                                      "lto_comm_allgather_dev (the library's RCCL all-gather of the defect slabs) after every sweep, on the %s" % ("sweep's stream" if serial_coll else "a side stream, overlapping the next sweep")
+                                      "lto_comm_allgather_dev of the defect slabs after every sweep, on the %s; transport: %s%s" % (
+                                          "sweep's stream" if serial_coll else "a side stream, overlapping the next sweep",
+                                          {"windows": "IPC receive windows + device copies + flag kernel (no RCCL kernel, no CU taken from the sweep)",
+                                           "rccl": "ncclAllGather (RCCL over xGMI)"}[transport],
+                                          "" if not native_note else " [tried first: %s]" % native_note)
                                       if native is not None else
                                       "torch.distributed all_gather_into_tensor (RCCL) after every sweep; the library's "
                                       "communicator was not used: %s" % native_note), "integrator": "see workload"},
@@ -554,7 +643,7 @@ def main():
             acc, rej = plan.step_counts(stream=st)
             trial = float((acc + rej).sum())
             f_rhs, dim, nbytes = (1490, 210, 1920) if a.ndim == 14 else (1070, 156, 1456)
-            out["roofline"] = roofline(wl, a.ndim, S, kern_ms, work=(dop853_flops(trial, f_rhs, dim) / S, nbytes), samples=samples, burst_n=burst_n)
+            out["roofline"] = roofline(wl, a.ndim, S, kern_ms, work=(dop853_flops(trial, f_rhs, dim) / S, nbytes), samples=samples, burst_n=burst_n, method="dop853")
             out["roofline"]["flops_from"] = ("measured step counts of this sweep: %.2f accepted + %.2f rejected trial steps per segment (max %d) x "
                                              "(12 x %d + 148 x %d)" % (acc.mean(), rej.mean(), int((acc + rej).max()), f_rhs, dim))
         if c5:
@@ -596,13 +685,16 @@ def main():
             out["host_api"] = leg_host_api(lto, ctx, XC, T, prm, integ, a.ndim, S)
         if ref12 is not None:
             out["reference_system_12dim"] = ref12[0]
+            out["reference_integrator"] = refint[0]
             if not a.no_cpu_baseline:
                 ref12[1]()
+                refint[1]()
         print(json.dumps(out), flush=True)
+    if use_coll:
+        dist.barrier()              # nobody unmaps a window a peer may still be pushing into
     if native is not None:
         native.close()
     if use_coll:
-        dist.barrier()
         dist.destroy_process_group()
     plan.close()       # plans before their context (lto_destroy frees what lto_*_plan_destroy touches)
     ctx.close()

@@ -356,12 +356,30 @@ int lto_comm_size(const lto_comm* comm);
 int lto_comm_rank(const lto_comm* comm);
 /* recv [world][count] <- send [count] of every rank (equal counts); asynchronous on `stream` (hipStream_t). */
 int lto_comm_allgather_dev(lto_comm* comm, void* stream, const double* send, double* recv, long count);
-/* buf [count] <- LTO_COMM_SUM / LTO_COMM_MAX over ranks, in place; asynchronous on `stream`. */
+/* buf [count] <- LTO_COMM_SUM / LTO_COMM_MAX over ranks, in place; asynchronous on `stream`.  Both propagate NaN (the max
+ * carries a NaN indicator per element), so a NaN on one rank reaches every rank: norm(defect, Inf) of indirect.jl:330. */
 int lto_comm_allreduce_dev(lto_comm* comm, void* stream, double* buf, long count, int op);
+/* Second transport for the same two collectives, without RCCL and without compute units for the payload ("windows"): every
+ * rank owns a receive window in device memory, its peers map it through HIP IPC, a rank pushes its slab into every window
+ * with device copies and raises a sequence flag there; the consumer's stream waits on the flags with a one-wavefront kernel
+ * (bounded: a rank that never arrives turns the result into NaN instead of hanging the stream).  It is also the transport for
+ * two ranks that share one device, which RCCL refuses.  Set-up, every rank:
+ *   lto_comm_window_export(ctx, world, rank, max_count, handle, &comm)   handle: LTO_COMM_WINDOW_BYTES bytes
+ *   the launcher gathers the world handles in rank order (torch.distributed all_gather, MPI_Allgather, a file)
+ *   lto_comm_window_open(comm, all_handles)
+ * then lto_comm_allgather_dev / lto_comm_allreduce_dev with count <= max_count, lto_comm_destroy at the end (after a
+ * barrier of the launcher: a peer may still be pushing).  One process per rank. */
+#define LTO_COMM_WINDOW_BYTES 128
+int lto_comm_window_export(lto_ctx* ctx, int world, int rank, long max_count, void* handle_out, lto_comm** out);
+int lto_comm_window_open(lto_comm* comm, const void* all_handles);
+int lto_comm_uses_windows(const lto_comm* comm);
 /* One host process, several GPUs: the communicators of an lto_group (ncclCommInitAll over its devices).  send[k] /
  * recv[k] / buf[k] live on member k's device; the work is enqueued on member k's context stream (lto_ctx_stream), after
  * the sweep that produced send[k] there.  A group that repeats one device (1-GPU boxes) uses device copies instead. */
 typedef struct lto_group_comm lto_group_comm;
+/* all-gather payloads up to this many bytes per member go by peer copies ordered by events (copy engines over xGMI, no
+ * compute unit taken from the sweeps) even when the group has an RCCL clique; larger ones through RCCL */
+#define LTO_GROUP_PEER_COPY_BYTES (1 << 20)
 int lto_group_comm_create(lto_group* group, lto_group_comm** out);
 void lto_group_comm_destroy(lto_group_comm* comm);
 const char* lto_group_comm_last_error(const lto_group_comm* comm);

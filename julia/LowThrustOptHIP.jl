@@ -13,7 +13,7 @@ module LowThrustOptHIP
 
 using SparseArrays, LinearAlgebra, Libdl
 
-export LtoIndirectPlan, LtoDirectPlan, LtoComm, pinned_array, pack_soa!, unpack_soa!, defect_norms!, indirect_defect_dev!,
+export LtoIndirectPlan, LtoDirectPlan, LtoComm, LtoCommWindows, pinned_array, pack_soa!, unpack_soa!, defect_norms!, indirect_defect_dev!,
        indirect_jacobian_dev!, newton_solve_dev!, axpy_dev!, direct_defect_dev!, direct_jacobian_dev!, rebalance!, set_kernel!,
        comm_unique_id, allgather_dev!, allreduce_dev!, ctx_stream, last_call_ms
 export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, indirect_solve, indirect_solve_batch, densify,
@@ -299,12 +299,14 @@ last_call_ms(ctx::LtoContext) = ccall((:lto_last_call_ms, liblto), Cdouble, (Ptr
 
 """`Array{Float64}` of the given size in page-locked host memory (lto_host_alloc): the GPU reads and writes such arrays (and
 contiguous views into them) in place during a host-pointer call -- no copy is queued (Jacobian call at 4 096 segments: 0.20 ms
-instead of 0.29 ms with ordinary arrays).  Freed by a finalizer."""
+instead of 0.29 ms with ordinary arrays).  Freed by a finalizer, which may run before or after the context's: the library finds
+the block's owner by itself (ctx = NULL) and a context whose destroy was deferred goes with its last block (lto.h, lifetime)."""
 function pinned_array(ctx::LtoContext, dims::Integer...)
     p = Ref{Ptr{Cvoid}}(C_NULL)
     check(ctx, ccall((:lto_host_alloc, liblto), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx.handle, 8 * prod(dims), p))
     A = unsafe_wrap(Array, convert(Ptr{Float64}, p[]), dims; own = false)
-    finalizer(_ -> ccall((:lto_host_free, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.handle, p[]), A)
+    blk = p[]
+    finalizer(_ -> ccall((:lto_host_free, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, blk), A)
     A
 end
 
@@ -419,10 +421,27 @@ mutable struct LtoComm
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:lto_comm_create, liblto), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}), ctx.handle, world, rank, id, h)
         rc == 0 || error("lto_comm_create failed with code $rc")
-        c = new(h[], ctx, world, rank)
+        LtoComm(h[], ctx, world, rank)
+    end
+    function LtoComm(handle::Ptr{Cvoid}, ctx::LtoContext, world::Integer, rank::Integer)
+        c = new(handle, ctx, world, rank)
         finalizer(q -> (q.handle == C_NULL || ccall((:lto_comm_destroy, liblto), Cvoid, (Ptr{Cvoid},), q.handle); q.handle = C_NULL), c)
         c
     end
+end
+"""The window transport (lto_comm_window_*): device copies into IPC-mapped receive windows -- no RCCL, no compute units for the
+payload, and the one that works for ranks sharing a device.  `exchange(handle::Vector{UInt8}) -> Vector{UInt8}` of world x 128 bytes in
+rank order is the launcher's all-gather (MPI.Allgather, a RemoteChannel, files)."""
+function LtoCommWindows(ctx::LtoContext, world::Integer, rank::Integer, max_count::Integer, exchange)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    blob = zeros(UInt8, 128)
+    rc = ccall((:lto_comm_window_export, liblto), Cint, (Ptr{Cvoid}, Cint, Cint, Clong, Ptr{UInt8}, Ref{Ptr{Cvoid}}), ctx.handle, world, rank, max_count, blob, h)
+    rc == 0 || error("lto_comm_window_export failed with code $rc")
+    c = LtoComm(h[], ctx, world, rank)
+    all = exchange(blob)
+    length(all) == 128 * world || error("exchange must return world x 128 bytes in rank order")
+    comm_check(c, ccall((:lto_comm_window_open, liblto), Cint, (Ptr{Cvoid}, Ptr{UInt8}), c.handle, all))
+    c
 end
 comm_check(c::LtoComm, rc::Cint) = rc == 0 || error("lto_comm error $rc: " * unsafe_string(ccall((:lto_comm_last_error, liblto), Cstring, (Ptr{Cvoid},), c.handle)))
 

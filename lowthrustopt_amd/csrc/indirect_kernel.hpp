@@ -101,7 +101,7 @@ __device__ __forceinline__ void run_rkf78_adaptive(const Sys& sys, const double 
   }
   // not at t1 (max_steps used up, ode78's step-size floor ode.jl:479,524, or a decreasing grid: forward integration
   // only): no result -- NaN, never a state at some t < t1 that looks propagated
-  if (t < span || span < 0.0) {
+  if (t < span || !(span >= 0.0)) {           // a NaN span counts as a negative one
 #pragma unroll
     for (int i = 0; i < D; ++i) y[i] = __builtin_nan("");
   }

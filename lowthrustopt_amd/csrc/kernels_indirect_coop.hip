@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
     // A segment that did not reach t1 -- max_steps trial steps used up, ode78's step-size floor, or a decreasing time
     // grid (span < 0: the adaptive controllers here integrate forward only) -- has no result: NaN, which the driver
     // reports as status_flag 2 (indirect.jl:339-341), instead of a state at some t < t1 that looks propagated.
-    if (mine && (t < span || span < 0.0)) {
+    if (mine && (t < span || !(span >= 0.0))) {   // unfinished, decreasing grid, or a NaN span (treated like a negative one)
 #pragma unroll
       for (int c = 0; c < ND; ++c) y[c] = __builtin_nan("");
     }

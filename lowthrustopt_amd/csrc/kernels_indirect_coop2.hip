@@ -330,7 +330,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
 #endif
   // A segment that did not reach t1 (max_steps trial steps used up, or a decreasing time grid: the controller integrates
   // forward only) has no result: NaN, which the driver reports as status_flag 2 (indirect.jl:339-341).
-  if (mine && (t < span || span < 0.0)) {
+  if (mine && (t < span || !(span >= 0.0))) {   // unfinished, decreasing grid, or a NaN span (treated like a negative one)
 #pragma unroll
     for (int j = 0; j < 6; ++j) y[j] = __builtin_nan("");
   }

@@ -405,8 +405,9 @@ __device__ __forceinline__ void pipe8_store_column(const IndirectArgs& a, const 
                                                    const bool fail) {
   if (L.in_range && col < ND) {
     const double sc = (col < NA) ? a.stm_scale : 1.0;
+    const double poison = (col < NA) ? 0.0 : L.h - L.h;     // a unit column of a segment with a NaN (or infinite) span is NaN like the rest
 #pragma unroll
-    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = fail ? __builtin_nan("") : y[r] * sc;
+    for (int r = 0; r < ND; ++r) a.Phi[(long)(col * ND + r) * a.ldp + L.s] = fail ? __builtin_nan("") : __builtin_fma(y[r], sc, poison);
   }
 }
 

@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include <vector>
 
@@ -55,8 +57,12 @@ struct lto_ctx {
   // page-locked blocks handed out by lto_host_alloc.  The GPU addresses them directly, so the host-pointer API reads and
   // writes a caller's buffer that lies inside one of them in place: the AoS <-> SoA kernels are the transfer, and no
   // copy-engine operation (about 10 us of latency each) is queued.
+  // A block keeps its context alive the way a plan does (lto_destroy defers while any is outstanding); `dev` is null for a
+  // block the device cannot address directly (still page-locked: the copy engine moves it).  The list has its own lock:
+  // a garbage collector may free a block from another thread while a sweep looks one up.
   struct Pinned { char* host; char* dev; size_t bytes; };
   std::vector<Pinned> pinned;
+  std::mutex pinned_mu;
   double last_call_ms;     // wall time of the last host-pointer call, entry to return (lto_last_call_ms)
   char err[512];
 };
@@ -237,9 +243,17 @@ int lto_create(lto_ctx** out, int device_id) {
   return LTO_OK;
 }
 
+// page-locked blocks -> owning context (lto_host_free may come without the handle, from any thread)
+static std::mutex g_blocks_mu;
+static std::unordered_map<void*, lto_ctx*> g_blocks;
+static void host_block_forget(void* ptr) { std::lock_guard<std::mutex> lk(g_blocks_mu); g_blocks.erase(ptr); }
+static bool ctx_has_blocks(lto_ctx* c) { std::lock_guard<std::mutex> lk(c->pinned_mu); return !c->pinned.empty(); }
+
 void lto_destroy(lto_ctx* c) {
   if (!c) return;
-  if (c->live_plans > 0) { c->closing = true; return; }   // freed by the last lto_*_plan_destroy
+  bool blocks;
+  { std::lock_guard<std::mutex> lk(c->pinned_mu); blocks = !c->pinned.empty(); }
+  if (c->live_plans > 0 || blocks) { c->closing = true; return; }   // freed by the last lto_*_plan_destroy / lto_host_free
   ctx_free(c);
 }
 
@@ -247,6 +261,8 @@ static void ctx_free(lto_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto& h : c->host_plans) { if (h.plan) plan_free(h.plan); std::free(h.prm); h.plan = nullptr; h.prm = nullptr; }
+  for (const lto_ctx::Pinned& b : c->pinned) { host_block_forget(b.host); (void)hipHostFree(b.host); }   // none left on the deferred path
+  c->pinned.clear();
   if (c->arena) (void)hipFree(c->arena);
   if (c->order_cache) (void)hipFree(c->order_cache);
   for (int i = 0; i < 8; ++i) if (c->pool[i].ptr) (void)hipFree(c->pool[i].ptr);
@@ -346,7 +362,7 @@ void lto_indirect_plan_destroy(lto_indirect_plan* p) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   plan_free(p);
-  if (--c->live_plans <= 0 && c->closing) ctx_free(c);
+  if (--c->live_plans <= 0 && c->closing && !ctx_has_blocks(c)) ctx_free(c);
 }
 
 static void plan_free(lto_indirect_plan* p) {
@@ -915,7 +931,7 @@ void lto_direct_plan_destroy(lto_direct_plan* p) {
   if (!p) return;
   lto_ctx* c = p->ctx;
   delete p;
-  if (--c->live_plans <= 0 && c->closing) ctx_free(c);
+  if (--c->live_plans <= 0 && c->closing && !ctx_has_blocks(c)) ctx_free(c);
 }
 
 int lto_direct_plan_set_kernel(lto_direct_plan* p, int kernel) {
@@ -1072,8 +1088,9 @@ static hipError_t stream_wait(hipStream_t st) {
 // Device view of a caller's buffer that lies wholly inside a block from lto_host_alloc; nullptr for any other memory.
 static double* pinned_view(lto_ctx* c, const double* host, size_t bytes) {
   const char* h = (const char*)host;
+  std::lock_guard<std::mutex> lk(c->pinned_mu);
   for (const lto_ctx::Pinned& b : c->pinned) {
-    if (h >= b.host && bytes <= b.bytes && (size_t)(h - b.host) <= b.bytes - bytes) return (double*)(b.dev + (h - b.host));
+    if (b.dev && h >= b.host && bytes <= b.bytes && (size_t)(h - b.host) <= b.bytes - bytes) return (double*)(b.dev + (h - b.host));
   }
   return nullptr;
 }
@@ -1110,9 +1127,14 @@ static int host_plan_acquire(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (!prm || !integ) return set_err(c, LTO_ENULL, "prm or integrator is NULL");
   if (n_prm != 1 && n_prm != n_batch) return set_err(c, LTO_EINVAL, "n_prm must be 1 or n_batch");
   lto_ctx::HostPlan* slot = nullptr;               // an empty entry, else the least recently used one
+  // the key compares the integrator field by field (the struct has padding a caller need not initialise) with the
+  // max_steps default applied, so that 0 and 100000 share a plan
+  const int want_max = integ->max_steps <= 0 ? 100000 : integ->max_steps;
   for (auto& h : c->host_plans) {
-    if (h.plan && h.ndim == ndim && h.n_nodes == n_nodes && h.n_batch == n_batch && h.n_prm == n_prm &&
-        std::memcmp(&h.integ, integ, sizeof *integ) == 0 && std::memcmp(h.prm, prm, sizeof(lto_params) * (size_t)n_prm) == 0) {
+    const bool same_integ = h.plan && h.integ.method == integ->method && h.integ.steps == integ->steps && h.integ.rtol == integ->rtol &&
+                            h.integ.atol == integ->atol && (h.integ.max_steps <= 0 ? 100000 : h.integ.max_steps) == want_max;
+    if (h.plan && h.ndim == ndim && h.n_nodes == n_nodes && h.n_batch == n_batch && h.n_prm == n_prm && same_integ &&
+        std::memcmp(h.prm, prm, sizeof(lto_params) * (size_t)n_prm) == 0) {
       h.stamp = ++c->stamp;
       *out = h.plan;
       return LTO_OK;
@@ -1145,20 +1167,36 @@ int lto_host_alloc(lto_ctx* c, size_t bytes, void** out) {
   hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "hipHostMalloc", e);
   void* dev = nullptr;
-  if (hipHostGetDevicePointer(&dev, *out, 0) == hipSuccess && dev)
-    c->pinned.push_back({(char*)*out, (char*)dev, bytes ? bytes : 1});
-  else
-    (void)hipGetLastError();   // still page-locked: the copy engine moves it
+  if (hipHostGetDevicePointer(&dev, *out, 0) != hipSuccess) { dev = nullptr; (void)hipGetLastError(); }   // still page-locked: the copy engine moves it
+  { std::lock_guard<std::mutex> lk(c->pinned_mu); c->pinned.push_back({(char*)*out, (char*)dev, bytes ? bytes : 1}); }
+  { std::lock_guard<std::mutex> lk(g_blocks_mu); g_blocks[*out] = c; }
   return LTO_OK;
 }
 
+// ctx may be NULL (a finalizer that no longer has the handle): the owner is looked up.  Freeing the last block of a context
+// whose lto_destroy was deferred completes that destroy.
 int lto_host_free(lto_ctx* c, void* ptr) {
-  if (!c) return LTO_ENULL;
   if (!ptr) return LTO_OK;
-  for (size_t k = 0; k < c->pinned.size(); ++k)
-    if (c->pinned[k].host == (char*)ptr) { c->pinned[k] = c->pinned.back(); c->pinned.pop_back(); break; }
-  hipError_t e = hipHostFree(ptr);
-  if (e != hipSuccess) return set_err(c, LTO_EHIP, "hipHostFree", e);
+  lto_ctx* owner = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_blocks_mu);
+    auto it = g_blocks.find(ptr);
+    if (it != g_blocks.end()) { owner = it->second; g_blocks.erase(it); }
+  }
+  if (!owner) return c ? set_err(c, LTO_EINVAL, "lto_host_free: not a block from lto_host_alloc (or freed twice)") : LTO_EINVAL;
+  bool last;
+  {
+    std::lock_guard<std::mutex> lk(owner->pinned_mu);
+    for (size_t k = 0; k < owner->pinned.size(); ++k)
+      if (owner->pinned[k].host == (char*)ptr) { owner->pinned[k] = owner->pinned.back(); owner->pinned.pop_back(); break; }
+    last = owner->pinned.empty();
+  }
+  (void)hipSetDevice(owner->device);
+  if (!owner->closing) (void)hipStreamSynchronize(owner->stream);   // a sweep may still be writing the block in place
+  else (void)hipDeviceSynchronize();
+  const hipError_t e = hipHostFree(ptr);
+  if (last && owner->closing && owner->live_plans <= 0) { ctx_free(owner); return e == hipSuccess ? LTO_OK : LTO_EHIP; }
+  if (e != hipSuccess) return set_err(owner, LTO_EHIP, "hipHostFree", e);
   return LTO_OK;
 }
 

@@ -7,6 +7,12 @@
 //
 //   lto_comm_*         one process per GPU (torchrun / MPI ranks): ncclCommInitRank on the context's device with an id the
 //                      launcher distributes; all-gather of equal slabs and in-place all-reduce (sum / max) on a caller stream
+//                      Second transport, no RCCL and no compute units for the payload ("windows", round 3): every rank owns a
+//                      receive window in device memory that its peers map through HIP IPC; a rank PUSHES its slab into every
+//                      window with device copies (copy engine / blit), then raises its sequence flag there; the consumer's
+//                      stream waits on the flags with one single-wavefront kernel.  The RCCL all-gather needs CUs while
+//                      the contract sweep holds a workgroup on every CU (+23 us per step measured at N = 1), a copy does
+//                      not; it is also the transport that works when two ranks share one device (RCCL refuses that).
 //   lto_group_comm_*   one host process, several GPUs (lto_group): ncclCommInitAll over the group's devices; the same two
 //                      collectives on every context's stream inside ncclGroupStart / End.  A group that repeats a device
 //                      (how a 1-GPU box exercises the sharding) cannot form an RCCL clique: there the gather is device
@@ -17,6 +23,7 @@
 // and the loader hands back that one (same SONAME), so both speak to the same runtime.
 // The payload is tiny (12 x S/G doubles per rank: 49 KB at 4 096 segments on 8 GPUs), the collective is latency-bound.
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstring>
@@ -82,19 +89,175 @@ __global__ void k_reduce_buffers(double* const* bufs, int n, long count, int op)
   for (int k = 0; k < n; ++k) bufs[k][i] = v;
 }
 
+// NaN-propagating max through a collective whose max does not promise it (ncclMax follows fmax): the buffer travels as
+// [count maxima with NaN replaced by -inf | count indicators 1 / 0], ONE all-reduce (max) over 2 count doubles, and an
+// element any rank held as NaN comes back as NaN -- what norm(defect, Inf) gives in the reference loop (indirect.jl:330).
+__global__ void k_max_encode(const double* buf, long count, double* packed) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double v = buf[i];
+  const bool nan = v != v;
+  packed[i] = nan ? -__builtin_huge_val() : v;
+  packed[count + i] = nan ? 1.0 : 0.0;
+}
+__global__ void k_max_decode(const double* packed, long count, double* buf) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  buf[i] = packed[count + i] > 0.0 ? __builtin_nan("") : packed[i];
+}
+
+// windows: wait until every rank's flag has reached `seq` (flags only grow; written by the peers' copy engines, read here at
+// system scope).  One wavefront, lane = rank; bounded: a rank that never arrives raises *fail instead of hanging the stream.
+constexpr long WINDOW_SPIN_LIMIT = 4000000L;     // x (s_sleep 8 + one uncached load) ~ a few seconds
+__global__ void k_window_wait(const unsigned int* flags, int world, unsigned int seq, int* fail) {
+  const int m = threadIdx.x;
+  if (m >= world) return;
+  long spins = 0;
+  while ((int)(__hip_atomic_load(flags + m, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    if (++spins > WINDOW_SPIN_LIMIT) { __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+// windows: out[i] = sum / NaN-propagating max over the world slabs of the gathered window (poisoned when a wait ran out)
+__global__ void k_window_reduce(const double* slabs, int world, long stride, long count, int op, const int* fail, double* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double v = slabs[i];
+  for (int k = 1; k < world; ++k) {
+    const double w = slabs[(long)k * stride + i];
+    if (op == LTO_COMM_SUM) v += w;
+    else v = (v != v || w != w) ? (v + w) : (w > v ? w : v);
+  }
+  out[i] = *fail ? __builtin_nan("") : v;
+}
+// windows, small payloads: the same exchange as two kernels on the caller's stream (a copy-engine operation between two kernels
+// costs ~10 us of queue hand-over each; a kernel after a kernel ~2 us).
+// push: blockIdx.y = destination rank; the blocks of a destination copy the slab into its window, and the last of them to finish
+// (counter in this rank's own window header) raises this rank's flag there, after a system-scope fence.
+struct WindowPeers { double* slab[64]; unsigned int* flag[64]; };
+__global__ void k_window_push(const double* send, long count, WindowPeers peers, unsigned int seq, unsigned int* done_counters) {
+  const int m = blockIdx.y;
+  double* dst = peers.slab[m];
+  // the window is uncached memory: every store is its own transaction, so store 16 bytes at a time where the alignment allows
+  if ((((size_t)send | (size_t)dst) & 15) == 0) {
+    const long pairs = count >> 1;
+    const double2* s2 = (const double2*)send;
+    double2* d2 = (double2*)dst;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
+      const double2 v = s2[i];
+      __builtin_nontemporal_store(v.x, &d2[i].x);
+      __builtin_nontemporal_store(v.y, &d2[i].y);
+    }
+    if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) __builtin_nontemporal_store(send[count - 1], dst + count - 1);
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+      __builtin_nontemporal_store(send[i], dst + i);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int arrived = atomicAdd(done_counters + m, 1u) + 1u;
+    if (arrived == gridDim.x) {
+      __threadfence_system();                     // the other blocks' stores (fenced before their increments) before the flag
+      done_counters[m] = 0;                       // ready for the next push (same stream: ordered)
+      __hip_atomic_store(peers.flag[m], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// collect: every block waits for all flags, then copies its share of the window's slabs into recv (NaN when a wait ran out)
+__global__ void k_window_collect(const unsigned int* flags, int world, unsigned int seq, int* fail, const double* slabs, long stride,
+                                 long count, double* recv) {
+  __shared__ int s_fail;
+  if (threadIdx.x == 0) s_fail = 0;
+  __syncthreads();
+  if (threadIdx.x < world) {
+    long spins = 0;
+    while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      if (++spins > WINDOW_SPIN_LIMIT) { s_fail = 1; __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  const bool bad = s_fail != 0 || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+  const long total = count * world;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long k = i / count, j = i - k * count;
+    recv[i] = bad ? __builtin_nan("") : __builtin_nontemporal_load(slabs + k * stride + j);
+  }
+}
+// the same wait, then the reduction over the slabs
+__global__ void k_window_collect_reduce(const unsigned int* flags, int world, unsigned int seq, int* fail, const double* slabs, long stride,
+                                        long count, int op, double* out) {
+  __shared__ int s_fail;
+  if (threadIdx.x == 0) s_fail = 0;
+  __syncthreads();
+  if (threadIdx.x < world) {
+    long spins = 0;
+    while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      if (++spins > WINDOW_SPIN_LIMIT) { s_fail = 1; __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  const bool bad = s_fail != 0 || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    double v = __builtin_nontemporal_load(slabs + i);
+    for (int k = 1; k < world; ++k) {
+      const double w = __builtin_nontemporal_load(slabs + (long)k * stride + i);
+      if (op == LTO_COMM_SUM) v += w;
+      else v = (v != v || w != w) ? (v + w) : (w > v ? w : v);
+    }
+    out[i] = bad ? __builtin_nan("") : v;
+  }
+}
+__global__ void k_copy_doubles(const double* src, long count, double* dst) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void k_window_poison(const int* fail, double* recv, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total && *fail) recv[i] = __builtin_nan("");
+}
+
 }  // namespace
+
+// What a rank exports for its peers (LTO_COMM_WINDOW_BYTES): the IPC handle of its window and the window's geometry.
+struct WindowHandle {
+  hipIpcMemHandle_t mem;
+  long max_count;
+  int world, rank;
+  int pid;
+  unsigned int magic;
+};
+static_assert(sizeof(WindowHandle) <= LTO_COMM_WINDOW_BYTES, "window handle size");
 
 struct lto_comm {
   int device = 0, world = 1, rank = 0;
   ncclComm_t comm = nullptr;
+  double* scratch = nullptr;     // [2 count] of the NaN-propagating max (grow-only)
+  long scratch_cap = 0;
+  // window transport
+  bool windows = false, opened = false;
+  long max_count = 0;
+  char* own = nullptr;                 // this rank's window: [flags: world x u32 | fail | push counters: 1024 B in all][2 halves][world][max_count] doubles
+  std::vector<char*> peer;             // every rank's window as mapped here (peer[rank] = own)
+  unsigned int seq = 0;
   char err[512] = {0};
 };
+namespace {
+constexpr size_t WINDOW_HEAD = 1024;   // flags at 0, fail word at 256, this rank's push counters at 512 (one per destination)
+constexpr size_t WINDOW_KERNEL_BYTES = 4u << 20;   // payloads up to this size go by kernels, larger ones by the copy engines
+inline size_t window_bytes(int world, long max_count) { return WINDOW_HEAD + sizeof(double) * 2 * (size_t)world * (size_t)max_count; }
+inline double* window_slab(char* base, int world, long max_count, int half, int rank) {
+  return (double*)(base + WINDOW_HEAD) + ((size_t)half * world + rank) * (size_t)max_count;
+}
+}
 
 struct lto_group_comm {
   std::vector<lto_ctx*> ctx;         // borrowed from the group
   std::vector<int> device;
   std::vector<ncclComm_t> comm;      // empty when the group repeats a device
   std::vector<hipEvent_t> ev;        // one per context: producer stream -> consumer streams (copy path)
+  std::vector<hipEvent_t> ev_done;   // one per context: its copies out of the others' slabs are complete
   double** d_ptrs = nullptr;         // device array of buffer pointers for k_reduce_buffers (copy path)
   bool clique = false;
   char err[512] = {0};
@@ -148,7 +311,13 @@ int lto_comm_create(lto_ctx* ctx, int world, int rank, const void* id128, lto_co
 
 void lto_comm_destroy(lto_comm* c) {
   if (!c) return;
-  if (c->comm) { (void)hipSetDevice(c->device); (void)rccl().CommDestroy(c->comm); }
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  if (c->scratch) (void)hipFree(c->scratch);
+  for (int m = 0; m < (int)c->peer.size(); ++m)
+    if (c->peer[m] && m != c->rank) (void)hipIpcCloseMemHandle(c->peer[m]);
+  if (c->own) (void)hipFree(c->own);
   delete c;
 }
 
@@ -156,27 +325,183 @@ const char* lto_comm_last_error(const lto_comm* c) { return c ? c->err : "null c
 int lto_comm_size(const lto_comm* c) { return c ? c->world : 0; }
 int lto_comm_rank(const lto_comm* c) { return c ? c->rank : -1; }
 
+/* ---- window transport: export (every rank) -> the launcher gathers the world handles -> open (every rank) ---- */
+int lto_comm_window_export(lto_ctx* ctx, int world, int rank, long max_count, void* handle_out, lto_comm** out) {
+  if (!ctx || !handle_out || !out) return LTO_ENULL;
+  *out = nullptr;
+  if (world < 1 || world > 64 || rank < 0 || rank >= world || max_count < 1) return LTO_EINVAL;
+  lto_comm* c = new (std::nothrow) lto_comm();
+  if (!c) return LTO_EHIP;
+  c->device = lto_ctx_device(ctx); c->world = world; c->rank = rank; c->windows = true; c->max_count = max_count;
+  const size_t bytes = window_bytes(world, max_count);
+  WindowHandle h;
+  std::memset(&h, 0, sizeof h);
+  // uncached device memory: the flags and slabs are written by other agents (peer copy engines) while this device polls them
+  if (hipSetDevice(c->device) != hipSuccess || hipExtMallocWithFlags((void**)&c->own, bytes, hipDeviceMallocUncached) != hipSuccess ||
+      hipMemset(c->own, 0, WINDOW_HEAD) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    lto_comm_destroy(c);
+    return LTO_EHIP;
+  }
+  if (world > 1 && hipIpcGetMemHandle(&h.mem, c->own) != hipSuccess) { (void)hipGetLastError(); lto_comm_destroy(c); return LTO_EHIP; }
+  h.max_count = max_count; h.world = world; h.rank = rank; h.pid = (int)getpid(); h.magic = 0x4c544f57u;   // "LTOW"
+  std::memset(handle_out, 0, LTO_COMM_WINDOW_BYTES);
+  std::memcpy(handle_out, &h, sizeof h);
+  c->peer.assign(world, nullptr);
+  c->peer[rank] = c->own;
+  if (world == 1) c->opened = true;
+  *out = c;
+  return LTO_OK;
+}
+
+int lto_comm_window_open(lto_comm* c, const void* all_handles) {
+  if (!c || !all_handles) return LTO_ENULL;
+  if (!c->windows) return comm_fail(c, LTO_EINVAL, "not a window communicator");
+  if (c->opened) return LTO_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return comm_fail(c, LTO_EHIP, "hipSetDevice");
+  for (int m = 0; m < c->world; ++m) {
+    WindowHandle h;
+    std::memcpy(&h, (const char*)all_handles + (size_t)m * LTO_COMM_WINDOW_BYTES, sizeof h);
+    if (h.magic != 0x4c544f57u || h.world != c->world || h.rank != m || h.max_count != c->max_count)
+      return comm_fail(c, LTO_EINVAL, "window handles must be in rank order, all with the same world and max_count");
+    if (m == c->rank) continue;
+    void* ptr = nullptr;
+    if (h.pid == (int)getpid()) return comm_fail(c, LTO_EINVAL, "two ranks in one process: use lto_group_comm");
+    const hipError_t e = hipIpcOpenMemHandle(&ptr, h.mem, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); std::snprintf(c->err, sizeof c->err, "hipIpcOpenMemHandle (rank %d): %s", m, hipGetErrorString(e)); return LTO_EHIP; }
+    c->peer[m] = (char*)ptr;
+  }
+  c->opened = true;
+  return LTO_OK;
+}
+
+int lto_comm_uses_windows(const lto_comm* c) { return c && c->windows ? 1 : 0; }
+
+namespace {
+// push this rank's slab into every window and raise the flag there (small payloads: one kernel; large ones: copy engines,
+// then a kernel that waits for everyone's flag here).  Once the flags have been seen, window half `half` of this rank holds
+// the world slabs (small payloads: the collect kernel of the caller waits for them itself).  Reuse of a half two gathers later is safe: a peer raises its
+// flag for gather k + 1 only after (in ITS stream order) it has finished reading gather k, and this rank pushes gather k + 2
+// only after it has seen that flag.
+int window_push(lto_comm* c, hipStream_t st, const double* send, long count, unsigned int* seq_out, int* half_out, bool* kernels_out) {
+  if (!c->opened) return comm_fail(c, LTO_EINVAL, "lto_comm_window_open has not been called");
+  if (count > c->max_count) return comm_fail(c, LTO_EINVAL, "count exceeds the window's max_count");
+  const unsigned int seq = ++c->seq;
+  const int half = (int)(seq & 1u);
+  const bool kernels = sizeof(double) * (size_t)count <= WINDOW_KERNEL_BYTES;
+  if (kernels) {
+    WindowPeers peers;
+    for (int m = 0; m < c->world; ++m) {
+      peers.slab[m] = window_slab(c->peer[m], c->world, c->max_count, half, c->rank);
+      peers.flag[m] = (unsigned int*)c->peer[m] + c->rank;
+    }
+    // one element per thread up to 1 024 blocks per destination: the window is uncached memory, every access a round trip, so the
+    // copy is as fast as the number of accesses in flight
+    const unsigned blocks = (unsigned)((count + 511) / 512 > 1024 ? 1024 : (count + 511) / 512);
+    hipLaunchKernelGGL(k_window_push, dim3(blocks, (unsigned)c->world), dim3(256), 0, st, send, count, peers, seq, (unsigned int*)(c->own + 512));
+    if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_window_push");
+  } else {
+    for (int m = 0; m < c->world; ++m) {
+      if (hipMemcpyAsync(window_slab(c->peer[m], c->world, c->max_count, half, c->rank), send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return comm_fail(c, LTO_EHIP, "hipMemcpyAsync (push)");
+      if (hipMemsetD32Async((hipDeviceptr_t)(c->peer[m] + sizeof(unsigned int) * (size_t)c->rank), (int)seq, 1, st) != hipSuccess)
+        return comm_fail(c, LTO_EHIP, "hipMemsetD32Async (flag)");
+    }
+    hipLaunchKernelGGL(k_window_wait, dim3(1), dim3(64), 0, st, (const unsigned int*)c->own, c->world, seq, (int*)(c->own + 256));
+    if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_window_wait");
+  }
+  *seq_out = seq; *half_out = half; *kernels_out = kernels;
+  return LTO_OK;
+}
+}  // namespace
+
 /* recv [world][count] <- every rank's send [count]; asynchronous on `stream` of this rank's device. */
 int lto_comm_allgather_dev(lto_comm* c, void* stream, const double* send, double* recv, long count) {
   if (!c || !send || !recv) return LTO_ENULL;
   if (count < 0) return comm_fail(c, LTO_EINVAL, "count < 0");
   if (count == 0) return LTO_OK;
   if (hipSetDevice(c->device) != hipSuccess) return comm_fail(c, LTO_EHIP, "hipSetDevice");
-  const ncclResult_t r = rccl().AllGather(send, recv, (size_t)count, ncclDouble, c->comm, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (c->world == 1) {             // nothing to exchange, whatever the transport: one copy kernel, no RCCL, no window round trip
+    if (c->windows && count > c->max_count) return comm_fail(c, LTO_EINVAL, "count exceeds the window's max_count");
+    if (send != recv) {
+      hipLaunchKernelGGL(k_copy_doubles, dim3((unsigned)((count + 1023) / 1024 > 1024 ? 1024 : (count + 1023) / 1024)), dim3(256), 0, st, send, count, recv);
+      if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_copy_doubles");
+    }
+    return LTO_OK;
+  }
+  if (c->windows) {
+    int half = 0; unsigned int seq = 0; bool kernels = false;
+    const int rc = window_push(c, st, send, count, &seq, &half, &kernels);
+    if (rc) return rc;
+    const double* slabs = window_slab(c->own, c->world, c->max_count, half, 0);
+    const long total = count * c->world;
+    if (kernels) {
+      const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+      hipLaunchKernelGGL(k_window_collect, dim3(blocks), dim3(256), 0, st, (const unsigned int*)c->own, c->world, seq, (int*)(c->own + 256), slabs,
+                         c->max_count, count, recv);
+      if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_window_collect");
+      return LTO_OK;
+    }
+    if (count == c->max_count) {   // the slabs are contiguous in the window
+      if (hipMemcpyAsync(recv, slabs, sizeof(double) * (size_t)total, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return comm_fail(c, LTO_EHIP, "hipMemcpyAsync (window -> recv)");
+    } else {
+      if (hipMemcpy2DAsync(recv, sizeof(double) * (size_t)count, slabs, sizeof(double) * (size_t)c->max_count,
+                           sizeof(double) * (size_t)count, (size_t)c->world, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return comm_fail(c, LTO_EHIP, "hipMemcpy2DAsync (window -> recv)");
+    }
+    hipLaunchKernelGGL(k_window_poison, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const int*)(c->own + 256), recv, total);
+    if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_window_poison");
+    return LTO_OK;
+  }
+  const ncclResult_t r = rccl().AllGather(send, recv, (size_t)count, ncclDouble, c->comm, st);
   if (r != ncclSuccess) return comm_fail(c, LTO_EHIP, "ncclAllGather", r);
   return LTO_OK;
 }
 
-/* buf [count] <- sum / max over ranks, in place; asynchronous on `stream`.  (RCCL's max does not promise NaN
- * propagation: reduce a NaN count next to the maxima if the driver's status_flag = 2 path matters.) */
+/* buf [count] <- sum / max over ranks, in place; asynchronous on `stream`.  Both propagate NaN: a sum does by itself, the
+ * max travels with a NaN indicator per element (k_max_encode), so a NaN on one rank reaches every rank's result -- the
+ * driver's status_flag = 2 path (indirect.jl:339-341) works across ranks. */
 int lto_comm_allreduce_dev(lto_comm* c, void* stream, double* buf, long count, int op) {
   if (!c || !buf) return LTO_ENULL;
   if (count < 0 || (op != LTO_COMM_SUM && op != LTO_COMM_MAX)) return comm_fail(c, LTO_EINVAL, "bad count or op");
   if (count == 0) return LTO_OK;
   if (hipSetDevice(c->device) != hipSuccess) return comm_fail(c, LTO_EHIP, "hipSetDevice");
-  const ncclResult_t r = rccl().AllReduce(buf, buf, (size_t)count, ncclDouble, op == LTO_COMM_SUM ? ncclSum : ncclMax, c->comm,
-                                          (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (c->world == 1) return LTO_OK;   // in place, one rank: nothing to do
+  if (c->windows) {
+    int half = 0; unsigned int seq = 0; bool kernels = false;
+    const int rc = window_push(c, st, buf, count, &seq, &half, &kernels);
+    if (rc) return rc;
+    const double* slabs = window_slab(c->own, c->world, c->max_count, half, 0);
+    const unsigned blocks = (unsigned)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
+    if (kernels)
+      hipLaunchKernelGGL(k_window_collect_reduce, dim3(blocks), dim3(256), 0, st, (const unsigned int*)c->own, c->world, seq, (int*)(c->own + 256),
+                         slabs, c->max_count, count, op, buf);
+    else
+      hipLaunchKernelGGL(k_window_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, slabs, c->world, c->max_count, count, op,
+                         (const int*)(c->own + 256), buf);
+    if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "window reduce");
+    return LTO_OK;
+  }
+  if (op == LTO_COMM_SUM) {
+    const ncclResult_t r = rccl().AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->comm, st);
+    if (r != ncclSuccess) return comm_fail(c, LTO_EHIP, "ncclAllReduce", r);
+    return LTO_OK;
+  }
+  if (c->scratch_cap < 2 * count) {
+    if (c->scratch) { (void)hipDeviceSynchronize(); (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_cap = 0; }
+    if (hipMalloc((void**)&c->scratch, sizeof(double) * 2 * (size_t)count) != hipSuccess) return comm_fail(c, LTO_EHIP, "hipMalloc");
+    c->scratch_cap = 2 * count;
+  }
+  const dim3 grid((unsigned)((count + 255) / 256));
+  hipLaunchKernelGGL(k_max_encode, grid, dim3(256), 0, st, (const double*)buf, count, c->scratch);
+  if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_max_encode");
+  const ncclResult_t r = rccl().AllReduce(c->scratch, c->scratch, (size_t)(2 * count), ncclDouble, ncclMax, c->comm, st);
   if (r != ncclSuccess) return comm_fail(c, LTO_EHIP, "ncclAllReduce", r);
+  hipLaunchKernelGGL(k_max_decode, grid, dim3(256), 0, st, (const double*)c->scratch, count, buf);
+  if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_max_decode");
   return LTO_OK;
 }
 
@@ -196,8 +521,10 @@ int lto_group_comm_create(lto_group* g, lto_group_comm** out) {
     for (int m = 0; m < k; ++m) distinct &= q->device[m] != q->device[k];
   }
   q->ev.resize(n, nullptr);
+  q->ev_done.resize(n, nullptr);
   for (int k = 0; k < n; ++k) {
-    if (hipSetDevice(q->device[k]) != hipSuccess || hipEventCreateWithFlags(&q->ev[k], hipEventDisableTiming) != hipSuccess) {
+    if (hipSetDevice(q->device[k]) != hipSuccess || hipEventCreateWithFlags(&q->ev[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&q->ev_done[k], hipEventDisableTiming) != hipSuccess) {
       lto_group_comm_destroy(q);
       return LTO_EHIP;
     }
@@ -206,6 +533,10 @@ int lto_group_comm_create(lto_group* g, lto_group_comm** out) {
     q->comm.resize(n, nullptr);
     if (rccl().CommInitAll(q->comm.data(), n, q->device.data()) != ncclSuccess) { q->comm.clear(); lto_group_comm_destroy(q); return LTO_EHIP; }
     q->clique = true;
+    for (int k = 0; k < n; ++k) {                      // direct peer copies where the topology allows; staged otherwise
+      if (hipSetDevice(q->device[k]) != hipSuccess) continue;
+      for (int m = 0; m < n; ++m) if (m != k) { (void)hipDeviceEnablePeerAccess(q->device[m], 0); (void)hipGetLastError(); }
+    }
   } else if (distinct && n > 1) {
     lto_group_comm_destroy(q);
     return LTO_EUNSUPPORTED;            // several GPUs but no RCCL in the process
@@ -228,6 +559,8 @@ void lto_group_comm_destroy(lto_group_comm* q) {
     if (q->comm[k]) { (void)hipSetDevice(q->device[k]); (void)rccl().CommDestroy(q->comm[k]); }
   for (size_t k = 0; k < q->ev.size(); ++k)
     if (q->ev[k]) { (void)hipSetDevice(q->device[k]); (void)hipEventDestroy(q->ev[k]); }
+  for (size_t k = 0; k < q->ev_done.size(); ++k)
+    if (q->ev_done[k]) { (void)hipSetDevice(q->device[k]); (void)hipEventDestroy(q->ev_done[k]); }
   if (q->d_ptrs) { (void)hipSetDevice(q->device[0]); (void)hipFree(q->d_ptrs); }
   delete q;
 }
@@ -243,29 +576,46 @@ int lto_group_comm_allgather_dev(lto_group_comm* q, const double* const* send, d
   const int n = (int)q->ctx.size();
   if (count == 0) return LTO_OK;
   for (int k = 0; k < n; ++k) if (!send[k] || !recv[k]) return comm_fail(q, LTO_ENULL, "send[k] or recv[k] is NULL");
-  if (q->clique) {
+  // Distinct devices, payload of at most LTO_GROUP_PEER_COPY_BYTES per member: peer copies ordered by events -- the copy engines
+  // move the slabs over xGMI and no compute unit is taken from the sweeps (the RCCL kernel would need some).  Larger payloads: RCCL.
+  const bool copies = !q->clique || sizeof(double) * (size_t)count <= LTO_GROUP_PEER_COPY_BYTES;
+  if (!copies) {
     ncclResult_t r = rccl().GroupStart();
-    for (int k = 0; k < n && r == ncclSuccess; ++k) {
-      if (hipSetDevice(q->device[k]) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipSetDevice");
-      r = rccl().AllGather(send[k], recv[k], (size_t)count, ncclDouble, q->comm[k], (hipStream_t)lto_ctx_stream(q->ctx[k]));
+    bool dev_ok = true;
+    for (int k = 0; k < n && r == ncclSuccess && dev_ok; ++k) {
+      dev_ok = hipSetDevice(q->device[k]) == hipSuccess;
+      if (dev_ok) r = rccl().AllGather(send[k], recv[k], (size_t)count, ncclDouble, q->comm[k], (hipStream_t)lto_ctx_stream(q->ctx[k]));
     }
-    const ncclResult_t e = rccl().GroupEnd();
+    const ncclResult_t e = rccl().GroupEnd();          // always: an open group would swallow the next collective
+    if (!dev_ok) return comm_fail(q, LTO_EHIP, "hipSetDevice");
     if (r != ncclSuccess) return comm_fail(q, LTO_EHIP, "ncclAllGather", r);
     if (e != ncclSuccess) return comm_fail(q, LTO_EHIP, "ncclGroupEnd", e);
     return LTO_OK;
   }
-  // one device, several contexts: every stream publishes an event after its producer, every stream waits for all of them
-  // and copies the slabs into its own receive buffer
-  if (hipSetDevice(q->device[0]) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipSetDevice");
-  for (int k = 0; k < n; ++k)
-    if (hipEventRecord(q->ev[k], (hipStream_t)lto_ctx_stream(q->ctx[k])) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipEventRecord");
+  // every stream publishes an event after its producer; every stream waits for all of them and copies the slabs into its own
+  // receive buffer; then every stream waits until ALL consumers have read its slab, so that the next sweep enqueued on it may
+  // overwrite send[k] at once (the typical Newton loop does)
   for (int k = 0; k < n; ++k) {
+    if (hipSetDevice(q->device[k]) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipSetDevice");
+    if (hipEventRecord(q->ev[k], (hipStream_t)lto_ctx_stream(q->ctx[k])) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipEventRecord");
+  }
+  for (int k = 0; k < n; ++k) {
+    if (hipSetDevice(q->device[k]) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipSetDevice");
     hipStream_t st = (hipStream_t)lto_ctx_stream(q->ctx[k]);
     for (int m = 0; m < n; ++m) {
       if (m != k && hipStreamWaitEvent(st, q->ev[m], 0) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipStreamWaitEvent");
-      if (hipMemcpyAsync(recv[k] + (long)m * count, send[m], sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return comm_fail(q, LTO_EHIP, "hipMemcpyAsync");
+      const hipError_t e = q->device[m] == q->device[k]
+          ? hipMemcpyAsync(recv[k] + (long)m * count, send[m], sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st)
+          : hipMemcpyPeerAsync(recv[k] + (long)m * count, q->device[k], send[m], q->device[m], sizeof(double) * (size_t)count, st);
+      if (e != hipSuccess) return comm_fail(q, LTO_EHIP, "device copy");
     }
+    if (hipEventRecord(q->ev_done[k], st) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipEventRecord");
+  }
+  for (int k = 0; k < n; ++k) {
+    if (hipSetDevice(q->device[k]) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipSetDevice");
+    hipStream_t st = (hipStream_t)lto_ctx_stream(q->ctx[k]);
+    for (int m = 0; m < n; ++m)
+      if (m != k && hipStreamWaitEvent(st, q->ev_done[m], 0) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipStreamWaitEvent");
   }
   return LTO_OK;
 }
@@ -279,12 +629,14 @@ int lto_group_comm_allreduce_dev(lto_group_comm* q, double* const* buf, long cou
   for (int k = 0; k < n; ++k) if (!buf[k]) return comm_fail(q, LTO_ENULL, "buf[k] is NULL");
   if (q->clique) {
     ncclResult_t r = rccl().GroupStart();
-    for (int k = 0; k < n && r == ncclSuccess; ++k) {
-      if (hipSetDevice(q->device[k]) != hipSuccess) return comm_fail(q, LTO_EHIP, "hipSetDevice");
-      r = rccl().AllReduce(buf[k], buf[k], (size_t)count, ncclDouble, op == LTO_COMM_SUM ? ncclSum : ncclMax, q->comm[k],
-                           (hipStream_t)lto_ctx_stream(q->ctx[k]));
+    bool dev_ok = true;
+    for (int k = 0; k < n && r == ncclSuccess && dev_ok; ++k) {
+      dev_ok = hipSetDevice(q->device[k]) == hipSuccess;
+      if (dev_ok) r = rccl().AllReduce(buf[k], buf[k], (size_t)count, ncclDouble, op == LTO_COMM_SUM ? ncclSum : ncclMax, q->comm[k],
+                                       (hipStream_t)lto_ctx_stream(q->ctx[k]));
     }
     const ncclResult_t e = rccl().GroupEnd();
+    if (!dev_ok) return comm_fail(q, LTO_EHIP, "hipSetDevice");
     if (r != ncclSuccess) return comm_fail(q, LTO_EHIP, "ncclAllReduce", r);
     if (e != ncclSuccess) return comm_fail(q, LTO_EHIP, "ncclGroupEnd", e);
     return LTO_OK;

@@ -62,7 +62,6 @@ class Context:
         self.handle = h
         self.device = int(device)
         self._plans = weakref.WeakSet()      # device-resident plans created on this context
-        self._pinned = []                    # page-locked host blocks handed out by pinned_empty
 
     def close(self):
         """Plans first, then the context.  (The C library tolerates the other order too -- lto_destroy defers while
@@ -70,21 +69,21 @@ class Context:
         if getattr(self, "handle", None):
             for pl in list(self._plans):
                 pl.close()
-            for ptr in self._pinned:
-                self.lib.lto_host_free(self.handle, ptr)
-            self._pinned = []
+            # page-locked blocks stay with their numpy arrays (pinned_empty): each is freed when its last view dies, and
+            # the library completes this destroy with the last of them (lto.h: lifetime)
             self.lib.lto_destroy(self.handle)
             self.handle = None
 
     def pinned_empty(self, shape, order="F"):
         """numpy float64 array in page-locked host memory (lto_host_alloc).  The host-pointer API reads and writes such
         arrays (and contiguous views into them) in place from the GPU: no copy-engine operation per operand.  The
-        memory lives until the context is closed."""
+        memory lives as long as the array or any view of it does, also beyond Context.close(): the block is freed when the
+        last of them is collected (lto_host_free finds the owning context by itself)."""
         n = int(np.prod(shape))
         ptr = C.c_void_p()
         self.check(self.lib.lto_host_alloc(self.handle, max(n, 1) * 8, C.byref(ptr)))
-        self._pinned.append(ptr)
         buf = (C.c_double * max(n, 1)).from_address(ptr.value)
+        weakref.finalize(buf, self.lib.lto_host_free, None, C.c_void_p(ptr.value))
         return np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape, order=order)
 
     def __del__(self):
@@ -181,6 +180,31 @@ class Comm:
         self.handle = h
         self.world, self.rank = int(world), int(rank)
 
+    WINDOW_BYTES = 128
+
+    @classmethod
+    def windows(cls, ctx, world, rank, max_count, exchange):
+        """The window transport (lto_comm_window_*): device copies into IPC-mapped receive windows, no RCCL, no compute units for
+        the payload; also works for ranks that share a device.  `exchange(handle: bytes) -> list of world handles in rank order`
+        is the launcher's all-gather of 128-byte blobs (torch.distributed.all_gather_object, MPI, queues)."""
+        self = cls.__new__(cls)
+        self.ctx, self.lib = ctx, ctx.lib
+        h = C.c_void_p()
+        blob = C.create_string_buffer(cls.WINDOW_BYTES)
+        rc = self.lib.lto_comm_window_export(ctx.handle, int(world), int(rank), int(max_count), blob, C.byref(h))
+        if rc != 0:
+            raise LtoError(rc, "lto_comm_window_export failed")
+        self.handle = h
+        self.world, self.rank = int(world), int(rank)
+        handles = exchange(blob.raw)
+        if len(handles) != self.world or any(len(b) != cls.WINDOW_BYTES for b in handles):
+            raise LtoError(-1, "exchange() must return the world handles in rank order")
+        self.check(self.lib.lto_comm_window_open(self.handle, C.create_string_buffer(b"".join(handles), cls.WINDOW_BYTES * self.world)))
+        return self
+
+    def uses_windows(self):
+        return bool(self.lib.lto_comm_uses_windows(self.handle))
+
     def check(self, rc):
         if rc != 0:
             msg = self.lib.lto_comm_last_error(self.handle)
@@ -212,7 +236,6 @@ class _MemberContext(Context):
         self.lib, self.handle = lib, handle
         self.device = int(lib.lto_ctx_device(handle))
         self._plans = weakref.WeakSet()
-        self._pinned = []
 
     def close(self):
         for pl in list(self._plans):
@@ -297,6 +320,14 @@ def _batch_dims(XC):
     raise ValueError("expected [ndim x n_nodes] or [ndim x n_nodes x n_batch]")
 
 
+def _check_out(arrays, shapes, what):
+    """Caller-supplied output arrays are written in place by the library (by the GPU itself when page-locked): exact shape,
+    Fortran order, float64 and writeable, or nothing is touched."""
+    for a, sh in zip(arrays, shapes):
+        if not isinstance(a, np.ndarray) or a.shape != sh or not a.flags.f_contiguous or a.dtype != np.float64 or not a.flags.writeable:
+            raise LtoError(-1, "out arrays must be writeable Fortran-ordered float64 arrays of shapes " + what)
+
+
 def _tgrids(t, n_nodes, n_batch):
     t = _f64(t)
     if t.ndim == 1:
@@ -321,8 +352,7 @@ def indirect_defectCalc(XC_all, t_TU, params, integ=None, ctx=None, out=None):
     prm, nprm = _params_array(params)
     if out is not None:
         defect, errors = out
-        if defect.shape != (ndim, n - 1, B) or errors.shape != (n - 1, B) or not (defect.flags.f_contiguous and errors.flags.f_contiguous):
-            raise LtoError(-1, "out arrays must be Fortran-ordered (ndim, n-1, B) and (n-1, B)")
+        _check_out((defect, errors), ((ndim, n - 1, B), (n - 1, B)), "(ndim, n-1, B) and (n-1, B)")
     else:
         defect = np.zeros((ndim, n - 1, B), order="F")
         errors = np.zeros((n - 1, B), order="F")
@@ -345,8 +375,7 @@ def indirect_stm(XC_all, t_TU, params, integ=None, ctx=None, out=None):
     prm, nprm = _params_array(params)
     if out is not None:
         Phi, defect = out
-        if Phi.shape != (ndim, ndim, n - 1, B) or defect.shape != (ndim, n - 1, B) or not (Phi.flags.f_contiguous and defect.flags.f_contiguous):
-            raise LtoError(-1, "out arrays must be Fortran-ordered (ndim, ndim, n-1, B) and (ndim, n-1, B)")
+        _check_out((Phi, defect), ((ndim, ndim, n - 1, B), (ndim, n - 1, B)), "(ndim, ndim, n-1, B) and (ndim, n-1, B)")
     else:
         Phi = np.empty((ndim, ndim, n - 1, B), order="F")
         defect = np.empty((ndim, n - 1, B), order="F")
@@ -518,8 +547,7 @@ def direct_jacobian_blocks(X_all, u_all, t_TU, nsteps, MU, DU, TU, Isp, ctx=None
     if out is not None:
         Jt, dtf, defect, errors = out
         shapes = ((ns, nvar, n - 1, B), (ns, n - 1, B), (ns, n - 1, B), (n - 1, B))
-        if any(a.shape != sh or not a.flags.f_contiguous or a.dtype != np.float64 for a, sh in zip(out, shapes)):
-            raise LtoError(-1, "out arrays must be Fortran-ordered float64 of shapes %s" % (shapes,))
+        _check_out(out, shapes, "%s" % (shapes,))
     else:
         Jt = np.zeros((ns, nvar, n - 1, B), order="F")
         dtf = np.zeros((ns, n - 1, B), order="F")

@@ -139,3 +139,129 @@ def test_two_ranks_product_sweep_plus_native_allgather(gpu_ctx):
     d_ref, _ = lto.indirect_defectCalc(XC[:, :, 0], T[:, 0], lto.make_params(*PRM), lto.integrator(lto.RK4, steps=8), ctx=gpu_ctx)
     for r in (0, 1):
         assert np.array_equal(res[r], d_ref)
+
+
+# ------------------------------------------------------------------------------------------- two ranks, ONE device
+# The N > 1 hand-off of the one-process-per-GPU layout, on the box's single GPU: two PROCESSES, each with its own lto_ctx on
+# device 0.  RCCL refuses two ranks on one device -- that refusal must surface as an error of lto_comm_create, not be
+# swallowed -- and the window transport (lto_comm_window_*: IPC-mapped receive windows, device copies, flag kernel) carries
+# the same two collectives across the process boundary.
+
+def _shared_device_rank(rank, world, port, n_nodes, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = {"rank": rank}
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # the launcher: carries ids and window handles
+        ctx = lto.Context(0)
+        # (1) RCCL across processes on one device: unique id on rank 0 -> hand-off -> lto_comm_create on every rank
+        box = [lto.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        try:
+            c = lto.Comm(ctx, world, rank, box[0])
+            out["rccl"] = "created"
+            c.close()
+        except lto._lib.LtoError as e:
+            out["rccl"] = "refused rc=%d" % e.code
+        dist.barrier()
+        # (2) the window transport
+        XC, T = synth.indirect_problem(n_nodes, seed=5)
+        S = n_nodes - 1
+        cmax = sharding.partition(S, world, 0)[1]
+
+        def exchange(blob):
+            got = [None] * world
+            dist.all_gather_object(got, blob)
+            return got
+        comm = lto.Comm.windows(ctx, world, rank, 12 * cmax, exchange)
+        out["windows"] = comm.uses_windows()
+        prm, integ = lto.make_params(*PRM), lto.integrator(lto.RK4, steps=8)
+        ln, lt, s0, cnt = sharding.local_nodes(XC[:, :, 0], T[:, 0], world, rank)
+        plan = lto.IndirectPlan(ctx, cnt + 1, 1, prm, integ)
+        Xd = torch.from_numpy(synth.to_soa_nodes(np.asfortranarray(ln)[:, :, None])).cuda()
+        td = torch.from_numpy(np.ascontiguousarray(lt)).cuda()
+        st = lto.current_stream_ptr()
+        fulls = []
+        for rep in range(3):                      # repeated: both window halves and their reuse
+            slab = torch.zeros(12, cmax, dtype=torch.float64, device="cuda")
+            recv = torch.full((world, 12, cmax), -7.0, dtype=torch.float64, device="cuda")
+            plan.defect(Xd, cnt + 1, td, 1, slab, cmax, stream=st)       # device-resident sweep of this rank's block
+            comm.allgather(slab, recv, 12 * cmax, stream=st)
+            torch.cuda.synchronize()
+            full = np.zeros((12, S))
+            for r in range(world):
+                r0, rc = sharding.partition(S, world, r)
+                full[:, r0:r0 + rc] = recv[r, :, :rc].cpu().numpy()
+            fulls.append(full)
+        out["full"] = fulls
+        # norms of the local slab -> all-reduce (sum, NaN-propagating max); then a NaN planted on rank 1 only
+        nm = torch.zeros(2, dtype=torch.float64, device="cuda")
+        ctx.check(ctx.lib.lto_defect_norms_dev(ctx.handle, st, lto.hotpath._dptr(slab), cmax, 12, cmax, 1, lto.hotpath._dptr(nm[0:1]), lto.hotpath._dptr(nm[1:2])))
+        ss, mx = nm[0:1].clone(), nm[1:2].clone()
+        comm.allreduce(ss, 1, "sum", stream=st)
+        comm.allreduce(mx, 1, "max", stream=st)
+        bad = torch.tensor([float("nan") if rank == 1 else 3.0, 1.0 + rank], dtype=torch.float64, device="cuda")
+        comm.allreduce(bad, 2, "max", stream=st)
+        torch.cuda.synchronize()
+        out["ss"], out["mx"], out["bad"] = float(ss), float(mx), bad.cpu().numpy()
+        dist.barrier()                            # nobody unmaps a window a peer may still be pushing into
+        plan.close(); comm.close(); ctx.close()
+        dist.destroy_process_group()
+    except Exception as e:                        # report instead of hanging the parent
+        import traceback
+        out["error"] = "%s\n%s" % (e, traceback.format_exc())
+    q.put(out)
+
+
+def test_two_processes_share_the_gpu_rccl_refusal_is_reported_and_windows_carry_the_collectives(gpu_ctx):
+    import torch.multiprocessing as mp
+    n_nodes, world = 64, 2
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_shared_device_rank, args=(r, world, port, n_nodes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        o = q.get(timeout=300)
+        res[o["rank"]] = o
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert "error" not in res[r], res[r].get("error")
+    # RCCL on a shared device: whatever it decides, both ranks must see the same outcome, and a refusal is an error code
+    assert res[0]["rccl"] == res[1]["rccl"] or all(o["rccl"].startswith("refused") for o in res.values()), (res[0]["rccl"], res[1]["rccl"])
+    XC, T = synth.indirect_problem(n_nodes, seed=5)
+    d_ref, _ = lto.indirect_defectCalc(XC[:, :, 0], T[:, 0], lto.make_params(*PRM), lto.integrator(lto.RK4, steps=8), ctx=gpu_ctx)
+    for r in range(world):
+        assert res[r]["windows"]
+        for full in res[r]["full"]:
+            assert np.array_equal(full, d_ref), "rank %d" % r
+        assert abs(res[r]["ss"] - float((d_ref ** 2).sum())) <= 1e-12 * float((d_ref ** 2).sum())
+        assert res[r]["mx"] == float(np.abs(d_ref).max())
+        assert np.isnan(res[r]["bad"][0]) and res[r]["bad"][1] == 2.0          # the NaN of rank 1 reaches every rank
+
+
+def test_window_transport_world1_and_misuse(gpu_ctx):
+    import torch
+    comm = lto.Comm.windows(gpu_ctx, 1, 0, 500, lambda blob: [blob])
+    st = lto.current_stream_ptr()
+    send = torch.arange(500, dtype=torch.float64, device="cuda") * 0.25
+    recv = torch.full((1, 500), -1.0, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        comm.allgather(send, recv, 500, stream=st)
+    part = torch.full((1, 100), -1.0, dtype=torch.float64, device="cuda")
+    comm.allgather(send, part, 100, stream=st)                                  # count < max_count
+    b = send.clone(); b[3] = float("nan")
+    comm.allreduce(b, 500, "max", stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(recv[0], send) and torch.equal(part[0], send[:100])
+    assert torch.isnan(b[3]) and torch.equal(b[4:], send[4:])
+    with pytest.raises(lto._lib.LtoError):
+        comm.allgather(send, recv, 501, stream=st)                              # beyond the window
+    comm.close()

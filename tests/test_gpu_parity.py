@@ -505,6 +505,54 @@ def test_indirect_adaptive_unfinished_segment_is_nan(gpu_ctx, ndim, mname, kerne
     assert np.array_equal(d_d[:, ok], d_ok[:, ok]) and np.array_equal(Phi_d[:, ok], Phi_ok[:, ok])
 
 
+@pytest.mark.parametrize("ndim", [12, 14])
+@pytest.mark.parametrize("mname", ["rkf78_adaptive", "dop853_adaptive", "rk4x64"])
+@pytest.mark.parametrize("kernel", ["auto", "per_lane", "coop"])
+def test_indirect_nan_time_grid_poisons_stm_and_defect_sweeps_alike(gpu_ctx, ndim, mname, kernel):
+    """A NaN in the time grid gives the two segments that touch it a NaN span.  Neither has a result: defect AND STM are NaN
+    in the STM sweep and in the defect-only sweep of the same plan -- whichever kernel AUTO resolves to (the two-lane
+    cooperative / defect kernels for the reference's integrator setting) -- so the driver's NaN path (status_flag = 2,
+    indirect.jl:339-341) is taken on either.  The other segments are untouched."""
+    import torch
+    method, steps = METHODS[mname]
+    n = 20
+    XC, T = synth.indirect_problem(n, seed=9)
+    XC, t = XC[:, :, 0], T[:, 0].copy()
+    if ndim == 14:
+        X = np.zeros((14, n), order="F")
+        X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+        prm_l = [MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+    else:
+        X = XC.copy()
+        prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+    S = n - 1
+    Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+
+    def sweep(tgrid):
+        plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(method, steps=steps), ndim=ndim)
+        if kernel != "auto":
+            plan.set_kernel(plan.KERNEL_COOP if kernel == "coop" else plan.KERNEL_PER_LANE)
+        td = torch.from_numpy(np.ascontiguousarray(tgrid)).cuda()
+        Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        d0 = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+        plan.defect(Xd, n, td, 1, d0, S)
+        torch.cuda.synchronize()
+        plan.close()
+        return Phi.cpu().numpy(), d.cpu().numpy(), d0.cpu().numpy()
+
+    Phi_ok, d_ok, d0_ok = sweep(t)
+    assert np.all(np.isfinite(Phi_ok)) and np.all(np.isfinite(d_ok)) and np.all(np.isfinite(d0_ok))
+    t2 = t.copy()
+    t2[6] = np.nan                                  # segments 5 and 6 have NaN spans
+    Phi_n, d_n, d0_n = sweep(t2)
+    bad = [5, 6]
+    assert np.all(np.isnan(d_n[:, bad])) and np.all(np.isnan(d0_n[:, bad])) and np.all(np.isnan(Phi_n[:, bad]))
+    ok = np.ones(S, bool); ok[bad] = False
+    assert np.array_equal(d_n[:, ok], d_ok[:, ok]) and np.array_equal(d0_n[:, ok], d0_ok[:, ok]) and np.array_equal(Phi_n[:, ok], Phi_ok[:, ok])
+
+
 def test_indirect_homotopy_full_size_properties(gpu_ctx, oracle):
     """BASELINE configs[3] size (64 trajectories x 64 rho-levels x 64 segments = 262 144 segments, RK4 x 64, defect
     only): the batched launch equals per-level launches bit for bit on a sample of levels, matches the oracle on a

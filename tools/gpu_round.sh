@@ -24,11 +24,28 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c3" -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c4" -- python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/prof_c4.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_dop853" -- python bench.py --ndim 12 --method dop853 --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2_dop853.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5_stm" -- python bench.py --workload c5_stm --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_c5_stm.log" 2>&1
-# PMC passes, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-for W in c2 c3; do
-  WL=""; [ "$W" = c3 ] && WL="--workload c3"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$W/pmc_fetch" -- python bench.py $WL --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_fetch_$W.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$W/pmc_write" -- python bench.py $WL --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_write_$W.log" 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/$W/pmc_sq" -- python bench.py $WL --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_sq_$W.log" 2>&1
-done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5" -- python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_c5.log" 2>&1
+# PMC passes for EVERY workload that has a roofline row, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one
+# pass; the program itself right after `--`).  Layout: $OUT/<key>/pmc_{fetch,write,sq}; key = bench.py's pmc_key().
+pmc_passes() {   # pmc_passes <key> <bench.py arguments...>
+  local KEY=$1; shift
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$KEY/pmc_fetch" -- python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_fetch_$KEY.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$KEY/pmc_write" -- python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_write_$KEY.log" 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/$KEY/pmc_sq" -- python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_sq_$KEY.log" 2>&1
+  echo "pmc $KEY done"
+}
+pmc_passes c2                                   # also holds the 12-dim leg (pmc_c2_ndim12) and the reference-integrator leg
+pmc_passes c3 --workload c3
+pmc_passes c4 --workload c4
+pmc_passes c5 --workload c5
+pmc_passes c5_stm --workload c5_stm
+pmc_passes c2_ndim12_dop853 --ndim 12 --method dop853
 find "$OUT" -name "*.csv" | wc -l
+# condense into profiles/ (tag = $1):
+#   python tools/summarize_profile.py $OUT <tag> c2 "k_indirect_pipe8<14"
+#   python tools/summarize_profile.py $OUT <tag> c2_ndim12 "k_indirect_pipe8<12" c2
+#   python tools/summarize_profile.py $OUT <tag> c3 "k_direct_jacobian_pipe<6"
+#   python tools/summarize_profile.py $OUT <tag> c4 "k_indirect_pipe48<12"
+#   python tools/summarize_profile.py $OUT <tag> c5 "k_indirect_defect2"
+#   python tools/summarize_profile.py $OUT <tag> c5_stm "k_indirect_coop2"
+#   python tools/summarize_profile.py $OUT <tag> c2_ndim12_dop853 "k_indirect_coop2" c2_dop853

@@ -31,6 +31,7 @@ def rows(pattern):
 def main():
     run, tag, workload, kname = sys.argv[1:5]
     src = sys.argv[5] if len(sys.argv) > 5 else workload      # prof_<src>/ holds the kernel trace (one trace, several kernels)
+    pmc_src = src if os.path.isdir(os.path.join(run, src)) else workload   # <run>/<pmc_src>/pmc_* hold the counter passes
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     # kernel stats
     stats = list(rows(os.path.join(run, "prof_%s" % src, "**", "*_kernel_stats.csv")))
@@ -49,7 +50,7 @@ def main():
                                 "max_ns": float(dom[0]["MaxNs"])} if dom else None, "pmc": {}}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         acc = {}
-        for r in list(rows(os.path.join(run, sub, "**", "*_counter_collection.csv"))) + list(rows(os.path.join(run, src, sub, "**", "*_counter_collection.csv"))):
+        for r in list(rows(os.path.join(run, sub, "**", "*_counter_collection.csv"))) + list(rows(os.path.join(run, pmc_src, sub, "**", "*_counter_collection.csv"))):
             if kname not in r["Kernel_Name"]:
                 continue
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
@@ -66,6 +67,12 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_%s.json" % workload), "w") as fh:
             json.dump({"hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "hbm_bytes_per_launch_raw": summary["hbm_bytes_per_launch_raw"],
                        "fetch_kib": fetch_kib, "write_kib": write_kib, "source": "%s (%s)" % (run, tag)}, fh, indent=1)
+    if not any(k != "_meta" for k in summary["pmc"]):
+        raise SystemExit("no counter rows for kernel %r under %s/%s/pmc_*: nothing written (an empty pmc object is not evidence)" % (kname, run, pmc_src))
+    # issue occupancy x useful-slot fraction, the decomposition DESIGN section 6 quotes per row
+    sq = summary["pmc"]
+    if "SQ_INSTS_VALU" in sq and "SQ_BUSY_CYCLES" in sq:
+        summary["valu_wave_instructions_per_launch"] = sq["SQ_INSTS_VALU"]["per_launch_mean"]
     with open(os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (tag, workload)), "w") as fh:
         json.dump(summary, fh, indent=1)
     print(json.dumps(summary, indent=1))
