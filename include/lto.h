@@ -226,23 +226,25 @@ int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
 int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
 
 /* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4 with >= 6 steps per segment, the three-role
- * pipeline kernels (eight-wave form up to 4 096 segments; above that, whichever of eight-wave (ndim = 14) / four-wave
- * (ndim = 12) form, 48-segment form and per-lane kernel needs the cheapest rounds for the segment count -- from ~30 000
- * segments on always the 48-segment form) and otherwise the per-lane kernel (each lane re-integrates the base state with 1-3
- * columns); for the 13-stage integrators the wave-specialised kernel (base wave + column waves per 16 segments,
- * coefficients handed over through LDS at every RK stage) -- for ndim = 12 with DOP853_ADAPTIVE, the reference's setting,
- * its form with two lanes per state (LTO_KERNEL_COOP2). */
+ * pipeline kernels -- the eight-wave form while the batch is one round (16 segments per CU: 4 096 on MI355X), above that
+ * whichever of eight-wave form (rounds of 16 x CUs segments), 48-segment form (rounds of 48 x CUs) and, for ndim = 12, per-lane
+ * kernel with 3 columns per lane (rounds of 64 x CUs) needs the cheapest rounds for the segment count -- and otherwise the
+ * per-lane kernel (each lane re-integrates the base state with 1-3 columns); for the 13-stage integrators the wave-specialised
+ * kernel (base wave + column waves per 16 segments, coefficients handed over through LDS at every RK stage) -- for ndim = 12
+ * with DOP853_ADAPTIVE, the reference's setting, its form with two lanes per state (LTO_KERNEL_COOP2). */
 #define LTO_KERNEL_AUTO 0
 #define LTO_KERNEL_PER_LANE 1
 #define LTO_KERNEL_COOP 2
-/* RK4 plans only: base wave, coefficient wave and column waves per 16 segments run as a software pipeline skewed by
- * one RK4 step (one workgroup barrier per step); other integrators: LTO_EINVAL.  _PIPE: two column waves, two STM
- * columns per lane, coefficients read from LDS.  _PIPE6: four column waves, one column per lane, a DPP row = one
- * segment and the coefficients broadcast inside the FMA (v_fmac_f64_dpp row_newbcast).  _PIPE8: the DPP column role
- * with TWO RK4 steps per phase and eight waves -- a fourth of the column work alternates between two SIMDs so that all
- * four SIMDs of a CU carry the same load (one workgroup per CU: 91 KB of LDS). */
+/* RK4 plans only (other integrators: LTO_EINVAL): base wave, coefficient wave and column waves per 16 segments run as a software
+ * pipeline skewed by one RK4 step.  _PIPE8: four column waves, one STM column per lane, a DPP row = one segment and the
+ * coefficients broadcast inside the FMA (v_fmac_f64_dpp row_newbcast), TWO RK4 steps per phase and eight waves -- a fourth of
+ * the column work alternates between two SIMDs so that all four SIMDs of a CU carry the same load -- and a base wave that
+ * evaluates RK4 stages 1|2 and then 3|4 side by side in neighbouring lanes (one workgroup per CU: 91 KB of LDS).
+ * On an INDIRECT plan selector 3 (the four-wave form of rounds 1-2, two columns per lane) and selector 4 (the six-wave form)
+ * are gone since round 3 -- _PIPE8 is faster at every size -- and return LTO_EINVAL; LTO_KERNEL_PIPE remains the selector of
+ * the direct plans' pipelined Jacobian kernel. */
 #define LTO_KERNEL_PIPE 3
-#define LTO_KERNEL_PIPE6 4
+#define LTO_KERNEL_PIPE6_REMOVED 4
 #define LTO_KERNEL_PIPE8 5
 /* ndim = 12, DOP853_ADAPTIVE plans only: the cooperative kernel with every 12-component state split over two lanes (top /
  * bottom halves of a column in different waves, the two halves of the base state in neighbouring DPP banks): six components
@@ -280,10 +282,10 @@ int lto_indirect_dense_dev(lto_indirect_plan* plan, void* stream, const double* 
 int lto_direct_plan_create(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, int nsteps,
                            const lto_direct_params* prm, lto_direct_plan** out);
 void lto_direct_plan_destroy(lto_direct_plan* plan);
-/* Jacobian kernel: LTO_KERNEL_PER_LANE (each lane re-integrates the half-arc with one sensitivity column),
- * LTO_KERNEL_COOP (base wave + column waves per 16 segments, coefficients through LDS, one barrier per RK stage) or
+/* Jacobian kernel: LTO_KERNEL_PER_LANE (each lane re-integrates the half-arc with one sensitivity column) or
  * LTO_KERNEL_PIPE (base wave + one wave per sensitivity column for 32 segments, skewed by one RKF7(8) step: one barrier
- * per step).  AUTO = PIPE from 3 072 segments, PER_LANE below. */
+ * per step).  AUTO = PIPE from 3 072 segments, PER_LANE below.  LTO_KERNEL_COOP (the wave-specialised form of rounds 1-2,
+ * one barrier per RK stage, never the fastest) was removed in round 3: LTO_EINVAL. */
 int lto_direct_plan_set_kernel(lto_direct_plan* plan, int kernel);
 int lto_direct_defect_dev(lto_direct_plan* plan, void* stream, const double* X, long ldx, const double* U, long ldu,
                           const double* t, int n_tgrids, double* defect, long ldd, double* errors);

@@ -631,6 +631,19 @@ struct BaseParts12 {
   double inv_n;       // 1 / |lambda_v| (guarded)
 };
 
+// lambda_v = 0 exactly: the reference's guard sets the control to 0 (stateCostate_deriv.jl:59-64: a constant), so du / dlambda_v = 0
+// there.  The slopes are right by themselves -- the guarded 1 / n is a finite 2^500 and the thrust -(umag / n) lambda_v an exact
+// 0 -- but umag / n itself, which the column lanes build U from, would be ~1e148 for the laws whose umag does not vanish with n
+// (p = 0, p = 1).  The unclamped p > 1 laws have umag / n -> a finite limit and keep their values (p = 2: U = -I / 2).
+template <int PM>
+__device__ __forceinline__ void parts_guard_zero_norm(const double n2, BaseParts12& bp) {
+  if constexpr (PM == PM_P0 || PM == PM_P1) {
+    const bool nz = n2 > 0.0;
+    bp.ua = nz ? bp.ua : 0.0;
+    bp.ub = nz ? bp.ub : 0.0;
+  }
+}
+
 // rhs12_base plus the parts.  Same arithmetic for the slopes.
 template <int PM>
 __device__ __forceinline__ void rhs12_base_parts(const double (&y)[12], const TrajParams& tp, double (&dy)[12], BaseParts12& bp) {
@@ -678,6 +691,7 @@ __device__ __forceinline__ void rhs12_base_parts(const double (&y)[12], const Tr
   dy[10] = __builtin_fma(-w2, lx, -y[7]);
   dy[11] = -y[8];
   bp.c1 = c1; bp.c2 = c2; bp.i1s = i1s; bp.i2s = i2s; bp.ua = ua; bp.ub = ub; bp.inv_n = inv_n;
+  parts_guard_zero_norm<PM>(n2, bp);
 }
 
 // The base slopes of one HALF of the 12-dim state in a lane (cooperative kernel, two lanes per segment): lane A owns
@@ -736,6 +750,7 @@ __device__ __forceinline__ void rhs12_base_half(const double (&R)[3], const doub
   const double gz = __builtin_fma(cs, lz, -es * z);
   kq[0] = is_a ? ax : gx; kq[1] = is_a ? ay : gy; kq[2] = is_a ? az : gz;
   bp.c1 = c1; bp.c2 = c2; bp.i1s = i1s; bp.i2s = i2s; bp.ua = ua; bp.ub = ub; bp.inv_n = inv_n;
+  parts_guard_zero_norm<PM>(n2, bp);
 }
 
 // The two halves of coef12_from_parts / var_col12 for a column split over two lanes in different waves (cooperative kernel):

@@ -62,18 +62,14 @@ hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const Indirect
 hipError_t launch_indirect_stm_coop2(int pm, const IndirectArgs& a, hipStream_t st);
 // defect-only sweep with two lanes per segment (kernels_indirect_defect2.hip): 12-dim, DOP853 adaptive only
 hipError_t launch_indirect_defect2(int pm, const IndirectArgs& a, hipStream_t st);
-// three-role pipeline (kernels_indirect_pipe.hip): base wave, coefficient wave and two column waves per 16 segments,
-// skewed by one RK4 step; fixed-step RK4 only
-hipError_t launch_indirect_stm_pipe(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
-// six-wave form: one STM column per lane, coefficients broadcast inside the FMA (v_fmac_f64_dpp row_newbcast)
-hipError_t launch_indirect_stm_pipe6(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
-// eight-wave form (kernels_indirect_pipe8.hip): two RK4 steps per phase, a fourth of the column work alternates between two SIMDs
+// three-role pipeline, fixed-step RK4 only: base wave, coefficient wave and column waves per 16 segments, skewed by one RK4 step.
+// Eight-wave form (kernels_indirect_pipe8.hip): one STM column per lane with the coefficients broadcast inside the FMA (v_fmac_f64_dpp
+// row_newbcast), two RK4 steps per phase, a fourth of the column work alternates between two SIMDs, base role with paired stages
 hipError_t launch_indirect_stm_pipe8(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 // large batches (kernels_indirect_pipe48.hip): 48 segments and 16 waves per workgroup, base lane = segment, DPP column rows
 hipError_t launch_indirect_stm_pipe48(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
-hipError_t launch_direct_jacobian_coop(int nstate, const DirectArgs& a, hipStream_t st);
 // base wave + one wave per sensitivity column for 32 segments, skewed by one RKF7(8) step (one barrier per step)
 hipError_t launch_direct_jacobian_pipe(int nstate, const DirectArgs& a, hipStream_t st);
 

@@ -191,147 +191,8 @@ __global__ __launch_bounds__(64) void k_direct_jacobian(const DirectArgs a) {
   }
 }
 
-// K4': wave-specialised Jacobian kernel.  Workgroup = 16 segments x 6 wavefronts:
-//   wave 0      base roles: lanes 0-15 forward half-arc, lanes 16-31 backward half-arc.  Integrates the NS-dim state and
-//               publishes each stage's variational coefficients (G, k/m [, dv/dm]) to LDS.
-//   waves 1-5   sensitivity columns: lane = (segment, direction, column of [Phi | Psi]); integrates only its NS-dim
-//               column  c' = A(t) c + forcing  with the coefficients from LDS -- no gravity work, no base RK bookkeeping.
-// Same tableau, step grid and output layout as k_direct_jacobian; one barrier per RK stage (double-buffered LDS).
-template <int NS>
-__global__ __launch_bounds__(384) void k_direct_jacobian_coop(const DirectArgs a) {
-  constexpr int SEGW = 16;
-  constexpr int NCOL = NS + 3;                 // columns per direction
-  constexpr int NC = (NS == 7) ? 10 : 7;       // doubles handed over per (segment, direction, stage)
-  __shared__ double s_coef[2][2][NC][SEGW];
-  __shared__ double s_x[2][2 * NS + 1][SEGW];  // mid-point exchange: [dir][xe (NS) | R f (NS) | maxErr][segment]
-
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int seg = lane & (SEGW - 1), slot = lane >> 4;
-  const bool is_base = (wave == 0);
-  // base wave: slot 0 = forward, slot 1 = backward, slots 2,3 shadow them.  column waves: role r = (wave-1)*4 + slot
-  const int r_raw = (wave - 1) * 4 + slot;
-  const int r_col = r_raw < 2 * NCOL ? r_raw : 2 * NCOL - 1;      // shadow lanes repeat the last column
-  const int dir = is_base ? (slot & 1) : (r_col / NCOL);
-  const int j = is_base ? 0 : (r_col % NCOL);
-  const int s_raw = blockIdx.x * SEGW + seg;
-  const int s = s_raw < a.S ? s_raw : a.S - 1;
-  const bool writer = (s_raw < a.S) && (is_base ? slot < 2 : r_raw < 2 * NCOL);
-
-  const int traj = s / a.seg_per_traj;
-  const int i = s - traj * a.seg_per_traj;
-  const long node = (long)traj * a.n_nodes + i + dir;
-  const long tg = (long)traj * a.t_stride;
-  const double hhalf = 0.5 * (a.t[tg + i + 1] - a.t[tg + i]);
-  const double span_total = a.t[tg + a.n_nodes - 1] - a.t[tg];
-  const double td = dir ? -1.0 : 1.0;
-  DirectLane L;
-  L.MU = a.MU; L.w2 = 2.0 * td; L.kk = a.kk;
-  L.cx = a.U[0 * a.ldu + node]; L.cy = a.U[1 * a.ldu + node]; L.cz = a.U[2 * a.ldu + node];
-  const double nc = sqrt(__builtin_fma(L.cx, L.cx, __builtin_fma(L.cy, L.cy, L.cz * L.cz)));
-  L.mdot = -td * nc / a.isp_g0 * a.TU;
-
-  double y[NS], K[13][NS];
-  const bool is_ctrl = j >= NS;
-  const int jc = j - NS;
-  double fx = 0.0, fy = 0.0, fz = 0.0, fm = 0.0;
-  if (is_base) {
-#pragma unroll
-    for (int c = 0; c < NS; ++c) y[c] = a.X[c * a.ldx + node];
-    if (dir) { y[3] = -y[3]; y[4] = -y[4]; y[5] = -y[5]; }
-  } else {
-#pragma unroll
-    for (int c = 0; c < NS; ++c) y[c] = (c == j) ? 1.0 : 0.0;
-    fx = (is_ctrl && jc == 0) ? 1.0 : 0.0;
-    fy = (is_ctrl && jc == 1) ? 1.0 : 0.0;
-    fz = (is_ctrl && jc == 2) ? 1.0 : 0.0;
-    if (NS == 7 && is_ctrl) {
-      const double cj = (jc == 0) ? L.cx : (jc == 1 ? L.cy : L.cz);
-      const double dn = (nc > 0.0) ? cj / nc : 1.0;
-      fm = -td * dn / a.isp_g0 * a.TU;
-    }
-  }
-
-  const double h = hhalf / (double)a.half_steps;
-  double maxErr = 0.0;
-  int buf = 0;
-  for (int step = 0; step < a.half_steps; ++step) {
-#pragma unroll
-    for (int st = 0; st < 13; ++st) {
-      double arg[NS];
-#pragma unroll
-      for (int c = 0; c < NS; ++c) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < st; ++k)
-          if (TabRKF78::A[st][k] != 0.0) acc = __builtin_fma(TabRKF78::A[st][k], K[k][c], acc);
-        arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc, y[c]);
-      }
-      if (is_base) {
-        VarCoef6 vc;
-        rhs_direct<NS, true>(arg, L, K[st], vc);
-        if (slot < 2) {
-          s_coef[buf][dir][0][seg] = vc.Gxx; s_coef[buf][dir][1][seg] = vc.Gyy; s_coef[buf][dir][2][seg] = vc.Gzz;
-          s_coef[buf][dir][3][seg] = vc.Gxy; s_coef[buf][dir][4][seg] = vc.Gxz; s_coef[buf][dir][5][seg] = vc.Gyz;
-          s_coef[buf][dir][6][seg] = vc.k_over_m;
-          if (NS == 7) { s_coef[buf][dir][7][seg] = vc.dvdm_x; s_coef[buf][dir][8][seg] = vc.dvdm_y; s_coef[buf][dir][9][seg] = vc.dvdm_z; }
-        }
-      }
-      __syncthreads();
-      if (!is_base) {
-        VarCoef6 vc;
-        vc.Gxx = s_coef[buf][dir][0][seg]; vc.Gyy = s_coef[buf][dir][1][seg]; vc.Gzz = s_coef[buf][dir][2][seg];
-        vc.Gxy = s_coef[buf][dir][3][seg]; vc.Gxz = s_coef[buf][dir][4][seg]; vc.Gyz = s_coef[buf][dir][5][seg];
-        vc.k_over_m = s_coef[buf][dir][6][seg];
-        if (NS == 7) { vc.dvdm_x = s_coef[buf][dir][7][seg]; vc.dvdm_y = s_coef[buf][dir][8][seg]; vc.dvdm_z = s_coef[buf][dir][9][seg]; }
-        var_col_direct<NS>(vc, L.w2, arg, fx * vc.k_over_m, fy * vc.k_over_m, fz * vc.k_over_m, fm, K[st]);
-      }
-      buf ^= 1;
-    }
-#pragma unroll
-    for (int c = 0; c < NS; ++c) {
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < 13; ++k)
-        if (TabRKF78::B[k] != 0.0) acc = __builtin_fma(TabRKF78::B[k], K[k][c], acc);
-      if (is_base) maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
-      y[c] = __builtin_fma(h, acc, y[c]);
-    }
-  }
-
-  if (!is_base) {
-    if (writer && a.Jac) {
-      const int col = is_ctrl ? (2 * NS + 3 * dir + jc) : (NS * dir + j);
-      const double rj = (!is_ctrl && j >= 3 && j < 6) ? -1.0 : 1.0;
-#pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        const double rr = (r >= 3 && r < 6) ? -1.0 : 1.0;
-        a.Jac[(long)(col * NS + r) * a.ldj + s] = dir ? -(rr * rj) * y[r] : y[r];
-      }
-    }
-  } else {
-    // forward and backward halves meet: publish (x_end, R f(x_end), maxErr) per direction, combine on the forward lane
-    double f[NS];
-    VarCoef6 vc;
-    rhs_direct<NS, false>(y, L, f, vc);
-    if (dir) { y[3] = -y[3]; y[4] = -y[4]; y[5] = -y[5]; f[3] = -f[3]; f[4] = -f[4]; f[5] = -f[5]; }
-    if (slot < 2) {
-#pragma unroll
-      for (int c = 0; c < NS; ++c) { s_x[dir][c][seg] = y[c]; s_x[dir][NS + c][seg] = f[c]; }
-      s_x[dir][2 * NS][seg] = maxErr;
-    }
-  }
-  __syncthreads();
-  if (is_base && writer && dir == 0) {
-    const double scale = hhalf / span_total;
-#pragma unroll
-    for (int c = 0; c < NS; ++c) {
-      if (a.defect) a.defect[c * a.ldd + s] = s_x[0][c][seg] - s_x[1][c][seg];
-      if (a.dtf) a.dtf[c * a.ldd + s] = (s_x[0][NS + c][seg] - s_x[1][NS + c][seg]) * scale;
-    }
-    if (a.errors) a.errors[s] = fmax(s_x[0][2 * NS][seg], s_x[1][2 * NS][seg]);
-  }
-}
-
+// (A wave-specialised form with one barrier per RK stage -- base wave + five column waves per 16 segments -- measured no faster than
+// the per-lane kernel and slower than the pipeline below at every size; AUTO never chose it.  Removed in round 3.)
 // K4'': software-pipelined Jacobian kernel (BASELINE configs[2]).  In the per-lane kernel every sensitivity column lane
 // re-integrates the half-arc base state (RHS, gravity gradient and the stage arguments of the base: ~85 of its ~125
 // instructions per RK stage), nine times per arc (arc = segment x direction); the cooperative kernel removes that but
@@ -508,15 +369,6 @@ hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st)
   dim3 grid((2 * (long)a.S + 63) / 64);
   if (nstate == 6) hipLaunchKernelGGL((k_direct_defect<6>), grid, dim3(64), 0, st, a);
   else if (nstate == 7) hipLaunchKernelGGL((k_direct_defect<7>), grid, dim3(64), 0, st, a);
-  else return hipErrorInvalidValue;
-  return hipGetLastError();
-}
-
-hipError_t launch_direct_jacobian_coop(int nstate, const DirectArgs& a, hipStream_t st) {
-  if (a.S <= 0) return hipSuccess;
-  dim3 grid((a.S + 15) / 16);
-  if (nstate == 6) hipLaunchKernelGGL((k_direct_jacobian_coop<6>), grid, dim3(384), 0, st, a);
-  else if (nstate == 7) hipLaunchKernelGGL((k_direct_jacobian_coop<7>), grid, dim3(384), 0, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

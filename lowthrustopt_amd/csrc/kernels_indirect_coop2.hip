@@ -29,6 +29,7 @@
 #include "kernels.hpp"
 #include "rk.hpp"
 #include "halves.hpp"
+#include <pipe_hooks.hpp>   // product: hooks/ (no-ops); `make probe`: tools/probe_hooks/
 
 namespace lto {
 
@@ -47,11 +48,8 @@ struct C2Shared {
 
 // Probe build (make probe): ticks every role waits at the stage barriers and the ticks of its trial loop, per workgroup,
 // into rows 16-19 (base), 20-21 (top wave 0), 22-23 (bottom wave 0) of a 24-row defect buffer (tools/probe_coop2.py).
-#ifdef PIPE_PROBE
-#define C2_SYNC() do { const long long c2_t = clock64(); __syncthreads(); c2_wait += clock64() - c2_t; } while (0)
-#else
-#define C2_SYNC() __syncthreads()
-#endif
+// The hooks are no-ops in the product build (hooks/pipe_hooks.hpp).
+#define C2_SYNC() c2_wait.sync()
 
 template <int PM, int ROLE>
 __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, const int lane, const int cwave) {
@@ -100,9 +98,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     for (int j = 0; j < 6; ++j) y[j] = (grow[j] == col) ? 1.0 : 0.0;
   }
 
-#ifdef PIPE_PROBE
-  long long c2_wait = 0;
-#endif
+  hook::BarrierWait c2_wait;
   // slope of the stage argument `arg` (own six rows) into `out`.  Called by ALL threads: one barrier inside.  `overlap` is work
   // that needs neither this stage's slope nor LDS (the next argument's sum over the older slopes): the base lanes run it
   // between their LDS stores and the barrier, the column lanes between issuing their LDS loads and the first use.
@@ -201,14 +197,11 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     h_abs = fmin(fmin(100.0 * h0, h1), span);
   }
 
-#ifdef PIPE_PROBE
-  const long long c2_t0 = clock64();
-  int c2_trials = 0;
-#endif
+  hook::RegionClock c2_loop;
+  hook::Counter c2_trials;
+  c2_loop.start();
   for (int trial = 0; trial < a.max_steps; ++trial) {
-#ifdef PIPE_PROBE
-    ++c2_trials;
-#endif
+    c2_trials.bump();
     // every lane of a segment holds identical (t, h_abs, done): they are updated from identical data below
     double h = h_abs;
     double last = 0.0;
@@ -319,15 +312,13 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     }
     if (!__syncthreads_or(!done)) break;   // workgroup-uniform exit: all 16 segments done
   }
-#ifdef PIPE_PROBE
-  if (a.defect && (lane & 15) == 0 && (BASE ? lane == 0 : (cwave == 0 && lane == 0))) {
+  if ((lane & 15) == 0 && (BASE ? lane == 0 : (cwave == 0 && lane == 0))) {      // probe build only: the hooks write nothing otherwise
     const int r0 = BASE ? 16 : (ROLE == C2_TOP ? 20 : 22);
     const long at = (long)blockIdx.x * C2_SEG;
-    a.defect[(r0 + 0) * a.ldd + at] = (double)c2_wait;
-    a.defect[(r0 + 1) * a.ldd + at] = (double)(clock64() - c2_t0);
-    if (BASE) a.defect[18 * a.ldd + at] = (double)c2_trials;
+    c2_wait.report(a.defect, a.ldd, r0, at);
+    c2_loop.report_ticks(a.defect, a.ldd, r0 + 1, at);
+    if (BASE) c2_trials.report(a.defect, a.ldd, 18, at);
   }
-#endif
   // A segment that did not reach t1 (max_steps trial steps used up, or a decreasing time grid: the controller integrates
   // forward only) has no result: NaN, which the driver reports as status_flag 2 (indirect.jl:339-341).
   if (mine && (t < span || !(span >= 0.0))) {   // unfinished, decreasing grid, or a NaN span (treated like a negative one)

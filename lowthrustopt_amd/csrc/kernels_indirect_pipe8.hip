@@ -41,15 +41,11 @@ namespace lto {
 
 constexpr int P8_SPIN_LIMIT = 1 << 22;   // polls before a waiting wave gives up (never hangs)
 
-#ifdef PIPE_PROBE   // development build: cycles each wave waits at the phase barriers -> defect[16][16 block + wave] (the probe script passes a defect buffer of 20 rows)
-#define P8_SYNC() do { const long long p8_t = clock64(); __syncthreads(); p8_wait += clock64() - p8_t; } while (0)
-#define P8_WAIT_DECL long long p8_wait = 0
-#define P8_WAIT_REPORT(a) do { if ((threadIdx.x & 63) == 0 && (a).defect) (a).defect[16 * (a).ldd + blockIdx.x * PIPE_SEG + (threadIdx.x >> 6)] = (double)p8_wait; } while (0)
-#else
-#define P8_SYNC() __syncthreads()
-#define P8_WAIT_DECL
-#define P8_WAIT_REPORT(a)
-#endif
+// Probe hooks (pipe_hooks.hpp: no-ops in the product build): ticks each wave waits at the phase barriers -> row 16 of the probe
+// script's defect buffer, column 16 block + wave.
+#define P8_SYNC() p8_wait.sync()
+#define P8_WAIT_DECL hook::BarrierWait p8_wait
+#define P8_WAIT_REPORT(a) do { if ((threadIdx.x & 63) == 0) p8_wait.report((a).defect, (a).ldd, 16, blockIdx.x * PIPE_SEG + (threadIdx.x >> 6)); } while (0)
 
 template <int ND, int PM> struct Pipe8 {
   using Arg = PipeArg<ND, PM>;
@@ -107,9 +103,8 @@ __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const Pip
   double y[ND];
 #pragma unroll
   for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + L.node];
-#ifdef PIPE_PROBE
-  const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
-#endif
+  hook::RegionClock loop_clock;
+  loop_clock.start();
   P8_WAIT_DECL;
   for (int p = 0; p < npairs + 1; ++p) {
     if (p < npairs && PIPE_ROLE_ON(a, 1) && (PIPE_ROLE_ON(a, 16) || slot == 0)) {
@@ -159,9 +154,7 @@ __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const Pip
     if (a.errors) a.errors[L.s] = 0.0;
     if (a.nacc) a.nacc[L.s] = steps;
     if (a.nrej) a.nrej[L.s] = 0;
-#ifdef PIPE_PROBE   // s_memtime ticks and 100 MHz ticks of the phase loop, per workgroup
-    if (seg == 0 && a.defect) { a.defect[17 * a.ldd + L.s] = (double)(clock64() - probe_c0); a.defect[18 * a.ldd + L.s] = (double)(wall_clock64() - probe_w0); }
-#endif
+    if (seg == 0) loop_clock.report(a.defect, a.ldd, 17, 18, L.s);     // probe build: ticks of the phase loop, per workgroup
   }
 }
 
@@ -213,6 +206,8 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
   for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + L.node];
   double inv_m = 0.0;
   if constexpr (M14) inv_m = rcp_nr(y[MI]);
+  hook::RegionClock loop_clock;
+  loop_clock.start();
   P8_WAIT_DECL;
   // one barrier per phase of two steps (after every odd step and after the last one), then the drain phase: npairs + 1 in all
   for (int step = 0; step < steps; ++step) {
@@ -335,6 +330,7 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
     if (a.errors) a.errors[L.s] = 0.0;
     if (a.nacc) a.nacc[L.s] = steps;
     if (a.nrej) a.nrej[L.s] = 0;
+    if (seg == 0) loop_clock.report(a.defect, a.ldd, 17, 18, L.s);     // probe build: ticks of the step loop, per workgroup
   }
 }
 
@@ -504,10 +500,6 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   __shared__ double s_hand[P::HAND_DOUBLES];
   __shared__ double s_lm[4 * PIPE_SEG];
   __shared__ Pipe8Flags s_fl;
-#ifdef PIPE_PROBE
-  __shared__ long long s_probe_t0;
-  if (threadIdx.x == 128) s_probe_t0 = wall_clock64();     // kernel entry, as seen by the base wave's first lane
-#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   // waves 0, 1, 7: column waves 0, 1, 2; waves 4, 5: the alternating column job 3; wave 2 base, wave 3 coefficients
@@ -519,9 +511,6 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   if (threadIdx.x == 0) { s_fl.base_steps = 0; s_fl.coef_steps = 0; s_fl.hand = 0; s_fl.fail = 0; }
   if (!__syncthreads_or(L.mine)) return;         // workgroup-uniform
   if (wave == 6) return;                         // shares the base wave's SIMD: leaves before the first phase barrier
-#ifdef PIPE_PROBE
-  if (threadIdx.x == 128 && a.defect) a.defect[19 * a.ldd + blockIdx.x * PIPE_SEG] = (double)(wall_clock64() - s_probe_t0);   // prologue: entry -> roles start (100 MHz ticks)
-#endif
   if (wave == 2) {
     if constexpr (PAIRED) pipe8_role_base_paired<ND, PM>(a, L, seg, lane & 3, s_int, &s_fl);
     else pipe8_role_base<ND, PM>(a, L, seg, lane >> 4, s_int, &s_fl);

@@ -23,6 +23,7 @@ using namespace lto;
 
 struct lto_ctx {
   int device;
+  int cu_count;    // compute units of the device: the kernel choice works in rounds of workgroups per CU
   hipStream_t stream;
   bool timing;
   hipEvent_t ev0, ev1;
@@ -230,6 +231,8 @@ int lto_create(lto_ctx** out, int device_id) {
   lto_ctx* c = new (std::nothrow) lto_ctx();   // value-initialised: every scalar member zero, the vector empty
   if (!c) return LTO_EHIP;
   c->device = device_id;
+  c->cu_count = 0;
+  if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) { c->cu_count = 0; (void)hipGetLastError(); }
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return LTO_EHIP;
@@ -419,14 +422,17 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
 
 int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
-  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE && kernel != LTO_KERNEL_PIPE6 &&
+  if (kernel == LTO_KERNEL_PIPE6_REMOVED)
+    return set_err(p->ctx, LTO_EINVAL, "the six-wave pipeline kernel (selector 4) was removed in round 3: LTO_KERNEL_PIPE8 replaced it");
+  if (kernel == LTO_KERNEL_PIPE)
+    return set_err(p->ctx, LTO_EINVAL, "the four-wave pipeline kernel (selector 3 on an indirect plan) was removed in round 3: LTO_KERNEL_PIPE8 is faster at every size");
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP &&
       kernel != LTO_KERNEL_PIPE8 && kernel != LTO_KERNEL_COOP2 && kernel != LTO_KERNEL_PIPE48)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE, _PIPE6, _PIPE8, _COOP2 or _PIPE48");
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE8, _COOP2 or _PIPE48");
   if (kernel == LTO_KERNEL_COOP2 && (p->integ.method != LTO_DOP853_ADAPTIVE || p->ndim != 12))
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_COOP2 is built for 12-dim DOP853_ADAPTIVE plans");
-  if ((kernel == LTO_KERNEL_PIPE || kernel == LTO_KERNEL_PIPE6 || kernel == LTO_KERNEL_PIPE8 || kernel == LTO_KERNEL_PIPE48) &&
-      p->integ.method != LTO_RK4)
-    return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_PIPE is built for fixed-step RK4 plans");
+  if ((kernel == LTO_KERNEL_PIPE8 || kernel == LTO_KERNEL_PIPE48) && p->integ.method != LTO_RK4)
+    return set_err(p->ctx, LTO_EINVAL, "the pipeline kernels are built for fixed-step RK4 plans");
   p->kernel = kernel;
   return LTO_OK;
 }
@@ -502,42 +508,34 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  // Kernel choice (DESIGN.md "Kernels", measured on MI355X, tools/probe_kernels.py).  RK4: the three-role pipeline
-  // kernels -- the eight-wave form (two steps per phase, a fourth of the column work alternating between two SIMDs) up
-  // to one workgroup per CU (4 096 segments, 14-dim: 81 us against 89 us six-wave, 104 us four-wave, 174 us per-lane,
-  // 243 us cooperative; 12-dim: 78 / 80 / 87 / 134 / 142 us).  Above that: eight-wave (14-dim) / four-wave (12-dim) form in
-  // rounds of 4 096 segments, the per-lane kernel with 3 columns per lane (12-dim) in rounds of 16 384, or the 48-segment,
-  // 16-wave form, which fills its wavefronts, in rounds of 12 288 -- whichever is cheapest for the segment count (262 144
-  // segments: 14-dim 4.17 ms against 4.85 four-wave, 4.95 eight-wave, 6.3 per-lane; 12-dim 3.55 ms against 3.86 per-lane,
-  // 4.06 four-wave; 12 288: 0.19 / 0.23 ms and 0.16 / 0.21 ms; 16 384: 0.31 ms eight-wave and 0.25 ms per-lane win).  13-stage methods -> wave-specialised
-  // kernel (DOP853 @1e-13, 4 096 segments: 0.32 ms vs 1.9 ms; RKF7(8) x4: 0.046 ms vs 0.36 ms); for the reference's setting
-  // (12-dim, DOP853) its form with six components per lane, which keeps all slopes in addressable registers.
+  // Kernel choice (DESIGN.md "Kernels"; measured on MI355X with tools/probe_kernels.py, profiles/r03_probe_kernels.txt).
+  // RK4 with >= 6 steps per segment: the three-role pipeline kernels.  A workgroup of the eight-wave form owns 16 segments and a
+  // CU holds one (91 KB of LDS), so up to 16 x CUs segments (4 096 on MI355X) the sweep is one round -- 14-dim 76 us, 12-dim 66 us
+  // against 106 / 89 us (four-wave form, removed), 173 / 136 us per-lane, 238 / 116 us cooperative -- and above that every family
+  // runs in rounds of the segments the chip holds at once, a partly filled round costing a whole one: the family with the
+  // cheapest rounds for THIS segment count wins (us per round at 64 steps; the ratios do not depend on the step count): the
+  // eight-wave form in rounds of 16 x CUs, the 48-segment / 16-wave form in rounds of 48 x CUs, for 12-dim also the per-lane
+  // kernel with 3 columns per lane in rounds of 64 x CUs.  13-stage methods: the wave-specialised kernel (DOP853 @1e-13,
+  // 4 096 segments: 0.32 ms vs 1.9 ms per-lane), for the reference's setting (12-dim, DOP853) its two-lanes-per-state form.
   int kern = p->kernel;
   if (kern == LTO_KERNEL_AUTO) {
-    if (p->integ.method != LTO_RK4)   // 12-dim DOP853: the two-lanes-per-state form (0.233 against 0.260 ms at 4 096 segments)
+    const long cus = c->cu_count > 0 ? c->cu_count : 256;
+    if (p->integ.method != LTO_RK4)   // 12-dim DOP853: the two-lanes-per-state form (0.221 against 0.260 ms at 4 096 segments)
       kern = (p->integ.method == LTO_DOP853_ADAPTIVE && p->ndim == 12) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
     else if (p->integ.steps < 6) kern = LTO_KERNEL_PER_LANE;   // fill and drain phases outweigh the shorter phase
-    else if (p->S <= 4096) kern = LTO_KERNEL_PIPE8;
+    else if (p->S <= 16 * cus) kern = LTO_KERNEL_PIPE8;
     else {
-      // Above one workgroup per CU every family runs in rounds of the segments the chip holds at once, and a partly filled
-      // round costs a whole one: the family with the cheapest rounds for THIS segment count wins (us per round at 64 steps,
-      // tools/probe_kernels.py; the ratios do not depend on the step count).
       const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };
-      if (p->ndim == 14) {
-        const double t8 = rounds(4096) * 78.0, t48 = rounds(12288) * 190.0;
-        kern = (t48 < t8) ? LTO_KERNEL_PIPE48 : LTO_KERNEL_PIPE8;
-      } else {
-        const double t4 = rounds(4096) * 69.0, t48 = rounds(12288) * 163.0, tl = rounds(16384) * 249.0;
-        kern = (t48 <= t4 && t48 <= tl) ? LTO_KERNEL_PIPE48 : (t4 <= tl ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE);
-      }
+      const double t8 = rounds(16 * cus) * (p->ndim == 14 ? 76.0 : 66.0);
+      const double t48 = rounds(48 * cus) * (p->ndim == 14 ? 190.0 : 163.0);
+      const double tl = (p->ndim == 12) ? rounds(64 * cus) * 249.0 : 1e300;
+      kern = (t48 <= t8 && t48 <= tl) ? LTO_KERNEL_PIPE48 : (t8 <= tl ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PER_LANE);
     }
   }
   p->last_kernel = kern;
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
   else if (kern == LTO_KERNEL_COOP2) e = launch_indirect_stm_coop2(p->pm, a, st);
-  else if (kern == LTO_KERNEL_PIPE) e = launch_indirect_stm_pipe(p->ndim, p->pm, a, st);
-  else if (kern == LTO_KERNEL_PIPE6) e = launch_indirect_stm_pipe6(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, st);
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
@@ -936,8 +934,10 @@ void lto_direct_plan_destroy(lto_direct_plan* p) {
 
 int lto_direct_plan_set_kernel(lto_direct_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
-  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_PIPE)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP or _PIPE");
+  if (kernel == LTO_KERNEL_COOP)
+    return set_err(p->ctx, LTO_EINVAL, "the wave-specialised direct Jacobian kernel was removed in round 3 (never faster than _PER_LANE or _PIPE)");
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_PIPE)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE or _PIPE");
   p->kernel = kernel;
   return LTO_OK;
 }
@@ -1022,9 +1022,7 @@ int lto_direct_jacobian_dev(lto_direct_plan* p, void* stream, const double* X, l
   // longer fits the chip in one round.
   int kern = p->kernel;
   if (kern == LTO_KERNEL_AUTO) kern = (p->S >= 3072) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
-  hipError_t e = (kern == LTO_KERNEL_COOP)   ? launch_direct_jacobian_coop(p->nstate, a, st)
-                 : (kern == LTO_KERNEL_PIPE) ? launch_direct_jacobian_pipe(p->nstate, a, st)
-                                             : launch_direct_jacobian(p->nstate, a, st);
+  hipError_t e = (kern == LTO_KERNEL_PIPE) ? launch_direct_jacobian_pipe(p->nstate, a, st) : launch_direct_jacobian(p->nstate, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_direct_jacobian", e);
   return LTO_OK;

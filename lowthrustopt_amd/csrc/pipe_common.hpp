@@ -2,6 +2,7 @@
 // forms, one RK4 step per phase; kernels_indirect_pipe8.hip: eight-wave form, two RK4 steps per phase).
 #pragma once
 #include "kernels.hpp"
+#include <pipe_hooks.hpp>   // product: hooks/ (no-ops); `make probe`: tools/probe_hooks/
 
 namespace lto {
 
@@ -74,11 +75,8 @@ __device__ __forceinline__ PipeLane pipe_lane(const IndirectArgs& a, const int s
   return L;
 }
 
-#ifdef PIPE_PROBE   // development build (make probe, tools/probe_pipe_roles.py): max_steps carries a role mask
-#define PIPE_ROLE_ON(a, bit) (!((a).max_steps & (bit)))
-#else
-#define PIPE_ROLE_ON(a, bit) true
-#endif
+// role switches: always on in the product build, a mask in IndirectArgs::max_steps in the probe build (pipe_hooks.hpp)
+#define PIPE_ROLE_ON(a, bit) hook::role_on((a), (bit))
 
 // ----------------------------------------------------------- column role, one column per lane, coefficients through DPP
 // The 16 lanes of a DPP row are the 14 (12) STM columns of ONE segment; lane j of the row holds coefficients j and 16 + j

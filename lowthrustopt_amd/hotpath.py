@@ -626,14 +626,14 @@ class IndirectPlan:
         self.handle = h
         ctx._plans.add(self)
 
-    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE, KERNEL_PIPE6, KERNEL_PIPE8, KERNEL_COOP2, KERNEL_PIPE48 = 0, 1, 2, 3, 4, 5, 6, 7
+    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE8, KERNEL_COOP2, KERNEL_PIPE48 = 0, 1, 2, 5, 6, 7   # 3, 4: removed in round 3 (four- / six-wave forms)
 
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
 
     def last_kernel(self):
         """Name of the kernel family the last STM sweep ran (what AUTO resolved to)."""
-        return {0: "none yet", 1: "per-lane", 2: "cooperative", 3: "pipeline", 4: "pipeline6", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
+        return {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
 
     def set_cols_per_lane(self, cols):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_cols_per_lane(self.handle, int(cols)))

@@ -1,6 +1,6 @@
-"""CPU: static check of the inline-asm DPP instructions of the six-wave pipeline kernel.
+"""CPU: static check of the inline-asm DPP instructions of the pipeline kernels' column role.
 
-k_indirect_pipe6 issues its coefficient x column products as `v_fmac_f64_dpp ... row_newbcast:n` through inline asm
+k_indirect_pipe8 / k_indirect_pipe48 (col_dpp_stage, pipe_common.hpp) issue their coefficient x column products as `v_fmac_f64_dpp ... row_newbcast:n` through inline asm
 (the compiler has no pattern that folds a 64-bit DPP move into an FMA).  The compiler's hazard recognizer does not look
 inside inline asm, so the two gfx9 DPP hazards are checked here on the generated assembly of every instantiation:
   * a VALU instruction that writes a VGPR read by a DPP instruction through its DPP operand (src0) needs 2 wait states
@@ -29,17 +29,18 @@ def regs(tok):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_inline_asm_dpp_sources_are_never_written_by_a_valu_instruction_nearby(tmp_path):
-    out = str(tmp_path / "pipe.s")
-    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-exceptions", "--cuda-device-only", "-S",
-                           os.path.join(CSRC, "kernels_indirect_pipe.hip"), "-o", out])
     instrs = []          # (mnemonic, operand string) in stream order, one kernel after the other
     n_dpp = 0
-    for line in open(out):
-        line = line.split(";")[0].strip()
-        if not line or line.startswith(".") or line.endswith(":") or line.startswith("//"):
-            continue
-        parts = line.split(None, 1)
-        instrs.append((parts[0], parts[1] if len(parts) > 1 else ""))
+    for src in ("kernels_indirect_pipe8.hip", "kernels_indirect_pipe48.hip"):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-exceptions", "--cuda-device-only", "-S", "-I" + os.path.join(CSRC, "hooks"),
+                               os.path.join(CSRC, src), "-o", out])
+        for line in open(out):
+            line = line.split(";")[0].strip()
+            if not line or line.startswith(".") or line.endswith(":") or line.startswith("//"):
+                continue
+            parts = line.split(None, 1)
+            instrs.append((parts[0], parts[1] if len(parts) > 1 else ""))
     for i, (mn, ops) in enumerate(instrs):
         if mn != "v_fmac_f64_dpp":       # DPP instructions the compiler itself emits (wave reductions) are its business
             continue
@@ -56,5 +57,6 @@ def test_inline_asm_dpp_sources_are_never_written_by_a_valu_instruction_nearby(t
             pmn, pops = instrs[i - back]
             if pmn.startswith("v_") and re.match(r"\s*exec", pops):
                 raise AssertionError("VALU write of EXEC %d instruction(s) before a DPP instruction" % back)
-    # 45 DPP FMAs per RK stage for ND = 14, 37 for ND = 12, 4 stages, 4 control-law classes each
-    assert n_dpp == 4 * 4 * (45 + 37), n_dpp
+    # per RK stage 44 / 45 DPP FMAs for ND = 14 (without / with lambda_m on the chain), 37 for ND = 12; 4 stages; the eight-wave
+    # kernel carries the column step in four places (both steps of a phase, the alternating job's two waves), the 48-segment form in one
+    assert n_dpp >= 4 * 4 * (44 + 37), n_dpp

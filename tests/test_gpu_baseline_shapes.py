@@ -47,8 +47,7 @@ def test_configs3_homotopy_sweep_256_levels_x_1024_segments_with_stm(gpu_ctx, or
     S1 = n - 1
     for b in (0, 1, 100, 255):
         p1 = lto.IndirectPlan(gpu_ctx, n, 1, prms[b], integ)
-        p1.set_kernel({"per-lane": p1.KERNEL_PER_LANE, "pipeline": p1.KERNEL_PIPE, "pipeline6": p1.KERNEL_PIPE6,
-                       "pipeline8": p1.KERNEL_PIPE8, "cooperative": p1.KERNEL_COOP, "cooperative2": p1.KERNEL_COOP2, "pipeline48": p1.KERNEL_PIPE48}[kernel])    # the family the batch ran
+        p1.set_kernel({"per-lane": p1.KERNEL_PER_LANE, "pipeline8": p1.KERNEL_PIPE8, "cooperative": p1.KERNEL_COOP, "cooperative2": p1.KERNEL_COOP2, "pipeline48": p1.KERNEL_PIPE48}[kernel])    # the family the batch ran
         if kernel == "per-lane":
             p1.set_cols_per_lane(3)           # what AUTO picks for the 262 144-segment batch (kernels_indirect.hip)
         Phi1 = torch.zeros(144, S1, dtype=torch.float64, device="cuda")
@@ -152,3 +151,68 @@ def test_reference_halo_tables_through_the_hip_direct_defect(gpu_ctx, which):
     assert d.shape == (6, n - 1) and e.shape == (n - 1,)
     assert np.abs(d).max() <= 1e-8
     assert e.max() < 1e-12
+
+
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("mname", ["rk4x64", "dop853"])
+def test_reference_halo_tables_through_the_hip_indirect_kernels(gpu_ctx, which, mname):
+    """The reference's halo tables as shooting nodes of the INDIRECT transcription with zero costates: lambda_v = 0 takes the
+    lambda_v = 0 guard of CRTBP_stateCostate_deriv! (stateCostate_deriv.jl:59-64: control = 0), so the state rows are the
+    ballistic trajectory of the table -- |defect| <= 1e-8, its precision, on all 99 segments -- and the costate rows of the
+    defect are exactly 0 (lambda_dot = 0 at lambda = 0).  Fixed-step RK4 x 64 (pipeline kernels) and the reference's integrator
+    setting (adaptive order 8 @ 1e-13: the two-lane cooperative / defect kernels), STM sweep and defect-only sweep."""
+    tab = synth.halo_orbits()[which]
+    n = tab.shape[1]
+    t = synth.HALO_DT[which] * np.arange(n)
+    XC = np.zeros((12, n), order="F")
+    XC[:6] = tab
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    integ = lto.integrator(lto.RK4, steps=64) if mname == "rk4x64" else lto.integrator()
+    Phi, d = lto.indirect_stm(XC, t, prm, integ, ctx=gpu_ctx)
+    d0, _ = lto.indirect_defectCalc(XC, t, prm, integ, ctx=gpu_ctx)
+    for dd in (d, d0):
+        assert dd.shape == (12, n - 1) and np.all(np.isfinite(dd))
+        assert np.abs(dd[:6]).max() <= 1e-8
+        assert np.all(dd[6:] == 0.0)
+    assert np.all(np.isfinite(Phi))
+    # the ballistic 6x6 block of Phi has determinant 1 (Liouville); the costates do not feed the state at lambda = 0 exactly
+    # only through U = du/dlambda_v, so the full 12x12 determinant is 1 as well
+    dets = np.linalg.det(np.transpose(Phi, (2, 0, 1)))
+    assert np.abs(dets - 1.0).max() < 1e-8
+
+
+def test_configs3_size_14dim_pipe48_oracle_sample(gpu_ctx, oracle):
+    """262 144 segments of the 14-dim system (256 trajectories x 1 024 segments), RK4 x 64, defect + 14x14 STM: AUTO resolves to
+    the 48-segment pipeline; blocks of segments spread over the batch equal the oracle's dual-number STM and defect."""
+    import torch
+    n, B = 1025, 256
+    S1 = n - 1
+    S = S1 * B
+    XC1, T1 = synth.indirect_problem(n, n_batch=4, seed=21)
+    reps = B // 4
+    X14 = np.zeros((14, n, 4), order="F")
+    X14[:6] = XC1[:6]; X14[6] = (1000.0 - 0.01 * np.arange(n))[:, None]; X14[7:13] = XC1[6:]; X14[13] = 0.1
+    XC = np.asfortranarray(np.tile(X14, (1, 1, reps)))             # trajectory b = copy of trajectory b % 4
+    T = np.asfortranarray(np.tile(T1, (1, reps)))
+    prm_l = [MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0]
+    plan = lto.IndirectPlan(gpu_ctx, n, B, lto.make_params(*prm_l), lto.integrator(lto.RK4, steps=64), ndim=14)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()
+    Phi = torch.zeros(196, S, dtype=torch.float64, device="cuda")
+    d = torch.zeros(14, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(X, n * B, t, B, Phi, S, d, S)
+    torch.cuda.synchronize()
+    assert plan.last_kernel() == "pipeline48"
+    assert bool(torch.isfinite(Phi).all()) and bool(torch.isfinite(d).all())
+    plan.close()
+    for b, i0 in ((0, 0), (1, 500), (130, 47), (255, S1 - 8)):
+        tr = b % 4
+        P_o, d_o, rc = oracle.indirect14(X14[:, i0:i0 + 9, tr], T1[i0:i0 + 9, tr], prm_l, oracle.RK4, 64)
+        assert rc == 0
+        sl = slice(b * S1 + i0, b * S1 + i0 + 8)
+        Pn = Phi[:, sl].cpu().numpy().reshape(14, 14, 8).transpose(1, 0, 2)
+        dn = d[:, sl].cpu().numpy()
+        assert np.linalg.norm(dn - d_o) / np.linalg.norm(d_o + X14[:, i0 + 1:i0 + 9, tr]) < 1e-10
+        assert np.abs(Pn - P_o).max() < 1e-10 * np.abs(P_o).max()
+    # copies of a trajectory inside the batch give the same bits wherever they sit
+    assert torch.equal(Phi[:, :S1], Phi[:, 4 * S1:5 * S1]) and torch.equal(d[:, 3 * S1:4 * S1], d[:, 255 * S1:256 * S1])

@@ -1,0 +1,34 @@
+// pipe_hooks.hpp (probe version) -- same interface as lowthrustopt_amd/csrc/hooks/pipe_hooks.hpp, with the counters behind it.
+// Used by `make probe` only (build/liblto_probe.so; tools/probe_pipe_roles.py, tools/probe_coop2.py): the probe scripts pass a
+// defect buffer with spare rows, and the hooks write their figures there.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lto {
+namespace hook {
+
+constexpr bool kProbeBuild = true;
+
+struct BarrierWait {
+  long long waited = 0;
+  __device__ __forceinline__ void sync() { const long long t = clock64(); __syncthreads(); waited += clock64() - t; }
+  __device__ __forceinline__ void report(double* rows, long ld, int row, long col) const { if (rows) rows[row * ld + col] = (double)waited; }
+};
+struct RegionClock {
+  long long c0 = 0, w0 = 0;
+  __device__ __forceinline__ void start() { c0 = clock64(); w0 = wall_clock64(); }
+  __device__ __forceinline__ void report(double* rows, long ld, int row_ticks, int row_wall, long col) const {
+    if (rows) { rows[row_ticks * ld + col] = (double)(clock64() - c0); rows[row_wall * ld + col] = (double)(wall_clock64() - w0); }
+  }
+  __device__ __forceinline__ void report_ticks(double* rows, long ld, int row, long col) const { if (rows) rows[row * ld + col] = (double)(clock64() - c0); }
+};
+struct Counter {
+  int n = 0;
+  __device__ __forceinline__ void bump() { ++n; }
+  __device__ __forceinline__ void report(double* rows, long ld, int row, long col) const { if (rows) rows[row * ld + col] = (double)n; }
+};
+template <class Args>
+__device__ __forceinline__ bool role_on(const Args& a, int bit) { return !(a.max_steps & bit); }
+
+}  // namespace hook
+}  // namespace lto

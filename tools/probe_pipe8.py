@@ -31,7 +31,7 @@ def main():
             t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
             res = []
             ref = None
-            for kern, name in ((4, "pipe6"), (5, "pipe8"), (3, "pipe")):
+            for kern, name in ((5, "pipe8"), (7, "pipe48")):
                 d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
                 Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
                 plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=64), ndim=ndim)

@@ -35,8 +35,6 @@ for ndim in (14, 12):
         dh = d.cpu().numpy()
         cyc, wall = dh[17, ::16], dh[18, ::16]
         clk = " loop %.1f us, %.0f kcycles, shader clock %.3f GHz" % (np.median(wall) / 100.0, np.median(cyc) / 1e3, np.median(cyc / wall) * 0.1) if np.median(wall) > 100 else ""
-        if os.environ.get("KERNEL", "3") == "5":
-            clk += "  prologue %.2f us" % (np.median(dh[19, ::16]) / 100.0)
         if os.environ.get("KERNEL", "3") == "5":     # pipe8 probe build: cycles every wave waited at the phase barriers
             w = dh[16].reshape(-1, 16)[:, :8]
             clk += "  barrier wait kcycles by wave " + " ".join("%.0f" % (np.median(w[:, i]) / 1e3) for i in range(8))
