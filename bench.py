@@ -324,14 +324,30 @@ def leg_12dim(lto, synth, ctx, st, torch, a, reference_integrator=False):
             plan.defect(X, n, t, 1, defect, S, stream=st)
         torch.cuda.synchronize()
         el_d = time.perf_counter() - t1
-        plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)     # leave the STM sweep's outputs for the parity check
+        # the same two sweeps with the controller's warm start (lto_indirect_plan_set_warm_start): what consecutive Newton iterations see
+        plan.set_warm_start(True)
+        warm = {}
+        for name, run in (("stm", lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)), ("defect_only", lambda: plan.defect(X, n, t, 1, defect, S, stream=st))):
+            for _ in range(max(a.warmup, 2)):
+                run()
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for k in range(a.steps):
+                run()
+            torch.cuda.synchronize()
+            warm[name] = (time.perf_counter() - tw) / a.steps * 1e3
+        plan.set_warm_start(False)
+        plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st)     # leave the (cold) STM sweep's outputs for the parity check
         torch.cuda.synchronize()
         out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
                "workload": "C2 segments on the reference's 12-dim system with the reference's integrator setting: adaptive order 8 (DOP853 for "
                            "Vern8), reltol = abstol = 1e-13, defect + 12x12 STM (what jacobianCalc, indirect.jl:93-146, runs)",
                "stm_kernel": plan.last_kernel(), "roofline": roof,
                "defect_only": {"ms_per_step": el_d / a.steps * 1e3, "value": S * a.steps / el_d,
-                               "workload": "defectCalc (indirect.jl:63-90) with the same setting"}}
+                               "workload": "defectCalc (indirect.jl:63-90) with the same setting"},
+               "warm_start": {"ms_per_step": warm["stm"], "defect_only_ms_per_step": warm["defect_only"],
+                              "note": "lto_indirect_plan_set_warm_start: every segment starts from its first accepted step size of the plan's previous "
+                                      "sweep (what consecutive Newton iterations / line-search trials see); off by default, `value` is the cold sweep"}}
     else:
         out = {"value": S * a.steps / el, "unit": "segment-integrations/s", "ms_per_step": el / a.steps * 1e3,
                "workload": "C2 on the reference's CRTBP_stateCostate_deriv! system: 12-dim state+costate + 12x12 STM, 4 096 "

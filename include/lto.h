@@ -224,6 +224,14 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* plan, void* stream, int* acc
  * swept yet: LTO_EINVAL. */
 int lto_indirect_plan_rebalance(lto_indirect_plan* plan, void* stream);
 int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
+/* Warm start of the adaptive step-size controller (ndim = 12, DOP853_ADAPTIVE -- the reference's integrator setting, whose
+ * sweeps last as long as their slowest segment; other plans: LTO_EINVAL).  When on, every STM sweep / defect-only sweep of
+ * this plan that runs the two-lane kernels starts each segment from the step size that segment's first accepted step had in
+ * the plan's PREVIOUS sweep of the same kind, instead of Hairer's start rule (an extra right-hand-side evaluation and a start a
+ * decade or two low).  Consecutive Newton iterations and line-search trials sweep nearly the same trajectory, and any positive
+ * start is valid: the controller corrects it.  Results then depend on the plan's history at the level of the tolerance
+ * (1e-13), which is why it is off by default: with it off, equal inputs give equal bits.  Turning it off forgets the stored sizes. */
+int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
 
 /* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4 with >= 6 steps per segment, the three-role
  * pipeline kernels -- the eight-wave form while the batch is one round (16 segments per CU: 4 096 on MI355X), above that

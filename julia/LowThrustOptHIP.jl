@@ -14,7 +14,7 @@ module LowThrustOptHIP
 using SparseArrays, LinearAlgebra, Libdl
 
 export LtoIndirectPlan, LtoDirectPlan, LtoComm, LtoCommWindows, pinned_array, pack_soa!, unpack_soa!, defect_norms!, indirect_defect_dev!,
-       indirect_jacobian_dev!, newton_solve_dev!, axpy_dev!, direct_defect_dev!, direct_jacobian_dev!, rebalance!, set_kernel!,
+       indirect_jacobian_dev!, newton_solve_dev!, axpy_dev!, direct_defect_dev!, direct_jacobian_dev!, rebalance!, set_kernel!, set_warm_start!,
        comm_unique_id, allgather_dev!, allreduce_dev!, ctx_stream, last_call_ms
 export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, indirect_solve, indirect_solve_batch, densify,
        direct_defectCalc, direct_jacobianCalc, direct_midpoints, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
@@ -359,6 +359,8 @@ axpy_dev!(ctx::LtoContext, stream, x, d, alpha::Real, y, count::Integer) =
 rebalance!(pl::LtoIndirectPlan, stream) = check(pl.ctx, ccall((:lto_indirect_plan_rebalance, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), pl.handle, devptr(stream)))
 "LTO_KERNEL_*: 0 auto, 1 per-lane, 2 cooperative, 3 / 4 / 5 pipeline forms (RK4 plans), 6 cooperative with two lanes per state (12-dim DOP853 plans), 7 pipeline for large batches (RK4 plans)."
 set_kernel!(pl::LtoIndirectPlan, kernel::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_kernel, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, kernel))
+"Adaptive sweeps start every segment from its first accepted step size of the plan's previous sweep of the same kind (12-dim DOP853 plans; lto.h)."
+set_warm_start!(pl::LtoIndirectPlan, on::Bool = true) = check(pl.ctx, ccall((:lto_indirect_plan_set_warm_start, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, on ? 1 : 0))
 
 "Julia column-major [ndim x count] on the device -> SoA [ndim][ld] (and back)."
 pack_soa!(ctx::LtoContext, stream, aos, ndim::Integer, count::Integer, soa, ld::Integer) =

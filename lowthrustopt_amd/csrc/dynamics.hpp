@@ -980,6 +980,7 @@ struct DirectLane {
   double MU;
   double w2;       // 2 * time_direction
   double cx, cy, cz;  // control [N]
+  double tx, ty, tz;  // NS = 6 (mass literal 1000.0, :20): the thrust acceleration control * (kk * 1e-3), constant along the arc
   double kk;       // TU^2 / DU / 1e3: thrust [N] / mass [kg] -> DU/TU^2        (:32)
   double mdot;     // -time_direction * |control| / (Isp * 9.81) * TU           (:41-42)
 };
@@ -1004,9 +1005,12 @@ __device__ __forceinline__ void rhs_direct(const double (&x)[NS], const DirectLa
   const double inv_m = (NS == 7) ? rcp_nr(x[NS - 1]) : 1e-3;  // 1 / 1000.0
   const double k = L.kk * inv_m;
   dx[0] = x[3]; dx[1] = x[4]; dx[2] = x[5];
-  dx[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(L.w2, x[4], X))) + L.cx * k;  // :48
-  dx[4] = __builtin_fma(-cs, Y, __builtin_fma(-L.w2, x[3], Y)) + L.cy * k;                        // :49
-  dx[5] = __builtin_fma(-cs, Z, L.cz * k);                                                        // :50
+  // NS = 6: control * k does not change along the arc (L.tx = L.cx * (L.kk * 1e-3), the same product): kept in the lane record so
+  // that the control itself need not stay in registers through the step loops
+  const double tx = (NS == 7) ? L.cx * k : L.tx, ty = (NS == 7) ? L.cy * k : L.ty, tz = (NS == 7) ? L.cz * k : L.tz;
+  dx[3] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, __builtin_fma(L.w2, x[4], X))) + tx;        // :48
+  dx[4] = __builtin_fma(-cs, Y, __builtin_fma(-L.w2, x[3], Y)) + ty;                              // :49
+  dx[5] = __builtin_fma(-cs, Z, tz);                                                              // :50
   if (NS == 7) dx[NS - 1] = L.mdot;
   if (VAR) {
     const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;

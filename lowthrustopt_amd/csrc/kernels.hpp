@@ -24,6 +24,8 @@ struct IndirectArgs {
   const int* order;                // [S] or null: lane -> segment map of adaptive sweeps (lto_indirect_plan_rebalance)
   int class_filter;                // set by the launchers: 1 = this launch handles only trajectories of the kernel's p-class
   double stm_scale;                // 3^-(steps mod 256): the DPP column lanes of the pipeline kernels carry 3^k Phi (pipe_common.hpp)
+  double* h_first;                 // [S] or null: step size of the segment's first ACCEPTED trial step (written by the two-lane adaptive kernels)
+  int warm;                        // 1: start every segment from h_first (the previous sweep of this kind) instead of Hairer's rule
 };
 
 struct DirectArgs {

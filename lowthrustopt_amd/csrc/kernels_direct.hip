@@ -66,6 +66,7 @@ __device__ __forceinline__ void direct_setup(const DirectArgs& a, int& s, int& d
   L.w2 = 2.0 * td;
   L.cx = a.U[0 * a.ldu + node]; L.cy = a.U[1 * a.ldu + node]; L.cz = a.U[2 * a.ldu + node];
   L.kk = a.kk;
+  { const double k6 = L.kk * 1e-3; L.tx = L.cx * k6; L.ty = L.cy * k6; L.tz = L.cz * k6; }   // NS = 6: control * kk / 1000.0
   nc = sqrt(__builtin_fma(L.cx, L.cx, __builtin_fma(L.cy, L.cy, L.cz * L.cz)));
   L.mdot = -td * nc / a.isp_g0 * a.TU;                       // prop_EP_deriv.jl:42
 }
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
   constexpr int NC = (NS == 7) ? 10 : 7;       // doubles handed over per (arc, stage)
   __shared__ double s_coef[2][13][NC][ARCS];
   __shared__ double s_x[2 * NS + 1][ARCS];     // mid-point exchange: [xe (NS) | R f (NS) | maxErr][arc]
+  __shared__ double s_keep[ARCS];              // per arc: what only the epilogue needs
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), arc = threadIdx.x & 63;
   const bool is_base = (wave == 0);
@@ -230,8 +232,7 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
   const int j = jw;                            // sensitivity column of this wave
   const int seg = arc >> 1, dir = arc & 1;     // forward / backward half-arcs of a segment are lane neighbours
   const int s_raw = blockIdx.x * (ARCS / 2) + seg;
-  const int s = s_raw < a.S ? s_raw : a.S - 1; // shadow lanes repeat the last segment, store nothing
-  const bool writer = s_raw < a.S;
+  const int s = s_raw < a.S ? s_raw : a.S - 1; // shadow lanes repeat the last segment, store nothing (the epilogue decides from the lane id again)
 
   const int traj = s / a.seg_per_traj;
   const int i = s - traj * a.seg_per_traj;
@@ -239,10 +240,15 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
   const long tg = (long)traj * a.t_stride;
   const double hhalf = 0.5 * (a.t[tg + i + 1] - a.t[tg + i]);            // direct.jl:70
   const double span_total = a.t[tg + a.n_nodes - 1] - a.t[tg];           // direct.jl:506-510
+  // d(half length) / d tf is needed after the step loop only: formed here and parked in LDS, so that neither it nor the three grid
+  // values it comes from occupy registers through the loop (at 168 registers per lane they went to scratch: 10 MB of HBM writes
+  // per launch at 16 384 segments)
+  if (is_base) s_keep[arc] = hhalf / span_total;
   const double td = dir ? -1.0 : 1.0;
   DirectLane L;
   L.MU = a.MU; L.w2 = 2.0 * td; L.kk = a.kk;
   L.cx = a.U[0 * a.ldu + node]; L.cy = a.U[1 * a.ldu + node]; L.cz = a.U[2 * a.ldu + node];
+  { const double k6 = L.kk * 1e-3; L.tx = L.cx * k6; L.ty = L.cy * k6; L.tz = L.cz * k6; }   // NS = 6: control * kk / 1000.0
   const double nc = sqrt(__builtin_fma(L.cx, L.cx, __builtin_fma(L.cy, L.cy, L.cz * L.cz)));
   L.mdot = -td * nc / a.isp_g0 * a.TU;                                   // prop_EP_deriv.jl:42
 
@@ -271,28 +277,65 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
   const double h = hhalf / (double)steps;
   double maxErr = 0.0;
   // one RKF7(8) step of this lane's NS components; slope(st, arg, out) evaluates stage st
+  // NS = 7: slope by slope with the tableau coefficient materialised where it is used (coef_here, rk.hpp): with seven components,
+  // ten column waves and the mass couplings the compiler otherwise hoists the 64-bit literals of the unrolled stage loop, runs out
+  // of scalar registers and parks two dozen of them in scratch (48 dwords, reloaded every step).
+  constexpr bool BY_SLOPE = (NS == 7);
   auto rk_step = [&](auto&& slope) {
 #pragma unroll
     for (int st = 0; st < 13; ++st) {
       double arg[NS];
+      if constexpr (BY_SLOPE) {
+        double acc[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int k = 0; k < st; ++k)
+          if (TabRKF78::A[st][k] != 0.0) {
+            const double w = coef_here(TabRKF78::A[st][k]);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) acc[c] = __builtin_fma(w, K[k][c], acc[c]);
+          }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc[c], y[c]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < st; ++k)
+            if (TabRKF78::A[st][k] != 0.0) acc = __builtin_fma(TabRKF78::A[st][k], K[k][c], acc);
+          arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc, y[c]);
+        }
+      }
+      slope(st, arg, K[st]);
+    }
+    if constexpr (BY_SLOPE) {
+      double acc[NS];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) acc[c] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 13; ++k)
+        if (TabRKF78::B[k] != 0.0) {
+          const double w = coef_here(TabRKF78::B[k]);
+#pragma unroll
+          for (int c = 0; c < NS; ++c) acc[c] = __builtin_fma(w, K[k][c], acc[c]);
+        }
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        if (is_base) maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
+        y[c] = __builtin_fma(h, acc[c], y[c]);
+      }
+    } else {
 #pragma unroll
       for (int c = 0; c < NS; ++c) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < st; ++k)
-          if (TabRKF78::A[st][k] != 0.0) acc = __builtin_fma(TabRKF78::A[st][k], K[k][c], acc);
-        arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc, y[c]);
+        for (int k = 0; k < 13; ++k)
+          if (TabRKF78::B[k] != 0.0) acc = __builtin_fma(TabRKF78::B[k], K[k][c], acc);
+        if (is_base) maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
+        y[c] = __builtin_fma(h, acc, y[c]);
       }
-      slope(st, arg, K[st]);
-    }
-#pragma unroll
-    for (int c = 0; c < NS; ++c) {
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < 13; ++k)
-        if (TabRKF78::B[k] != 0.0) acc = __builtin_fma(TabRKF78::B[k], K[k][c], acc);
-      if (is_base) maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
-      y[c] = __builtin_fma(h, acc, y[c]);
     }
   };
 
@@ -323,14 +366,19 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
     __syncthreads();
   }
 
+  // Epilogue.  Who this lane is comes from the lane id again (two instructions) rather than from registers kept through the loop.
+  const int arc_e = __lane_id();
+  const int dir_e = arc_e & 1;
+  const int s_e = blockIdx.x * (ARCS / 2) + (arc_e >> 1);
+  const bool writer_e = s_e < a.S;
   if (!is_base) {
-    if (writer && a.Jac) {
-      const int col = is_ctrl ? (2 * NS + 3 * dir + jc) : (NS * dir + j);
+    if (writer_e && a.Jac) {
+      const int col = is_ctrl ? (2 * NS + 3 * dir_e + jc) : (NS * dir_e + j);
       const double rj = (!is_ctrl && j >= 3 && j < 6) ? -1.0 : 1.0;
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         const double rr = (r >= 3 && r < 6) ? -1.0 : 1.0;
-        a.Jac[(long)(col * NS + r) * a.ldj + s] = dir ? -(rr * rj) * y[r] : y[r];
+        a.Jac[(long)(col * NS + r) * a.ldj + s_e] = dir_e ? -(rr * rj) * y[r] : y[r];
       }
     }
   } else {
@@ -338,20 +386,20 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
     double f[NS];
     VarCoef6 vc;
     rhs_direct<NS, false>(y, L, f, vc);
-    if (dir) { y[3] = -y[3]; y[4] = -y[4]; y[5] = -y[5]; f[3] = -f[3]; f[4] = -f[4]; f[5] = -f[5]; }   // direct.jl:98
+    if (dir_e) { y[3] = -y[3]; y[4] = -y[4]; y[5] = -y[5]; f[3] = -f[3]; f[4] = -f[4]; f[5] = -f[5]; }   // direct.jl:98
 #pragma unroll
-    for (int c = 0; c < NS; ++c) { s_x[c][arc] = y[c]; s_x[NS + c][arc] = f[c]; }
-    s_x[2 * NS][arc] = maxErr;
+    for (int c = 0; c < NS; ++c) { s_x[c][arc_e] = y[c]; s_x[NS + c][arc_e] = f[c]; }
+    s_x[2 * NS][arc_e] = maxErr;
   }
   __syncthreads();
-  if (is_base && writer && dir == 0) {
-    const double scale = hhalf / span_total;     // d(half length) / d tf
+  if (is_base && writer_e && dir_e == 0) {
+    const double scale = s_keep[arc_e];          // d(half length) / d tf
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
-      if (a.defect) a.defect[c * a.ldd + s] = s_x[c][arc] - s_x[c][arc + 1];                            // :101
-      if (a.dtf) a.dtf[c * a.ldd + s] = (s_x[NS + c][arc] - s_x[NS + c][arc + 1]) * scale;
+      if (a.defect) a.defect[c * a.ldd + s_e] = s_x[c][arc_e] - s_x[c][arc_e + 1];                            // :101
+      if (a.dtf) a.dtf[c * a.ldd + s_e] = (s_x[NS + c][arc_e] - s_x[NS + c][arc_e + 1]) * scale;
     }
-    if (a.errors) a.errors[s] = fmax(s_x[2 * NS][arc], s_x[2 * NS][arc + 1]);                            // :104
+    if (a.errors) a.errors[s_e] = fmax(s_x[2 * NS][arc_e], s_x[2 * NS][arc_e + 1]);                            // :104
   }
 }
 

@@ -159,9 +159,17 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   int done = !(span > 0.0) || !mine;
   constexpr double NCOMP = 156.0;              // 12 + 144 components
 
-  // ---- Hairer's initial step over all components.  Row r of every column is scaled with the BASE value of row r (a dual
-  // number's partials share the scale of its value), published by the base lanes.
-  {
+  // ---- first step size.  Warm start (lto_indirect_plan_set_warm_start): the first accepted step of this segment in the plan's
+  // previous STM sweep -- consecutive Newton iterations sweep nearly the same trajectory -- which saves the two extra stage
+  // evaluations of Hairer's rule and the trial steps it takes to grow from a start that is a decade or two low.  a.warm is
+  // launch-uniform (every wave takes the same barriers); any positive value is a valid start.
+  if (a.warm) {
+    const double hw = a.h_first[s];
+    h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
+    slope(y, K[0], buf, nothing); buf ^= 1;
+  } else {
+    // Hairer's initial step over all components.  Row r of every column is scaled with the BASE value of row r (a dual
+    // number's partials share the scale of its value), published by the base lanes.
     if (BASE && !shadow) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
@@ -196,6 +204,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : cbrt(cbrt(0.01 / fmax(d1, d2)));
     h_abs = fmin(fmin(100.0 * h0, h1), span);
   }
+  double h_rec = 0.0;            // proposal that led to the first accepted step (what the next sweep starts from)
 
   hook::RegionClock c2_loop;
   hook::Counter c2_trials;
@@ -204,6 +213,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     c2_trials.bump();
     // every lane of a segment holds identical (t, h_abs, done): they are updated from identical data below
     double h = h_abs;
+    const double h_prop = h_abs;
     double last = 0.0;
     if (t + h >= span) { h = span - t; last = 1.0; }
     // Argument st (st = 1..11: stage st, weights DP8_A[st][.]; st = 12: the new state, weights DP8_B) is y + h (older + w K[st-1])
@@ -299,6 +309,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
         for (int j = 0; j < 6; ++j) y[j] = bad;
         t = span;
       } else if (accept != 0.0) {
+        if (nacc == 0) h_rec = h_prop;
         t = (last != 0.0) ? span : t + h;
 #pragma unroll
         for (int j = 0; j < 6; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
@@ -336,6 +347,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
         if (a.errors) a.errors[s] = 0.0;
         if (a.nacc) a.nacc[s] = nacc;
         if (a.nrej) a.nrej[s] = nrej;
+        if (a.h_first) a.h_first[s] = h_rec;
       }
     } else {
 #pragma unroll

@@ -55,7 +55,13 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
   if (span > 0.0) {
     rhs(y, K[0]);
     double h_abs;
-    {   // Hairer's initial step over the 12 components
+    // warm start (lto_indirect_plan_set_warm_start): the first accepted step size of this segment in the previous defect-only sweep of
+    // the plan -- consecutive Newton iterations and line-search trials sweep nearly the same trajectory -- instead of Hairer's rule,
+    // which costs an extra RHS evaluation and starts a decade or two low.  Wave-uniform choice; any positive value is a valid start.
+    if (a.warm) {
+      const double hw = a.h_first[s];
+      h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
+    } else {   // Hairer's initial step over the 12 components
       double isc[6], p0 = 0.0, p1 = 0.0;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
       const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : cbrt(cbrt(0.01 / fmax(d1, d2)));
       h_abs = fmin(fmin(100.0 * h0, h1), span);
     }
+    double h_rec = 0.0;          // proposal that led to the first accepted step (what the next sweep starts from)
     double rejected = 0.0;       // per-lane flags as doubles (DESIGN.md "Compiler hazards")
     while (t < span && nacc + nrej < a.max_steps) {
       double h = h_abs;
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
       if (err < 1.0) {
         double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 / sqrt(sqrt(sqrt(err))));
         if (rejected != 0.0) factor = fmin(1.0, factor);
+        if (nacc == 0) h_rec = h_abs;
         h_abs = h * factor;
         t = (last != 0.0) ? span : t + h;
 #pragma unroll
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) y[j] = __builtin_nan("");
     }
+    if (is_a && a.h_first) a.h_first[s] = h_rec;
   } else if (span != 0.0) {                   // decreasing grid (forward integration only) or NaN span: no result
 #pragma unroll
     for (int j = 0; j < 6; ++j) y[j] = __builtin_nan("");

@@ -87,6 +87,11 @@ struct lto_indirect_plan {
   double* d_bvp;    // workspace of the device Newton solve (lazily allocated)
   size_t bvp_bytes;
   int bvp_variant;  // -1 none, 0 square system, 1 adjoints-only least squares: what the stored factorisation is
+  // warm start of the adaptive controllers (lto_indirect_plan_set_warm_start): first accepted step size of every segment in the
+  // last STM sweep / defect-only sweep (they control different error norms, hence two arrays; lazily allocated)
+  int warm_start;
+  double* d_hfirst[2];      // [0] STM sweeps, [1] defect-only sweeps
+  int hfirst_valid[2];
 };
 
 struct lto_direct_plan {
@@ -376,6 +381,7 @@ static void plan_free(lto_indirect_plan* p) {
   pool_free(p->ctx, p->d_nrej, sizeof(int) * (size_t)p->S);
   if (!p->order_borrowed) pool_free(p->ctx, p->d_order, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS));
   pool_free(p->ctx, p->d_bvp, p->bvp_bytes);
+  for (int k = 0; k < 2; ++k) pool_free(p->ctx, p->d_hfirst[k], sizeof(double) * (size_t)p->S);
   delete p;
 }
 
@@ -439,6 +445,30 @@ int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
 
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* p) { return p ? p->last_kernel : LTO_KERNEL_AUTO; }
 
+int lto_indirect_plan_set_warm_start(lto_indirect_plan* p, int on) {
+  if (!p) return LTO_ENULL;
+  if (on && !(p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE))
+    return set_err(p->ctx, LTO_EINVAL, "warm start is built for 12-dim DOP853_ADAPTIVE plans (the reference's integrator setting)");
+  p->warm_start = on ? 1 : 0;
+  if (!on) { p->hfirst_valid[0] = 0; p->hfirst_valid[1] = 0; }
+  return LTO_OK;
+}
+
+// The h_first array of sweep kind `which` (0 STM, 1 defect-only), allocated on first use; args get it with the warm flag.
+static int warm_args(lto_indirect_plan* p, int which, bool kernel_records, IndirectArgs* a) {
+  a->h_first = nullptr; a->warm = 0;
+  if (!p->warm_start || !kernel_records) return LTO_OK;
+  if (!p->d_hfirst[which]) {
+    hipError_t e = pool_alloc(p->ctx, (void**)&p->d_hfirst[which], sizeof(double) * (size_t)p->S);
+    if (e != hipSuccess) { p->d_hfirst[which] = nullptr; return set_err(p->ctx, LTO_EHIP, "warm-start array", e); }
+    p->hfirst_valid[which] = 0;
+  }
+  a->h_first = p->d_hfirst[which];
+  a->warm = p->hfirst_valid[which];
+  p->hfirst_valid[which] = 1;          // the sweep about to be launched fills it (stream order)
+  return LTO_OK;
+}
+
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
   if (!p) return LTO_ENULL;
   if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2 or 3");
@@ -485,6 +515,8 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   // LTO_KERNEL_PER_LANE / LTO_KERNEL_COOP2 on the plan force one form.
   const bool two_lane = p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE &&
                         (p->kernel == LTO_KERNEL_COOP2 || (p->kernel == LTO_KERNEL_AUTO && p->S <= 262144));
+  rc = warm_args(p, 1, two_lane, &a);
+  if (rc) return rc;
   hipError_t e = two_lane          ? launch_indirect_defect2(p->pm, a, st)
                  : (p->ndim == 12) ? launch_indirect_defect(p->pm, p->integ.method, a, st)
                                    : launch_indirect14_defect(p->pm, p->integ.method, a, st);
@@ -533,6 +565,8 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
     }
   }
   p->last_kernel = kern;
+  rc = warm_args(p, 0, kern == LTO_KERNEL_COOP2, &a);
+  if (rc) return rc;
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
   else if (kern == LTO_KERNEL_COOP2) e = launch_indirect_stm_coop2(p->pm, a, st);

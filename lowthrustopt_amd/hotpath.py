@@ -631,6 +631,11 @@ class IndirectPlan:
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
 
+    def set_warm_start(self, on=True):
+        """Adaptive sweeps of this plan start every segment from its first accepted step size of the plan's previous sweep of
+        the same kind (lto_indirect_plan_set_warm_start; 12-dim DOP853 plans)."""
+        self.ctx.check(self.ctx.lib.lto_indirect_plan_set_warm_start(self.handle, 1 if on else 0))
+
     def last_kernel(self):
         """Name of the kernel family the last STM sweep ran (what AUTO resolved to)."""
         return {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]

@@ -639,6 +639,60 @@ def test_indirect_adaptive_full_size_properties(gpu_ctx, oracle, inputs):
     plan.close()
 
 
+def test_indirect_warm_start_of_the_step_size_controller(gpu_ctx, oracle):
+    """lto_indirect_plan_set_warm_start (12-dim DOP853, the reference's integrator setting): sweeps after the first start every
+    segment from its first accepted step size of the previous sweep of the same kind.  Same flow to the tolerance (vs the cold
+    sweep and vs the oracle), no more trial steps than cold, no rejected first steps to speak of; off again: the cold bits; other
+    plans refuse it."""
+    import torch
+    n = 200
+    S = n - 1
+    XC, T = synth.indirect_problem(n, seed=4, dt_range=(0.05, 0.4))
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1e-2]
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator())
+
+    def sweeps():
+        Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+        d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        d0 = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(X, n, t, 1, Phi, S, d, S)
+        torch.cuda.synchronize()
+        acc, rej = plan.step_counts()
+        plan.defect(X, n, t, 1, d0, S)
+        torch.cuda.synchronize()
+        acc0, rej0 = plan.step_counts()
+        return Phi.cpu().numpy(), d.cpu().numpy(), d0.cpu().numpy(), acc + rej, acc0 + rej0, rej, rej0
+
+    cold = sweeps()
+    assert np.array_equal(sweeps()[0], cold[0])                       # off: equal inputs, equal bits
+    plan.set_warm_start(True)
+    first = sweeps()                                                  # nothing stored yet: still the cold start
+    assert np.array_equal(first[0], cold[0]) and np.array_equal(first[2], cold[2])
+    warm = sweeps()
+    pscale = np.abs(cold[0]).max()
+    assert np.abs(warm[0] - cold[0]).max() < 1e-11 * pscale and np.abs(warm[1] - cold[1]).max() < 1e-11 and np.abs(warm[2] - cold[2]).max() < 1e-11
+    assert warm[3].sum() <= cold[3].sum() and warm[4].sum() <= cold[4].sum()          # fewer trial steps in all
+    assert warm[3].max() <= cold[3].max() and warm[4].max() <= cold[4].max()          # and for the slowest segment, which sets the sweep time
+    assert warm[5].sum() <= cold[5].sum() + S // 20 and warm[6].sum() <= cold[6].sum() + S // 20
+    Pw = warm[0].reshape(12, 12, S).transpose(1, 0, 2)
+    for i in (0, 57, S - 1):
+        y, P_o, rc, _, _ = oracle.flow_stm_state_costate(XC[:, i, 0], prm_l, T[i + 1, 0] - T[i, 0], oracle.DOP853_ADAPTIVE, 0)
+        assert rc == 0
+        assert np.abs(Pw[:, :, i] - P_o).max() < 1e-9 * np.abs(P_o).max()
+        assert np.linalg.norm(warm[1][:, i] - (y - XC[:, i + 1, 0])) < 1e-10 * np.linalg.norm(y)
+    plan.set_warm_start(False)
+    again = sweeps()
+    assert np.array_equal(again[0], cold[0]) and np.array_equal(again[2], cold[2])
+    plan.close()
+    for ndim, integ in ((14, lto.integrator()), (12, lto.integrator(lto.RK4, steps=8))):
+        p2 = lto.IndirectPlan(gpu_ctx, 8, 1, lto.make_params(MU, DU, TU, 0.05, 2000.0 if ndim == 14 else 1000.0, 1.0, 1.0, 1.0), integ, ndim=ndim)
+        with pytest.raises(lto.LtoError):
+            p2.set_warm_start(True)
+        p2.close()
+
+
 @pytest.mark.parametrize("ndim", [12, 14])
 @pytest.mark.parametrize("kernel", ["per_lane", "coop"])
 def test_indirect_rebalance_changes_order_not_results(gpu_ctx, ndim, kernel):
