@@ -6,7 +6,8 @@ OUT=gpurun_out/${1:-run}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 last() { tail -1 "$1" | cut -c1-400; }
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > "$OUT/pytest_gpu.log"
+# progress goes straight into the log (a pipe into tail would hold it back until the end: the GPU box kills a run that stays silent for 7 minutes)
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
 tail -3 "$OUT/pytest_gpu.log"
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null > "$OUT/bench_c2_driver.json"; last "$OUT/bench_c2_driver.json"
 python bench.py --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_200.json"; last "$OUT/bench_c2_200.json"
