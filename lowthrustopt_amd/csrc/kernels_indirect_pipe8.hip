@@ -1,27 +1,36 @@
-// kernels_indirect_pipe8.hip -- eight-wave form of the three-role pipeline for the fixed-step RK4 STM sweep (BASELINE
-// configs[1]); replaces the serial loop of jacobianCalc (src/multiShoot_CRTBP_indirect.jl:93-146).
+// kernels_indirect_pipe8.hip -- the three-role software pipeline for the fixed-step RK4 STM sweep (BASELINE configs[1]); replaces
+// the serial loop of jacobianCalc (src/multiShoot_CRTBP_indirect.jl:93-146).
 //
-// Why another form.  In the six-wave kernel (kernels_indirect_pipe.hip) a workgroup of 16 segments carries, per RK4 step,
-// ~560 instructions of base wave (alone on its SIMD: the sweep's dependent chain), ~180 of coefficient wave (alone on its
-// SIMD) and 4 x ~340 of column waves, two per SIMD on the remaining two SIMDs.  A wavefront cannot be split and cannot
-// move, so the only way to level the SIMDs is to let a fourth of the column work ALTERNATE between two SIMDs in time.
-// Here a phase is TWO RK4 steps (one workgroup barrier per phase) and the columns of segments 12..15 are advanced by two
-// wavefronts in turn:
+// At 4 096 segments the chip offers 16 lanes per segment (1 024 SIMDs x 64 lanes) and a sweep lasts as long as the longest
+// instruction stream of a workgroup.  A workgroup owns 16 segments and runs three roles in different wavefronts, skewed by one RK4
+// STEP each, so that they execute concurrently:
 //
-//   wave  SIMD  role                                         instructions per phase (two steps)
+//   base      integrates the ND-dim base state and publishes, per stage, the part of the stage argument the coefficients depend
+//             on (r, lambda_v [, m]); round 3: two lanes of a segment's quad evaluate stages 1 | 2 and then 3 | 4 side by side
+//             (pipe8_role_base_paired)
+//   coef      one step behind: lane = (segment, RK stage); builds G, H, U (+ mass couplings) at those arguments
+//   columns   two steps behind: c' = F(t) c with the coefficients of the stage -- no gravity, no control law, no base state in
+//             these lanes; lane = (segment, ONE column), a DPP row = one segment, coefficient x entry = v_fmac_f64_dpp row_newbcast
+//
+// Four column waves do not fit three SIMDs evenly (a wavefront cannot be split and cannot move), so a phase is TWO RK4 steps (one
+// workgroup barrier per phase) and the columns of segments 12..15 are advanced by two wavefronts in turn:
+//
+//   wave  SIMD  role                                         instructions per phase (two steps), ND = 14
 //   w0    A     columns of segments 0..3,  both steps        680
 //   w4    A     columns of segments 12..15, EVEN step        340   -> hands the 14 doubles per lane to w5 through LDS
 //   w1    B     columns of segments 4..7,  both steps        680
 //   w5    B     columns of segments 12..15, ODD step         340   <- waits for w4's flag
-//   w2    C     base trajectory, both steps                  ~1100 (the chain: nothing else on this SIMD)
+//   w2    C     base trajectory, both steps                  ~860 (paired stages; round 2: ~1100)
 //   w6    C     exits at once
 //   w3    D     coefficients of both steps                   ~360
 //   w7    D     columns of segments 8..11, both steps        680
 //
 // (hardware places wave i and wave i + 4 of a workgroup on the same SIMD: tools/micro/sync_probe.hip).  w4 runs with
-// raised priority so that its step finishes early in the phase and w5 can interleave with w1.
+// raised priority so that its step finishes early in the phase and w5 can follow.  A SIMD works through its wavefronts' streams
+// essentially one after the other at the issue rate of a lone wavefront (tools/micro/prio_probe.hip), so what bounds the sweep is
+// (sum of the workgroup's streams) / 4: DESIGN.md section 6.
 //
-// Skew: ONE RK4 step per hand-over, as in the one-step-per-phase kernels, although the barrier comes every two steps.  In
+// Skew: ONE RK4 step per hand-over although the barrier comes every two steps.  In
 // phase p the base wave integrates steps 2p, 2p + 1; the coefficient wave builds steps 2p - 1 (published before the last
 // barrier) and 2p (published during this phase: it waits for the base wave's counter); the column waves advance steps
 // 2p - 2 (coefficients complete since the last barrier) and 2p - 1 (built during this phase: they wait for the coefficient
@@ -84,9 +93,10 @@ __device__ __forceinline__ void p8_signal(int* flag, const int value) {
   asm volatile("" ::: "memory");
 }
 
-// ---------------------------------------------------------------------------------------------------------- base role
-// As pipe_role_base (row g of the wave keeps the argument of stage g in registers; ONE set of stores per step publishes all
-// four stages), two steps per phase.  Tried and dropped: rows 1..3 switched off and the stage arguments stored stage by
+// ------------------------------------------------- base role, one stage after the other (ND = 14 with lambda_m on the chain only)
+// Row g of the wave keeps the argument of stage g in registers; ONE set of stores per step publishes all four stages; two steps per
+// phase.  The unclamped p > 1 laws of the 14-dim system depend on the stage's lambda_m and mass, so their stages do not pair: every
+// other instantiation uses pipe8_role_base_paired below.  Tried and dropped: rows 1..3 switched off and the stage arguments stored stage by
 // stage from row 0 -- the three redundant rows cost ~5 us while the device is still raising its clocks (nothing in steady state), but twelve more
 // LDS stores per step on the chain cost more (S = 29: 79 -> 84 us).
 template <int ND, int PM>

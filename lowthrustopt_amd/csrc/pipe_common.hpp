@@ -1,5 +1,5 @@
-// pipe_common.hpp -- pieces shared by the three-role pipeline kernels (kernels_indirect_pipe.hip: four- and six-wave
-// forms, one RK4 step per phase; kernels_indirect_pipe8.hip: eight-wave form, two RK4 steps per phase).
+// pipe_common.hpp -- pieces shared by the three-role pipeline kernels (kernels_indirect_pipe8.hip: 16 segments and eight waves per
+// workgroup, two RK4 steps per phase; kernels_indirect_pipe48.hip: 48 segments and sixteen waves, one step per phase).
 #pragma once
 #include "kernels.hpp"
 #include <pipe_hooks.hpp>   // product: hooks/ (no-ops); `make probe`: tools/probe_hooks/
@@ -28,12 +28,7 @@ template <int PM> struct PipeArg<14, PM> {
   using Coef = VarCoef14;
 };
 
-// Layout of the coefficient records in LDS, one record per (step parity, stage, segment).
-struct CoefByValue {     // [value][segment]: what a lane that reads ALL values of its segment wants (k_indirect_pipe)
-  static constexpr bool SCALED = false;
-  template <int NC> static constexpr int stage_doubles() { return NC * PIPE_SEG; }
-  template <int ND> __device__ static int at(int e, int seg) { return e * PIPE_SEG + seg; }
-};
+// Layout of the coefficient records in LDS, one record per (ring slot, stage, segment).
 struct CoefBySegment {   // [segment][value], records padded to 33 doubles: the coefficient wave's stores (one record per
   static constexpr int LD = 33;   // lane) and the column rows' loads (one record per row) are both conflict-free
   static constexpr bool SCALED = true;
