@@ -916,6 +916,7 @@ __device__ __forceinline__ void rhs14_base(const double (&y)[14], const TrajPara
 }
 
 // ----------------------------------------------------- the base RHS split for the paired-stage base role (pipe8)
+// (and, inside a stage, the two gravitating bodies split over two lanes)
 // In classical RK4 on this system the arguments r and lambda_v of stage 2 do not depend on the expensive part of stage 1
 // (gravity, control law): r_2 = r + h/2 v, lambda_v,2 = lambda_v + h/2 (2 w J lambda_v - lambda_r); likewise stage 4's on stage
 // 3's.  Two lanes of a segment therefore evaluate the expensive parts of stages (1, 2) and then (3, 4) side by side.  What a
@@ -929,34 +930,39 @@ struct StageOwn {
   double av[3], gl[3];
   double gf, sc;
 };
-template <int ND, int PM>
+// `swap_body` returns its argument as held by the lane that evaluates the OTHER gravitating body of the same stage (a DPP move in
+// the caller's lane layout).  A lane evaluates ONE body's inverse-distance powers: body_off = MU (primary 1) or MU - 1 (primary
+// 2), body_kap = 1 - MU or MU, body_sgn = -1 or +1 (the other body's x offset relative to this one's); the two lanes swap
+// c_b = kappa_b / d_b^{3/2} and t_b = e_b (rho_b . lambda_v).  In the lanes of primary 1 every sum below has the operand order of
+// rhs12_base / rhs14_base (same bits); the lanes of primary 2 differ from them by round-off and are never used as a source.
+template <int ND, int PM, class Swap>
 __device__ __forceinline__ void base_stage_own(const double x, const double yy, const double z, const double lx, const double ly,
-                                               const double lz, const TrajParams& tp, StageOwn& o) {
+                                               const double lz, const TrajParams& tp, const double body_off, const double body_kap,
+                                               const double body_sgn, Swap&& swap_body, StageOwn& o) {
   static_assert(ND == 12 || PM == PM_P0 || PM == PM_P1, "ND = 14: only the laws whose thrust is cT sigma(n) / mass");
-  const double MU = tp.MU;
-  const double a = x + MU, b = a - 1.0;
+  const double rx = x + body_off, rx_o = rx + body_sgn;
   const double yz2 = __builtin_fma(yy, yy, z * z);
-  const double d1 = __builtin_fma(a, a, yz2), d2 = __builtin_fma(b, b, yz2);
-  const double i1 = rsqrt_nr(d1), i2 = rsqrt_nr(d2);
-  const double i1s = i1 * i1, i2s = i2 * i2;
-  const double c1 = (1.0 - MU) * (i1s * i1), c2 = MU * (i2s * i2);
-  const double cs = c1 + c2, omc = 1.0 - cs;
-  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double d = __builtin_fma(rx, rx, yz2);
+  const double i = rsqrt_nr(d);
+  const double is = i * i;
+  const double c = body_kap * (is * i);
+  const double e = 3.0 * c * is;
   const double n2 = __builtin_fma(lx, lx, __builtin_fma(ly, ly, lz * lz));
   const double inv_n = inv_norm_guarded(n2);
   const double n = n2 * inv_n;
   const double yzl = __builtin_fma(yy, ly, z * lz);
-  const double s1 = __builtin_fma(a, lx, yzl), s2 = __builtin_fma(b, lx, yzl);
-  const double t1 = e1 * s1, t2 = e2 * s2;
-  const double es = t1 + t2;
-  const double tA = __builtin_fma(t1, a, t2 * b);
+  const double t = e * __builtin_fma(rx, lx, yzl);
+  const double c_o = swap_body(c), t_o = swap_body(t);
+  const double cs = c + c_o, omc = 1.0 - cs;
+  const double es = t + t_o;
+  const double tA = __builtin_fma(t, rx, t_o * rx_o);
   o.gl[0] = __builtin_fma(-omc, lx, -tA);
   o.gl[1] = __builtin_fma(-omc, ly, -es * yy);
   o.gl[2] = __builtin_fma(cs, lz, -es * z);
   if constexpr (ND == 12) {
     double m, ua;
     control_base12<PM>(tp, n, inv_n, m, ua);
-    o.av[0] = __builtin_fma(-ua, lx, __builtin_fma(-c1, a, __builtin_fma(-c2, b, x)));
+    o.av[0] = __builtin_fma(-ua, lx, __builtin_fma(-c, rx, __builtin_fma(-c_o, rx_o, x)));
     o.av[1] = __builtin_fma(-ua, ly, __builtin_fma(-cs, yy, yy));
     o.av[2] = __builtin_fma(-ua, lz, -cs * z);
     o.gf = 0.0; o.sc = 0.0;
@@ -968,7 +974,7 @@ __device__ __forceinline__ void base_stage_own(const double x, const double yy, 
       o.sc = tp.cT;
     }
     o.gf = o.sc * inv_n;
-    o.av[0] = __builtin_fma(-c1, a, __builtin_fma(-c2, b, x));
+    o.av[0] = __builtin_fma(-c, rx, __builtin_fma(-c_o, rx_o, x));
     o.av[1] = __builtin_fma(-cs, yy, yy);
     o.av[2] = -cs * z;
   }

@@ -182,8 +182,10 @@ __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const Pip
 // row_newbcast only), and everything that is cheap -- Coriolis and identity rows, the stage arguments, the RK4 sums -- is
 // computed by every lane of the quad redundantly, so after the exchange all four lanes hold the same bits again.
 // Each lane publishes the argument of its own stage before evaluating it (the old role's `remember` moves are gone); the
-// stage masses of ND = 14 follow once they exist.  Lanes 2 / 3 of a quad duplicate lanes 0 / 1 (same addresses, same
-// values).  ND = 14 with lambda_m on the chain (unclamped p > 1 laws: the law itself depends on the stage's lambda_m and
+// stage masses of ND = 14 follow once they exist.  Lanes 2 / 3 of a quad hold the same state as lanes 0 / 1 (they publish to the
+// same addresses the same values) and take the second gravitating body off them: inside an evaluation a lane forms the
+// inverse-distance powers of ONE primary and swaps c_b, t_b with the lane of the other (base_stage_own; one reciprocal square
+// root and 13 instructions fewer per evaluation, four more DPP moves).  ND = 14 with lambda_m on the chain (unclamped p > 1 laws: the law itself depends on the stage's lambda_m and
 // mass) keeps the one-stage-at-a-time role above.
 template <int CTRL>
 __device__ __forceinline__ double quad_from(const double x) {      // CTRL = quad_perm code
@@ -191,8 +193,11 @@ __device__ __forceinline__ double quad_from(const double x) {      // CTRL = qua
   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double from_a(const double x) { return quad_from<0xA0>(x); }   // quad_perm:[0,0,2,2]
-__device__ __forceinline__ double from_b(const double x) { return quad_from<0xF5>(x); }   // quad_perm:[1,1,3,3]
+// Lane q of a segment's quad: stage slot q & 1 (A: stages 1, 3; B: stages 2, 4), gravitating body q >> 1.  Everything that leaves
+// an evaluation comes from lanes 0 (A) and 1 (B), the lanes of primary 1, whose operand order is that of rhs12_base / rhs14_base.
+__device__ __forceinline__ double from_a(const double x) { return quad_from<0x00>(x); }       // quad_perm:[0,0,0,0]
+__device__ __forceinline__ double from_b(const double x) { return quad_from<0x55>(x); }       // quad_perm:[1,1,1,1]
+__device__ __forceinline__ double other_body(const double x) { return quad_from<0x4E>(x); }   // quad_perm:[2,3,0,1]
 
 template <int ND, int PM>
 __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, const PipeLane& L, const int seg, const int q,
@@ -207,6 +212,9 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
   const int steps = a.steps;
   const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0), w2 = L.w2;
   const bool is_b = (q & 1) != 0;
+  const bool body2 = (q & 2) != 0;                   // this lane's gravitating body: primary 1 (x + MU) or primary 2 (x + MU - 1)
+  const double body_off = body2 ? L.tp.MU - 1.0 : L.tp.MU, body_kap = body2 ? L.tp.MU : 1.0 - L.tp.MU, body_sgn = body2 ? 1.0 : -1.0;
+  auto swap_body = [](const double v) { return other_body(v); };
   const double gA = is_b ? h2 : 0.0;                 // round 1, own stage argument (rows r, lambda_v): y + gA k1
   const double al = is_b ? 0.0 : h2, be = is_b ? h : 0.0;   // round 2: y + al k2 + be k3
   const int own = is_b ? SLAB : 0;                   // own stage's slab relative to the round's first
@@ -235,15 +243,19 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
 #pragma unroll
         for (int i = 0; i < 3; ++i) { pr[i] = __builtin_fma(gA, y[V + i], y[i]); pl[i] = __builtin_fma(gA, kl1[i], y[LV + i]); }
         publish(slab + own, pr, pl);
-        base_stage_own<ND, PM>(pr[0], pr[1], pr[2], pl[0], pl[1], pl[2], L.tp, o);
+        base_stage_own<ND, PM>(pr[0], pr[1], pr[2], pl[0], pl[1], pl[2], L.tp, body_off, body_kap, body_sgn, swap_body, o);
         double a1[3], a2[3], g1[3], g2[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { a1[i] = from_a(o.av[i]); a2[i] = from_b(o.av[i]); g1[i] = from_a(o.gl[i]); g2[i] = from_b(o.gl[i]); }
-        double kv1[3], kv2[3], km1 = 0.0, km2 = 0.0, y3m = 0.0, gf2 = 0.0;
+        double kv1[3], kv2[3], km1 = 0.0, km2 = 0.0, y2m = 0.0, y3m = 0.0, im2 = 0.0, im3 = 0.0, gf2 = 0.0;
         if constexpr (M14) {
           const double u1 = from_a(o.gf) * inv_m;
           gf2 = from_b(o.gf);
           km1 = -kt * from_a(o.sc); km2 = -kt * from_b(o.sc);
+          // the masses of stages 2 and 3 need only these two mass rates: both reciprocals from ONE (1/a = b/(ab), 1/b = a/(ab))
+          y2m = __builtin_fma(h2, km1, y[MI]); y3m = __builtin_fma(h2, km2, y[MI]);
+          const double r23 = rcp_nr(y2m * y3m);
+          im2 = y3m * r23; im3 = y2m * r23;
           kv1[0] = __builtin_fma(w2, y[V + 1], __builtin_fma(-u1, y[LV], a1[0]));
           kv1[1] = __builtin_fma(-w2, y[V], __builtin_fma(-u1, y[LV + 1], a1[1]));
           kv1[2] = __builtin_fma(-u1, y[LV + 2], a1[2]);
@@ -256,13 +268,11 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
           y2v[i] = __builtin_fma(h2, kv1[i], y[V + i]); y2g[i] = __builtin_fma(h2, g1[i], y[LR + i]); y2l[i] = __builtin_fma(h2, kl1[i], y[LV + i]);
         }
         if constexpr (M14) {
-          const double y2m = __builtin_fma(h2, km1, y[MI]);
           slab[3 * PIPE_SEG] = y[MI]; slab[SLAB + 3 * PIPE_SEG] = y2m;
-          const double u2 = gf2 * rcp_nr(y2m);
+          const double u2 = gf2 * im2;
           kv2[0] = __builtin_fma(w2, y2v[1], __builtin_fma(-u2, y2l[0], a2[0]));
           kv2[1] = __builtin_fma(-w2, y2v[0], __builtin_fma(-u2, y2l[1], a2[1]));
           kv2[2] = __builtin_fma(-u2, y2l[2], a2[2]);
-          y3m = __builtin_fma(h2, km2, y[MI]);
         } else {
           kv2[0] = __builtin_fma(w2, y2v[1], a2[0]); kv2[1] = __builtin_fma(-w2, y2v[0], a2[1]); kv2[2] = a2[2];
         }
@@ -285,15 +295,20 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
           pl[i] = __builtin_fma(be, kl3[i], __builtin_fma(al, kl2[i], y[LV + i]));
         }
         publish(slab + 2 * SLAB + own, pr, pl);
-        base_stage_own<ND, PM>(pr[0], pr[1], pr[2], pl[0], pl[1], pl[2], L.tp, o);
+        base_stage_own<ND, PM>(pr[0], pr[1], pr[2], pl[0], pl[1], pl[2], L.tp, body_off, body_kap, body_sgn, swap_body, o);
         double a3[3], a4[3], g3[3], g4[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { a3[i] = from_a(o.av[i]); a4[i] = from_b(o.av[i]); g3[i] = from_a(o.gl[i]); g4[i] = from_b(o.gl[i]); }
-        double kv3[3], kv4[3], km3 = 0.0, km4 = 0.0, gf4 = 0.0;
+        double kv3[3], kv4[3], km3 = 0.0, km4 = 0.0, y4m = 0.0, mnew = 0.0, im4 = 0.0, gf4 = 0.0;
         if constexpr (M14) {
-          const double u3 = from_a(o.gf) * rcp_nr(y3m);
+          const double u3 = from_a(o.gf) * im3;
           gf4 = from_b(o.gf);
           km3 = -kt * from_a(o.sc); km4 = -kt * from_b(o.sc);
+          // stage 4's mass and the next step's: again both reciprocals from one
+          y4m = __builtin_fma(h, km3, y[MI]);
+          mnew = __builtin_fma(h6, km4, __builtin_fma(h3, km3, am));
+          const double r4n = rcp_nr(y4m * mnew);
+          im4 = mnew * r4n; inv_m = y4m * r4n;
           kv3[0] = __builtin_fma(w2, y3v[1], __builtin_fma(-u3, y3l[0], a3[0]));
           kv3[1] = __builtin_fma(-w2, y3v[0], __builtin_fma(-u3, y3l[1], a3[1]));
           kv3[2] = __builtin_fma(-u3, y3l[2], a3[2]);
@@ -306,9 +321,8 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
           y4v[i] = __builtin_fma(h, kv3[i], y[V + i]); y4g[i] = __builtin_fma(h, g3[i], y[LR + i]); y4l[i] = __builtin_fma(h, kl3[i], y[LV + i]);
         }
         if constexpr (M14) {
-          const double y4m = __builtin_fma(h, km3, y[MI]);
           slab[2 * SLAB + 3 * PIPE_SEG] = y3m; slab[3 * SLAB + 3 * PIPE_SEG] = y4m;
-          const double u4 = gf4 * rcp_nr(y4m);
+          const double u4 = gf4 * im4;
           kv4[0] = __builtin_fma(w2, y4v[1], __builtin_fma(-u4, y4l[0], a4[0]));
           kv4[1] = __builtin_fma(-w2, y4v[0], __builtin_fma(-u4, y4l[1], a4[1]));
           kv4[2] = __builtin_fma(-u4, y4l[2], a4[2]);
@@ -323,7 +337,7 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
           y[LR + i] = __builtin_fma(h6, g4[i], __builtin_fma(h3, g3[i], ag[i]));
           y[LV + i] = __builtin_fma(h6, kl4[i], __builtin_fma(h3, kl3[i], alv[i]));
         }
-        if constexpr (M14) { y[MI] = __builtin_fma(h6, km4, __builtin_fma(h3, km3, am)); inv_m = rcp_nr(y[MI]); }
+        if constexpr (M14) y[MI] = mnew;
         if (!(step & 1)) p8_signal(&fl->base_steps, step + 1);   // the phase's first step: the coefficient wave is waiting for it
       }
     }
