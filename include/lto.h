@@ -264,6 +264,11 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  * different segments, twelve column waves with one segment per DPP row. */
 #define LTO_KERNEL_PIPE48 7
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
+/* Lanes per segment of the DEFECT-ONLY sweep of an ndim = 12 DOP853_ADAPTIVE plan (the reference's setting, indirect.jl:63-90):
+ * 0 = choose (default: four lanes -- a DPP quad per segment: r, v, lambda_v, lambda_r -- up to eight wavefronts of 16 segments per
+ * SIMD, i.e. 512 x CUs segments (131 072 on MI355X); two lanes up to 262 144 segments; one beyond), or 1, 2, 4.  Two and four
+ * lanes on other plans: LTO_EINVAL. */
+int lto_indirect_plan_set_defect_lanes(lto_indirect_plan* plan, int lanes);
 /* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* plan);
 /* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3); 0 = choose from S. */

@@ -95,6 +95,7 @@ SIGNATURES = {
     "lto_indirect_plan_rebalance": (C.c_int, [_vp, _vp]),
     "lto_indirect_plan_reset_order": (C.c_int, [_vp]),
     "lto_indirect_plan_set_warm_start": (C.c_int, [_vp, C.c_int]),
+    "lto_indirect_plan_set_defect_lanes": (C.c_int, [_vp, C.c_int]),
     "lto_indirect_plan_set_kernel": (C.c_int, [_vp, C.c_int]),
     "lto_direct_plan_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LtoDirectParams),
                                          C.POINTER(_vp)]),

@@ -64,6 +64,8 @@ hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const Indirect
 hipError_t launch_indirect_stm_coop2(int pm, const IndirectArgs& a, hipStream_t st);
 // defect-only sweep with two lanes per segment (kernels_indirect_defect2.hip): 12-dim, DOP853 adaptive only
 hipError_t launch_indirect_defect2(int pm, const IndirectArgs& a, hipStream_t st);
+// ... with four lanes per segment (same file): while the chip has a SIMD per 16 segments to spare
+hipError_t launch_indirect_defect4(int pm, const IndirectArgs& a, hipStream_t st);
 // three-role pipeline, fixed-step RK4 only: base wave, coefficient wave and column waves per 16 segments, skewed by one RK4 step.
 // Eight-wave form (kernels_indirect_pipe8.hip): one STM column per lane with the coefficients broadcast inside the FMA (v_fmac_f64_dpp
 // row_newbcast), two RK4 steps per phase, a fourth of the column work alternates between two SIMDs, base role with paired stages

@@ -34,13 +34,14 @@
 namespace lto {
 
 constexpr int C2_SEG = 16;      // segments per workgroup
-constexpr int C2_ROLES = 26;    // 12 top halves, 12 bottom halves, base A, base B
+constexpr int C2_ROLES = 28;    // 12 top halves, 12 bottom halves, the four base lanes (r, v, lambda_v, lambda_r)
+constexpr int C2_PUB = 14;      // rows of the published stage record (13 + one spare row for the lanes that have nothing to add)
 constexpr int C2_PAD = 28;      // row pitch of the partial-sum table (16-byte aligned rows)
 
 enum C2Role : int { C2_TOP = 0, C2_BOTTOM = 1, C2_BASE = 2 };
 
 struct C2Shared {
-  double pub[2][13][C2_SEG];                 // base argument (r, lambda_v) + by-products of the stage, double-buffered
+  double pub[2][C2_PUB][C2_SEG];                // base argument (r, lambda_v) + by-products of the stage, double-buffered
   double xch[2][2][12][3][C2_SEG];           // [buffer][half that wrote][column][j][segment]: first triple of the stage argument
   alignas(16) double part[2][3][C2_SEG][C2_PAD];  // partial norms [trial parity][which][segment][role]
   double scale[12][C2_SEG];                  // 1 / (atol + rtol |base value|) of global row r
@@ -55,28 +56,28 @@ template <int PM, int ROLE>
 __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, const int lane, const int cwave) {
   constexpr bool BASE = (ROLE == C2_BASE);
   constexpr int NS = 12;
+  constexpr int NC = BASE ? 3 : 6;       // components per lane: a base lane owns one triple, a column lane half a column
   // ---- who is this lane
   int seg, col = 0;
-  bool is_a = true, shadow = false;
+  const int q4 = lane & 3;               // base wave: the quad's lane (r, v, lambda_v, lambda_r)
+  constexpr bool shadow = false;
   if (BASE) {
-    // rows of 16 lanes = banks A B A B of four segments each; rows 2, 3 repeat rows 0, 1 (store nothing)
-    seg = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + (lane & 3);
-    is_a = ((lane >> 2) & 1) == 0;
-    shadow = lane >= 32;
+    seg = lane >> 2;
   } else {
     seg = lane & (C2_SEG - 1);
     col = cwave * 4 + (lane >> 4);
   }
-  const bool natural = BASE ? is_a : (ROLE == C2_TOP);      // own rows are global rows 0..5; else (9, 10, 11, 6, 7, 8)
-  int grow[6];
+  // own rows in global numbering.  Column halves: top 0..5, bottom (9, 10, 11, 6, 7, 8); base lanes: 0.., 3.., 9.., 6..
+  int grow[NC];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) grow[j] = natural ? j : (j < 3 ? 9 + j : 3 + j);
-  const int role = BASE ? (is_a ? 24 : 25) : (ROLE == C2_TOP ? col : 12 + col);
+  for (int j = 0; j < NC; ++j)
+    grow[j] = BASE ? ((q4 == 0) ? 0 : (q4 == 1) ? 3 : (q4 == 2) ? 9 : 6) + j : (ROLE == C2_TOP) ? j : (j < 3 ? 9 + j : 3 + j);
+  const int role = BASE ? 24 + q4 : (ROLE == C2_TOP ? col : 12 + col);
 
   const int s_raw = blockIdx.x * C2_SEG + seg;
   const int s_lin = s_raw < a.S ? s_raw : a.S - 1;             // shadow lanes repeat the last segment
   const int s = a.order ? a.order[s_lin] : s_lin;              // balanced order (lto_indirect_plan_rebalance)
-  const bool in_range = (s_raw < a.S) && !shadow;
+  const bool in_range = (s_raw < a.S);
   const int traj = s / a.seg_per_traj;
   const int i = s - traj * a.seg_per_traj;
   const long node = (long)traj * a.n_nodes + i;
@@ -86,41 +87,39 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   const double w2 = 2.0 * tp.omega;
   const bool mine = !a.class_filter || p_class(tp.p) == PM;
   if (!__syncthreads_or(mine)) return;         // workgroup-uniform (wave 7 voted 0 and left)
-  const double sg = is_a ? 1.0 : -1.0, kap = is_a ? 0.0 : w2;   // base lanes: slope of the first triple = sg q + kap J L
+  const QuadLane Q = quad_lane(q4, tp);        // base lanes: per-lane constants of the quad evaluation (halves.hpp)
+  // where the base lanes publish what they hold after the exchange: P = (r r lambda_v lambda_v) -> rows 0..2 / 3..5; c, 1/d of
+  // the own primary -> rows 6, 7 / 8, 9 (the lambda_v lanes: a spare row)
+  const int pub_p = (q4 < 2) ? 0 : 3, pub_c = (q4 == 0) ? 6 : (q4 == 1) ? 7 : 13, pub_is = (q4 == 0) ? 8 : (q4 == 1) ? 9 : 13;
 
   // ---- state of this lane: six rows of the base state or of one STM column
-  double y[6], K[13][6];
+  double y[NC], K[13][NC];
   if (BASE) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) y[j] = a.X[grow[j] * a.ldx + node];
+    for (int j = 0; j < NC; ++j) y[j] = a.X[grow[j] * a.ldx + node];
   } else {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) y[j] = (grow[j] == col) ? 1.0 : 0.0;
+    for (int j = 0; j < NC; ++j) y[j] = (grow[j] == col) ? 1.0 : 0.0;
   }
 
   hook::BarrierWait c2_wait;
   // slope of the stage argument `arg` (own six rows) into `out`.  Called by ALL threads: one barrier inside.  `overlap` is work
   // that needs neither this stage's slope nor LDS (the next argument's sum over the older slopes): the base lanes run it
   // between their LDS stores and the barrier, the column lanes between issuing their LDS loads and the first use.
-  auto slope = [&](const double (&arg)[6], double (&out)[6], const int buf, auto&& overlap) {
+  auto slope = [&](const double (&arg)[NC], double (&out)[NC], const int buf, auto&& overlap) {
     if constexpr (BASE) {
-      double R[3], L[3], q[3], kp[3], kq[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        R[j] = from_lane_a(arg[j]);      // B lanes take r from their A lane (row_shr:4)
-        L[j] = from_lane_b(arg[j]);      // A lanes take lambda_v from their B lane (row_shl:4)
-        q[j] = arg[3 + j];
-      }
+      QuadParts qp;
+      double P[3];
+      rhs12_base_quad<PM>(arg, Q, tp, out, qp, P);
       BaseParts12 bp;
-      rhs12_base_half<PM>(R, L, q, is_a, sg, kap, tp, kp, kq, bp);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) { out[j] = kp[j]; out[3 + j] = kq[j]; }
-      if (is_a && !shadow) {
-        double (&p)[13][C2_SEG] = sh.pub[buf];
-        p[0][seg] = R[0]; p[1][seg] = R[1]; p[2][seg] = R[2];
-        p[3][seg] = L[0]; p[4][seg] = L[1]; p[5][seg] = L[2];
-        p[6][seg] = bp.c1; p[7][seg] = bp.c2; p[8][seg] = bp.i1s; p[9][seg] = bp.i2s;
-        p[10][seg] = bp.ua; p[11][seg] = bp.ub; p[12][seg] = bp.inv_n;
+      bp.ua = qp.ua; bp.ub = qp.ub;
+      parts_guard_zero_norm<PM>(qp.n2, bp);
+      {
+        // eight stores instead of thirteen: the lanes of a quad hold different quantities under the same name
+        double (&p)[C2_PUB][C2_SEG] = sh.pub[buf];
+        p[pub_p][seg] = P[0]; p[pub_p + 1][seg] = P[1]; p[pub_p + 2][seg] = P[2];
+        p[pub_c][seg] = qp.c; p[pub_is][seg] = qp.is;
+        p[10][seg] = bp.ua; p[11][seg] = bp.ub; p[12][seg] = qp.inv_n;
       }
       overlap();
     } else {
@@ -129,7 +128,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     }
     C2_SYNC();
     if constexpr (!BASE) {
-      const double (&p)[13][C2_SEG] = sh.pub[buf];
+      const double (&p)[C2_PUB][C2_SEG] = sh.pub[buf];
       double v[13], other[3];
 #pragma unroll
       for (int e = 0; e < 13; ++e) v[e] = p[e][seg];
@@ -152,6 +151,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   auto nothing = [] {};
 
   const double rtol = a.rtol, atol = a.atol;
+  const unsigned long tab = dp8_tab_base();
   double h_abs = 0.0, t = 0.0;
   double rejected = 0.0;
   int nacc = 0, nrej = 0;
@@ -170,35 +170,35 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   } else {
     // Hairer's initial step over all components.  Row r of every column is scaled with the BASE value of row r (a dual
     // number's partials share the scale of its value), published by the base lanes.
-    if (BASE && !shadow) {
+    if (BASE) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
+      for (int j = 0; j < NC; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
     }
     slope(y, K[0], buf, nothing); buf ^= 1;
-    double isc0[6];
+    double isc0[NC];
     double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < NC; ++j) {
       const double isc = sh.scale[grow[j]][seg];
       isc0[j] = isc;
       p0 = __builtin_fma(y[j] * isc, y[j] * isc, p0);
       p1 = __builtin_fma(K[0][j] * isc, K[0][j] * isc, p1);
     }
-    if (!shadow) { sh.part[1][0][seg][role] = p0; sh.part[1][1][seg][role] = p1; }
+    sh.part[1][0][seg][role] = p0; sh.part[1][1][seg][role] = p1;
     __syncthreads();
     const double d0 = sqrt(total(1, 0) / NCOMP), d1 = sqrt(total(1, 1) / NCOMP);
     const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-    double arg[6];
+    double arg[NC];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) arg[j] = __builtin_fma(h0, K[0][j], y[j]);
+    for (int j = 0; j < NC; ++j) arg[j] = __builtin_fma(h0, K[0][j], y[j]);
     slope(arg, K[1], buf, nothing); buf ^= 1;   // the barrier inside also separates the reads above from the writes below
     double p2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < NC; ++j) {
       const double df = (K[1][j] - K[0][j]) * isc0[j];
       p2 = __builtin_fma(df, df, p2);
     }
-    if (!shadow) sh.part[1][2][seg][role] = p2;
+    sh.part[1][2][seg][role] = p2;
     __syncthreads();
     const double d2 = sqrt(total(1, 2) / NCOMP) / h0;
     const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : cbrt(cbrt(0.01 / fmax(d1, d2)));
@@ -219,66 +219,69 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     // Argument st (st = 1..11: stage st, weights DP8_A[st][.]; st = 12: the new state, weights DP8_B) is y + h (older + w K[st-1])
     // with older = the sum over the slopes before the newest one, formed one stage earlier in the shadow of that stage's LDS
     // traffic (same summation order as the one-piece loop: bit-identical arguments).
-    double older[6], yn[6], a5[6], a3[6];
+    double older[NC], yn[NC], a5[NC], a3[NC];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) older[j] = 0.0;
+    for (int j = 0; j < NC; ++j) older[j] = 0.0;
+    // the tableau rows come by scalar loads (rk.hpp: dp8_load_row), the row of argument st + 1 while stage st is evaluated
+    double wrow[2][12], we5[13], we3[13];
+    dp8_load_row<1>(tab, wrow[1]);
+    static_for<1, NS + 1>([&](auto st_c) {       // enters with K[0] = f(y) (FSAL)
+      constexpr int st = decltype(st_c)::value;
+      double arg[NC], next[NC];
+      constexpr double wn_c = (st < NS) ? DP8_A[st < NS ? st : 0][st - 1] : DP8_B[st - 1];
+      const double (&wc)[12] = wrow[st & 1];
 #pragma unroll
-    for (int st = 1; st <= NS; ++st) {       // enters with K[0] = f(y) (FSAL)
-      double arg[6], next[6];
-      const double wn_c = (st < NS) ? DP8_A[st < NS ? st : 0][st - 1] : DP8_B[st - 1];
-      const double wn = (wn_c != 0.0) ? coef_here(wn_c) : 0.0;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const double acc = (wn_c != 0.0) ? __builtin_fma(wn, K[st - 1][j], older[j]) : older[j];
+      for (int j = 0; j < NC; ++j) {
+        const double acc = (wn_c != 0.0) ? __builtin_fma(wc[st - 1], K[st - 1][j], older[j]) : older[j];
         arg[j] = __builtin_fma(h, acc, y[j]);
       }
-      if (st < NS) {
+      if constexpr (st < NS) {
+        double (&wx)[12] = wrow[(st + 1) & 1];
+        dp8_load_row<st + 1>(tab, wx);
         slope(arg, K[st], buf, [&] {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) next[j] = 0.0;
+          for (int j = 0; j < NC; ++j) next[j] = 0.0;
 #pragma unroll
           for (int k = 0; k < st; ++k) {
             const double w_c = (st + 1 < NS) ? DP8_A[st + 1 < NS ? st + 1 : 0][k] : DP8_B[k];
             if (w_c != 0.0) {
-              const double w = coef_here(w_c);
 #pragma unroll
-              for (int j = 0; j < 6; ++j) next[j] = __builtin_fma(w, K[k][j], next[j]);
+              for (int j = 0; j < NC; ++j) next[j] = __builtin_fma(wx[k], K[k][j], next[j]);
             }
           }
         });
 #pragma unroll
-        for (int j = 0; j < 6; ++j) older[j] = next[j];
+        for (int j = 0; j < NC; ++j) older[j] = next[j];
       } else {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) yn[j] = arg[j];
-        if (BASE && !shadow) {
+        for (int j = 0; j < NC; ++j) yn[j] = arg[j];
+        if (BASE) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
+          for (int j = 0; j < NC; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
         }
+        dp8_load_err(tab, we5, we3);
         slope(yn, K[12], buf, [&] {          // FSAL slope; in its shadow: the error sums over the twelve older slopes
 #pragma unroll
-          for (int j = 0; j < 6; ++j) { a5[j] = 0.0; a3[j] = 0.0; }
+          for (int j = 0; j < NC; ++j) { a5[j] = 0.0; a3[j] = 0.0; }
 #pragma unroll
           for (int k = 0; k < 12; ++k) {
             if (DP8_E5[k] != 0.0) {
-              const double w = coef_here(DP8_E5[k]);
 #pragma unroll
-              for (int j = 0; j < 6; ++j) a5[j] = __builtin_fma(w, K[k][j], a5[j]);
+              for (int j = 0; j < NC; ++j) a5[j] = __builtin_fma(we5[k], K[k][j], a5[j]);
             }
             if (DP8_E3[k] != 0.0) {
-              const double w = coef_here(DP8_E3[k]);
 #pragma unroll
-              for (int j = 0; j < 6; ++j) a3[j] = __builtin_fma(w, K[k][j], a3[j]);
+              for (int j = 0; j < NC; ++j) a3[j] = __builtin_fma(we3[k], K[k][j], a3[j]);
             }
           }
         });
       }
       buf ^= 1;
-    }
+    });
     const int par = trial & 1;
     double e5 = 0.0, e3 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < NC; ++j) {
       double s5 = a5[j], s3 = a3[j];
       if (DP8_E5[12] != 0.0) s5 = __builtin_fma(DP8_E5[12], K[12][j], s5);
       if (DP8_E3[12] != 0.0) s3 = __builtin_fma(DP8_E3[12], K[12][j], s3);
@@ -287,7 +290,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       e5 = __builtin_fma(s5, s5, e5);
       e3 = __builtin_fma(s3, s3, e3);
     }
-    if (!shadow) { sh.part[par][0][seg][role] = e5; sh.part[par][1][seg][role] = e3; }
+    sh.part[par][0][seg][role] = e5; sh.part[par][1][seg][role] = e3;
     __syncthreads();
     const double E5 = total(par, 0), E3 = total(par, 1);
     const double err = (E5 == 0.0 && E3 == 0.0) ? 0.0 : fabs(h) * E5 / sqrt((E5 + 0.01 * E3) * NCOMP);
@@ -306,13 +309,13 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     if (!done) {
       if (bad != 0.0) {                    // NaN in the step: NaN results (status_flag 2 upstream), no max_steps stall
 #pragma unroll
-        for (int j = 0; j < 6; ++j) y[j] = bad;
+        for (int j = 0; j < NC; ++j) y[j] = bad;
         t = span;
       } else if (accept != 0.0) {
         if (nacc == 0) h_rec = h_prop;
         t = (last != 0.0) ? span : t + h;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
+        for (int j = 0; j < NC; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
         ++nacc;
         rejected = 0.0;
       } else {
@@ -334,16 +337,16 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   // forward only) has no result: NaN, which the driver reports as status_flag 2 (indirect.jl:339-341).
   if (mine && (t < span || !(span >= 0.0))) {   // unfinished, decreasing grid, or a NaN span (treated like a negative one)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) y[j] = __builtin_nan("");
+    for (int j = 0; j < NC; ++j) y[j] = __builtin_nan("");
   }
 
   if (in_range && mine) {
     if (BASE) {
       if (a.defect) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) a.defect[grow[j] * a.ldd + s] = y[j] - a.X[grow[j] * a.ldx + node + 1];
+        for (int j = 0; j < NC; ++j) a.defect[grow[j] * a.ldd + s] = y[j] - a.X[grow[j] * a.ldx + node + 1];
       }
-      if (is_a) {
+      if (q4 == 0) {
         if (a.errors) a.errors[s] = 0.0;
         if (a.nacc) a.nacc[s] = nacc;
         if (a.nrej) a.nrej[s] = nrej;
@@ -351,7 +354,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) a.Phi[(long)(col * 12 + grow[j]) * a.ldp + s] = y[j];
+      for (int j = 0; j < NC; ++j) a.Phi[(long)(col * 12 + grow[j]) * a.ldp + s] = y[j];
     }
   }
 }

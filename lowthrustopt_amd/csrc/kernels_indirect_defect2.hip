@@ -188,10 +188,199 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- FOUR LANES PER SEGMENT
+// A sweep of a few thousand segments lasts as long as the instruction stream of its slowest segment (4 096 segments: 16 trial
+// steps against a mean of 5.3), so the stream is what to shorten: with a DPP quad per segment -- lane 0 owns r, lane 1 v, lane 2
+// lambda_v, lane 3 lambda_r -- the tableau arithmetic per lane is half that of the two-lane kernel, and the three
+// reciprocal-square-root chains of an evaluation run as one (rhs12_base_quad, halves.hpp).  The tableau rows come by scalar loads
+// one stage ahead of their use (rk.hpp: dp8_load_row) instead of two s_mov_b32 per coefficient.  Same step control; the error
+// norms are quad sums formed in the same order in all four lanes, so a quad's control flow never diverges.  Measured
+// (tools/probe_defect2.py): 4 096 segments 90 -> 77 us per sweep, 29: 73 -> 63 us, 65 536 ordered: 0.31 -> 0.27 ms; AUTO up to
+// eight wavefronts per SIMD (lto_api.hip).
+template <int PM>
+__global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
+  const int lane = threadIdx.x;
+  const int q4 = lane & 3;
+  const int sl = blockIdx.x * 16 + (lane >> 2);                        // 16 segments per wavefront
+  if (sl >= a.S) return;                                               // the four lanes of a quad leave together
+  const int s = a.order ? a.order[sl] : sl;
+  const int traj = s / a.seg_per_traj;
+  const int i = s - traj * a.seg_per_traj;
+  const long node = (long)traj * a.n_nodes + i;
+  const long tg = (long)traj * a.t_stride + i;
+  const double span = a.t[tg + 1] - a.t[tg];
+  const TrajParams tp = a.tp[(long)traj * a.tp_stride];
+  if (a.class_filter && p_class(tp.p) != PM) return;                   // mixed-class batch: another launch owns this trajectory
+  const QuadLane Q = quad_lane(q4, tp);
+  const int row0 = (q4 == 0) ? 0 : (q4 == 1) ? 3 : (q4 == 2) ? 9 : 6;  // own rows in global numbering
+
+  double y[3], K[13][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) y[j] = a.X[(row0 + j) * a.ldx + node];
+
+  auto rhs = [&](const double (&arg)[3], double (&out)[3]) {
+    QuadParts bp;
+    double P[3];
+    rhs12_base_quad<PM>(arg, Q, tp, out, bp, P);
+  };
+
+  const double rtol = a.rtol, atol = a.atol;
+  const unsigned long tab = dp8_tab_base();
+  int nacc = 0, nrej = 0;
+  double t = 0.0;
+  if (span > 0.0) {
+    rhs(y, K[0]);
+    double h_abs;
+    if (a.warm) {                // warm start: see k_indirect_defect2
+      const double hw = a.h_first[s];
+      h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
+    } else {                     // Hairer's initial step over the 12 components
+      double isc[3], p0 = 0.0, p1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        isc[j] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
+        p0 = __builtin_fma(y[j] * isc[j], y[j] * isc[j], p0);
+        p1 = __builtin_fma(K[0][j] * isc[j], K[0][j] * isc[j], p1);
+      }
+      const double d0 = sqrt(quad_sum(p0) / 12.0), d1 = sqrt(quad_sum(p1) / 12.0);
+      const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+      double yt[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) yt[j] = __builtin_fma(h0, K[0][j], y[j]);
+      rhs(yt, K[1]);
+      double p2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double df = (K[1][j] - K[0][j]) * isc[j];
+        p2 = __builtin_fma(df, df, p2);
+      }
+      const double d2 = sqrt(quad_sum(p2) / 12.0) / h0;
+      const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : cbrt(cbrt(0.01 / fmax(d1, d2)));
+      h_abs = fmin(fmin(100.0 * h0, h1), span);
+    }
+    double h_rec = 0.0;
+    double rejected = 0.0;
+    while (t < span && nacc + nrej < a.max_steps) {
+      double h = h_abs;
+      double last = 0.0;
+      if (t + h >= span) { h = span - t; last = 1.0; }
+      // the weights of an argument are fetched (scalar loads, dp8_load_row) while the previous stage is evaluated
+      double yn[3];
+      double wrow[2][12], we5[13], we3[13];
+      dp8_load_row<1>(tab, wrow[1]);
+      static_for<1, 13>([&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+        double (&w)[12] = wrow[st & 1];
+        double arg[3], acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < st; ++k) {
+          const double c = (st < 12) ? DP8_A[st < 12 ? st : 0][k] : DP8_B[k];
+          if (c != 0.0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = __builtin_fma(w[k], K[k][j], acc[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) arg[j] = __builtin_fma(h, acc[j], y[j]);
+        if constexpr (st < 12) dp8_load_row<st + 1>(tab, wrow[(st + 1) & 1]);
+        else dp8_load_err(tab, we5, we3);
+        if constexpr (st == 12) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) yn[j] = arg[j];
+        }
+        rhs(arg, K[st]);
+      });
+      double a5[3], a3[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { a5[j] = 0.0; a3[j] = 0.0; }
+#pragma unroll
+      for (int k = 0; k <= 12; ++k) {
+        if (DP8_E5[k] != 0.0) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) a5[j] = __builtin_fma(we5[k], K[k][j], a5[j]);
+        }
+        if (DP8_E3[k] != 0.0) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) a3[j] = __builtin_fma(we3[k], K[k][j], a3[j]);
+        }
+      }
+      double e5 = 0.0, e3 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double isc = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
+        const double s5 = a5[j] * isc, s3 = a3[j] * isc;
+        e5 = __builtin_fma(s5, s5, e5);
+        e3 = __builtin_fma(s3, s3, e3);
+      }
+      const double E5 = quad_sum(e5), E3 = quad_sum(e3);
+      const double err = (E5 == 0.0 && E3 == 0.0) ? 0.0 : fabs(h) * E5 / sqrt((E5 + 0.01 * E3) * 12.0);
+      if (err < 1.0) {
+        double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 / sqrt(sqrt(sqrt(err))));
+        if (rejected != 0.0) factor = fmin(1.0, factor);
+        if (nacc == 0) h_rec = h_abs;
+        h_abs = h * factor;
+        t = (last != 0.0) ? span : t + h;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
+        ++nacc;
+        rejected = 0.0;
+      } else {
+        h_abs = h * fmax(0.2, 0.9 / sqrt(sqrt(sqrt(err))));
+        rejected = 1.0;
+        ++nrej;
+        if (err != err) {                     // a NaN never recovers: poison and stop instead of max_steps retries
+#pragma unroll
+          for (int j = 0; j < 3; ++j) y[j] = err;
+          t = span;
+        }
+      }
+    }
+    if (t < span) {                           // max_steps trial steps used up before t1: no result
+#pragma unroll
+      for (int j = 0; j < 3; ++j) y[j] = __builtin_nan("");
+    }
+    if (q4 == 0 && a.h_first) a.h_first[s] = h_rec;
+  } else if (span != 0.0) {                   // decreasing grid (forward integration only) or NaN span: no result
+#pragma unroll
+    for (int j = 0; j < 3; ++j) y[j] = __builtin_nan("");
+  }
+
+  if (a.defect) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a.defect[(row0 + j) * a.ldd + s] = y[j] - a.X[(row0 + j) * a.ldx + node + 1];
+  }
+  if (q4 == 0) {
+    if (a.errors) a.errors[s] = 0.0;
+    if (a.nacc) a.nacc[s] = nacc;
+    if (a.nrej) a.nrej[s] = nrej;
+  }
+}
+
 template <int PM>
 static hipError_t launch_defect2_one(const IndirectArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((k_indirect_defect2<PM>), dim3((a.S + 31) / 32), dim3(64), 0, st, a);
   return hipGetLastError();
+}
+
+template <int PM>
+static hipError_t launch_defect4_one(const IndirectArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((k_indirect_defect4<PM>), dim3((a.S + 15) / 16), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// 12-dim system, DOP853 adaptive, defect only, four lanes per segment.
+hipError_t launch_indirect_defect4(int pm, const IndirectArgs& a0, hipStream_t st) {
+  if (a0.S <= 0) return hipSuccess;
+  IndirectArgs a = a0;
+  a.class_filter = single_class(pm) ? 0 : 1;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_defect4_one<PM_P0>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_defect4_one<PM_P1>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_defect4_one<PM_P2>(a, st);
+  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_defect4_one<PM_PGEN>(a, st);
+  return e;
 }
 
 // 12-dim system, DOP853 adaptive, defect only.

@@ -434,7 +434,7 @@ __device__ __forceinline__ void pipe8_store_column(const IndirectArgs& a, const 
 // ------------------------------------------------------------------------------ column role, both steps of every phase
 template <int ND, int PM>
 __device__ __forceinline__ void pipe8_role_columns(const IndirectArgs& a, const PipeLane& L, const int seg, const int col,
-                                                   const double* s_coef, Pipe8Flags* fl) {
+                                                   const double* s_coef, Pipe8Flags* fl, const int probe_bit) {
   using P = Pipe8<ND, PM>;
   constexpr int SD = P::SD;
   const int steps = a.steps, npairs = (steps + 1) >> 1;
@@ -445,7 +445,7 @@ __device__ __forceinline__ void pipe8_role_columns(const IndirectArgs& a, const 
   for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
   P8_WAIT_DECL;
   for (int p = 0; p < npairs + 1; ++p) {
-    if (p >= 1 && PIPE_ROLE_ON(a, 4)) {
+    if (p >= 1 && PIPE_ROLE_ON(a, 4) && PIPE_ROLE_ON(a, probe_bit)) {
       const int s0 = 2 * p - 2, s1 = 2 * p - 1;
       if (col < P::NA) col_dpp_step<ND, SD, P::Arg::LM, P::NA>(rec + ((s0 & 3) * 4) * SD, k, s0, y);   // spare lanes stay off: never DPP sources
       if (s1 < steps) {
@@ -491,7 +491,7 @@ __device__ __forceinline__ void pipe8_role_columns_alt(const IndirectArgs& a, co
   if (!ODD) __builtin_amdgcn_s_setprio(2);
   P8_WAIT_DECL;
   for (int p = 0; p < npairs + 1; ++p) {
-    if (p >= 1 && PIPE_ROLE_ON(a, 4)) {
+    if (p >= 1 && PIPE_ROLE_ON(a, 4) && PIPE_ROLE_ON(a, 32)) {
       const int step = 2 * p - 2 + (ODD ? 1 : 0);
       if (!ODD) {
         if (p > 1) load();
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   else if (wave == 3) pipe8_role_coef<ND, PM>(a, L, seg, lane >> 4, s_int, s_coef, s_lm, &s_fl);
   else if (wave == 4) pipe8_role_columns_alt<ND, PM, false>(a, L, seg, lane & 15, s_coef, s_hand, &s_fl);
   else if (wave == 5) pipe8_role_columns_alt<ND, PM, true>(a, L, seg, lane & 15, s_coef, s_hand, &s_fl);
-  else pipe8_role_columns<ND, PM>(a, L, seg, lane & 15, s_coef, &s_fl);
+  else pipe8_role_columns<ND, PM>(a, L, seg, lane & 15, s_coef, &s_fl, wave == 7 ? 64 : 8);   // probe build: role switches per wave
 }
 
 template <int ND, int PM>

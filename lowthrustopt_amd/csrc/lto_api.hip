@@ -90,6 +90,7 @@ struct lto_indirect_plan {
   // warm start of the adaptive controllers (lto_indirect_plan_set_warm_start): first accepted step size of every segment in the
   // last STM sweep / defect-only sweep (they control different error norms, hence two arrays; lazily allocated)
   int warm_start;
+  int defect_lanes;         // lanes per segment of the defect-only sweep with the reference's setting: 0 = choose, 1, 2, 4
   double* d_hfirst[2];      // [0] STM sweeps, [1] defect-only sweeps
   int hfirst_valid[2];
 };
@@ -445,6 +446,15 @@ int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
 
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* p) { return p ? p->last_kernel : LTO_KERNEL_AUTO; }
 
+int lto_indirect_plan_set_defect_lanes(lto_indirect_plan* p, int lanes) {
+  if (!p) return LTO_ENULL;
+  if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4) return set_err(p->ctx, LTO_EINVAL, "defect lanes must be 0 (choose), 1, 2 or 4");
+  if (lanes > 1 && !(p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE))
+    return set_err(p->ctx, LTO_EINVAL, "two and four lanes per segment are built for 12-dim DOP853_ADAPTIVE plans (the reference's integrator setting)");
+  p->defect_lanes = lanes;
+  return LTO_OK;
+}
+
 int lto_indirect_plan_set_warm_start(lto_indirect_plan* p, int on) {
   if (!p) return LTO_ENULL;
   if (on && !(p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE))
@@ -510,14 +520,22 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(c, st);
-  // The reference's setting (12-dim, DOP853): two lanes per segment (tools/probe_defect2.py: 29 segments 99 -> 73 us, 4 096:
+  // The reference's setting (12-dim, DOP853).  Two lanes per segment (tools/probe_defect2.py: 29 segments 99 -> 73 us, 4 096:
   // 119 -> 88 us, 65 536 ordered: 0.43 -> 0.32 ms, 262 144: 0.44 -> 0.38 ms; 524 288: 0.60 -> 0.73 ms, so one lane beyond);
-  // LTO_KERNEL_PER_LANE / LTO_KERNEL_COOP2 on the plan force one form.
-  const bool two_lane = p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE &&
-                        (p->kernel == LTO_KERNEL_COOP2 || (p->kernel == LTO_KERNEL_AUTO && p->S <= 262144));
-  rc = warm_args(p, 1, two_lane, &a);
+  // round 3: four lanes per segment (a DPP quad, 16 segments per wavefront) up to eight wavefronts per SIMD -- 4 096 segments:
+  // 90 -> 77 us, 65 536 ordered: 0.31 -> 0.27 ms, 131 072: 0.32 -> 0.30 ms; 262 144: 0.39 -> 0.52 ms, so two lanes there.
+  // LTO_KERNEL_PER_LANE / LTO_KERNEL_COOP2 on the plan, or lto_indirect_plan_set_defect_lanes, force one form.
+  const bool ref_setting = p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE;
+  int lanes = 1;
+  if (ref_setting) {
+    if (p->defect_lanes) lanes = p->defect_lanes;
+    else if (p->kernel == LTO_KERNEL_COOP2) lanes = 2;
+    else if (p->kernel == LTO_KERNEL_AUTO) lanes = ((long)(p->S + 15) / 16 <= 32L * c->cu_count) ? 4 : (p->S <= 262144 ? 2 : 1);
+  }
+  rc = warm_args(p, 1, lanes > 1, &a);
   if (rc) return rc;
-  hipError_t e = two_lane          ? launch_indirect_defect2(p->pm, a, st)
+  hipError_t e = lanes == 4        ? launch_indirect_defect4(p->pm, a, st)
+                 : lanes == 2      ? launch_indirect_defect2(p->pm, a, st)
                  : (p->ndim == 12) ? launch_indirect_defect(p->pm, p->integ.method, a, st)
                                    : launch_indirect14_defect(p->pm, p->integ.method, a, st);
   timing_end(c, st);

@@ -10,6 +10,7 @@
 //   DOP853       Hairer/Norsett/Wanner 8(5,3) pair (dop853_tableau.h), standing in for Vern8
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "dop853_tableau.h"
 #include "dynamics.hpp"  // rcp_nr
 
@@ -233,6 +234,88 @@ static __device__ __constant__ TabMem kTabRKF78 = {
     {0}};
 
 static __device__ __constant__ TabMem kTabDP8 = DP8_TABMEM_INIT;
+
+// The DOP853 tableau for code that reads its coefficients with scalar loads where they are needed (the lone-wavefront kernels of the
+// reference's integrator setting: as literals every coefficient costs two s_mov_b32 in an instruction stream that IS the sweep's
+// duration -- 152 of ~2 000 instructions per trial step).  Packed: the non-zero weights of argument 1, 2, .. 11 (rows of A), of
+// the new state (B) and of the two error estimators, each row contiguous and starting at an even index, so that one or two
+// s_load_dwordx4..x16 fetch a row.
+struct Dp8Packed {
+  static constexpr int ROWS = 14;           // 0..10: A rows 1..11; 11: B; 12: E5; 13: E3
+  double w[96];
+};
+constexpr double dp8_row_entry(int row, int k) {
+  return row < 11 ? DP8_A[row + 1][k < 12 ? k : 0] * (k < 12 ? 1.0 : 0.0) : row == 11 ? (k < 12 ? DP8_B[k] : 0.0) : row == 12 ? DP8_E5[k] : DP8_E3[k];
+}
+constexpr int dp8_row_len(int row) { return row < 11 ? row + 1 : row == 11 ? 12 : 13; }      // entries that can be non-zero
+constexpr int dp8_row_nnz(int row) {
+  int n = 0;
+  for (int k = 0; k < dp8_row_len(row); ++k) n += (dp8_row_entry(row, k) != 0.0) ? 1 : 0;
+  return n;
+}
+constexpr int dp8_row_off(int row) {
+  int off = 0;
+  for (int r = 0; r < row; ++r) off += (dp8_row_nnz(r) + 1) & ~1;
+  return off;
+}
+constexpr int dp8_slot(int row, int k) {     // position of entry k inside its packed row
+  int n = 0;
+  for (int i = 0; i < k; ++i) n += (dp8_row_entry(row, i) != 0.0) ? 1 : 0;
+  return n;
+}
+constexpr Dp8Packed dp8_pack() {
+  Dp8Packed P{};
+  for (int r = 0; r < Dp8Packed::ROWS; ++r)
+    for (int k = 0; k < dp8_row_len(r); ++k)
+      if (dp8_row_entry(r, k) != 0.0) P.w[dp8_row_off(r) + dp8_slot(r, k)] = dp8_row_entry(r, k);
+  return P;
+}
+static_assert(dp8_row_off(Dp8Packed::ROWS) <= 96, "packed DOP853 tableau");
+static __device__ __constant__ Dp8Packed kDp8Packed = dp8_pack();
+
+// The empty asm makes the address opaque, so the loads stay where the caller puts them -- one stage ahead of their use -- instead
+// of being hoisted to the top of the kernel (74 doubles do not fit the scalar register file); constant address space: scalar loads.
+typedef const Dp8Packed __attribute__((address_space(4))) * Dp8ConstPtr;
+// dp8_tab_base(): once per kernel (an opaque value in a scalar register pair: the pc-relative address costs three instructions);
+// dp8_tab_here(base): the pointer to load through, at the point of the call.
+__device__ __forceinline__ unsigned long dp8_tab_base() {
+  unsigned long p = (unsigned long)&kDp8Packed;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+__device__ __forceinline__ Dp8ConstPtr dp8_tab_here(unsigned long base) {
+  asm volatile("" : "+s"(base));
+  return (Dp8ConstPtr)base;
+}
+// f(integral_constant<int, I>) for I = FIRST .. LAST - 1: a stage loop whose index is a constant expression inside the body
+template <int FIRST, int LAST, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (FIRST < LAST) {
+    f(std::integral_constant<int, FIRST>{});
+    static_for<FIRST + 1, LAST>(f);
+  }
+}
+// the non-zero weights of argument ST (ST = 1..11: row ST of A; ST = 12: B) into w[k], k < ST
+template <int ST>
+__device__ __forceinline__ void dp8_load_row(const unsigned long base, double (&w)[12]) {
+  const Dp8ConstPtr T = dp8_tab_here(base);
+  static_for<0, ST>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr bool used = dp8_row_entry(ST - 1, k) != 0.0;
+    constexpr int at = dp8_row_off(ST - 1) + dp8_slot(ST - 1, k);
+    if constexpr (used) w[k] = T->w[at];
+  });
+}
+// the non-zero weights of the two error estimators
+__device__ __forceinline__ void dp8_load_err(const unsigned long base, double (&e5)[13], double (&e3)[13]) {
+  const Dp8ConstPtr T = dp8_tab_here(base);
+  static_for<0, 13>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int at5 = dp8_row_off(12) + dp8_slot(12, k), at3 = dp8_row_off(13) + dp8_slot(13, k);
+    if constexpr (DP8_E5[k] != 0.0) e5[k] = T->w[at5];
+    if constexpr (DP8_E3[k] != 0.0) e3[k] = T->w[at3];
+  });
+}
 
 // Slopes 1 .. ns-1 from K[0] = f(y), runtime stage loop.
 template <class Sys>

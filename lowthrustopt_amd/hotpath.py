@@ -631,6 +631,11 @@ class IndirectPlan:
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
 
+    def set_defect_lanes(self, lanes=0):
+        """Lanes per segment of the defect-only sweep of a 12-dim DOP853 plan: 0 = choose, 1, 2 or 4
+        (lto_indirect_plan_set_defect_lanes)."""
+        self.ctx.check(self.ctx.lib.lto_indirect_plan_set_defect_lanes(self.handle, int(lanes)))
+
     def set_warm_start(self, on=True):
         """Adaptive sweeps of this plan start every segment from its first accepted step size of the plan's previous sweep of
         the same kind (lto_indirect_plan_set_warm_start; 12-dim DOP853 plans)."""

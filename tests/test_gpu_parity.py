@@ -255,10 +255,11 @@ def test_indirect_mixed_control_law_classes(gpu_ctx, ndim, mname, kernel):
 
 @pytest.mark.parametrize("pcase", list(P_CASES))
 def test_indirect_defect_two_lanes_per_segment(gpu_ctx, oracle, pcase):
-    """Defect-only sweep with the reference's integrator setting (12-dim, DOP853 @ 1e-13): the form with two lanes per segment
-    (lane A: r, v; lane B: lambda_v, lambda_r; what AUTO runs up to 262 144 segments) and the one-lane form, forced through
-    the plan's kernel knob, both against the oracle; ragged segment count (pairs in the last wavefront missing), counters
-    from the A lane, a zero-length and a decreasing segment in the same wavefront."""
+    """Defect-only sweep with the reference's integrator setting (12-dim, DOP853 @ 1e-13): the forms with four lanes per segment
+    (a DPP quad: r, v, lambda_v, lambda_r; what AUTO runs while a wavefront of 16 segments has a SIMD to itself), with two lanes
+    (lane A: r, v; lane B: lambda_v, lambda_r) and with one, forced through the plan's knobs, all against the oracle; ragged
+    segment count (quads / pairs in the last wavefront missing), counters from the first lane, a zero-length and a decreasing
+    segment in the same wavefront."""
     import torch
     p, rho, thr, lam = P_CASES[pcase]
     n = 75
@@ -270,9 +271,12 @@ def test_indirect_defect_two_lanes_per_segment(gpu_ctx, oracle, pcase):
     assert rc == 0
     X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
     res = {}
-    for name, kern in (("one", lto.IndirectPlan.KERNEL_PER_LANE), ("two", lto.IndirectPlan.KERNEL_COOP2), ("auto", lto.IndirectPlan.KERNEL_AUTO)):
+    for name, kern, lanes in (("one", lto.IndirectPlan.KERNEL_PER_LANE, 0), ("two", lto.IndirectPlan.KERNEL_COOP2, 0),
+                              ("two_by_lanes", lto.IndirectPlan.KERNEL_AUTO, 2), ("four", lto.IndirectPlan.KERNEL_AUTO, 4),
+                              ("auto", lto.IndirectPlan.KERNEL_AUTO, 0)):
         plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator())
         plan.set_kernel(kern)
+        plan.set_defect_lanes(lanes)
         td = torch.from_numpy(np.ascontiguousarray(t)).cuda()
         d = torch.full((12, S), 7.0, dtype=torch.float64, device="cuda")
         plan.defect(X, n, td, 1, d, S)
@@ -292,8 +296,13 @@ def test_indirect_defect_two_lanes_per_segment(gpu_ctx, oracle, pcase):
         keep = [i for i in range(S) if i not in (9, 10, 11, 39, 40, 41)]
         assert np.array_equal(d2[:, keep], res[name][0][:, keep])
         plan.close()
-    assert np.array_equal(res["auto"][0], res["two"][0])
+    assert np.array_equal(res["auto"][0], res["four"][0])
+    assert np.array_equal(res["two_by_lanes"][0], res["two"][0])
     assert np.abs(res["one"][0] - res["two"][0]).max() < 1e-11
+    assert np.abs(res["one"][0] - res["four"][0]).max() < 1e-11
+    for k in ("two", "four"):     # same controller on the same problem: the same step sequences but for the odd borderline decision
+        dn = np.abs((res[k][1] + res[k][2]) - (res["one"][1] + res["one"][2]))   # (a switching segment then takes another path: seen 6)
+        assert np.mean(dn == 0) >= 0.9
 
 
 def test_indirect_backward_time_direction(gpu_ctx, oracle):

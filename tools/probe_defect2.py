@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Defect-only sweep with the reference's integrator setting (DOP853 @ 1e-13, 12-dim): one lane per segment
-(LTO_KERNEL_PER_LANE on the plan) against two lanes per segment (LTO_KERNEL_COOP2), ordered lanes above 8 192 segments."""
+against two and four lanes per segment (lto_indirect_plan_set_defect_lanes), ordered lanes above 8 192 segments."""
 import os
 import sys
 import time
@@ -23,9 +23,9 @@ def main():
         X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
         t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
         out = {}
-        for name, kern in (("one lane", 1), ("two lanes", 6)):
+        for name, lanes in (("one lane", 1), ("two lanes", 2), ("four lanes", 4)):
             plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator())
-            plan.set_kernel(kern)
+            plan.set_defect_lanes(lanes)
             d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
             for _ in range(3):
                 plan.defect(X, n, t, 1, d, S, stream=st)
@@ -45,8 +45,10 @@ def main():
             print("S=%7d %-9s %.4f ms per sweep (%.3e seg/s); trial steps %.2f per segment (max %d)" % (
                 S, name, ms, S / ms * 1e3, (acc + rej).mean(), (acc + rej).max()), flush=True)
             plan.close()
-        d1, a1, r1 = out["one lane"]; d2, a2, r2 = out["two lanes"]
-        print("   max |ddefect| = %.2e; step counts equal: %s" % (np.abs(d1 - d2).max(), bool(np.array_equal(a1, a2) and np.array_equal(r1, r2))), flush=True)
+        d1, a1, r1 = out["one lane"]
+        for name in ("two lanes", "four lanes"):
+            d2, a2, r2 = out[name]
+            print("   %-10s vs one lane: max |ddefect| = %.2e; step counts equal: %s" % (name, np.abs(d1 - d2).max(), bool(np.array_equal(a1, a2) and np.array_equal(r1, r2))), flush=True)
     ctx.close()
 
 
