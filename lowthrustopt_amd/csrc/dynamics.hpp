@@ -757,48 +757,36 @@ __device__ __forceinline__ void rhs12_base_half(const double (&R)[3], const doub
 // the TOP lane owns (a, b) = (delta r, delta v) and needs G and U, the BOTTOM lane owns (d, g) = (delta lambda_v, delta
 // lambda_r) and needs G and H; each receives the other's first triple.  Same arithmetic per entry as the one-piece forms.
 struct CoefG12 { double Gxx, Gyy, Gzz, Gxy, Gxz, Gyz; };
-__device__ __forceinline__ void coefG12_from_parts(const double x, const double yy, const double z, const BaseParts12& bp, const double MU,
-                                                   CoefG12& g, double& st, double& ee, double& e1, double& e2, double& a, double& b) {
-  a = x + MU; b = a - 1.0;
-  const double c1 = bp.c1, c2 = bp.c2;
-  const double cs = c1 + c2;
-  e1 = 3.0 * c1 * bp.i1s; e2 = 3.0 * c2 * bp.i2s;
-  ee = e1 + e2;
-  const double sa = e1 * a, tb = e2 * b;
-  st = sa + tb;
-  g.Gxx = __builtin_fma(sa, a, __builtin_fma(tb, b, 1.0 - cs));
-  g.Gyy = __builtin_fma(ee * yy, yy, 1.0 - cs);
-  g.Gzz = __builtin_fma(ee * z, z, -cs);
-  g.Gxy = st * yy; g.Gxz = st * z; g.Gyz = ee * yy * z;
-}
-// top half: (a', b') from own (a, b) and the received d
-__device__ __forceinline__ void var_col12_top(const double x, const double yy, const double z, const double lx0, const double ly0,
-                                              const double lz0, const BaseParts12& bp, const double MU, const double w2,
-                                              const double (&w)[6], const double (&d)[3], double (&dw)[6]) {
-  CoefG12 g; double st, ee, e1, e2, a, b;
-  coefG12_from_parts(x, yy, z, bp, MU, g, st, ee, e1, e2, a, b);
-  const double lx = lx0 * bp.inv_n, ly = ly0 * bp.inv_n, lz = lz0 * bp.inv_n;
+// top half: (a', b') from own (a, b) and the received d, with G as published by the base wave; lx0.. = lambda_v of the stage argument
+__device__ __forceinline__ void var_col12_top_g(const CoefG12& g, const double lx0, const double ly0, const double lz0, const double inv_n,
+                                                const double ua, const double ub, const double w2, const double (&w)[6],
+                                                const double (&d)[3], double (&dw)[6]) {
+  const double lx = lx0 * inv_n, ly = ly0 * inv_n, lz = lz0 * inv_n;
   const double ax = w[0], ay = w[1], az = w[2];
   const double dx = d[0], dyv = d[1], dz = d[2];
   dw[0] = w[3]; dw[1] = w[4]; dw[2] = w[5];
   const double ld = __builtin_fma(lx, dx, __builtin_fma(ly, dyv, lz * dz));
-  const double tl = bp.ub * ld;
+  const double tl = ub * ld;
   dw[3] = __builtin_fma(g.Gxx, ax, __builtin_fma(g.Gxy, ay, __builtin_fma(g.Gxz, az,
-          __builtin_fma(w2, w[4], __builtin_fma(-bp.ua, dx, tl * lx)))));
+          __builtin_fma(w2, w[4], __builtin_fma(-ua, dx, tl * lx)))));
   dw[4] = __builtin_fma(g.Gxy, ax, __builtin_fma(g.Gyy, ay, __builtin_fma(g.Gyz, az,
-          __builtin_fma(-w2, w[3], __builtin_fma(-bp.ua, dyv, tl * ly)))));
+          __builtin_fma(-w2, w[3], __builtin_fma(-ua, dyv, tl * ly)))));
   dw[5] = __builtin_fma(g.Gxz, ax, __builtin_fma(g.Gyz, ay, __builtin_fma(g.Gzz, az,
-          __builtin_fma(-bp.ua, dz, tl * lz))));
+          __builtin_fma(-ua, dz, tl * lz))));
 }
-// bottom half: own w = (d, g) = (delta lambda_v, delta lambda_r), received a = delta r; returns (d', g')
-__device__ __forceinline__ void var_col12_bottom(const double x, const double yy, const double z, const double lx0, const double ly0,
-                                                 const double lz0, const BaseParts12& bp, const double MU, const double w2,
-                                                 const double (&w)[6], const double (&av)[3], double (&dw)[6]) {
-  CoefG12 g; double st, ee, e1, e2, a, b;
-  coefG12_from_parts(x, yy, z, bp, MU, g, st, ee, e1, e2, a, b);
+// bottom half: own w = (d, g) = (delta lambda_v, delta lambda_r), received a = delta r; returns (d', g').  G as published by the
+// base wave, H from the parts (same arithmetic per entry as coef12_from_parts)
+__device__ __forceinline__ void var_col12_bottom_g(const CoefG12& g, const double x, const double yy, const double z, const double lx0,
+                                                   const double ly0, const double lz0, const double c1, const double c2, const double i1s,
+                                                   const double i2s, const double MU, const double w2, const double (&w)[6],
+                                                   const double (&av)[3], double (&dw)[6]) {
+  const double a = x + MU, b = a - 1.0;
+  const double e1 = 3.0 * c1 * i1s, e2 = 3.0 * c2 * i2s;
+  const double ee = e1 + e2;
+  const double st = e1 * a + e2 * b;
   const double yzl = __builtin_fma(yy, ly0, z * lz0);
   const double s1 = __builtin_fma(a, lx0, yzl), s2 = __builtin_fma(b, lx0, yzl);
-  const double q1 = 5.0 * e1 * bp.i1s * s1, q2 = 5.0 * e2 * bp.i2s * s2;
+  const double q1 = 5.0 * e1 * i1s * s1, q2 = 5.0 * e2 * i2s * s2;
   const double es = __builtin_fma(e1, s1, e2 * s2);
   const double qq = q1 + q2;
   const double qa = __builtin_fma(q1, a, q2 * b);
@@ -820,7 +808,6 @@ __device__ __forceinline__ void var_col12_bottom(const double x, const double yy
   dw[5] = -__builtin_fma(Hxz, ax, __builtin_fma(Hyz, ay, __builtin_fma(Hzz, az,
            __builtin_fma(g.Gxz, dx, __builtin_fma(g.Gyz, dyv, g.Gzz * dz)))));
 }
-
 // G, H, U of the 12-dim system from the base argument's position r, lambda_v and the base lane's by-products: the
 // VAR block of rhs12 without its reciprocal square roots and control law.
 __device__ __forceinline__ void coef12_from_parts(const double x, const double yy, const double z, const double lx0, const double ly0,

@@ -47,18 +47,20 @@ __device__ __forceinline__ double quad_sum(const double x) {
 // 1 / |lambda_v| (from lane 2), and lane 3 takes lambda_r' from lane 1, which holds everything it is made of.  Every sum in lane 1
 // -- the lane whose v' and lambda_r' are used -- has the operand order of rhs12_base_parts (same bits).
 struct QuadLane {
-  double off;       // x offset of the lane's distance argument: MU (lane 0), MU - 1 (lane 1), 0 (lanes 2, 3: |lambda_v|)
+  double off1;      // x offset to primary 1 where the lane's argument is a position: MU, MU, 0, 0
+  double off2;      // from there to the lane's own primary: 0, -1, 0, 0  (a = x + MU, b = a - 1: the reference's two roundings)
+  double off2_o;    // ... and to the other one: -1, 0, 0, 0
   double kapb;      // 1 - MU, MU, 0, 0
-  double sgn_o;     // the other primary's x offset relative to the own one: -1, +1, 0, 0
   double floor;     // -inf for the distance lanes (no clamp, NaN kept), the zero-norm guard of inv_norm_guarded for lanes 2, 3
   double kap_lin, sg_lin;   // slope of a linear lane: lane 0 r' = v: (0, 1); lane 2 lambda_v' = 2 w J lambda_v - lambda_r: (2 w, -1)
   bool lane1, lane3;
 };
 __device__ __forceinline__ QuadLane quad_lane(const int q4, const TrajParams& tp) {
   QuadLane Q;
-  Q.off = (q4 == 0) ? tp.MU : (q4 == 1) ? tp.MU - 1.0 : 0.0;
+  Q.off1 = (q4 < 2) ? tp.MU : 0.0;
+  Q.off2 = (q4 == 1) ? -1.0 : 0.0;
+  Q.off2_o = (q4 == 0) ? -1.0 : 0.0;
   Q.kapb = (q4 == 0) ? 1.0 - tp.MU : (q4 == 1) ? tp.MU : 0.0;
-  Q.sgn_o = (q4 == 0) ? -1.0 : (q4 == 1) ? 1.0 : 0.0;
   Q.floor = (q4 < 2) ? -__builtin_inf() : 9.33263618503218879e-302;
   Q.kap_lin = (q4 == 2) ? 2.0 * tp.omega : 0.0;
   Q.sg_lin = (q4 == 2) ? -1.0 : 1.0;
@@ -69,9 +71,11 @@ __device__ __forceinline__ QuadLane quad_lane(const int q4, const TrajParams& tp
 struct QuadParts { double c, is, inv_n, n2, ua, ub; };
 // w: the lane's argument triple; k: its slope; P: (r r lambda_v lambda_v) as the lanes hold it after the exchange (what the
 // cooperative kernel publishes)
-template <int PM>
+// WITH_G: also the gravity-gradient block G of the variational equations (valid in lane 1; same arithmetic as coefG12_from_parts),
+// which the cooperative kernel's base wave has the time to build once per segment and stage for all 24 column halves.
+template <int PM, bool WITH_G = false>
 __device__ __forceinline__ void rhs12_base_quad(const double (&w)[3], const QuadLane& Q, const TrajParams& tp, double (&k)[3], QuadParts& bp,
-                                                double (&P)[3]) {
+                                                double (&P)[3], CoefG12* G = nullptr) {
   auto t0022 = [](const double v) { return quad_take<quad_perm(0, 0, 2, 2)>(v); };
   auto t1133 = [](const double v) { return quad_take<quad_perm(1, 1, 3, 3)>(v); };
   auto t2222 = [](const double v) { return quad_take<quad_perm(2, 2, 2, 2)>(v); };
@@ -81,7 +85,8 @@ __device__ __forceinline__ void rhs12_base_quad(const double (&w)[3], const Quad
 #pragma unroll
   for (int j = 0; j < 3; ++j) { P[j] = t0022(w[j]); S[j] = t1133(w[j]); L[j] = t2222(w[j]); }   // (r r lv lv), (v v lr lr), lambda_v
   const double w2 = 2.0 * tp.omega;
-  const double u0 = P[0] + Q.off, u0_o = u0 + Q.sgn_o;
+  const double a0 = P[0] + Q.off1;
+  const double u0 = a0 + Q.off2, u0_o = a0 + Q.off2_o;
   const double yz2 = __builtin_fma(P[1], P[1], P[2] * P[2]);
   const double d = __builtin_fma(u0, u0, yz2);
   const double i = rsqrt_nr(fmax(d, Q.floor));
@@ -126,6 +131,16 @@ __device__ __forceinline__ void rhs12_base_quad(const double (&w)[3], const Quad
   k[1] = Q.lane1 ? ay : (Q.lane3 ? g3y : lin1);
   k[2] = Q.lane1 ? az : (Q.lane3 ? g3z : lin2);
   bp.c = c; bp.is = is; bp.inv_n = inv_n; bp.n2 = n2; bp.ua = ua; bp.ub = ub;
+  if constexpr (WITH_G) {
+    const double e_o = t1032(e);
+    const double ee = e_o + e;
+    const double sa = e_o * u0_o, tb = e * u0;
+    const double stt = sa + tb;
+    G->Gxx = __builtin_fma(sa, u0_o, __builtin_fma(tb, u0, omc));
+    G->Gyy = __builtin_fma(ee * yy, yy, omc);
+    G->Gzz = __builtin_fma(ee * z, z, -cs);
+    G->Gxy = stt * yy; G->Gxz = stt * z; G->Gyz = ee * yy * z;
+  }
 }
 
 }  // namespace lto

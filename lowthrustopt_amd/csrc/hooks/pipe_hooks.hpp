@@ -15,6 +15,7 @@ constexpr bool kProbeBuild = false;
 // a workgroup barrier, and the ticks this wave waited at such barriers
 struct BarrierWait {
   __device__ __forceinline__ void sync() { __syncthreads(); }
+  __device__ __forceinline__ int sync_or(const int pred) { return __syncthreads_or(pred); }
   __device__ __forceinline__ void report(double*, long, int, long) const {}          // (rows, ld, row, column)
 };
 // ticks (s_memtime) and 100 MHz ticks of a region

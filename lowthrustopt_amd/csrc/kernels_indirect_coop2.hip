@@ -10,19 +10,25 @@
 // One workgroup = 16 segments = 8 wavefronts (wave i and wave i + 4 share a SIMD):
 //   waves 0-2  TOP halves of the 12 STM columns: lane = (segment, column), owns (a, b) = (delta r, delta v); needs G and U.
 //   waves 4-6  BOTTOM halves: owns (d, g) = (delta lambda_v, delta lambda_r); needs G and H.  A top and a bottom wave share a
-//              SIMD (123 + 159 instructions per stage between them).
-//   wave 3     base wave, alone on its SIMD (wave 7 leaves at once).  Two lanes per segment in neighbouring 4-lane banks:
-//              lane A owns (r, v), lane B owns (lambda_v, lambda_r).  The three doubles each needs from the other (r, lambda_v)
-//              cross over in v_mov_b32_dpp row_shl:4 / row_shr:4 with a bank mask, so both lanes hold R = r and L = lambda_v
-//              and run ONE instruction stream (rhs12_base_half: per-lane constants select the first triple's slope, a
-//              v_cndmask the second's).
-// Per RK stage one __syncthreads(): before it the base lanes evaluate the stage and publish their argument (r, lambda_v) and
-// by-products (13 doubles, double-buffered), and the column halves -- whose stage argument needs only their own earlier
-// slopes -- publish the triple their partner needs; after it the column halves assemble their coefficients from the parts
-// (wave-uniform code per half: var_col12_top / var_col12_bottom) while the base lanes are already in the next stage.
+//              SIMD (92 + 135 instructions per stage between them; round 2: 123 + 159).
+//   wave 3     base wave, alone on its SIMD (wave 7 leaves at once).  Round 3: FOUR lanes per segment, a DPP quad -- lane 0 owns
+//              r, lane 1 v, lane 2 lambda_v, lane 3 lambda_r (three components and 13 x 3 slopes each) -- and one instruction
+//              stream in which the three reciprocal-square-root chains of an evaluation (two primaries, |lambda_v|) are ONE
+//              (rhs12_base_quad, halves.hpp); the lanes trade their pieces by v_mov_b32_dpp quad_perm.  Lane 1, which then
+//              holds both primaries' terms, also builds the gravity-gradient block G of the variational equations once per
+//              segment and stage (the 24 column halves of a segment used to assemble it 24 times).
+// Per RK stage one __syncthreads(): before it the base lanes evaluate the stage and publish their argument (r, lambda_v), the
+// by-products and G (20 doubles, double-buffered; 14 store instructions: the lanes of a quad hold different quantities under the
+// same name), and the column halves -- whose stage argument needs only their own earlier slopes -- publish the triple their
+// partner needs; after it the column halves finish their coefficients (wave-uniform code per half: var_col12_top_g, and
+// var_col12_bottom_g, which builds H from the parts) while the base lanes are already in the next stage.  The DOP853 tableau
+// rows come by scalar loads one stage ahead of their use (rk.hpp: dp8_load_row) instead of two s_mov_b32 per coefficient, and the
+// workgroup's exit vote rides on the first stage barrier of the next trial step instead of a barrier of its own.
+// Measured at 4 096 segments (tools/probe_coop2.py, probe build): 22.0 k -> 18.8 k ticks per trial step; per sweep 236 -> 219 us
+// cold start, 224 -> 206 us with the controller's warm start (tools/probe_warm.py).
 //
 // Step control as in kernels_indirect_coop.hip: one common step sequence per segment, the error norm over the base state AND
-// all 144 column components (what ForwardDiff duals see inside the adaptive solver), partial sums of the 26 roles of a
+// all 144 column components (what ForwardDiff duals see inside the adaptive solver), partial sums of the 28 roles of a
 // segment through LDS, identical arithmetic in every lane of the segment => identical decision, no broadcast.
 // Every loop is bounded (max_steps trial steps), every wavefront executes the same barriers, out-of-range lanes shadow a valid
 // segment without storing: the grid always drains.
@@ -35,7 +41,7 @@ namespace lto {
 
 constexpr int C2_SEG = 16;      // segments per workgroup
 constexpr int C2_ROLES = 28;    // 12 top halves, 12 bottom halves, the four base lanes (r, v, lambda_v, lambda_r)
-constexpr int C2_PUB = 14;      // rows of the published stage record (13 + one spare row for the lanes that have nothing to add)
+constexpr int C2_PUB = 20;      // rows of the published stage record: 13 parts, a spare row for the lanes that have nothing to add, G (6)
 constexpr int C2_PAD = 28;      // row pitch of the partial-sum table (16-byte aligned rows)
 
 enum C2Role : int { C2_TOP = 0, C2_BOTTOM = 1, C2_BASE = 2 };
@@ -90,6 +96,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   const QuadLane Q = quad_lane(q4, tp);        // base lanes: per-lane constants of the quad evaluation (halves.hpp)
   // where the base lanes publish what they hold after the exchange: P = (r r lambda_v lambda_v) -> rows 0..2 / 3..5; c, 1/d of
   // the own primary -> rows 6, 7 / 8, 9 (the lambda_v lanes: a spare row)
+  const int pub_g = (q4 == 1) ? 14 : 13, pub_gs = (q4 == 1) ? 1 : 0;
   const int pub_p = (q4 < 2) ? 0 : 3, pub_c = (q4 == 0) ? 6 : (q4 == 1) ? 7 : 13, pub_is = (q4 == 0) ? 8 : (q4 == 1) ? 9 : 13;
 
   // ---- state of this lane: six rows of the base state or of one STM column
@@ -103,14 +110,20 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   }
 
   hook::BarrierWait c2_wait;
-  // slope of the stage argument `arg` (own six rows) into `out`.  Called by ALL threads: one barrier inside.  `overlap` is work
+  // slope of the stage argument `arg` (own rows) into `out`.  Called by ALL threads: one barrier inside.  `overlap` is work
   // that needs neither this stage's slope nor LDS (the next argument's sum over the older slopes): the base lanes run it
-  // between their LDS stores and the barrier, the column lanes between issuing their LDS loads and the first use.
-  auto slope = [&](const double (&arg)[NC], double (&out)[NC], const int buf, auto&& overlap) {
+  // between their LDS stores and the barrier, the column lanes between issuing their LDS loads and the first use.  (Splitting it
+  // around the column lanes' barrier -- half behind their stores, half behind their loads -- measured no different.)
+  // VOTE (the first stage of a trial step): the barrier also carries the workgroup's "anyone still integrating?" vote, which
+  // otherwise cost a barrier of its own at the end of every trial step; returns the vote (1 without VOTE).
+  auto slope = [&](const double (&arg)[NC], double (&out)[NC], const int buf, auto&& overlap, auto vote_c, const int alive_in) {
+    constexpr bool VOTE = decltype(vote_c)::value;
+    int alive = 1;
     if constexpr (BASE) {
       QuadParts qp;
       double P[3];
-      rhs12_base_quad<PM>(arg, Q, tp, out, qp, P);
+      CoefG12 G;
+      rhs12_base_quad<PM, true>(arg, Q, tp, out, qp, P, &G);
       BaseParts12 bp;
       bp.ua = qp.ua; bp.ub = qp.ub;
       parts_guard_zero_norm<PM>(qp.n2, bp);
@@ -120,33 +133,50 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
         p[pub_p][seg] = P[0]; p[pub_p + 1][seg] = P[1]; p[pub_p + 2][seg] = P[2];
         p[pub_c][seg] = qp.c; p[pub_is][seg] = qp.is;
         p[10][seg] = bp.ua; p[11][seg] = bp.ub; p[12][seg] = qp.inv_n;
+        // G once per segment and stage, from the lane that holds both primaries' terms (lane 1); the others write the spare row
+        p[pub_g][seg] = G.Gxx; p[pub_g + pub_gs][seg] = G.Gyy; p[pub_g + 2 * pub_gs][seg] = G.Gzz;
+        p[pub_g + 3 * pub_gs][seg] = G.Gxy; p[pub_g + 4 * pub_gs][seg] = G.Gxz; p[pub_g + 5 * pub_gs][seg] = G.Gyz;
       }
       overlap();
     } else {
 #pragma unroll
       for (int j = 0; j < 3; ++j) sh.xch[buf][ROLE][col][j][seg] = arg[j];
     }
-    C2_SYNC();
+    if constexpr (VOTE) alive = c2_wait.sync_or(alive_in);
+    else C2_SYNC();
+    if constexpr (VOTE) { if (!alive) return 0; }
     if constexpr (!BASE) {
       const double (&p)[C2_PUB][C2_SEG] = sh.pub[buf];
-      double v[13], other[3];
+      // top halves: G, lambda_v, 1 / |lambda_v|, ua, ub (rows 3..5, 10..19); bottom halves: G and the parts H is made of (rows 0..9, 14..19)
+      double v[C2_PUB], other[3];
 #pragma unroll
-      for (int e = 0; e < 13; ++e) v[e] = p[e][seg];
+      for (int e = 0; e < C2_PUB; ++e) {
+        const bool need = (ROLE == C2_TOP) ? ((e >= 3 && e <= 5) || (e >= 10 && e != 13)) : (e <= 9 || e >= 14);
+        if (need) v[e] = p[e][seg];
+      }
 #pragma unroll
       for (int j = 0; j < 3; ++j) other[j] = sh.xch[buf][1 - ROLE][col][j][seg];
       overlap();
-      BaseParts12 bp;
-      bp.c1 = v[6]; bp.c2 = v[7]; bp.i1s = v[8]; bp.i2s = v[9]; bp.ua = v[10]; bp.ub = v[11]; bp.inv_n = v[12];
-      if constexpr (ROLE == C2_TOP) var_col12_top(v[0], v[1], v[2], v[3], v[4], v[5], bp, tp.MU, w2, arg, other, out);
-      else var_col12_bottom(v[0], v[1], v[2], v[3], v[4], v[5], bp, tp.MU, w2, arg, other, out);
+      CoefG12 g;
+      g.Gxx = v[14]; g.Gyy = v[15]; g.Gzz = v[16]; g.Gxy = v[17]; g.Gxz = v[18]; g.Gyz = v[19];
+      if constexpr (ROLE == C2_TOP) var_col12_top_g(g, v[3], v[4], v[5], v[12], v[10], v[11], w2, arg, other, out);
+      else var_col12_bottom_g(g, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], tp.MU, w2, arg, other, out);
     }
+    return alive;
   };
-  // sum over all roles of partial `which` for this lane's segment (fixed order => identical in every lane)
+  const std::false_type no_vote{};
+  const std::true_type with_vote{};
+  // sum over all roles of partial `which` for this lane's segment (fixed order => identical in every lane); four interleaved
+  // chains: the sum sits between the trial step's last barrier and the decision every wavefront waits for
   auto total = [&](const int parity, const int which) {
-    double t = 0.0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    static_assert(C2_ROLES % 4 == 0, "four chains");
 #pragma unroll
-    for (int r = 0; r < C2_ROLES; ++r) t += sh.part[parity][which][seg][r];
-    return t;
+    for (int r = 0; r < C2_ROLES; r += 4) {
+      t0 += sh.part[parity][which][seg][r]; t1 += sh.part[parity][which][seg][r + 1];
+      t2 += sh.part[parity][which][seg][r + 2]; t3 += sh.part[parity][which][seg][r + 3];
+    }
+    return (t0 + t1) + (t2 + t3);
   };
   auto nothing = [] {};
 
@@ -166,7 +196,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   if (a.warm) {
     const double hw = a.h_first[s];
     h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
-    slope(y, K[0], buf, nothing); buf ^= 1;
+    slope(y, K[0], buf, nothing, no_vote, 1); buf ^= 1;
   } else {
     // Hairer's initial step over all components.  Row r of every column is scaled with the BASE value of row r (a dual
     // number's partials share the scale of its value), published by the base lanes.
@@ -174,7 +204,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
 #pragma unroll
       for (int j = 0; j < NC; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
     }
-    slope(y, K[0], buf, nothing); buf ^= 1;
+    slope(y, K[0], buf, nothing, no_vote, 1); buf ^= 1;
     double isc0[NC];
     double p0 = 0.0, p1 = 0.0;
 #pragma unroll
@@ -191,7 +221,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     double arg[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) arg[j] = __builtin_fma(h0, K[0][j], y[j]);
-    slope(arg, K[1], buf, nothing); buf ^= 1;   // the barrier inside also separates the reads above from the writes below
+    slope(arg, K[1], buf, nothing, no_vote, 1); buf ^= 1;   // the barrier inside also separates the reads above from the writes below
     double p2 = 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -225,7 +255,8 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     // the tableau rows come by scalar loads (rk.hpp: dp8_load_row), the row of argument st + 1 while stage st is evaluated
     double wrow[2][12], we5[13], we3[13];
     dp8_load_row<1>(tab, wrow[1]);
-    static_for<1, NS + 1>([&](auto st_c) {       // enters with K[0] = f(y) (FSAL)
+    int alive = 1;
+    auto stage = [&](auto st_c) {                // enters with K[0] = f(y) (FSAL)
       constexpr int st = decltype(st_c)::value;
       double arg[NC], next[NC];
       constexpr double wn_c = (st < NS) ? DP8_A[st < NS ? st : 0][st - 1] : DP8_B[st - 1];
@@ -238,7 +269,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       if constexpr (st < NS) {
         double (&wx)[12] = wrow[(st + 1) & 1];
         dp8_load_row<st + 1>(tab, wx);
-        slope(arg, K[st], buf, [&] {
+        auto sums = [&] {
 #pragma unroll
           for (int j = 0; j < NC; ++j) next[j] = 0.0;
 #pragma unroll
@@ -249,7 +280,10 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
               for (int j = 0; j < NC; ++j) next[j] = __builtin_fma(wx[k], K[k][j], next[j]);
             }
           }
-        });
+        };
+        // the first stage's barrier carries the vote that ends the sweep of this workgroup (every segment done)
+        if constexpr (st == 1) alive = slope(arg, K[st], buf, sums, with_vote, !done);
+        else slope(arg, K[st], buf, sums, no_vote, 1);
 #pragma unroll
         for (int j = 0; j < NC; ++j) older[j] = next[j];
       } else {
@@ -274,10 +308,13 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
               for (int j = 0; j < NC; ++j) a3[j] = __builtin_fma(we3[k], K[k][j], a3[j]);
             }
           }
-        });
+        }, no_vote, 1);
       }
       buf ^= 1;
-    });
+    };
+    stage(std::integral_constant<int, 1>{});
+    if (!alive) break;                       // workgroup-uniform: the vote is the barrier's
+    static_for<2, NS + 1>(stage);
     const int par = trial & 1;
     double e5 = 0.0, e3 = 0.0;
 #pragma unroll
@@ -324,7 +361,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       }
       if (!(t < span)) done = 1;
     }
-    if (!__syncthreads_or(!done)) break;   // workgroup-uniform exit: all 16 segments done
+    // (the exit vote rides on the next trial step's first stage barrier)
   }
   if ((lane & 15) == 0 && (BASE ? lane == 0 : (cwave == 0 && lane == 0))) {      // probe build only: the hooks write nothing otherwise
     const int r0 = BASE ? 16 : (ROLE == C2_TOP ? 20 : 22);

@@ -1364,6 +1364,16 @@ def test_indirect_pipeline_kernel_is_rk4_only(gpu_ctx):
             plan.set_kernel(kern)
         assert ei.value.code == -1 and "removed" in str(ei.value)
     plan.set_kernel(plan.KERNEL_PIPE8)
+    # lanes per segment of the defect-only sweep: two and four are built for the reference's integrator setting only
+    for lanes in (2, 4, 3, -1):
+        with pytest.raises(lto.LtoError) as ei:
+            plan.set_defect_lanes(lanes)
+        assert ei.value.code == -1
+    plan.set_defect_lanes(1); plan.set_defect_lanes(0)
+    plan.close()
+    plan = lto.IndirectPlan(gpu_ctx, 8, 1, prm, lto.integrator(lto.DOP853_ADAPTIVE), ndim=14)
+    with pytest.raises(lto.LtoError):
+        plan.set_defect_lanes(4)
     plan.close()
 
 

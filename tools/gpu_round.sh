@@ -47,6 +47,6 @@ find "$OUT" -name "*.csv" | wc -l
 #   python tools/summarize_profile.py $OUT <tag> c2_ndim12 "k_indirect_pipe8<12" c2
 #   python tools/summarize_profile.py $OUT <tag> c3 "k_direct_jacobian_pipe<6"
 #   python tools/summarize_profile.py $OUT <tag> c4 "k_indirect_pipe48<12"
-#   python tools/summarize_profile.py $OUT <tag> c5 "k_indirect_defect2"
+#   python tools/summarize_profile.py $OUT <tag> c5 "k_indirect_defect4"
 #   python tools/summarize_profile.py $OUT <tag> c5_stm "k_indirect_coop2"
 #   python tools/summarize_profile.py $OUT <tag> c2_ndim12_dop853 "k_indirect_coop2" c2_dop853

@@ -12,6 +12,7 @@ constexpr bool kProbeBuild = true;
 struct BarrierWait {
   long long waited = 0;
   __device__ __forceinline__ void sync() { const long long t = clock64(); __syncthreads(); waited += clock64() - t; }
+  __device__ __forceinline__ int sync_or(const int pred) { const long long t = clock64(); const int r = __syncthreads_or(pred); waited += clock64() - t; return r; }
   __device__ __forceinline__ void report(double* rows, long ld, int row, long col) const { if (rows) rows[row * ld + col] = (double)waited; }
 };
 struct RegionClock {
