@@ -27,7 +27,7 @@ template <int PM> static void parts12(const double (&y)[12], const TrajParams& t
   std::memcpy(vc_b, &w, sizeof w);
 }
 // two-lanes-per-state forms of the cooperative kernel: the base slopes assembled from lane A (r, v) and lane B (lambda_v,
-// lambda_r) of rhs12_base_half, the column slopes from var_col12_top / var_col12_bottom, against the one-piece functions
+// lambda_r) of rhs12_base_half, the column slopes from var_col12_top_g / var_col12_bottom_g, against the one-piece functions
 template <int PM> static void halves12(const double (&y)[12], const double (&c)[12], const TrajParams& tp, double* dy_a, double* dc_a,
                                        double* dy_b, double* dc_b, double* parts_ab) {
   double d[12], dc[12]; VarCoef12 v; rhs12<PM, true>(y, tp, d, v);
@@ -45,8 +45,10 @@ template <int PM> static void halves12(const double (&y)[12], const double (&c)[
   const double wt[6] = {c[0], c[1], c[2], c[3], c[4], c[5]}, wb[6] = {c[9], c[10], c[11], c[6], c[7], c[8]};
   const double dd[3] = {c[9], c[10], c[11]}, aa[3] = {c[0], c[1], c[2]};
   double ot[6], ob[6];
-  var_col12_top(y[0], y[1], y[2], y[9], y[10], y[11], bpa, tp.MU, w2, wt, dd, ot);
-  var_col12_bottom(y[0], y[1], y[2], y[9], y[10], y[11], bpa, tp.MU, w2, wb, aa, ob);
+  // G as the base wave publishes it (the cooperative kernel's lane 1 builds it with the arithmetic of rhs12's VAR block)
+  const CoefG12 g = {v.Gxx, v.Gyy, v.Gzz, v.Gxy, v.Gxz, v.Gyz};
+  var_col12_top_g(g, y[9], y[10], y[11], bpa.inv_n, bpa.ua, bpa.ub, w2, wt, dd, ot);
+  var_col12_bottom_g(g, y[0], y[1], y[2], y[9], y[10], y[11], bpa.c1, bpa.c2, bpa.i1s, bpa.i2s, tp.MU, w2, wb, aa, ob);
   for (int j = 0; j < 6; ++j) dc_b[j] = ot[j];
   for (int j = 0; j < 3; ++j) { dc_b[9 + j] = ob[j]; dc_b[6 + j] = ob[3 + j]; }
 }
