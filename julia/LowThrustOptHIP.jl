@@ -14,7 +14,7 @@ module LowThrustOptHIP
 using SparseArrays, LinearAlgebra, Libdl
 
 export LtoIndirectPlan, LtoDirectPlan, LtoComm, LtoCommWindows, pinned_array, pack_soa!, unpack_soa!, defect_norms!, indirect_defect_dev!,
-       indirect_jacobian_dev!, newton_solve_dev!, axpy_dev!, direct_defect_dev!, direct_jacobian_dev!, rebalance!, set_kernel!, set_warm_start!,
+       indirect_jacobian_dev!, newton_solve_dev!, axpy_dev!, direct_defect_dev!, direct_jacobian_dev!, rebalance!, set_kernel!, set_warm_start!, set_defect_lanes!,
        comm_unique_id, allgather_dev!, allreduce_dev!, ctx_stream, last_call_ms
 export LtoContext, LtoGroup, indirect_defectCalc, indirect_jacobianCalc, indirect_stm, indirect_newton_step, indirect_solve, indirect_solve_batch, densify,
        direct_defectCalc, direct_jacobianCalc, direct_midpoints, LTO_RK4, LTO_RKF78_FIXED, LTO_RKF78_ADAPTIVE, LTO_DOP853_ADAPTIVE
@@ -361,6 +361,8 @@ rebalance!(pl::LtoIndirectPlan, stream) = check(pl.ctx, ccall((:lto_indirect_pla
 set_kernel!(pl::LtoIndirectPlan, kernel::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_kernel, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, kernel))
 "Adaptive sweeps start every segment from its first accepted step size of the plan's previous sweep of the same kind (12-dim DOP853 plans; lto.h)."
 set_warm_start!(pl::LtoIndirectPlan, on::Bool = true) = check(pl.ctx, ccall((:lto_indirect_plan_set_warm_start, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, on ? 1 : 0))
+"Lanes per segment of the defect-only sweep of a 12-dim DOP853 plan: 0 = choose (four up to 131 072 segments, then two, then one), 1, 2 or 4."
+set_defect_lanes!(pl::LtoIndirectPlan, lanes::Integer = 0) = check(pl.ctx, ccall((:lto_indirect_plan_set_defect_lanes, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, lanes))
 
 "Julia column-major [ndim x count] on the device -> SoA [ndim][ld] (and back)."
 pack_soa!(ctx::LtoContext, stream, aos, ndim::Integer, count::Integer, soa, ld::Integer) =
