@@ -305,6 +305,43 @@ def test_indirect_defect_two_lanes_per_segment(gpu_ctx, oracle, pcase):
         assert np.mean(dn == 0) >= 0.9
 
 
+def test_device_entry_points_replay_from_a_captured_graph(gpu_ctx):
+    """The device-resident entry points are stream-ordered and allocate nothing after their first call, so a caller may capture
+    a whole Newton iteration (STM sweep with the reference's integrator setting, block-bidiagonal solve, update, defect sweep at
+    the new point) into ONE HIP graph: the replay equals the direct calls bit for bit (tools/probe_graph.py times both)."""
+    import torch
+    n = 30; S = n - 1
+    XC, T = synth.indirect_problem(n, seed=4)
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, prm, lto.integrator())
+    Xn = torch.zeros_like(X)
+    d = torch.zeros(12, S, dtype=torch.float64, device="cuda"); d2 = torch.zeros_like(d)
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+    delta = torch.zeros(12, n, dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream(); sp = s.cuda_stream
+
+    def iteration():
+        plan.jacobian(X, n, t, 1, Phi, S, d, S, stream=sp)
+        plan.newton_solve(Phi, S, d, S, delta, n, stream=sp)
+        gpu_ctx.check(gpu_ctx.lib.lto_axpy_dev(gpu_ctx.handle, sp, X.data_ptr(), delta.data_ptr(), 1.0, Xn.data_ptr(), 12 * n))
+        plan.defect(Xn, n, t, 1, d2, S, stream=sp)
+
+    with torch.cuda.stream(s):
+        iteration(); iteration()          # the first calls allocate the plan's scratch: never inside a capture
+        s.synchronize()
+        ref = (Xn.clone(), d2.clone(), Phi.clone())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            iteration()
+        Xn.zero_(); d2.zero_(); Phi.zero_()
+        g.replay(); s.synchronize()
+    assert torch.equal(Xn, ref[0]) and torch.equal(d2, ref[1]) and torch.equal(Phi, ref[2])
+    assert bool(torch.isfinite(d2).all()) and float(d2.abs().max()) > 0.0
+    plan.close()
+
+
 def test_indirect_backward_time_direction(gpu_ctx, oracle):
     XC, T = synth.indirect_problem(12, seed=8)
     XC, t = XC[:, :, 0], T[:, 0]
