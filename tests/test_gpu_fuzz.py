@@ -44,8 +44,10 @@ def make_case(seed):
     else:
         X, slot = XC, 1000.0
     prm_l = [[MU, DU, TU, thr[b], slot, td, ps[b], rhos[b]] for b in range(B)]
+    # lanes per segment of the defect-only sweep with the reference's setting (own generator: the other draws stay put)
+    lanes = int(np.random.default_rng(9000 + seed).choice([0, 1, 2, 4])) if (ndim == 12 and method == lto.DOP853_ADAPTIVE) else 0
     return dict(ndim=ndim, method=method, steps=steps, adaptive=adaptive, B=B, n=n, X=X, T=T, prm_l=prm_l, kernel=kernel,
-                cols=cols)
+                cols=cols, lanes=lanes)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LTO_FUZZ_SEEDS", "96"))))
@@ -56,6 +58,7 @@ def test_indirect_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
     plan = lto.IndirectPlan(gpu_ctx, n, B, [lto.make_params(*q) for q in c["prm_l"]], lto.integrator(c["method"], steps=c["steps"]),
                             ndim=ndim)
     plan.set_kernel(c["kernel"])
+    plan.set_defect_lanes(c["lanes"])
     if ndim == 14 and c["cols"] == 3:                # 14 columns do not split into groups of 3: refused, auto is kept
         with pytest.raises(lto.LtoError) as ei:
             plan.set_cols_per_lane(3)
@@ -92,8 +95,8 @@ def test_indirect_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
             P_o, d_o, rc = oracle.indirect14(Xb, tb, c["prm_l"][b], c["method"], c["steps"])
         assert rc == 0
         scale = np.linalg.norm(d_o + Xb[:, 1:])
-        what = "seed %d: ndim %d method %d B %d n %d kernel %d cols %d p %g" % (seed, ndim, c["method"], B, n, c["kernel"],
-                                                                              c["cols"], c["prm_l"][b][6])
+        what = "seed %d: ndim %d method %d B %d n %d kernel %d cols %d lanes %d p %g" % (seed, ndim, c["method"], B, n, c["kernel"],
+                                                                                       c["cols"], c["lanes"], c["prm_l"][b][6])
         assert np.linalg.norm(dn[:, sl] - d_o) < tol_d * scale, what
         assert np.linalg.norm(d0n[:, sl] - d_o) < tol_d * scale, what
         assert np.abs(Pn[:, :, sl] - P_o).max() < tol_P * np.abs(P_o).max(), what
