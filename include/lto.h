@@ -256,9 +256,10 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
 #define LTO_KERNEL_PIPE8 5
 /* ndim = 12, DOP853_ADAPTIVE plans only: the cooperative kernel with every 12-component state split over two lanes (top /
  * bottom halves of a column in different waves, the two halves of the base state in neighbouring DPP banks): six components
- * per lane keep all slopes of the 13-stage method in addressable registers.  Other plans: LTO_EINVAL.  The defect-only
- * sweep of such a plan has the same two forms (one lane per segment / two lanes per segment; AUTO: two lanes up to 262 144
- * segments); LTO_KERNEL_PER_LANE and LTO_KERNEL_COOP2 select them explicitly. */
+ * per lane keep all slopes of the 13-stage method in addressable registers (round 3: the base state takes a DPP quad, three
+ * components per lane).  Other plans: LTO_EINVAL.  The defect-only sweep of such a plan comes with one, two or four lanes per
+ * segment (AUTO: four up to 131 072 segments on MI355X, two up to 262 144, one beyond): LTO_KERNEL_PER_LANE and LTO_KERNEL_COOP2
+ * select the first two, lto_indirect_plan_set_defect_lanes any of them. */
 #define LTO_KERNEL_COOP2 6
 /* RK4 plans only: the pipeline for large batches -- 48 segments and 16 wavefronts per workgroup, the base wave's lanes are 48
  * different segments, twelve column waves with one segment per DPP row. */

@@ -1,5 +1,6 @@
 // kernels_indirect_defect2.hip -- defect-only sweep with the reference's integrator setting (adaptive order 8, rtol = atol =
-// 1e-13; src/multiShoot_CRTBP_indirect.jl:63-90, :79) on the 12-dim system, TWO LANES PER SEGMENT.
+// 1e-13; src/multiShoot_CRTBP_indirect.jl:63-90, :79) on the 12-dim system, TWO LANES PER SEGMENT (k_indirect_defect2, round 2)
+// and FOUR (k_indirect_defect4, round 3: below; what AUTO runs up to 131 072 segments on MI355X).
 //
 // The one-lane kernel (k_indirect<12, PM, M_DOP853_ADAPTIVE, 0>) keeps ten live slopes of 12 components: 240 of the 256
 // registers a VALU instruction can address, so state, argument and temporaries overflow into AGPRs (620 v_accvgpr moves per
@@ -8,7 +9,7 @@
 // and 13 x 6 slopes per lane, the tableau arithmetic per lane halves, nothing spills.  Both lanes hold r and lambda_v (three
 // doubles each cross over by v_mov_b32_dpp) and run one instruction stream (rhs12_base_half); error norms are pair sums
 // formed in the same order in both lanes, so both take the same decisions and the pair's control flow never diverges.
-// Twice the wavefronts: chosen while the chip holds them at two per SIMD (launcher below).
+// Twice the wavefronts of the one-lane kernel: AUTO runs it between 131 072 and 262 144 segments (lto_api.hip).
 #include "kernels.hpp"
 #include "rk.hpp"
 #include "halves.hpp"
