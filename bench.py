@@ -87,6 +87,11 @@ def parse():
                          "reference's own constant-mass system (parity path; default of the other workloads)")
     ap.add_argument("--method", default="", choices=["", "rk4", "rkf78", "dop853"], help="override the workload's integrator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
+                    help="roofline.traffic from counter passes of THIS run: rank 0 at N = 1 starts `rocprofv3 --pmc FETCH_SIZE` and "
+                         "`--pmc WRITE_SIZE` (separate passes) on a child that runs the workload's sweep only; auto = when rocprofv3 is on "
+                         "PATH and the baseline legs run too (not with --no-cpu-baseline); on failure the stored profile's figure stays")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child of --live-traffic: W + K sweeps, no output
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--device-warmup-ms", type=float, default=30.0,
                     help="untimed sweeps before the W + K region so that it runs at ramped device clocks (0: off; the cold run is reported either way)")
@@ -191,6 +196,53 @@ def pmc_key(wl, ndim, method=None):
     if method:
         key += "_" + method
     return key
+
+
+def live_traffic(argv_workload, timeout_s=150.0):
+    """HBM bytes per launch of the workload's dominant kernel from counter passes of THIS run: two children under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass; the program itself right after `--`), each running
+    `bench.py --pmc-child` = the workload's sweeps only.  Units and the gfx950 correction as tools/summarize_profile.py
+    (MI355X_MICROARCH.md, HBM section): KiB, FETCH_SIZE x 2.  Returns (bytes_per_launch or None, how / why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="lto_pmc_")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                   "--steps", "5", "--warmup", "2"] + argv_workload
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s, cwd="/tmp", env=env)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s pass took longer than %.0f s" % (counter, timeout_s)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s pass failed (exit %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:])
+            per_kernel = {}
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and "lto::k_" in row.get("Kernel_Name", ""):
+                            per_kernel.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not per_kernel:
+                return None, "no %s rows for an lto:: kernel in the pass's output" % counter
+            name = max(per_kernel, key=lambda k: len(per_kernel[k]))      # the child launches the workload's sweep kernel and little else
+            got[counter] = (name, sum(per_kernel[name]) / len(per_kernel[name]), len(per_kernel[name]))
+        if got["FETCH_SIZE"][0] != got["WRITE_SIZE"][0]:
+            return None, "the two passes disagree on the dominant kernel"
+        fetch_kib, write_kib = got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]
+        return (2.0 * fetch_kib + write_kib) * 1024.0, (
+            "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on a child running the same sweep, "
+            "%d launches of %s: FETCH_SIZE %.0f KiB (x 2, gfx950) + WRITE_SIZE %.0f KiB" % (got["FETCH_SIZE"][2], got["FETCH_SIZE"][0][:60], fetch_kib, write_kib))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def roofline(wl, ndim, S, kern_ms, work=None, samples=None, burst_n=N_BURST, method=None):
@@ -482,6 +534,12 @@ def main():
         desc = "C3: direct 6-dim, RKF7(8) nsteps=10 per half, on-device Jacobian blocks 6x18 + tf column + defect + errors"
         gather_rows = 6
 
+    if a.pmc_child:          # under rocprofv3 --pmc (live_traffic below): the workload's sweeps and nothing else
+        for _ in range(a.warmup + a.steps):
+            sweep(defect)
+        torch.cuda.synchronize()
+        plan.close(); ctx.close()
+        return
     use_coll = dist is not None
     # The collective of the product: the library's own RCCL all-gather (lto_comm_allgather_dev; communicator created from an
     # id that rank 0 makes and torch.distributed hands round).  If any rank cannot set it up, every rank falls back to
@@ -709,6 +767,21 @@ def main():
                                                              ndim=a.ndim)
         if world == 1 and wl == "c2" and not a.method and not a.segments:
             out["host_api"] = leg_host_api(lto, ctx, XC, T, prm, integ, a.ndim, S)
+        want_live = a.live_traffic == "on" or (a.live_traffic == "auto" and not a.no_cpu_baseline)
+        if world == 1 and want_live and "roofline" in out and wl in ("c2", "c2_defect", "c3", "c4", "hbm"):   # (the C5 sweeps order their lanes first)
+            argv_wl = ["--workload", wl, "--ndim", str(a.ndim)]
+            if a.segments: argv_wl += ["--segments", str(a.segments)]
+            if a.method: argv_wl += ["--method", a.method]
+            if a.kernel: argv_wl += ["--kernel", str(a.kernel)]
+            if a.cols: argv_wl += ["--cols", str(a.cols)]
+            if a.no_rebalance: argv_wl += ["--no-rebalance"]
+            live, how = live_traffic(argv_wl)
+            rf = out["roofline"]
+            if live is not None:
+                rf["traffic_stored"], rf["traffic_stored_from"] = rf.get("traffic"), rf.get("traffic_from")
+                rf["traffic"], rf["traffic_from"] = live, how
+            else:
+                rf["traffic_live"] = "not measured in this run (%s): the stored profile's figure stands" % how
         if ref12 is not None:
             out["reference_system_12dim"] = ref12[0]
             out["reference_integrator"] = refint[0]
