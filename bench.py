@@ -211,6 +211,8 @@ def live_traffic(argv_workload, timeout_s=150.0):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this process already runs under a profiler"
     tmp = tempfile.mkdtemp(prefix="lto_pmc_")
     got = {}
     try:
