@@ -225,6 +225,8 @@ def live_traffic(argv_workload, timeout_s=150.0):
                 r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s, cwd="/tmp", env=env)
             except subprocess.TimeoutExpired:
                 return None, "rocprofv3 --pmc %s pass took longer than %.0f s" % (counter, timeout_s)
+            except OSError as ex:
+                return None, "rocprofv3 could not be started: %s" % ex
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s pass failed (exit %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:])
             per_kernel = {}
@@ -777,7 +779,10 @@ def main():
             if a.kernel: argv_wl += ["--kernel", str(a.kernel)]
             if a.cols: argv_wl += ["--cols", str(a.cols)]
             if a.no_rebalance: argv_wl += ["--no-rebalance"]
-            live, how = live_traffic(argv_wl)
+            try:
+                live, how = live_traffic(argv_wl)
+            except Exception as ex:      # noqa: BLE001 -- the counter passes are an extra: never lose the line to them
+                live, how = None, "%s: %s" % (type(ex).__name__, ex)
             rf = out["roofline"]
             if live is not None:
                 rf["traffic_stored"], rf["traffic_stored_from"] = rf.get("traffic"), rf.get("traffic_from")
