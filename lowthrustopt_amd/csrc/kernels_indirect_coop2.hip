@@ -110,6 +110,10 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   }
 
   hook::BarrierWait c2_wait;
+  // A top and a bottom wave share a SIMD and the top wave -- the older one, which the SIMD serves first -- has the shorter stream (92
+  // against 135 instructions per stage): it used to finish early and wait while the bottom wave ran on alone.  With the bottom
+  // wave at raised priority the two finish together: 217-222 -> 213.6 us per sweep on the same box (tools/probe_warm.py).
+  if (ROLE == C2_BOTTOM) __builtin_amdgcn_s_setprio(2);
   // slope of the stage argument `arg` (own rows) into `out`.  Called by ALL threads: one barrier inside.  `overlap` is work
   // that needs neither this stage's slope nor LDS (the next argument's sum over the older slopes): the base lanes run it
   // between their LDS stores and the barrier, the column lanes between issuing their LDS loads and the first use.  (Splitting it
