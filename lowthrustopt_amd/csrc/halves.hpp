@@ -39,6 +39,20 @@ __device__ __forceinline__ double quad_sum(const double x) {
   return quad_take<quad_perm(0, 0, 0, 0)>(h) + quad_take<quad_perm(2, 2, 2, 2)>(h);
 }
 
+// x summed over the four 16-lane rows of the wavefront (lanes l, l + 16, l + 32, l + 48), the same bits in all four: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers, so with both operands = x one register
+// ends up holding (r0 r0 r2 r2) and the other (r1 r1 r3 r3), then (lo lo) and (hi hi).  Five instructions per level and dword pair.
+__device__ __forceinline__ double rows_sum(const double x) {
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double s = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  const unsigned slo = (unsigned)__double2loint(s), shi = (unsigned)__double2hiint(s);
+  const auto c = __builtin_amdgcn_permlane32_swap(slo, slo, false, false);
+  const auto d = __builtin_amdgcn_permlane32_swap(shi, shi, false, false);
+  return __hiloint2double((int)d[0], (int)c[0]) + __hiloint2double((int)d[1], (int)c[1]);
+}
+
 // ---- the base RHS with FOUR lanes per segment (a DPP quad; kernels_indirect_defect2.hip, quad kernel): lane 0 owns r, lane 1
 // v, lane 2 lambda_v, lane 3 lambda_r -- three components and 13 x 3 slopes per lane, a quarter of the tableau arithmetic of
 // the one-lane kernel -- and the three reciprocal square roots of an evaluation (the two primaries' distances, |lambda_v|) are

@@ -40,16 +40,16 @@
 namespace lto {
 
 constexpr int C2_SEG = 16;      // segments per workgroup
-constexpr int C2_ROLES = 28;    // 12 top halves, 12 bottom halves, the four base lanes (r, v, lambda_v, lambda_r)
 constexpr int C2_PUB = 20;      // rows of the published stage record: 13 parts, a spare row for the lanes that have nothing to add, G (6)
-constexpr int C2_PAD = 28;      // row pitch of the partial-sum table (16-byte aligned rows)
+constexpr int C2_WAVES = 7;     // wavefronts that contribute to a norm: three top, three bottom, the base wave
+constexpr int C2_PLD = 9;       // entries per segment of the partial-sum table (seven used): 16-byte entries at a pitch of 36 dwords are conflict-free
 
 enum C2Role : int { C2_TOP = 0, C2_BOTTOM = 1, C2_BASE = 2 };
 
 struct C2Shared {
   double pub[2][C2_PUB][C2_SEG];                // base argument (r, lambda_v) + by-products of the stage, double-buffered
   double xch[2][2][12][3][C2_SEG];           // [buffer][half that wrote][column][j][segment]: first triple of the stage argument
-  alignas(16) double part[2][3][C2_SEG][C2_PAD];  // partial norms [trial parity][which][segment][role]
+  alignas(16) double part[C2_SEG][C2_PLD][2];   // partial norms [segment][wavefront][which]: every wavefront sums its own lanes of a segment first
   double scale[12][C2_SEG];                  // 1 / (atol + rtol |base value|) of global row r
 };
 
@@ -78,7 +78,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
 #pragma unroll
   for (int j = 0; j < NC; ++j)
     grow[j] = BASE ? ((q4 == 0) ? 0 : (q4 == 1) ? 3 : (q4 == 2) ? 9 : 6) + j : (ROLE == C2_TOP) ? j : (j < 3 ? 9 + j : 3 + j);
-  const int role = BASE ? 24 + q4 : (ROLE == C2_TOP ? col : 12 + col);
+  const int widx = BASE ? 6 : (ROLE == C2_TOP ? cwave : 3 + cwave);     // this wavefront's entry in the partial-sum table
 
   const int s_raw = blockIdx.x * C2_SEG + seg;
   const int s_lin = s_raw < a.S ? s_raw : a.S - 1;             // shadow lanes repeat the last segment
@@ -120,7 +120,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   // around the column lanes' barrier -- half behind their stores, half behind their loads -- measured no different.)
   // VOTE (the first stage of a trial step): the barrier also carries the workgroup's "anyone still integrating?" vote, which
   // otherwise cost a barrier of its own at the end of every trial step; returns the vote (1 without VOTE).
-  auto slope = [&](const double (&arg)[NC], double (&out)[NC], const int buf, auto&& overlap, auto vote_c, const int alive_in) {
+  auto slope = [&](const double (&arg)[NC], double (&out)[NC], const int buf, auto&& overlap, auto vote_c, const int alive_in, auto&& base_tail) {
     constexpr bool VOTE = decltype(vote_c)::value;
     int alive = 1;
     if constexpr (BASE) {
@@ -142,6 +142,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
         p[pub_g + 3 * pub_gs][seg] = G.Gxy; p[pub_g + 4 * pub_gs][seg] = G.Gxz; p[pub_g + 5 * pub_gs][seg] = G.Gyz;
       }
       overlap();
+      base_tail();          // base lanes only: work on the slope just formed that must be in LDS before this stage's barrier
     } else {
 #pragma unroll
       for (int j = 0; j < 3; ++j) sh.xch[buf][ROLE][col][j][seg] = arg[j];
@@ -170,17 +171,25 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   };
   const std::false_type no_vote{};
   const std::true_type with_vote{};
-  // sum over all roles of partial `which` for this lane's segment (fixed order => identical in every lane); four interleaved
-  // chains: the sum sits between the trial step's last barrier and the decision every wavefront waits for
-  auto total = [&](const int parity, const int which) {
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    static_assert(C2_ROLES % 4 == 0, "four chains");
+  // Norms over all 156 components of a segment in two levels: every wavefront first sums its own lanes of the segment -- the four
+  // columns of a column wave sit in the four 16-lane rows (rows_sum: row / half swaps), the base quad by DPP -- and publishes ONE
+  // pair per segment; after the barrier every lane adds the seven pairs in the same order => identical bits, identical decision
+  // in every lane, no broadcast.  (Round 3: 28 entries per segment, 56 LDS reads per lane and trial step.)
+  auto post2 = [&](const double p0, const double p1) {
+    const double s0 = BASE ? quad_sum(p0) : rows_sum(p0), s1 = BASE ? quad_sum(p1) : rows_sum(p1);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 v; v.x = s0; v.y = s1;
+    *reinterpret_cast<d2*>(&sh.part[seg][widx][0]) = v;
+  };
+  auto totals2 = [&](double& T0, double& T1) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 acc = *reinterpret_cast<const d2*>(&sh.part[seg][0][0]);
 #pragma unroll
-    for (int r = 0; r < C2_ROLES; r += 4) {
-      t0 += sh.part[parity][which][seg][r]; t1 += sh.part[parity][which][seg][r + 1];
-      t2 += sh.part[parity][which][seg][r + 2]; t3 += sh.part[parity][which][seg][r + 3];
+    for (int w = 1; w < C2_WAVES; ++w) {
+      const d2 v = *reinterpret_cast<const d2*>(&sh.part[seg][w][0]);
+      acc.x += v.x; acc.y += v.y;
     }
-    return (t0 + t1) + (t2 + t3);
+    T0 = acc.x; T1 = acc.y;
   };
   auto nothing = [] {};
 
@@ -189,7 +198,6 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   double h_abs = 0.0, t = 0.0;
   double rejected = 0.0;
   int nacc = 0, nrej = 0;
-  int buf = 0;
   int done = !(span > 0.0) || !mine;
   constexpr double NCOMP = 156.0;              // 12 + 144 components
 
@@ -197,10 +205,12 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   // previous STM sweep -- consecutive Newton iterations sweep nearly the same trajectory -- which saves the two extra stage
   // evaluations of Hairer's rule and the trial steps it takes to grow from a start that is a decade or two low.  a.warm is
   // launch-uniform (every wave takes the same barriers); any positive value is a valid start.
+  // (Stage records and exchanged triples are double-buffered by the parity of the stage index: the loop's first stage uses
+  // buffer 1, and both evaluations here are consumed before a barrier that precedes it.)
   if (a.warm) {
     const double hw = a.h_first[s];
     h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
-    slope(y, K[0], buf, nothing, no_vote, 1); buf ^= 1;
+    slope(y, K[0], 0, nothing, no_vote, 1, nothing);
   } else {
     // Hairer's initial step over all components.  Row r of every column is scaled with the BASE value of row r (a dual
     // number's partials share the scale of its value), published by the base lanes.
@@ -208,7 +218,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
 #pragma unroll
       for (int j = 0; j < NC; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
     }
-    slope(y, K[0], buf, nothing, no_vote, 1); buf ^= 1;
+    slope(y, K[0], 0, nothing, no_vote, 1, nothing);
     double isc0[NC];
     double p0 = 0.0, p1 = 0.0;
 #pragma unroll
@@ -218,28 +228,41 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       p0 = __builtin_fma(y[j] * isc, y[j] * isc, p0);
       p1 = __builtin_fma(K[0][j] * isc, K[0][j] * isc, p1);
     }
-    sh.part[1][0][seg][role] = p0; sh.part[1][1][seg][role] = p1;
+    post2(p0, p1);
     __syncthreads();
-    const double d0 = sqrt(total(1, 0) / NCOMP), d1 = sqrt(total(1, 1) / NCOMP);
+    double t0, t1;
+    totals2(t0, t1);
+    const double d0 = sqrt(t0 / NCOMP), d1 = sqrt(t1 / NCOMP);
     const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     double arg[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) arg[j] = __builtin_fma(h0, K[0][j], y[j]);
-    slope(arg, K[1], buf, nothing, no_vote, 1); buf ^= 1;   // the barrier inside also separates the reads above from the writes below
+    slope(arg, K[1], 1, nothing, no_vote, 1, nothing);   // the barrier inside also separates the reads above from the writes below
     double p2 = 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const double df = (K[1][j] - K[0][j]) * isc0[j];
       p2 = __builtin_fma(df, df, p2);
     }
-    sh.part[1][2][seg][role] = p2;
+    post2(p2, 0.0);
     __syncthreads();
-    const double d2 = sqrt(total(1, 2) / NCOMP) / h0;
+    double t2, tu;
+    totals2(t2, tu);
+    const double d2 = sqrt(t2 / NCOMP) / h0;
     const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : cbrt(cbrt(0.01 / fmax(d1, d2)));
     h_abs = fmin(fmin(100.0 * h0, h1), span);
   }
   double h_rec = 0.0;            // proposal that led to the first accepted step (what the next sweep starts from)
 
+  // ---- trial steps.  Round 4: the error estimate of the 8(5,3) pair does not involve the FSAL slope f(y_new) (E5[12] = E3[12] = 0), so
+  // a trial step's error sums are formed and published as soon as the twelfth slope K[11] is there, BEFORE the barrier of the
+  // FSAL evaluation; behind that barrier every lane reads the sums and takes the step decision in the same instruction stream
+  // in which the column lanes form K[12] and the base lanes (one stage ahead, as in every stage) already evaluate the first
+  // stage of the NEXT trial step.  The pipeline of base and column roles therefore never drains between trial steps: twelve
+  // barriers per trial step instead of thirteen, no interval in which only one side works, and the decision's dependent chain
+  // (table reads, sums, three reciprocal square roots) is hidden behind the FSAL slopes.  (Round 3: after the FSAL barrier the
+  // columns formed K[12] with the base idle, then a barrier of its own for the sums, then every role evaluated the decision --
+  // IEEE square roots and a division -- before the base lanes could start the next step alone: 18.7 k ticks per trial step.)
   hook::RegionClock c2_loop;
   hook::Counter c2_trials;
   c2_loop.start();
@@ -253,56 +276,43 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     // Argument st (st = 1..11: stage st, weights DP8_A[st][.]; st = 12: the new state, weights DP8_B) is y + h (older + w K[st-1])
     // with older = the sum over the slopes before the newest one, formed one stage earlier in the shadow of that stage's LDS
     // traffic (same summation order as the one-piece loop: bit-identical arguments).
-    double older[NC], yn[NC], a5[NC], a3[NC];
+    double older[NC], yn[NC], a5[NC], a3[NC], iscb[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) older[j] = 0.0;
     // the tableau rows come by scalar loads (rk.hpp: dp8_load_row), the row of argument st + 1 while stage st is evaluated
     double wrow[2][12], we5[13], we3[13];
     dp8_load_row<1>(tab, wrow[1]);
     int alive = 1;
-    auto stage = [&](auto st_c) {                // enters with K[0] = f(y) (FSAL)
+    auto stage = [&](auto st_c) {                // enters with K[0] = f(y) (FSAL); stages 1 .. 11
       constexpr int st = decltype(st_c)::value;
+      static_assert(st >= 1 && st < NS, "stage index");
       double arg[NC], next[NC];
-      constexpr double wn_c = (st < NS) ? DP8_A[st < NS ? st : 0][st - 1] : DP8_B[st - 1];
+      constexpr double wn_c = DP8_A[st][st - 1];
       const double (&wc)[12] = wrow[st & 1];
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const double acc = (wn_c != 0.0) ? __builtin_fma(wc[st - 1], K[st - 1][j], older[j]) : older[j];
         arg[j] = __builtin_fma(h, acc, y[j]);
       }
-      if constexpr (st < NS) {
-        double (&wx)[12] = wrow[(st + 1) & 1];
-        dp8_load_row<st + 1>(tab, wx);
-        auto sums = [&] {
+      double (&wx)[12] = wrow[(st + 1) & 1];
+      dp8_load_row<st + 1>(tab, wx);
+      if constexpr (st == NS - 1) dp8_load_err(tab, we5, we3);
+      auto sums = [&] {
 #pragma unroll
-          for (int j = 0; j < NC; ++j) next[j] = 0.0;
+        for (int j = 0; j < NC; ++j) next[j] = 0.0;
 #pragma unroll
-          for (int k = 0; k < st; ++k) {
-            const double w_c = (st + 1 < NS) ? DP8_A[st + 1 < NS ? st + 1 : 0][k] : DP8_B[k];
-            if (w_c != 0.0) {
+        for (int k = 0; k < st; ++k) {
+          const double w_c = (st + 1 < NS) ? DP8_A[st + 1 < NS ? st + 1 : 0][k] : DP8_B[k];
+          if (w_c != 0.0) {
 #pragma unroll
-              for (int j = 0; j < NC; ++j) next[j] = __builtin_fma(wx[k], K[k][j], next[j]);
-            }
+            for (int j = 0; j < NC; ++j) next[j] = __builtin_fma(wx[k], K[k][j], next[j]);
           }
-        };
-        // the first stage's barrier carries the vote that ends the sweep of this workgroup (every segment done)
-        if constexpr (st == 1) alive = slope(arg, K[st], buf, sums, with_vote, !done);
-        else slope(arg, K[st], buf, sums, no_vote, 1);
-#pragma unroll
-        for (int j = 0; j < NC; ++j) older[j] = next[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < NC; ++j) yn[j] = arg[j];
-        if (BASE) {
-#pragma unroll
-          for (int j = 0; j < NC; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
         }
-        dp8_load_err(tab, we5, we3);
-        slope(yn, K[12], buf, [&] {          // FSAL slope; in its shadow: the error sums over the twelve older slopes
+        if constexpr (st == NS - 1) {           // in the shadow of the last stage: the error sums over the slopes before K[11]
 #pragma unroll
           for (int j = 0; j < NC; ++j) { a5[j] = 0.0; a3[j] = 0.0; }
 #pragma unroll
-          for (int k = 0; k < 12; ++k) {
+          for (int k = 0; k < NS - 1; ++k) {
             if (DP8_E5[k] != 0.0) {
 #pragma unroll
               for (int j = 0; j < NC; ++j) a5[j] = __builtin_fma(we5[k], K[k][j], a5[j]);
@@ -312,41 +322,60 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
               for (int j = 0; j < NC; ++j) a3[j] = __builtin_fma(we3[k], K[k][j], a3[j]);
             }
           }
-        }, no_vote, 1);
-      }
-      buf ^= 1;
+        }
+      };
+      // base lanes, last stage: K[11] is theirs before the barrier, so the new state and with it the scale of the error norm
+      // (which the column lanes need right behind this barrier) are formed and published here
+      auto tail = [&] {
+        if constexpr (BASE && st == NS - 1) {
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            const double acc = (DP8_B[NS - 1] != 0.0) ? __builtin_fma(wx[NS - 1], K[NS - 1][j], next[j]) : next[j];
+            yn[j] = __builtin_fma(h, acc, y[j]);
+            iscb[j] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
+            sh.scale[grow[j]][seg] = iscb[j];
+          }
+        }
+      };
+      // the first stage's barrier carries the vote that ends the sweep of this workgroup (every segment done)
+      if constexpr (st == 1) alive = slope(arg, K[st], st & 1, sums, with_vote, !done, tail);
+      else slope(arg, K[st], st & 1, sums, no_vote, 1, tail);
+#pragma unroll
+      for (int j = 0; j < NC; ++j) older[j] = next[j];
     };
     stage(std::integral_constant<int, 1>{});
     if (!alive) break;                       // workgroup-uniform: the vote is the barrier's
-    static_for<2, NS + 1>(stage);
-    const int par = trial & 1;
-    double e5 = 0.0, e3 = 0.0;
+    static_for<2, NS>(stage);
+    // new state and error sums of this lane's rows; the sums go into the table before the FSAL barrier
+    {
+      const double (&wb)[12] = wrow[NS & 1];
+      double e5 = 0.0, e3 = 0.0;
 #pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      double s5 = a5[j], s3 = a3[j];
-      if (DP8_E5[12] != 0.0) s5 = __builtin_fma(DP8_E5[12], K[12][j], s5);
-      if (DP8_E3[12] != 0.0) s3 = __builtin_fma(DP8_E3[12], K[12][j], s3);
-      const double isc = sh.scale[grow[j]][seg];
-      s5 *= isc; s3 *= isc;
-      e5 = __builtin_fma(s5, s5, e5);
-      e3 = __builtin_fma(s3, s3, e3);
+      for (int j = 0; j < NC; ++j) {
+        if constexpr (!BASE) {
+          const double acc = (DP8_B[NS - 1] != 0.0) ? __builtin_fma(wb[NS - 1], K[NS - 1][j], older[j]) : older[j];
+          yn[j] = __builtin_fma(h, acc, y[j]);
+        }
+        double s5 = a5[j], s3 = a3[j];
+        if (DP8_E5[NS - 1] != 0.0) s5 = __builtin_fma(we5[NS - 1], K[NS - 1][j], s5);
+        if (DP8_E3[NS - 1] != 0.0) s3 = __builtin_fma(we3[NS - 1], K[NS - 1][j], s3);
+        const double isc = BASE ? iscb[j] : sh.scale[grow[j]][seg];
+        s5 *= isc; s3 *= isc;
+        e5 = __builtin_fma(s5, s5, e5);
+        e3 = __builtin_fma(s3, s3, e3);
+      }
+      post2(e5, e3);
     }
-    sh.part[par][0][seg][role] = e5; sh.part[par][1][seg][role] = e3;
-    __syncthreads();
-    const double E5 = total(par, 0), E3 = total(par, 1);
-    const double err = (E5 == 0.0 && E3 == 0.0) ? 0.0 : fabs(h) * E5 / sqrt((E5 + 0.01 * E3) * NCOMP);
-    double accept, bad = 0.0;
-    if (err < 1.0) {
-      double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 / sqrt(sqrt(sqrt(err))));
-      if (rejected != 0.0) factor = fmin(1.0, factor);
-      h_abs = h * factor;
-      accept = 1.0;
-    } else {
-      h_abs = h * fmax(0.2, 0.9 / sqrt(sqrt(sqrt(err))));
-      accept = 0.0;
-      if (err != err) bad = err;           // a NaN never recovers: poison the segment and stop (below)
-    }
-    // (no barrier here: the next trial writes the partial sums of the other parity)
+    static_assert(DP8_E5[NS] == 0.0 && DP8_E3[NS] == 0.0, "the error estimate must not involve the FSAL slope");
+    slope(yn, K[NS], NS & 1, nothing, no_vote, 1, nothing);      // FSAL slope; behind its barrier: the decision
+    // (K[12] is used only by an accepted step: unpinned, the compiler sinks its whole evaluation into that branch, behind the decision)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(K[NS][j]));
+    double E5, E3;
+    totals2(E5, E3);
+    double accept, bad;
+    dp8_decide(E5, E3, h, rejected, NCOMP, h_abs, accept, bad);
+    asm volatile("" : "+v"(h_abs));          // (likewise: the next proposal would sink to the loop's tail, behind the commit branch)
     if (!done) {
       if (bad != 0.0) {                    // NaN in the step: NaN results (status_flag 2 upstream), no max_steps stall
 #pragma unroll
@@ -356,7 +385,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
         if (nacc == 0) h_rec = h_prop;
         t = (last != 0.0) ? span : t + h;
 #pragma unroll
-        for (int j = 0; j < NC; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
+        for (int j = 0; j < NC; ++j) { y[j] = yn[j]; K[0][j] = K[NS][j]; }
         ++nacc;
         rejected = 0.0;
       } else {

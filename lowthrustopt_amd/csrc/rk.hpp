@@ -200,6 +200,31 @@ __device__ __forceinline__ double dop853_try(const Sys& sys, const double h, con
 }
 
 
+// Step decision of the adaptive 8(5,3) controller from the two error sums (E5 = sum (e5_i / scale_i)^2, E3 likewise, over n
+// components) -- Hairer's rule as in dop853_try's callers: err = |h| E5 / sqrt((E5 + 0.01 E3) n); accept if err < 1 with
+// factor min(10, 0.9 err^(-1/8)) (at most 1 straight after a rejection), else factor max(0.2, 0.9 err^(-1/8)).  The roots are
+// reciprocal-square-root chains (v_rsq_f64 + one third-order step each, ~1 ulp) instead of IEEE sqrt / divide sequences: the
+// decision sits between a trial step's error sums and the next trial step of EVERY wavefront of a cooperative workgroup.
+// Contraction is off so that every role (different template instantiations of the caller) forms the same bits from the same sums.
+__device__ __forceinline__ void dp8_decide(const double E5, const double E3, const double h, const double rejected, const double ncomp,
+                                           double& h_abs, double& accept, double& bad) {
+#pragma clang fp contract(off)
+  // selects only, no branch: the caller's scheduler interleaves this chain with the FSAL slopes of the same basic block
+  const double den = (E5 + 0.01 * E3) * ncomp;
+  const bool zero = (E5 == 0.0) & (E3 == 0.0);
+  const double err_raw = (fabs(h) * E5) * rsqrt_nr(den);
+  const double err = zero ? 0.0 : err_raw;
+  const double r8 = rsqrt_nr(rsqrt_nr(rsqrt_nr(err)));          // err^(-1/8); NaN for err = 0 or inf, which the selects below never pick
+  const double f = 0.9 * r8;
+  const bool acc = err < 1.0;
+  double fa = zero ? 10.0 : fmin(10.0, f);
+  fa = (rejected != 0.0) ? fmin(1.0, fa) : fa;
+  const double fr = fmax(0.2, f);
+  h_abs = h * (acc ? fa : fr);
+  accept = acc ? 1.0 : 0.0;
+  bad = (err != err) ? err : 0.0;                                // a NaN never recovers: the caller poisons the segment
+}
+
 // ------------------------------------------------------------------------------------ memory-resident slopes
 // 13-stage methods on base + STM column (D = 24 or 28) need 13 D slopes = 312-364 doubles per lane, more than
 // the 256-double register file: fully unrolled code then spills >1000 registers to scratch (and hipcc 7.2 was
