@@ -808,6 +808,64 @@ __device__ __forceinline__ void var_col12_bottom_g(const CoefG12& g, const doubl
   dw[5] = -__builtin_fma(Hxz, ax, __builtin_fma(Hyz, ay, __builtin_fma(Hzz, az,
            __builtin_fma(g.Gxz, dx, __builtin_fma(g.Gyz, dyv, g.Gzz * dz)))));
 }
+// Round 4 forms of the two halves: no matrix is assembled or published any more, G, H and U are applied through their dyadic
+// structure from what the base wave has at hand (A = x + MU, y, z; per primary e_b = 3 kappa_b / d_b^{5/2} and
+// q_b = 5 e_b (rho_b . lambda_v) / d_b; omc = 1 - sum_b kappa_b / d_b^{3/2}; es = sum_b e_b (rho_b . lambda_v); lambda_v;
+// ua = umag / n and ubn = (umag / n - umag') / n^2), rho_1 = (A, y, z), rho_2 = (A - 1, y, z):
+//   G x = omc x - (0, 0, x_z) + sum_b e_b rho_b (rho_b . x)
+//   H a = es a + sum_b [ e_b (rho_b (lambda_v . a) + lambda_v (rho_b . a)) - q_b rho_b (rho_b . a) ]
+//   U d = -ua d + ubn (lambda_v . d) lambda_v
+// -- the same matrices as coef12_from_parts builds entry by entry (Gxx = omc + e1 a^2 + e2 b^2, Hxx = es + 2 st lx - q1 a^2 -
+// q2 b^2, ...), associated differently: the last bit or two may differ.  Top half 31 instructions per stage, bottom half 47
+// (round 3: 92 - tableau and 135 - tableau with G from LDS and H built per lane), and the base wave neither builds nor stores G.
+struct DyadParts { double A, yy, z, e1, e2, omc; };
+__device__ __forceinline__ void dyad_G(const DyadParts& p, const double B, const double x0, const double x1, const double x2, double& g0,
+                                       double& g1, double& g2) {
+  const double yz = __builtin_fma(p.yy, x1, p.z * x2);
+  const double k1 = p.e1 * __builtin_fma(p.A, x0, yz), k2 = p.e2 * __builtin_fma(B, x0, yz);
+  const double ks = k1 + k2;
+  g0 = __builtin_fma(p.omc, x0, __builtin_fma(k1, p.A, k2 * B));
+  g1 = __builtin_fma(p.omc, x1, ks * p.yy);
+  g2 = __builtin_fma(p.omc, x2, __builtin_fma(ks, p.z, -x2));
+}
+// top half: (a', b') from own w = (a, b) = (delta r, delta v) and the received d = delta lambda_v
+__device__ __forceinline__ void var_col12_top_dy(const DyadParts& p, const double lx, const double ly, const double lz, const double ua,
+                                                 const double ubn, const double w2, const double (&w)[6], const double (&d)[3],
+                                                 double (&dw)[6]) {
+  const double B = p.A - 1.0;
+  double g0, g1, g2;
+  dyad_G(p, B, w[0], w[1], w[2], g0, g1, g2);
+  const double dx = d[0], dyv = d[1], dz = d[2];
+  dw[0] = w[3]; dw[1] = w[4]; dw[2] = w[5];
+  const double ld = __builtin_fma(lx, dx, __builtin_fma(ly, dyv, lz * dz));
+  const double tl = ubn * ld;
+  dw[3] = __builtin_fma(w2, w[4], __builtin_fma(-ua, dx, __builtin_fma(tl, lx, g0)));
+  dw[4] = __builtin_fma(-w2, w[3], __builtin_fma(-ua, dyv, __builtin_fma(tl, ly, g1)));
+  dw[5] = __builtin_fma(-ua, dz, __builtin_fma(tl, lz, g2));
+}
+// bottom half: own w = (d, g) = (delta lambda_v, delta lambda_r), received av = delta r; returns (d', g')
+__device__ __forceinline__ void var_col12_bottom_dy(const DyadParts& p, const double lx, const double ly, const double lz, const double q1,
+                                                    const double q2, const double es, const double w2, const double (&w)[6],
+                                                    const double (&av)[3], double (&dw)[6]) {
+  const double B = p.A - 1.0;
+  const double ax = av[0], ay = av[1], az = av[2];
+  const double dx = w[0], dyv = w[1], dz = w[2];
+  double g0, g1, g2;
+  dyad_G(p, B, dx, dyv, dz, g0, g1, g2);
+  const double la = __builtin_fma(lx, ax, __builtin_fma(ly, ay, lz * az));
+  const double yz = __builtin_fma(p.yy, ay, p.z * az);
+  const double p1 = __builtin_fma(p.A, ax, yz), p2 = __builtin_fma(B, ax, yz);
+  const double k1 = __builtin_fma(p.e1, la, -q1 * p1), k2 = __builtin_fma(p.e2, la, -q2 * p2);
+  const double kl = __builtin_fma(p.e1, p1, p.e2 * p2);
+  const double ks = k1 + k2;
+  const double hx = __builtin_fma(es, ax, __builtin_fma(kl, lx, __builtin_fma(k1, p.A, __builtin_fma(k2, B, g0))));
+  const double hy = __builtin_fma(es, ay, __builtin_fma(kl, ly, __builtin_fma(ks, p.yy, g1)));
+  const double hz = __builtin_fma(es, az, __builtin_fma(kl, lz, __builtin_fma(ks, p.z, g2)));
+  dw[0] = __builtin_fma(w2, dyv, -w[3]);
+  dw[1] = __builtin_fma(-w2, dx, -w[4]);
+  dw[2] = -w[5];
+  dw[3] = -hx; dw[4] = -hy; dw[5] = -hz;
+}
 // G, H, U of the 12-dim system from the base argument's position r, lambda_v and the base lane's by-products: the
 // VAR block of rhs12 without its reciprocal square roots and control law.
 __device__ __forceinline__ void coef12_from_parts(const double x, const double yy, const double z, const double lx0, const double ly0,

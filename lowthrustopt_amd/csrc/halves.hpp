@@ -82,14 +82,17 @@ __device__ __forceinline__ QuadLane quad_lane(const int q4, const TrajParams& tp
   return Q;
 }
 // by-products of an evaluation as the quad holds them: c, is in lanes 0 / 1 (primary 1 / 2), inv_n everywhere; ua, ub everywhere
-struct QuadParts { double c, is, inv_n, n2, ua, ub; };
+// (cooperative kernel, WITH_PARTS: also a0 = the argument's x plus the lane's offset -- x + MU in lanes 0 / 1, lambda_v,x in lanes 2 / 3 --,
+// e = 3 kappa_b / d_b^{5/2} and q = 5 e (rho_b . lambda_v) / d_b of the lane's own primary, es = sum_b e_b (rho_b . lambda_v),
+// omc = 1 - sum_b kappa_b / d_b^{3/2}: what the column halves apply G, H through their dyadic structure from, dynamics.hpp)
+struct QuadParts { double c, is, inv_n, n2, ua, ub, a0, e, q, es, omc; };
 // w: the lane's argument triple; k: its slope; P: (r r lambda_v lambda_v) as the lanes hold it after the exchange (what the
 // cooperative kernel publishes)
-// WITH_G: also the gravity-gradient block G of the variational equations (valid in lane 1; same arithmetic as coefG12_from_parts),
-// which the cooperative kernel's base wave has the time to build once per segment and stage for all 24 column halves.
-template <int PM, bool WITH_G = false>
+// WITH_PARTS: also the extra by-products listed at QuadParts (two instructions).  (Round 3 built the gravity-gradient block G
+// here, in lane 1, and published it: 16 instructions and three stores on the sweep's longest chain.)
+template <int PM, bool WITH_PARTS = false>
 __device__ __forceinline__ void rhs12_base_quad(const double (&w)[3], const QuadLane& Q, const TrajParams& tp, double (&k)[3], QuadParts& bp,
-                                                double (&P)[3], CoefG12* G = nullptr) {
+                                                double (&P)[3]) {
   auto t0022 = [](const double v) { return quad_take<quad_perm(0, 0, 2, 2)>(v); };
   auto t1133 = [](const double v) { return quad_take<quad_perm(1, 1, 3, 3)>(v); };
   auto t2222 = [](const double v) { return quad_take<quad_perm(2, 2, 2, 2)>(v); };
@@ -145,16 +148,7 @@ __device__ __forceinline__ void rhs12_base_quad(const double (&w)[3], const Quad
   k[1] = Q.lane1 ? ay : (Q.lane3 ? g3y : lin1);
   k[2] = Q.lane1 ? az : (Q.lane3 ? g3z : lin2);
   bp.c = c; bp.is = is; bp.inv_n = inv_n; bp.n2 = n2; bp.ua = ua; bp.ub = ub;
-  if constexpr (WITH_G) {
-    const double e_o = t1032(e);
-    const double ee = e_o + e;
-    const double sa = e_o * u0_o, tb = e * u0;
-    const double stt = sa + tb;
-    G->Gxx = __builtin_fma(sa, u0_o, __builtin_fma(tb, u0, omc));
-    G->Gyy = __builtin_fma(ee * yy, yy, omc);
-    G->Gzz = __builtin_fma(ee * z, z, -cs);
-    G->Gxy = stt * yy; G->Gxz = stt * z; G->Gyz = ee * yy * z;
-  }
+  if constexpr (WITH_PARTS) { bp.a0 = a0; bp.e = e; bp.q = 5.0 * t * is; bp.es = es; bp.omc = omc; }
 }
 
 }  // namespace lto

@@ -40,17 +40,27 @@
 namespace lto {
 
 constexpr int C2_SEG = 16;      // segments per workgroup
-constexpr int C2_PUB = 20;      // rows of the published stage record: 13 parts, a spare row for the lanes that have nothing to add, G (6)
 constexpr int C2_WAVES = 7;     // wavefronts that contribute to a norm: three top, three bottom, the base wave
 constexpr int C2_PLD = 9;       // entries per segment of the partial-sum table (seven used): 16-byte entries at a pitch of 36 dwords are conflict-free
+// The stage record of a segment, as 16-byte pairs (a pitch of 44 dwords keeps the 16 segments of a 128-bit access in different banks):
+//   0 (A, y)  2 (z, e1)  4 (q1, es)            from base lane 0: A = x + MU, e_b = 3 kappa_b / d_b^{5/2}, q_b = 5 e_b (rho_b . lambda_v) / d_b
+//   6 (z, e2) 8 (q2, omc)                      from base lane 1: omc = 1 - sum_b kappa_b / d_b^{3/2}
+//   10 (l0, l1)  12 (l2, -)  14 (ua, ubn)      from base lane 2: lambda_v, umag / n, (umag / n - umag') / n^2
+//   16 .. 21                                   where the lanes that have nothing to add to a store write
+// -- everything the column halves apply G, H and U from (dynamics.hpp: var_col12_top_dy / var_col12_bottom_dy); no matrix is built.
+constexpr int C2_LD = 22;
+constexpr int C2_SLD = 18;      // pitch of the scale table: [segment][base lane][4]
 
 enum C2Role : int { C2_TOP = 0, C2_BOTTOM = 1, C2_BASE = 2 };
 
+typedef double c2_d2 __attribute__((ext_vector_type(2)));
+
 struct C2Shared {
-  double pub[2][C2_PUB][C2_SEG];                // base argument (r, lambda_v) + by-products of the stage, double-buffered
-  double xch[2][2][12][3][C2_SEG];           // [buffer][half that wrote][column][j][segment]: first triple of the stage argument
-  alignas(16) double part[C2_SEG][C2_PLD][2];   // partial norms [segment][wavefront][which]: every wavefront sums its own lanes of a segment first
-  double scale[12][C2_SEG];                  // 1 / (atol + rtol |base value|) of global row r
+  alignas(16) double rec[2][C2_SEG][C2_LD];        // stage records, double-buffered by the parity of the stage index
+  alignas(16) c2_d2 xa[2][2][12][C2_SEG];          // [buffer][half that wrote][column][segment]: first triple of the stage argument, (0, 1) ...
+  double xb[2][2][12][C2_SEG];                     // ... and 2
+  alignas(16) double part[C2_SEG][C2_PLD][2];      // partial norms [segment][wavefront][which]: every wavefront sums its own lanes of a segment first
+  alignas(16) double scale[C2_SEG][C2_SLD];        // 1 / (atol + rtol |base value|): base lane q's rows at 4 q .. 4 q + 2
 };
 
 // Probe build (make probe): ticks every role waits at the stage barriers and the ticks of its trial loop, per workgroup,
@@ -94,10 +104,12 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   const bool mine = !a.class_filter || p_class(tp.p) == PM;
   if (!__syncthreads_or(mine)) return;         // workgroup-uniform (wave 7 voted 0 and left)
   const QuadLane Q = quad_lane(q4, tp);        // base lanes: per-lane constants of the quad evaluation (halves.hpp)
-  // where the base lanes publish what they hold after the exchange: P = (r r lambda_v lambda_v) -> rows 0..2 / 3..5; c, 1/d of
-  // the own primary -> rows 6, 7 / 8, 9 (the lambda_v lanes: a spare row)
-  const int pub_g = (q4 == 1) ? 14 : 13, pub_gs = (q4 == 1) ? 1 : 0;
-  const int pub_p = (q4 < 2) ? 0 : 3, pub_c = (q4 == 0) ? 6 : (q4 == 1) ? 7 : 13, pub_is = (q4 == 0) ? 8 : (q4 == 1) ? 9 : 13;
+  // where this base lane's part of each of the four record stores goes (slots of C2_LD; 16.. = nobody reads)
+  const int o1 = (q4 == 0) ? 0 : (q4 == 2) ? 10 : 16;                       // (a0, P1): (A, y) / (l0, l1)
+  const int o2 = (q4 == 0) ? 2 : (q4 == 1) ? 6 : (q4 == 2) ? 12 : 18;       // (P2, e): (z, e1) / (z, e2) / (l2, -)
+  const int o3 = (q4 == 0) ? 4 : (q4 == 1) ? 8 : 18;                        // (q, es | omc)
+  const int o4 = (q4 == 2) ? 14 : 20;                                       // (ua, ubn): the same in every lane of the quad
+  const int sc0 = BASE ? 4 * q4 : (ROLE == C2_TOP ? 0 : 8);                 // this lane's rows in the scale table: sc0 .. +2 (and sc0 + 4 .. +6)
 
   // ---- state of this lane: six rows of the base state or of one STM column
   double y[NC], K[13][NC];
@@ -126,46 +138,48 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     if constexpr (BASE) {
       QuadParts qp;
       double P[3];
-      CoefG12 G;
-      rhs12_base_quad<PM, true>(arg, Q, tp, out, qp, P, &G);
+      rhs12_base_quad<PM, true>(arg, Q, tp, out, qp, P);
       BaseParts12 bp;
       bp.ua = qp.ua; bp.ub = qp.ub;
       parts_guard_zero_norm<PM>(qp.n2, bp);
       {
-        // eight stores instead of thirteen: the lanes of a quad hold different quantities under the same name
-        double (&p)[C2_PUB][C2_SEG] = sh.pub[buf];
-        p[pub_p][seg] = P[0]; p[pub_p + 1][seg] = P[1]; p[pub_p + 2][seg] = P[2];
-        p[pub_c][seg] = qp.c; p[pub_is][seg] = qp.is;
-        p[10][seg] = bp.ua; p[11][seg] = bp.ub; p[12][seg] = qp.inv_n;
-        // G once per segment and stage, from the lane that holds both primaries' terms (lane 1); the others write the spare row
-        p[pub_g][seg] = G.Gxx; p[pub_g + pub_gs][seg] = G.Gyy; p[pub_g + 2 * pub_gs][seg] = G.Gzz;
-        p[pub_g + 3 * pub_gs][seg] = G.Gxy; p[pub_g + 4 * pub_gs][seg] = G.Gxz; p[pub_g + 5 * pub_gs][seg] = G.Gyz;
+        // four 128-bit stores (round 3: fourteen 64-bit ones, a quarter of the base wave's issue time): the lanes of a quad
+        // hold different quantities under the same name, and each writes its pair where the record wants it
+        double* r = &sh.rec[buf][seg][0];
+        const double ubn = (bp.ub * qp.inv_n) * qp.inv_n;
+        const double x3 = Q.lane1 ? qp.omc : qp.es;
+        *reinterpret_cast<c2_d2*>(r + o1) = c2_d2{qp.a0, P[1]};
+        *reinterpret_cast<c2_d2*>(r + o2) = c2_d2{P[2], qp.e};
+        *reinterpret_cast<c2_d2*>(r + o3) = c2_d2{qp.q, x3};
+        *reinterpret_cast<c2_d2*>(r + o4) = c2_d2{bp.ua, ubn};
       }
       overlap();
       base_tail();          // base lanes only: work on the slope just formed that must be in LDS before this stage's barrier
     } else {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) sh.xch[buf][ROLE][col][j][seg] = arg[j];
+      sh.xa[buf][ROLE][col][seg] = c2_d2{arg[0], arg[1]};
+      sh.xb[buf][ROLE][col][seg] = arg[2];
     }
     if constexpr (VOTE) alive = c2_wait.sync_or(alive_in);
     else C2_SYNC();
     if constexpr (VOTE) { if (!alive) return 0; }
     if constexpr (!BASE) {
-      const double (&p)[C2_PUB][C2_SEG] = sh.pub[buf];
-      // top halves: G, lambda_v, 1 / |lambda_v|, ua, ub (rows 3..5, 10..19); bottom halves: G and the parts H is made of (rows 0..9, 14..19)
-      double v[C2_PUB], other[3];
-#pragma unroll
-      for (int e = 0; e < C2_PUB; ++e) {
-        const bool need = (ROLE == C2_TOP) ? ((e >= 3 && e <= 5) || (e >= 10 && e != 13)) : (e <= 9 || e >= 14);
-        if (need) v[e] = p[e][seg];
+      const double* r = &sh.rec[buf][seg][0];
+      auto pair = [&](const int slot) { return *reinterpret_cast<const c2_d2*>(r + slot); };
+      const c2_d2 ay = pair(0), ze1 = pair(2), ze2 = pair(6), qo = pair(8), l01 = pair(10), l2x = pair(12);
+      DyadParts dp;
+      dp.A = ay.x; dp.yy = ay.y; dp.z = ze1.x; dp.e1 = ze1.y; dp.e2 = ze2.y; dp.omc = qo.y;
+      const c2_d2 o01 = sh.xa[buf][1 - ROLE][col][seg];
+      double other[3];
+      other[0] = o01.x; other[1] = o01.y; other[2] = sh.xb[buf][1 - ROLE][col][seg];
+      if constexpr (ROLE == C2_TOP) {
+        const c2_d2 uu = pair(14);
+        overlap();
+        var_col12_top_dy(dp, l01.x, l01.y, l2x.x, uu.x, uu.y, w2, arg, other, out);
+      } else {
+        const c2_d2 qe = pair(4);
+        overlap();
+        var_col12_bottom_dy(dp, l01.x, l01.y, l2x.x, qe.x, qo.x, qe.y, w2, arg, other, out);
       }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) other[j] = sh.xch[buf][1 - ROLE][col][j][seg];
-      overlap();
-      CoefG12 g;
-      g.Gxx = v[14]; g.Gyy = v[15]; g.Gzz = v[16]; g.Gxy = v[17]; g.Gxz = v[18]; g.Gyz = v[19];
-      if constexpr (ROLE == C2_TOP) var_col12_top_g(g, v[3], v[4], v[5], v[12], v[10], v[11], w2, arg, other, out);
-      else var_col12_bottom_g(g, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], tp.MU, w2, arg, other, out);
     }
     return alive;
   };
@@ -216,14 +230,14 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     // number's partials share the scale of its value), published by the base lanes.
     if (BASE) {
 #pragma unroll
-      for (int j = 0; j < NC; ++j) sh.scale[grow[j]][seg] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
+      for (int j = 0; j < NC; ++j) sh.scale[seg][sc0 + j] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
     }
     slope(y, K[0], 0, nothing, no_vote, 1, nothing);
     double isc0[NC];
     double p0 = 0.0, p1 = 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      const double isc = sh.scale[grow[j]][seg];
+      const double isc = sh.scale[seg][sc0 + (j < 3 ? j : j + 1)];
       isc0[j] = isc;
       p0 = __builtin_fma(y[j] * isc, y[j] * isc, p0);
       p1 = __builtin_fma(K[0][j] * isc, K[0][j] * isc, p1);
@@ -333,7 +347,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
             const double acc = (DP8_B[NS - 1] != 0.0) ? __builtin_fma(wx[NS - 1], K[NS - 1][j], next[j]) : next[j];
             yn[j] = __builtin_fma(h, acc, y[j]);
             iscb[j] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
-            sh.scale[grow[j]][seg] = iscb[j];
+            sh.scale[seg][sc0 + j] = iscb[j];
           }
         }
       };
@@ -359,7 +373,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
         double s5 = a5[j], s3 = a3[j];
         if (DP8_E5[NS - 1] != 0.0) s5 = __builtin_fma(we5[NS - 1], K[NS - 1][j], s5);
         if (DP8_E3[NS - 1] != 0.0) s3 = __builtin_fma(we3[NS - 1], K[NS - 1][j], s3);
-        const double isc = BASE ? iscb[j] : sh.scale[grow[j]][seg];
+        const double isc = BASE ? iscb[j] : sh.scale[seg][sc0 + (j < 3 ? j : j + 1)];
         s5 *= isc; s3 *= isc;
         e5 = __builtin_fma(s5, s5, e5);
         e3 = __builtin_fma(s3, s3, e3);
