@@ -126,65 +126,77 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   // against 135 instructions per stage): it used to finish early and wait while the bottom wave ran on alone.  With the bottom
   // wave at raised priority the two finish together: 217-222 -> 213.6 us per sweep on the same box (tools/probe_warm.py).
   if (ROLE == C2_BOTTOM) __builtin_amdgcn_s_setprio(2);
-  // slope of the stage argument `arg` (own rows) into `out`.  Called by ALL threads: one barrier inside.  `overlap` is work
-  // that needs neither this stage's slope nor LDS (the next argument's sum over the older slopes): the base lanes run it
-  // between their LDS stores and the barrier, the column lanes between issuing their LDS loads and the first use.  (Splitting it
-  // around the column lanes' barrier -- half behind their stores, half behind their loads -- measured no different.)
-  // VOTE (the first stage of a trial step): the barrier also carries the workgroup's "anyone still integrating?" vote, which
-  // otherwise cost a barrier of its own at the end of every trial step; returns the vote (1 without VOTE).
-  auto slope = [&](const double (&arg)[NC], double (&out)[NC], const int buf, auto&& overlap, auto vote_c, const int alive_in, auto&& base_tail) {
-    constexpr bool VOTE = decltype(vote_c)::value;
-    int alive = 1;
-    if constexpr (BASE) {
-      QuadParts qp;
-      double P[3];
-      rhs12_base_quad<PM, true>(arg, Q, tp, out, qp, P);
-      BaseParts12 bp;
-      bp.ua = qp.ua; bp.ub = qp.ub;
-      parts_guard_zero_norm<PM>(qp.n2, bp);
-      {
-        // four 128-bit stores (round 3: fourteen 64-bit ones, a quarter of the base wave's issue time): the lanes of a quad
-        // hold different quantities under the same name, and each writes its pair where the record wants it
-        double* r = &sh.rec[buf][seg][0];
-        const double ubn = (bp.ub * qp.inv_n) * qp.inv_n;
-        const double x3 = Q.lane1 ? qp.omc : qp.es;
-        *reinterpret_cast<c2_d2*>(r + o1) = c2_d2{qp.a0, P[1]};
-        *reinterpret_cast<c2_d2*>(r + o2) = c2_d2{P[2], qp.e};
-        *reinterpret_cast<c2_d2*>(r + o3) = c2_d2{qp.q, x3};
-        *reinterpret_cast<c2_d2*>(r + o4) = c2_d2{bp.ua, ubn};
-      }
-      overlap();
-      base_tail();          // base lanes only: work on the slope just formed that must be in LDS before this stage's barrier
-    } else {
-      sh.xa[buf][ROLE][col][seg] = c2_d2{arg[0], arg[1]};
-      sh.xb[buf][ROLE][col][seg] = arg[2];
-    }
-    if constexpr (VOTE) alive = c2_wait.sync_or(alive_in);
-    else C2_SYNC();
-    if constexpr (VOTE) { if (!alive) return 0; }
-    if constexpr (!BASE) {
-      const double* r = &sh.rec[buf][seg][0];
-      auto pair = [&](const int slot) { return *reinterpret_cast<const c2_d2*>(r + slot); };
-      const c2_d2 ay = pair(0), ze1 = pair(2), ze2 = pair(6), qo = pair(8), l01 = pair(10), l2x = pair(12);
-      DyadParts dp;
-      dp.A = ay.x; dp.yy = ay.y; dp.z = ze1.x; dp.e1 = ze1.y; dp.e2 = ze2.y; dp.omc = qo.y;
-      const c2_d2 o01 = sh.xa[buf][1 - ROLE][col][seg];
-      double other[3];
-      other[0] = o01.x; other[1] = o01.y; other[2] = sh.xb[buf][1 - ROLE][col][seg];
-      if constexpr (ROLE == C2_TOP) {
-        const c2_d2 uu = pair(14);
-        overlap();
-        var_col12_top_dy(dp, l01.x, l01.y, l2x.x, uu.x, uu.y, w2, arg, other, out);
-      } else {
-        const c2_d2 qe = pair(4);
-        overlap();
-        var_col12_bottom_dy(dp, l01.x, l01.y, l2x.x, qe.x, qo.x, qe.y, w2, arg, other, out);
-      }
-    }
-    return alive;
+  // ---- the two sides of a stage.  Base lanes: evaluate the stage argument and publish the record the column halves apply G, H, U from.
+  auto base_eval = [&](const double (&arg)[NC], double (&out)[NC], const int buf) {
+   if constexpr (BASE) {
+    QuadParts qp;
+    double P[3];
+    rhs12_base_quad<PM, true>(arg, Q, tp, out, qp, P);
+    BaseParts12 bp;
+    bp.ua = qp.ua; bp.ub = qp.ub;
+    parts_guard_zero_norm<PM>(qp.n2, bp);
+    // four 128-bit stores (round 3: fourteen 64-bit ones, a quarter of the base wave's issue time): the lanes of a quad hold
+    // different quantities under the same name, and each writes its pair where the record wants it
+    double* r = &sh.rec[buf][seg][0];
+    const double ubn = (bp.ub * qp.inv_n) * qp.inv_n;
+    const double x3 = Q.lane1 ? qp.omc : qp.es;
+    *reinterpret_cast<c2_d2*>(r + o1) = c2_d2{qp.a0, P[1]};
+    *reinterpret_cast<c2_d2*>(r + o2) = c2_d2{P[2], qp.e};
+    *reinterpret_cast<c2_d2*>(r + o3) = c2_d2{qp.q, x3};
+    *reinterpret_cast<c2_d2*>(r + o4) = c2_d2{bp.ua, ubn};
+   }
   };
-  const std::false_type no_vote{};
-  const std::true_type with_vote{};
+  // Column halves: hand the first triple of a stage argument to the partner half (the other wave of this SIMD) ...
+  auto col_hand = [&](const double a0, const double a1, const double a2, const int buf) {
+    if constexpr (!BASE) {
+      sh.xa[buf][ROLE][col][seg] = c2_d2{a0, a1};
+      sh.xb[buf][ROLE][col][seg] = a2;
+    }
+  };
+  // ... and, behind the stage's barrier, the slope of the own half.  Order of work: the loads; `sums` (needs neither them nor
+  // this slope: the next argument's sum over the older slopes) in the shadow of their latency; the slope of the FIRST triple,
+  // which needs no loaded value (top: a' = b; bottom: d' = 2 w J d - g); `early(out)` -- the caller forms the next argument's
+  // first triple from it and hands it over at once, so that the store's latency hides behind the second triple's arithmetic
+  // instead of standing in front of the next barrier -- and then the second triple.
+  auto col_finish = [&](const double (&arg)[NC], double (&out)[NC], const int buf, auto&& sums, auto&& early) {
+   if constexpr (!BASE) {
+    const double* r = &sh.rec[buf][seg][0];
+    auto pair = [&](const int slot) { return *reinterpret_cast<const c2_d2*>(r + slot); };
+    // (only whole pairs as 128-bit loads: a pair with a dead half lends that half's registers to the next load's destination, and
+    // the compiler then waits for everything in between)
+    const c2_d2 ay = pair(0), ze1 = pair(2), l01 = pair(10);
+    const double e2v = r[7], l2v = r[12];
+    const c2_d2 rx = pair(ROLE == C2_TOP ? 14 : 4);            // top: (ua, ubn); bottom: (q1, es)
+    c2_d2 qo;                                                   // (q2, omc): the top half needs omc only
+    if constexpr (ROLE == C2_TOP) { qo.x = 0.0; qo.y = r[9]; } else qo = pair(8);
+    const c2_d2 o01 = sh.xa[buf][1 - ROLE][col][seg];
+    const double o2v = sh.xb[buf][1 - ROLE][col][seg];
+    // (scheduling fences: left alone, the compiler waits for all nine loads at once, two instructions behind them, and lets the
+    // hand-over's stores drift to the end of the stage, in front of the barrier)
+    __builtin_amdgcn_sched_barrier(0);
+    sums();
+    if constexpr (ROLE == C2_TOP) { out[0] = arg[3]; out[1] = arg[4]; out[2] = arg[5]; }
+    else { out[0] = __builtin_fma(w2, arg[1], -arg[3]); out[1] = __builtin_fma(-w2, arg[0], -arg[4]); out[2] = -arg[5]; }
+    early(out);
+    __builtin_amdgcn_sched_barrier(0);                          // the hand-over stays in front of the second triple
+    DyadParts dp;
+    dp.A = ay.x; dp.yy = ay.y; dp.z = ze1.x; dp.e1 = ze1.y; dp.e2 = e2v; dp.omc = qo.y;
+    const double other[3] = {o01.x, o01.y, o2v};
+    double dw[6];
+    if constexpr (ROLE == C2_TOP) var_col12_top_dy(dp, l01.x, l01.y, l2v, rx.x, rx.y, w2, arg, other, dw);
+    else var_col12_bottom_dy(dp, l01.x, l01.y, l2v, rx.x, qo.x, rx.y, w2, arg, other, dw);
+    out[3] = dw[3]; out[4] = dw[4]; out[5] = dw[5];
+   }
+  };
+  auto nothing = [] {};
+  auto nothing1 = [](const double (&)[NC]) {};
+  // one whole evaluation with its barrier (the first-step rule below)
+  auto slope = [&](const double (&arg)[NC], double (&out)[NC], const int buf) {
+    if constexpr (BASE) base_eval(arg, out, buf);
+    else col_hand(arg[0], arg[1], arg[2], buf);
+    C2_SYNC();
+    if constexpr (!BASE) col_finish(arg, out, buf, nothing, nothing1);
+  };
   // Norms over all 156 components of a segment in two levels: every wavefront first sums its own lanes of the segment -- the four
   // columns of a column wave sit in the four 16-lane rows (rows_sum: row / half swaps), the base quad by DPP -- and publishes ONE
   // pair per segment; after the barrier every lane adds the seven pairs in the same order => identical bits, identical decision
@@ -205,7 +217,6 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     }
     T0 = acc.x; T1 = acc.y;
   };
-  auto nothing = [] {};
 
   const double rtol = a.rtol, atol = a.atol;
   const unsigned long tab = dp8_tab_base();
@@ -224,7 +235,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   if (a.warm) {
     const double hw = a.h_first[s];
     h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
-    slope(y, K[0], 0, nothing, no_vote, 1, nothing);
+    slope(y, K[0], 0);
   } else {
     // Hairer's initial step over all components.  Row r of every column is scaled with the BASE value of row r (a dual
     // number's partials share the scale of its value), published by the base lanes.
@@ -232,7 +243,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
 #pragma unroll
       for (int j = 0; j < NC; ++j) sh.scale[seg][sc0 + j] = rcp_nr(__builtin_fma(rtol, fabs(y[j]), atol));
     }
-    slope(y, K[0], 0, nothing, no_vote, 1, nothing);
+    slope(y, K[0], 0);
     double isc0[NC];
     double p0 = 0.0, p1 = 0.0;
 #pragma unroll
@@ -251,7 +262,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     double arg[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) arg[j] = __builtin_fma(h0, K[0][j], y[j]);
-    slope(arg, K[1], 1, nothing, no_vote, 1, nothing);   // the barrier inside also separates the reads above from the writes below
+    slope(arg, K[1], 1);   // the barrier inside also separates the reads above from the writes below
     double p2 = 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -287,39 +298,36 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     const double h_prop = h_abs;
     double last = 0.0;
     if (t + h >= span) { h = span - t; last = 1.0; }
-    // Argument st (st = 1..11: stage st, weights DP8_A[st][.]; st = 12: the new state, weights DP8_B) is y + h (older + w K[st-1])
-    // with older = the sum over the slopes before the newest one, formed one stage earlier in the shadow of that stage's LDS
-    // traffic (same summation order as the one-piece loop: bit-identical arguments).
-    double older[NC], yn[NC], a5[NC], a3[NC], iscb[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) older[j] = 0.0;
-    // the tableau rows come by scalar loads (rk.hpp: dp8_load_row), the row of argument st + 1 while stage st is evaluated
+    // Argument st + 1 (st + 1 = 2..11: weights DP8_A[st + 1][.]; 12: the new state, weights DP8_B) is y + h (next + w K[st]) with
+    // next = the sum over the slopes before the newest one, formed in the shadow of the stage's LDS traffic (same summation order
+    // as the one-piece loop: bit-identical arguments).  The tableau rows come by scalar loads (rk.hpp: dp8_load_row), row st + 2
+    // while stage st runs, and are consumed (dp8_pin_row) BEFORE the stage's LDS traffic is issued: scalar loads and LDS
+    // operations share one counter, and the first use of a row would otherwise wait for the record stores / loads as well.
+    double arg[NC], yn[NC], a5[NC], a3[NC], iscb[NC];
     double wrow[2][12], we5[13], we3[13];
-    dp8_load_row<1>(tab, wrow[1]);
+    dp8_load_row<2>(tab, wrow[0]);
+    {
+      const double w10 = coef_here(DP8_A[1][0]);
+#pragma unroll
+      for (int j = 0; j < NC; ++j) arg[j] = __builtin_fma(h, w10 * K[0][j], y[j]);
+    }
+    if constexpr (!BASE) col_hand(arg[0], arg[1], arg[2], 1);
     int alive = 1;
-    auto stage = [&](auto st_c) {                // enters with K[0] = f(y) (FSAL); stages 1 .. 11
+    auto stage = [&](auto st_c) {                // enters with K[0] = f(y) (FSAL) and arg = argument st; leaves with K[st] and argument st + 1
       constexpr int st = decltype(st_c)::value;
       static_assert(st >= 1 && st < NS, "stage index");
-      double arg[NC], next[NC];
-      constexpr double wn_c = DP8_A[st][st - 1];
-      const double (&wc)[12] = wrow[st & 1];
-#pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        const double acc = (wn_c != 0.0) ? __builtin_fma(wc[st - 1], K[st - 1][j], older[j]) : older[j];
-        arg[j] = __builtin_fma(h, acc, y[j]);
-      }
-      double (&wx)[12] = wrow[(st + 1) & 1];
-      dp8_load_row<st + 1>(tab, wx);
-      if constexpr (st == NS - 1) dp8_load_err(tab, we5, we3);
+      const double (&wn)[12] = wrow[(st + 1) & 1];             // weights of argument st + 1
+      if constexpr (st + 2 <= NS) dp8_load_row<st + 2>(tab, wrow[st & 1]);
+      if constexpr (st == NS - 2) dp8_load_err(tab, we5, we3);
+      double next[NC], argn[NC];
       auto sums = [&] {
 #pragma unroll
         for (int j = 0; j < NC; ++j) next[j] = 0.0;
 #pragma unroll
         for (int k = 0; k < st; ++k) {
-          const double w_c = (st + 1 < NS) ? DP8_A[st + 1 < NS ? st + 1 : 0][k] : DP8_B[k];
-          if (w_c != 0.0) {
+          if (dp8_row_entry(st, k) != 0.0) {
 #pragma unroll
-            for (int j = 0; j < NC; ++j) next[j] = __builtin_fma(wx[k], K[k][j], next[j]);
+            for (int j = 0; j < NC; ++j) next[j] = __builtin_fma(wn[k], K[k][j], next[j]);
           }
         }
         if constexpr (st == NS - 1) {           // in the shadow of the last stage: the error sums over the slopes before K[11]
@@ -338,38 +346,52 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
           }
         }
       };
-      // base lanes, last stage: K[11] is theirs before the barrier, so the new state and with it the scale of the error norm
-      // (which the column lanes need right behind this barrier) are formed and published here
-      auto tail = [&] {
-        if constexpr (BASE && st == NS - 1) {
+      auto next_arg = [&](const int j) {
+        const double acc = (dp8_row_entry(st, st) != 0.0) ? __builtin_fma(wn[st], K[st][j], next[j]) : next[j];
+        argn[j] = __builtin_fma(h, acc, y[j]);
+      };
+      if constexpr (BASE) {
+        base_eval(arg, K[st], st & 1);
+        dp8_pin_row<st + 1>(wn);              // (arrived long ago: the wait is for the scalar loads only, in front of nothing)
+        if constexpr (st == NS - 1) dp8_pin_err(we5, we3);
+        sums();
+#pragma unroll
+        for (int j = 0; j < NC; ++j) next_arg(j);
+        if constexpr (st == NS - 1) {
+          // last stage: K[11] is the base lanes' before the barrier, so the new state and with it the scale of the error norm
+          // (which the column lanes need right behind this barrier) are formed and published here
 #pragma unroll
           for (int j = 0; j < NC; ++j) {
-            const double acc = (DP8_B[NS - 1] != 0.0) ? __builtin_fma(wx[NS - 1], K[NS - 1][j], next[j]) : next[j];
-            yn[j] = __builtin_fma(h, acc, y[j]);
-            iscb[j] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(yn[j])), atol));
+            iscb[j] = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[j]), fabs(argn[j])), atol));
             sh.scale[seg][sc0 + j] = iscb[j];
           }
         }
-      };
+      } else {
+        dp8_pin_row<st + 1>(wn);
+        if constexpr (st == NS - 1) dp8_pin_err(we5, we3);
+      }
       // the first stage's barrier carries the vote that ends the sweep of this workgroup (every segment done)
-      if constexpr (st == 1) alive = slope(arg, K[st], st & 1, sums, with_vote, !done, tail);
-      else slope(arg, K[st], st & 1, sums, no_vote, 1, tail);
+      if constexpr (st == 1) { alive = c2_wait.sync_or(!done); if (!alive) return; }
+      else C2_SYNC();
+      if constexpr (!BASE) {
+        col_finish(arg, K[st], st & 1, sums, [&](const double (&)[NC]) {
+          next_arg(0); next_arg(1); next_arg(2);
+          col_hand(argn[0], argn[1], argn[2], (st + 1) & 1);
+        });
+        next_arg(3); next_arg(4); next_arg(5);
+      }
 #pragma unroll
-      for (int j = 0; j < NC; ++j) older[j] = next[j];
+      for (int j = 0; j < NC; ++j) arg[j] = argn[j];
     };
     stage(std::integral_constant<int, 1>{});
     if (!alive) break;                       // workgroup-uniform: the vote is the barrier's
     static_for<2, NS>(stage);
-    // new state and error sums of this lane's rows; the sums go into the table before the FSAL barrier
+    // arg is the new state now.  Error sums of this lane's rows: into the table before the FSAL barrier
     {
-      const double (&wb)[12] = wrow[NS & 1];
       double e5 = 0.0, e3 = 0.0;
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
-        if constexpr (!BASE) {
-          const double acc = (DP8_B[NS - 1] != 0.0) ? __builtin_fma(wb[NS - 1], K[NS - 1][j], older[j]) : older[j];
-          yn[j] = __builtin_fma(h, acc, y[j]);
-        }
+        yn[j] = arg[j];
         double s5 = a5[j], s3 = a3[j];
         if (DP8_E5[NS - 1] != 0.0) s5 = __builtin_fma(we5[NS - 1], K[NS - 1][j], s5);
         if (DP8_E3[NS - 1] != 0.0) s3 = __builtin_fma(we3[NS - 1], K[NS - 1][j], s3);
@@ -381,7 +403,10 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       post2(e5, e3);
     }
     static_assert(DP8_E5[NS] == 0.0 && DP8_E3[NS] == 0.0, "the error estimate must not involve the FSAL slope");
-    slope(yn, K[NS], NS & 1, nothing, no_vote, 1, nothing);      // FSAL slope; behind its barrier: the decision
+    // FSAL slope (the column halves handed the new state's first triple over inside stage 11); behind its barrier: the decision
+    if constexpr (BASE) base_eval(yn, K[NS], NS & 1);
+    C2_SYNC();
+    if constexpr (!BASE) col_finish(yn, K[NS], NS & 1, nothing, nothing1);
     // (K[12] is used only by an accepted step: unpinned, the compiler sinks its whole evaluation into that branch, behind the decision)
 #pragma unroll
     for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(K[NS][j]));

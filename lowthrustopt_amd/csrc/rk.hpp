@@ -331,6 +331,23 @@ __device__ __forceinline__ void dp8_load_row(const unsigned long base, double (&
     if constexpr (used) w[k] = T->w[at];
   });
 }
+// The scalar loads share their counter with the LDS operations (lgkmcnt), and scalar loads return out of order: the first use of
+// a loaded coefficient makes the compiler wait for EVERYTHING outstanding.  A kernel that wants its LDS traffic to overlap with
+// arithmetic on these coefficients consumes them here, before it issues that traffic (an empty asm per entry: no instruction).
+template <int ST>
+__device__ __forceinline__ void dp8_pin_row(const double (&w)[12]) {
+#pragma unroll
+  for (int k = 0; k < ST; ++k) {
+    if (dp8_row_entry(ST - 1, k) != 0.0) asm volatile("" :: "s"(w[k]));
+  }
+}
+__device__ __forceinline__ void dp8_pin_err(const double (&e5)[13], const double (&e3)[13]) {
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    if (DP8_E5[k] != 0.0) asm volatile("" :: "s"(e5[k]));
+    if (DP8_E3[k] != 0.0) asm volatile("" :: "s"(e3[k]));
+  }
+}
 // the non-zero weights of the two error estimators
 __device__ __forceinline__ void dp8_load_err(const unsigned long base, double (&e5)[13], double (&e3)[13]) {
   const Dp8ConstPtr T = dp8_tab_here(base);
