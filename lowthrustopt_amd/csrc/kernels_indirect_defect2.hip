@@ -269,10 +269,11 @@ __global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
       double yn[3];
       double wrow[2][12], we5[13], we3[13];
       dp8_load_row<1>(tab, wrow[1]);
-      static_for<1, 13>([&](auto st_c) {
+      // stage arguments 1 .. 11 and the new state (12): y + h sum_k w_k K_k
+      auto argument = [&](auto st_c, double (&arg)[3]) {
         constexpr int st = decltype(st_c)::value;
-        double (&w)[12] = wrow[st & 1];
-        double arg[3], acc[3];
+        const double (&w)[12] = wrow[st & 1];
+        double acc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[j] = 0.0;
 #pragma unroll
@@ -285,19 +286,25 @@ __global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) arg[j] = __builtin_fma(h, acc[j], y[j]);
-        if constexpr (st < 12) dp8_load_row<st + 1>(tab, wrow[(st + 1) & 1]);
-        else dp8_load_err(tab, we5, we3);
-        if constexpr (st == 12) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) yn[j] = arg[j];
-        }
+      };
+      static_for<1, 12>([&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+        double arg[3];
+        argument(st_c, arg);
+        dp8_load_row<st + 1>(tab, wrow[(st + 1) & 1]);
+        if constexpr (st == 11) dp8_load_err(tab, we5, we3);
         rhs(arg, K[st]);
       });
+      argument(std::integral_constant<int, 12>{}, yn);
+      // Round 4: the error estimate of the 8(5,3) pair does not involve the FSAL slope f(y_new) (E5[12] = E3[12] = 0): the sums, the
+      // quad's norm and the step decision (rk.hpp: dp8_decide, reciprocal-square-root chains instead of IEEE square roots and a
+      // division) are formed BEFORE that evaluation, in whose instruction stream their dependent chains then hide.
+      static_assert(DP8_E5[12] == 0.0 && DP8_E3[12] == 0.0, "the error estimate must not involve the FSAL slope");
       double a5[3], a3[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) { a5[j] = 0.0; a3[j] = 0.0; }
 #pragma unroll
-      for (int k = 0; k <= 12; ++k) {
+      for (int k = 0; k < 12; ++k) {
         if (DP8_E5[k] != 0.0) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) a5[j] = __builtin_fma(we5[k], K[k][j], a5[j]);
@@ -316,27 +323,27 @@ __global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
         e3 = __builtin_fma(s3, s3, e3);
       }
       const double E5 = quad_sum(e5), E3 = quad_sum(e3);
-      const double err = (E5 == 0.0 && E3 == 0.0) ? 0.0 : fabs(h) * E5 / sqrt((E5 + 0.01 * E3) * 12.0);
-      if (err < 1.0) {
-        double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 / sqrt(sqrt(sqrt(err))));
-        if (rejected != 0.0) factor = fmin(1.0, factor);
+      double h_next, accept, bad;
+      dp8_decide(E5, E3, h, rejected, 12.0, h_next, accept, bad);
+      asm volatile("" : "+v"(h_next));        // (unpinned, the compiler sinks the next proposal's chain to the loop's tail, behind the commit branch)
+      rhs(yn, K[12]);
+      if (accept != 0.0) {
         if (nacc == 0) h_rec = h_abs;
-        h_abs = h * factor;
         t = (last != 0.0) ? span : t + h;
 #pragma unroll
         for (int j = 0; j < 3; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
         ++nacc;
         rejected = 0.0;
       } else {
-        h_abs = h * fmax(0.2, 0.9 / sqrt(sqrt(sqrt(err))));
         rejected = 1.0;
         ++nrej;
-        if (err != err) {                     // a NaN never recovers: poison and stop instead of max_steps retries
+        if (bad != 0.0) {                     // a NaN never recovers: poison and stop instead of max_steps retries
 #pragma unroll
-          for (int j = 0; j < 3; ++j) y[j] = err;
+          for (int j = 0; j < 3; ++j) y[j] = bad;
           t = span;
         }
       }
+      h_abs = h_next;
     }
     if (t < span) {                           // max_steps trial steps used up before t1: no result
 #pragma unroll
