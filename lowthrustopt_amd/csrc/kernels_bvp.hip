@@ -10,8 +10,16 @@
 // block row coupling the two outer unknowns.  log2(S) levels of independent 24 x 37 problems, one wavefront each
 // (lane = matrix column, 24 doubles in registers, reflector broadcast by v_readlane).  Only orthogonal
 // transformations are used, so -- unlike condensing (products of STMs) -- the elimination is backward stable for
-// long, unstable trajectories.  The reflectors are stored, so a second right-hand side (the second-order-correction
-// re-solve, :190-214) costs one cheap pass.
+// long, unstable trajectories.  The orthogonal factor of every pair is stored as an explicit 24 x 24 matrix (formed for
+// free by 24 lanes the stack leaves idle), so a second right-hand side (the second-order-correction re-solve, :190-214) is
+// one small matrix-vector product per pair and level.
+//
+// Round 4: SIXTEEN consecutive block rows per workgroup and FOUR levels per launch -- the eight pairs of the first level in
+// eight wavefronts, the rows of the levels in between in LDS, one block row per workgroup out -- with the level-0 rows read
+// straight from the sweep's outputs.  4 096 segments: chunk, chunk, tail (16 rows: four levels, the 12 x 12 solve, four levels
+// of back-substitution), two back-substitution launches of four levels each: 5 launches for 12 + 12 levels (round 3: 10
+// launches, two levels each, the rows of every level through HBM, and a re-solve that re-applied 12 reflectors per pair in ONE
+// lane reading its own 6 KB record).
 //
 // Node eliminated at level l by pair j:  mid = (2j+1) 2^l,  left = 2j 2^l,  right = min((2j+2) 2^l, n-1).
 #include "kernels.hpp"
@@ -29,73 +37,28 @@ namespace lto {
 template <int NU> struct BvpDims {
   static constexpr int NK = (NU == 12) ? 12 : 18;            // Householder reflections per pair
   static constexpr int NCOLS = 3 * NU + 1;                   // mid | left | right | rhs
+  static constexpr int NLANES = NCOLS + 24;                  // ... | the 24 columns of the identity, which end up as Q^T
   static constexpr int ROW = 24 * NU + 12;                   // A (12 x NU), B (12 x NU), r (12)
   static constexpr int REC_R = 0, REC_CA = NU * NU, REC_CB = 2 * NU * NU, REC_G = 3 * NU * NU;
-  static constexpr int REC_V = 3 * NU * NU + NU, REC_TAU = REC_V + 24 * NK, REC = REC_TAU + NK;
+  static constexpr int REC_QT = 3 * NU * NU + NU, REC = REC_QT + 24 * 24;    // QT[c][r] = (Q^T)_{r c}: lane r reads consecutive doubles
+  static_assert(NLANES <= 64, "one wavefront per pair");
 };
+constexpr int BVP_CHUNK = 16;      // block rows per workgroup of a chunk launch (four levels)
+constexpr int BVP_CHUNK_LEVELS = 4;
 
 struct BvpArgs {
   int n_nodes, n_batch, S_traj;       // S_traj = n_nodes - 1
-  double* rows0; double* rows1;       // ping-pong block rows  [n_batch][S_traj][ROW]
   double* rec;                        // [n_batch][n_nodes][REC]  (entries 1 .. n_nodes-2 used)
   double* delta; long ldx;            // SoA [12][ldx], node j = b*n_nodes + k
+  const double* Phi; long ldp;        // the sweep's outputs: level-0 rows are read from them directly
+  const double* defect; long ldd;
 };
 
-// level-0 rows from the STM sweep's outputs
+// ---- the stack of a pair, lane c = column c: [mid | left | right | rhs | identity]
+// from two block rows in memory (global or LDS)
 template <int NU>
-__global__ __launch_bounds__(256) void k_bvp_init(const double* __restrict__ Phi, long ldp, const double* __restrict__ defect,
-                                                  long ldd, BvpArgs a) {
+__device__ __forceinline__ void bvp_stack_rows(const double* top, const double* bot, const int c, double (&col)[24]) {
   using D = BvpDims<NU>;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long S_total = (long)a.S_traj * a.n_batch;
-  if (idx >= S_total * D::ROW) return;
-  const long s = idx / D::ROW;
-  const int e = (int)(idx - s * D::ROW);
-  const int i = (int)(s % a.S_traj);
-  double v;
-  if (e < 12 * NU) {                   // A: columns of Phi_i that belong to free unknowns
-    const int c = e / 12, r = e % 12;
-    const int pc = (NU == 12) ? c : 6 + c;
-    v = (NU == 12 && i == 0 && c < 6) ? 0.0 : Phi[(long)(pc * 12 + r) * ldp + s];   // fixed initial state (:141)
-  } else if (e < 24 * NU) {            // B = -I restricted to the free unknowns
-    const int c = (e - 12 * NU) / 12, r = (e - 12 * NU) % 12;
-    const int pc = (NU == 12) ? c : 6 + c;
-    v = (r == pc && !(NU == 12 && i == a.S_traj - 1 && c < 6)) ? -1.0 : 0.0;       // fixed final state (:142)
-  } else {
-    v = -defect[(long)(e - 24 * NU) * ldd + s];
-  }
-  a.rows0[idx] = v;
-}
-
-template <int NU>
-__global__ __launch_bounds__(256) void k_bvp_init_rhs(const double* __restrict__ defect, long ldd, BvpArgs a) {
-  using D = BvpDims<NU>;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over S_total * 12
-  const long S_total = (long)a.S_traj * a.n_batch;
-  if (idx >= S_total * 12) return;
-  const long s = idx / 12;
-  const int c = (int)(idx - s * 12);
-  a.rows0[s * D::ROW + 24 * NU + c] = -defect[(long)c * ldd + s];
-}
-
-// One wavefront per pair (j = pair index or the carry slot, b = trajectory, c = lane).  Lane c < NCOLS holds column c
-// of the stack.
-template <int NU>
-__device__ __forceinline__ void bvp_reduce_pair(const BvpArgs& a, int level, int M, const double* cur, double* nxt, const int j,
-                                                const int b, const int c) {
-  using D = BvpDims<NU>;
-  const int npairs = M / 2;
-  const double* rows = cur + (long)b * a.S_traj * D::ROW;
-  double* out = nxt + (long)b * a.S_traj * D::ROW;
-  if (j >= npairs) {                   // odd row carried to the next level unchanged
-    const double* src = rows + (long)(M - 1) * D::ROW;
-    double* dst = out + (long)npairs * D::ROW;
-    for (int e = c; e < D::ROW; e += 64) dst[e] = src[e];
-    return;
-  }
-  const double* top = rows + (long)(2 * j) * D::ROW;
-  const double* bot = top + D::ROW;
-  double col[24];
 #pragma unroll
   for (int r = 0; r < 24; ++r) col[r] = 0.0;
   if (c < NU) {                        // shared unknown: [B_top; A_bot]
@@ -110,8 +73,66 @@ __device__ __forceinline__ void bvp_reduce_pair(const BvpArgs& a, int level, int
   } else if (c == 3 * NU) {
 #pragma unroll
     for (int r = 0; r < 12; ++r) { col[r] = top[24 * NU + r]; col[12 + r] = bot[24 * NU + r]; }
+  } else if (c < D::NLANES) {
+#pragma unroll
+    for (int r = 0; r < 24; ++r) col[r] = (r == c - D::NCOLS) ? 1.0 : 0.0;
   }
-  double tau_mine = 0.0;
+}
+// element e of the level-0 block row of segment i of trajectory b (s = b S_traj + i): [A | B | r] from the sweep's outputs
+template <int NU>
+__device__ __forceinline__ double bvp_row0_A(const BvpArgs& a, const long s, const int i, const int c, const int r) {
+  const int pc = (NU == 12) ? c : 6 + c;                                            // columns of Phi_i that belong to free unknowns
+  return (NU == 12 && i == 0 && c < 6) ? 0.0 : a.Phi[(long)(pc * 12 + r) * a.ldp + s];   // fixed initial state (:141)
+}
+template <int NU>
+__device__ __forceinline__ double bvp_row0_B(const BvpArgs& a, const int i, const int c, const int r) {
+  const int pc = (NU == 12) ? c : 6 + c;                                            // -I restricted to the free unknowns
+  return (r == pc && !(NU == 12 && i == a.S_traj - 1 && c < 6)) ? -1.0 : 0.0;       // fixed final state (:142)
+}
+// ... the stack of the level-0 pair (2j, 2j + 1) without materialising the rows
+template <int NU>
+__device__ __forceinline__ void bvp_stack_sweep(const BvpArgs& a, const int b, const int j, const int c, double (&col)[24]) {
+  using D = BvpDims<NU>;
+  const int it = 2 * j, ib = 2 * j + 1;
+  const long st = (long)b * a.S_traj + it, sb = st + 1;
+#pragma unroll
+  for (int r = 0; r < 24; ++r) col[r] = 0.0;
+  if (c < NU) {
+#pragma unroll
+    for (int r = 0; r < 12; ++r) { col[r] = bvp_row0_B<NU>(a, it, c, r); col[12 + r] = bvp_row0_A<NU>(a, sb, ib, c, r); }
+  } else if (c < 2 * NU) {
+#pragma unroll
+    for (int r = 0; r < 12; ++r) col[r] = bvp_row0_A<NU>(a, st, it, c - NU, r);
+  } else if (c < 3 * NU) {
+#pragma unroll
+    for (int r = 0; r < 12; ++r) col[12 + r] = bvp_row0_B<NU>(a, ib, c - 2 * NU, r);
+  } else if (c == 3 * NU) {
+#pragma unroll
+    for (int r = 0; r < 12; ++r) { col[r] = -a.defect[(long)r * a.ldd + st]; col[12 + r] = -a.defect[(long)r * a.ldd + sb]; }
+  } else if (c < D::NLANES) {
+#pragma unroll
+    for (int r = 0; r < 24; ++r) col[r] = (r == c - D::NCOLS) ? 1.0 : 0.0;
+  }
+}
+// a level-0 row that has no partner (odd count): materialised as it is carried up
+template <int NU>
+__device__ __forceinline__ void bvp_row_from_sweep(const BvpArgs& a, const int b, const int i, double* dst, const int lane) {
+  using D = BvpDims<NU>;
+  const long s = (long)b * a.S_traj + i;
+  for (int e = lane; e < D::ROW; e += 64) {
+    double v;
+    if (e < 12 * NU) v = bvp_row0_A<NU>(a, s, i, e / 12, e % 12);
+    else if (e < 24 * NU) v = bvp_row0_B<NU>(a, i, (e - 12 * NU) / 12, (e - 12 * NU) % 12);
+    else v = -a.defect[(long)(e - 24 * NU) * a.ldd + s];
+    dst[e] = v;
+  }
+}
+
+// ---- NK Householder reflections on the stack (one wavefront, lane = column; the reflector of step k is lane k's column,
+// broadcast by v_readlane), then the record of the eliminated node `rec` and the new block row `nr`
+template <int NU>
+__device__ __forceinline__ void bvp_reflect_store(double (&col)[24], const int c, double* rec, double* nr) {
+  using D = BvpDims<NU>;
 #pragma unroll
   for (int k = 0; k < D::NK; ++k) {
     // reflector from column k (computed in every lane, only lane k's is used)
@@ -134,19 +155,16 @@ __device__ __forceinline__ void bvp_reduce_pair(const BvpArgs& a, int level, int
     const double beta = (alpha >= 0.0) ? -nrm : nrm;
     const double tau_k = trivial ? 0.0 : (beta - alpha) * rcp_nr(beta);
     const double scl = trivial ? 0.0 : rcp_nr(alpha - beta);
-    if (c == k) {
-      tau_mine = tau_k;
-      if (!trivial) {
-        col[k] = beta;
+    if (c == k && !trivial) {
+      col[k] = beta;
 #pragma unroll
-        for (int r = k + 1; r < 24; ++r) col[r] *= scl;
-      }
+      for (int r = k + 1; r < 24; ++r) col[r] *= scl;
     }
     const double tau_b = __shfl(tau_k, k);
     double v[24];
 #pragma unroll
     for (int r = k + 1; r < 24; ++r) v[r] = __shfl(col[r], k);
-    if (c > k && c < D::NCOLS) {
+    if (c > k && c < D::NLANES) {
       double w0 = col[k], w1 = 0.0, w2 = 0.0, w3 = 0.0;
 #pragma unroll
       for (int r = k + 1; r < 24; ++r) {
@@ -161,15 +179,6 @@ __device__ __forceinline__ void bvp_reduce_pair(const BvpArgs& a, int level, int
 #pragma unroll
       for (int r = k + 1; r < 24; ++r) col[r] = __builtin_fma(-w, v[r], col[r]);
     }
-  }
-  const int mid = (2 * j + 1) << level;
-  double* rec = a.rec + ((long)b * a.n_nodes + mid) * D::REC;
-  double* nr = out + (long)j * D::ROW;
-  // reflectors: lane k < NK holds v_k below the diagonal
-  if (c < D::NK) {
-#pragma unroll
-    for (int r = 0; r < 24; ++r) rec[D::REC_V + c * 24 + r] = (r > c) ? col[r] : (r == c ? 1.0 : 0.0);
-    rec[D::REC_TAU + c] = tau_mine;
   }
   // rows 0 .. NU-1: the eliminated unknown; rows NU .. NU+11: the new block row (entries below the diagonal of a
   // triangularised column are reflector storage, i.e. structural zeros of the matrix)
@@ -191,69 +200,142 @@ __device__ __forceinline__ void bvp_reduce_pair(const BvpArgs& a, int level, int
     for (int r = 0; r < NU; ++r) rec[D::REC_G + r] = col[r];
 #pragma unroll
     for (int r = 0; r < 12; ++r) nr[24 * NU + r] = col[NU + r];
+  } else if (c < D::NLANES) {          // column c' of the identity has become Q^T e_c'
+#pragma unroll
+    for (int r = 0; r < 24; ++r) rec[D::REC_QT + (c - D::NCOLS) * 24 + r] = col[r];
   }
 }
 
-template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_reduce(BvpArgs a, int level, int M, const double* __restrict__ cur, double* __restrict__ nxt) {
-  bvp_reduce_pair<NU>(a, level, M, cur, nxt, blockIdx.x, blockIdx.y, threadIdx.x);
-}
+// Node eliminated at level l by pair j
+__device__ __forceinline__ int bvp_mid(const int j, const int level) { return (2 * j + 1) << level; }
 
-// Re-apply the stored reflectors to a new right-hand side.  One lane per pair (+ carry).
+// ---- level-0 rows into a buffer (only when the whole problem fits the tail launch: at most 16 segments)
 template <int NU>
-__device__ __forceinline__ void bvp_reduce_rhs_pair(const BvpArgs& a, int level, int M, const double* cur, double* nxt, const int j,
-                                                    const int b) {
+__global__ __launch_bounds__(64) void k_bvp_rows0(BvpArgs a, double* rows) {
   using D = BvpDims<NU>;
-  const int npairs = M / 2;
-  const double* rows = cur + (long)b * a.S_traj * D::ROW;
-  double* out = nxt + (long)b * a.S_traj * D::ROW;
-  if (j == npairs && (M & 1)) {
-    for (int r = 0; r < 12; ++r) out[(long)npairs * D::ROW + 24 * NU + r] = rows[(long)(M - 1) * D::ROW + 24 * NU + r];
-    return;
-  }
-  if (j >= npairs) return;
-  double x[24];
-#pragma unroll
-  for (int r = 0; r < 12; ++r) { x[r] = rows[(long)(2 * j) * D::ROW + 24 * NU + r]; x[12 + r] = rows[(long)(2 * j + 1) * D::ROW + 24 * NU + r]; }
-  const int mid = (2 * j + 1) << level;
-  double* rec = a.rec + ((long)b * a.n_nodes + mid) * D::REC;
-#pragma unroll
-  for (int k = 0; k < D::NK; ++k) {
-    const double* v = rec + D::REC_V + k * 24;
-    double w = x[k];
-#pragma unroll
-    for (int r = k + 1; r < 24; ++r) w = __builtin_fma(v[r], x[r], w);
-    w *= rec[D::REC_TAU + k];
-    x[k] -= w;
-#pragma unroll
-    for (int r = k + 1; r < 24; ++r) x[r] = __builtin_fma(-w, v[r], x[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < NU; ++r) rec[D::REC_G + r] = x[r];
-#pragma unroll
-  for (int r = 0; r < 12; ++r) out[(long)j * D::ROW + 24 * NU + r] = x[NU + r];
+  const int i = blockIdx.x, b = blockIdx.y;
+  bvp_row_from_sweep<NU>(a, b, i, rows + ((long)b * a.S_traj + i) * D::ROW, threadIdx.x);
+}
+template <int NU>
+__global__ __launch_bounds__(256) void k_bvp_rhs0(BvpArgs a, double* rhs) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // over S_total * 12
+  const long S_total = (long)a.S_traj * a.n_batch;
+  if (idx >= S_total * 12) return;
+  const long s = idx / 12;
+  const int c = (int)(idx - s * 12);
+  rhs[idx] = -a.defect[(long)c * a.ldd + s];
 }
 
+// ---- FOUR levels of the reduction in one launch: workgroup g of trajectory b owns the rows [16 g, 16 g + 16) of level
+// `level0` (M0 rows; FIRST: level 0, read from the sweep's outputs) and everything that grows out of them: 8, 4, 2, 1 pairs in
+// as many wavefronts, the rows in between in LDS, its one row of level level0 + 4 to out[g].  A row without a partner (odd
+// count) is carried up unchanged.
+template <int NU, bool FIRST>
+__global__ __launch_bounds__(512) void k_bvp_chunk(BvpArgs a, const int level0, const int M0, const double* __restrict__ cur, double* __restrict__ out) {
+  using D = BvpDims<NU>;
+  __shared__ double bufA[8][D::ROW];
+  __shared__ double bufB[4][D::ROW];
+  const int g = blockIdx.x, b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double* rows = cur + (long)b * a.S_traj * D::ROW;
+  double* orow = out + ((long)b * a.S_traj + g) * D::ROW;
+  int M = M0;
+#pragma unroll
+  for (int l = 0; l < BVP_CHUNK_LEVELS; ++l) {
+    const int width = 8 >> l;                    // pairs of this workgroup at this level
+    const int j = g * width + wave;              // global pair index at this level
+    if (wave < width && 2 * j < M) {
+      double* dst = (l == 0) ? bufA[wave] : (l == 1) ? bufB[wave] : (l == 2) ? bufA[wave] : orow;
+      const double* top = (l == 0) ? rows + (long)(2 * j) * D::ROW : (l == 1) ? bufA[2 * wave] : (l == 2) ? bufB[2 * wave] : bufA[0];
+      const double* bot = (l == 0) ? top + D::ROW : (l == 1) ? bufA[2 * wave + 1] : (l == 2) ? bufB[2 * wave + 1] : bufA[1];
+      if (2 * j + 1 < M) {
+        double col[24];
+        if (FIRST && l == 0) bvp_stack_sweep<NU>(a, b, j, lane, col);
+        else bvp_stack_rows<NU>(top, bot, lane, col);
+        bvp_reflect_store<NU>(col, lane, a.rec + ((long)b * a.n_nodes + bvp_mid(j, level0 + l)) * D::REC, dst);
+      } else if (FIRST && l == 0) {
+        bvp_row_from_sweep<NU>(a, b, 2 * j, dst, lane);
+      } else {
+        for (int e = lane; e < D::ROW; e += 64) dst[e] = top[e];
+      }
+    }
+    __syncthreads();
+    M = (M + 1) / 2;
+  }
+}
+
+// ---- a new right-hand side through the stored orthogonal factors (the second-order-correction re-solve): per pair
+// x' = Q^T [r_top; r_bot], 32 lanes (lane r = row r), the first NU entries are the eliminated node's g, the next 12 the new
+// row's right-hand side.  Right-hand sides travel in their own small buffers [n_batch][S_traj][12].
 template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_reduce_rhs(BvpArgs a, int level, int M, const double* __restrict__ cur, double* __restrict__ nxt) {
-  bvp_reduce_rhs_pair<NU>(a, level, M, cur, nxt, blockIdx.x * 64 + threadIdx.x, blockIdx.y);
+__device__ __forceinline__ void bvp_rhs_pair(const double* xt, const double* xb, const double* rec_c, double* rec_g, double* nr, const int r) {
+  using D = BvpDims<NU>;
+  const int rr = r < 24 ? r : 23;
+  double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 12; c += 2) {
+    acc0 = __builtin_fma(rec_c[D::REC_QT + c * 24 + rr], xt[c], acc0);
+    acc1 = __builtin_fma(rec_c[D::REC_QT + (c + 1) * 24 + rr], xt[c + 1], acc1);
+  }
+#pragma unroll
+  for (int c = 0; c < 12; c += 2) {
+    acc0 = __builtin_fma(rec_c[D::REC_QT + (12 + c) * 24 + rr], xb[c], acc0);
+    acc1 = __builtin_fma(rec_c[D::REC_QT + (13 + c) * 24 + rr], xb[c + 1], acc1);
+  }
+  const double x = acc0 + acc1;
+  if (r < NU) rec_g[D::REC_G + r] = x;
+  else if (r < NU + 12) nr[r - NU] = x;
+}
+template <int NU, bool FIRST>
+__global__ __launch_bounds__(256) void k_bvp_chunk_rhs(BvpArgs a, const int level0, const int M0, const double* __restrict__ cur, double* __restrict__ out) {
+  using D = BvpDims<NU>;
+  __shared__ double x0[16][12];      // FIRST: this workgroup's level-0 right-hand sides
+  __shared__ double xA[8][12];
+  __shared__ double xB[4][12];
+  const int g = blockIdx.x, b = blockIdx.y, grp = threadIdx.x >> 5, r = threadIdx.x & 31;
+  const double* rows = cur + (long)b * a.S_traj * 12;
+  double* orow = out + ((long)b * a.S_traj + g) * 12;
+  int M = M0;
+  if (FIRST) {
+    if (threadIdx.x < 16 * 12) {
+      const int i = threadIdx.x / 12, c = threadIdx.x % 12;
+      const int ig = g * BVP_CHUNK + i;
+      x0[i][c] = (ig < M0) ? -a.defect[(long)c * a.ldd + (long)b * a.S_traj + ig] : 0.0;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int l = 0; l < BVP_CHUNK_LEVELS; ++l) {
+    const int width = 8 >> l;
+    const int j = g * width + grp;
+    if (grp < width && 2 * j < M) {
+      double* dst = (l == 0) ? xA[grp] : (l == 1) ? xB[grp] : (l == 2) ? xA[grp] : orow;
+      const double* top = (l == 0) ? (FIRST ? x0[2 * grp] : rows + (long)(2 * j) * 12) : (l == 1) ? xA[2 * grp] : (l == 2) ? xB[2 * grp] : xA[0];
+      const double* bot = (l == 0) ? (FIRST ? x0[2 * grp + 1] : top + 12) : (l == 1) ? xA[2 * grp + 1] : (l == 2) ? xB[2 * grp + 1] : xA[1];
+      if (2 * j + 1 < M) {
+        double* rec = a.rec + ((long)b * a.n_nodes + bvp_mid(j, level0 + l)) * D::REC;
+        bvp_rhs_pair<NU>(top, bot, rec, rec, dst, r);
+      } else if (r < 12) {
+        dst[r] = top[r];
+      }
+    }
+    __syncthreads();
+    M = (M + 1) / 2;
+  }
 }
 
 // Last level: one row  A d_first + B d_last = r.  NU = 12: the end states are fixed, 12 x 12 system for the two
 // end-node costate updates.  NU = 6: 12 x 12 system for the costates of the first and last node.  Gaussian elimination
-// with partial pivoting, one lane per trajectory.
+// with partial pivoting: one wavefront per trajectory, lane r < 12 holds row r of the augmented 12 x 13 system in registers;
+// pivot search, row swap and elimination go through cross-lane shuffles (no scratch arrays).  `rhs` != null: the row's
+// right-hand side comes from there (re-solve).
 template <int NU>
-__device__ __forceinline__ void bvp_final_one(const BvpArgs& a, const double* cur, const int b, const int lane) {
-  // One wavefront per trajectory: lane r < 12 holds row r of the augmented 12 x 13 system in registers; pivot search,
-  // row swap and elimination go through cross-lane shuffles (no scratch arrays).
-  using D = BvpDims<NU>;
-  const double* row = cur + (long)b * a.S_traj * D::ROW;
+__device__ __forceinline__ void bvp_final_one(const BvpArgs& a, const double* row, const double* rhs, const int b, const int lane) {
   const int r = lane < 12 ? lane : 11;
   constexpr int off = (NU == 12) ? 6 : 0;      // free columns of each block
   double m[13];
 #pragma unroll
   for (int c = 0; c < 6; ++c) { m[c] = row[(off + c) * 12 + r]; m[6 + c] = row[12 * NU + (off + c) * 12 + r]; }
-  m[12] = row[24 * NU + r];
+  m[12] = rhs ? rhs[r] : row[24 * NU + r];
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     // partial pivoting: row with the largest |m[.][k]| among rows >= k (ties -> lowest row)
@@ -296,46 +378,10 @@ __device__ __forceinline__ void bvp_final_one(const BvpArgs& a, const double* cu
   }
 }
 
-// Back-substitution at one level: d_mid = R^{-1} (g - Ca d_left - Cb d_right).  One lane per pair.
-template <int NU>
-__device__ __forceinline__ void bvp_backsub_pair(const BvpArgs& a, int level, int M, const int j, const int b) {
-  using D = BvpDims<NU>;
-  if (j >= M / 2) return;
-  const int mid = (2 * j + 1) << level, left = (2 * j) << level;
-  int right = (2 * j + 2) << level;
-  if (right > a.n_nodes - 1) right = a.n_nodes - 1;
-  const double* rec = a.rec + ((long)b * a.n_nodes + mid) * D::REC;
-  const long nb = (long)b * a.n_nodes;
-  constexpr int off = 12 - NU;                 // NU = 6: unknowns are components 6..11 (the costates)
-  double dl[NU], dr[NU], x[NU];
-#pragma unroll
-  for (int c = 0; c < NU; ++c) { dl[c] = a.delta[(long)(off + c) * a.ldx + nb + left]; dr[c] = a.delta[(long)(off + c) * a.ldx + nb + right]; }
-#pragma unroll
-  for (int r = 0; r < NU; ++r) {
-    double s = rec[D::REC_G + r];
-#pragma unroll
-    for (int c = 0; c < NU; ++c) s -= rec[D::REC_CA + c * NU + r] * dl[c] + rec[D::REC_CB + c * NU + r] * dr[c];
-    x[r] = s;
-  }
-#pragma unroll
-  for (int k = NU - 1; k >= 0; --k) {
-    double s = x[k];
-#pragma unroll
-    for (int c = k + 1; c < NU; ++c) s -= rec[D::REC_R + c * NU + k] * x[c];
-    x[k] = s / rec[D::REC_R + k * NU + k];
-  }
-#pragma unroll
-  for (int c = 0; c < NU; ++c) a.delta[(long)(off + c) * a.ldx + nb + mid] = x[c];
-  if (NU == 6) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) a.delta[(long)c * a.ldx + nb + mid] = 0.0;   // states are not updated
-  }
-}
-
-// The same with SIXTEEN lanes per pair (lane r = row r of the unknown): the record's matrices are read as rows of NU
-// consecutive doubles instead of one 6 KB record per lane (4 096 segments: a level took 15 us with one lane per pair, the
-// loads of 64 lanes going to 64 different records).  Lane r forms s_r = g_r - (Ca d_left + Cb d_right)_r, then the triangular
-// solve runs column by column: lane k divides, broadcasts x_k inside the 16-lane group, the lanes above it update their s.
+// Back-substitution of one pair: d_mid = R^{-1} (g - Ca d_left - Cb d_right), SIXTEEN lanes per pair (lane r = row r of the
+// unknown): the record's matrices are read as rows of NU consecutive doubles.  Lane r forms s_r = g_r - (Ca d_left + Cb
+// d_right)_r, then the triangular solve runs column by column: lane k divides, broadcasts x_k inside the 16-lane group, the
+// lanes above it update their s.
 template <int NU>
 __device__ __forceinline__ void bvp_backsub_pair16(const BvpArgs& a, int level, int M, const int j, const int b, const int r) {
   using D = BvpDims<NU>;
@@ -364,71 +410,67 @@ __device__ __forceinline__ void bvp_backsub_pair16(const BvpArgs& a, int level, 
   if (NU == 6 && r < 6) a.delta[(long)r * a.ldx + nb + mid] = 0.0;       // states are not updated
 }
 
-// one level: 16 lanes per pair, four pairs per wavefront
+// ---- FOUR levels of the back-substitution in one launch, the mirror image of k_bvp_chunk: workgroup g forms the unknowns its
+// chunk eliminated at levels level0 + 3 .. level0 (1, 2, 4, 8 pairs, sixteen lanes each); their outer unknowns are its own of
+// the level before or those of earlier launches.  (Workgroup-scope ordering of the unknowns through global memory.)
 template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_backsub(BvpArgs a, int level, int M) {
-  bvp_backsub_pair16<NU>(a, level, M, blockIdx.x * 4 + (threadIdx.x >> 4), blockIdx.y, threadIdx.x & 15);
+__global__ __launch_bounds__(128) void k_bvp_backchunk(BvpArgs a, const int level0, const int M0) {
+  const int g = blockIdx.x, b = blockIdx.y, grp = threadIdx.x >> 4, r = threadIdx.x & 15;
+  int Ms[BVP_CHUNK_LEVELS];
+  Ms[0] = M0;
+#pragma unroll
+  for (int l = 1; l < BVP_CHUNK_LEVELS; ++l) Ms[l] = (Ms[l - 1] + 1) / 2;
+#pragma unroll
+  for (int l = BVP_CHUNK_LEVELS - 1; l >= 0; --l) {
+    const int width = 8 >> l;
+    if (grp < width) bvp_backsub_pair16<NU>(a, level0 + l, Ms[l], g * width + grp, b, r);
+    __syncthreads();
+  }
 }
 
-// Two levels of the reduction in one launch (a level is ~15 us of launch + latency whatever its size, and 4 096 segments
-// are twelve levels).  Workgroup g: its two wavefronts reduce the pairs 2g and 2g + 1 of `level` (cur -> nxt), then --
-// block-scope barrier: both rows were written by this workgroup -- wavefront 0 reduces pair g of level + 1 (nxt -> out).
-// `out` is a third buffer: other workgroups may still be reading cur.
+// ---- the top of the tree in ONE launch: at most 16 block rows -- the remaining levels (8 pairs = 8 wavefronts, 2 per SIMD: the
+// full register budget), the final 12 x 12 solve and the matching back-substitution levels inside one 512-thread workgroup per
+// trajectory, separated by __syncthreads() (workgroup-scope ordering of the global-memory block rows).  A 30-node problem
+// (the reference demo) is a chunk launch, this one and a back-substitution launch.
+// factor = 0: the re-solve; `rows` then only supplies the last level's matrix (kept from the factorisation), the right-hand
+// sides travel through rhs_cur / rhs_nxt.
 template <int NU>
-__global__ __launch_bounds__(128) void k_bvp_reduce2(BvpArgs a, int level, int M, const double* __restrict__ cur, double* nxt, double* out) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = blockIdx.x, b = blockIdx.y;
-  const int M1 = M / 2 + (M & 1);
-  const int j = 2 * g + wave;
-  if (j < M1) bvp_reduce_pair<NU>(a, level, M, cur, nxt, j, b, lane);
-  __syncthreads();
-  if (wave == 0 && g < M1 / 2 + (M1 & 1)) bvp_reduce_pair<NU>(a, level + 1, M1, nxt, out, g, b, lane);
-}
-// the same for a new right-hand side: one lane does the pairs 2g, 2g + 1 of `level` and then pair g of level + 1
-template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_reduce_rhs2(BvpArgs a, int level, int M, const double* __restrict__ cur, double* nxt, double* out) {
-  const int g = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
-  const int M1 = M / 2 + (M & 1);
-  if (g >= M1 / 2 + (M1 & 1)) return;
-  bvp_reduce_rhs_pair<NU>(a, level, M, cur, nxt, 2 * g, b);
-  bvp_reduce_rhs_pair<NU>(a, level, M, cur, nxt, 2 * g + 1, b);
-  __threadfence_block();               // this lane reads back what it has just written
-  bvp_reduce_rhs_pair<NU>(a, level + 1, M1, nxt, out, g, b);
-}
-// Two levels of the back-substitution: the 16-lane group that forms the unknown of pair g at level + 1 then forms those of the
-// pairs 2g and 2g + 1 of `level`, whose outer unknowns are that one and unknowns of earlier launches.
-template <int NU>
-__global__ __launch_bounds__(64) void k_bvp_backsub2(BvpArgs a, int level, int M) {
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 4), r = threadIdx.x & 15, b = blockIdx.y;
-  const int M1 = M / 2 + (M & 1);
-  if (g >= M1 / 2 + (M1 & 1)) return;  // uniform for the 16 lanes of a group
-  bvp_backsub_pair16<NU>(a, level + 1, M1, g, b, r);
-  __threadfence_block();               // the group reads back the unknown it has just stored
-  bvp_backsub_pair16<NU>(a, level, M, 2 * g, b, r);
-  bvp_backsub_pair16<NU>(a, level, M, 2 * g + 1, b, r);
-}
-
-// Tail of the reduction in ONE launch: once a level has at most 16 block rows (8 pairs = 8 wavefronts, 2 per SIMD: the full register budget) the
-// remaining levels, the final 12 x 12 solve and the matching back-substitution levels run inside one 512-thread
-// workgroup per trajectory, separated by __syncthreads() (block-scope ordering of the global-memory block rows).
-// A 30-node problem (the reference demo) is then init + this kernel instead of 12 dependent tiny launches.
-constexpr int BVP_TAIL_MAX = 16;
-
-template <int NU>
-__global__ __launch_bounds__(512) void k_bvp_tail(BvpArgs a, int level0, int M0, double* cur, double* nxt, int factor) {
+__global__ __launch_bounds__(512) void k_bvp_tail(BvpArgs a, int level0, int M0, double* cur, double* nxt, double* rhs_cur, double* rhs_nxt, int factor) {
+  using D = BvpDims<NU>;
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int M = M0, level = level0;
   int Ms[8];
   while (M > 1) {
     Ms[level - level0] = M;
     const int npairs = M / 2, carry = M & 1;
-    if (factor) { if (wave < npairs + carry) bvp_reduce_pair<NU>(a, level, M, cur, nxt, wave, b, lane); }
-    else if (tid < npairs + carry) bvp_reduce_rhs_pair<NU>(a, level, M, cur, nxt, tid, b);
+    if (factor) {
+      const double* rows = cur + (long)b * a.S_traj * D::ROW;
+      double* orows = nxt + (long)b * a.S_traj * D::ROW;
+      if (wave < npairs) {
+        double col[24];
+        bvp_stack_rows<NU>(rows + (long)(2 * wave) * D::ROW, rows + (long)(2 * wave + 1) * D::ROW, lane, col);
+        bvp_reflect_store<NU>(col, lane, a.rec + ((long)b * a.n_nodes + bvp_mid(wave, level)) * D::REC, orows + (long)wave * D::ROW);
+      } else if (wave == npairs && carry) {
+        for (int e = lane; e < D::ROW; e += 64) orows[(long)npairs * D::ROW + e] = rows[(long)(M - 1) * D::ROW + e];
+      }
+    } else {
+      const double* rows = rhs_cur + (long)b * a.S_traj * 12;
+      double* orows = rhs_nxt + (long)b * a.S_traj * 12;
+      const int grp = tid >> 5, r = tid & 31;
+      if (grp < npairs) {
+        double* rec = a.rec + ((long)b * a.n_nodes + bvp_mid(grp, level)) * D::REC;
+        bvp_rhs_pair<NU>(rows + (long)(2 * grp) * 12, rows + (long)(2 * grp + 1) * 12, rec, rec, orows + (long)grp * 12, r);
+      } else if (grp == npairs && carry && r < 12) {
+        orows[(long)npairs * 12 + r] = rows[(long)(M - 1) * 12 + r];
+      }
+    }
     __syncthreads();
     double* t = cur; cur = nxt; nxt = t;
+    t = rhs_cur; rhs_cur = rhs_nxt; rhs_nxt = t;
     M = npairs + carry;
     ++level;
   }
-  if (wave == 0) bvp_final_one<NU>(a, cur, b, lane);
+  if (wave == 0) bvp_final_one<NU>(a, cur + (long)b * a.S_traj * D::ROW, factor ? nullptr : rhs_cur + (long)b * a.S_traj * 12, b, lane);
   __syncthreads();
   for (int l = level - 1; l >= level0; --l) {
     bvp_backsub_pair16<NU>(a, l, Ms[l - level0], tid >> 4, b, tid & 15);     // at most 8 pairs: 32 groups of 16 lanes
@@ -443,65 +485,65 @@ __global__ __launch_bounds__(256) void k_axpy(const double* __restrict__ x, cons
   if (i < count) y[i] = __builtin_fma(alpha, d[i], x[i]);
 }
 
+// Workspace: the rows of the levels that cross launches (level 4: a sixteenth of the segments, level 8: ...; the level-0 rows
+// of a problem of at most 16 segments), two of them; two right-hand-side buffers; the records; the last level's row kept
+// for the re-solve.  Sized for the larger (NU = 12) variant; the adjoints-only variant uses a prefix of every part.
+static size_t bvp_rows_doubles(int n_nodes, int n_batch) { return (size_t)(n_nodes - 1) * n_batch * BvpDims<12>::ROW; }
 size_t bvp_workspace_doubles(int n_nodes, int n_batch) {
-  // sized for the larger (NU = 12) variant; the adjoints-only variant uses a prefix of the same workspace
-  // three buffers of block rows (a two-level launch reads one and writes the other two; same per-trajectory pitch), the records
-  return (size_t)3 * (n_nodes - 1) * n_batch * BvpDims<12>::ROW + (size_t)n_nodes * n_batch * BvpDims<12>::REC;
+  // (the level-4 buffer needs a sixteenth of this, but a trajectory's rows keep the pitch S_traj * ROW in every buffer: simple
+  // indexing for 4 096 segments x 2.4 KB x 2 = 20 MB)
+  return 2 * bvp_rows_doubles(n_nodes, n_batch) + 2 * (size_t)(n_nodes - 1) * n_batch * 12 + (size_t)n_nodes * n_batch * BvpDims<12>::REC;
 }
 
 template <int NU>
 static hipError_t bvp_solve_impl(const double* Phi, long ldp, const double* defect, long ldd, int n_nodes, int n_batch,
                                  double* workspace, double* delta, long ldx, hipStream_t st) {
-  using D = BvpDims<NU>;
   BvpArgs a;
   a.n_nodes = n_nodes; a.n_batch = n_batch; a.S_traj = n_nodes - 1;
-  const size_t rows_sz = (size_t)a.S_traj * n_batch * D::ROW;
-  a.rows0 = workspace; a.rows1 = workspace + rows_sz; a.rec = workspace + 3 * rows_sz;
-  double* rows2 = workspace + 2 * rows_sz;
+  const size_t rows_sz = bvp_rows_doubles(n_nodes, n_batch), rhs_sz = (size_t)a.S_traj * n_batch * 12;
+  double* rowsA = workspace;
+  double* rowsB = workspace + rows_sz;
+  double* rhsA = workspace + 2 * rows_sz;
+  double* rhsB = rhsA + rhs_sz;
+  a.rec = rhsB + rhs_sz;
   a.delta = delta; a.ldx = ldx;
-  const long S_total = (long)a.S_traj * n_batch;
-  if (Phi) {
-    const long cnt = S_total * D::ROW;
-    hipLaunchKernelGGL((k_bvp_init<NU>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, Phi, ldp, defect, ldd, a);
-  } else {
-    const long cnt = S_total * 12;
-    hipLaunchKernelGGL((k_bvp_init_rhs<NU>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, defect, ldd, a);
-  }
-  double* cur = a.rows0;
-  double* nxt = a.rows1;
-  double* spare = rows2;
+  a.Phi = Phi; a.ldp = ldp; a.defect = defect; a.ldd = ldd;
+  const bool factor = (Phi != nullptr);
+  // The re-solve walks the same sequence of buffer swaps as the factorisation, so its tail finds the last level's row -- the
+  // matrix of the final 12 x 12 system, which only the factorisation forms -- where that pass left it.
   int M = a.S_traj, level = 0;
-  int Ms[40];
-  while (M > BVP_TAIL_MAX) {
-    const int M1 = M / 2 + (M & 1);
-    if (M1 > BVP_TAIL_MAX) {           // two levels in one launch: cur -> nxt -> spare
-      const int M2 = M1 / 2 + (M1 & 1);
-      Ms[level] = M; Ms[level + 1] = M1;
-      if (Phi) hipLaunchKernelGGL((k_bvp_reduce2<NU>), dim3(M2, n_batch), dim3(128), 0, st, a, level, M, cur, nxt, spare);
-      else hipLaunchKernelGGL((k_bvp_reduce_rhs2<NU>), dim3((M2 + 63) / 64, n_batch), dim3(64), 0, st, a, level, M, cur, nxt, spare);
-      double* t = cur; cur = spare; spare = t;
-      M = M2;
-      level += 2;
+  int Ms[48];
+  double* cur = rowsA;
+  double* nxt = rowsB;
+  double* rcur = rhsA;
+  double* rnxt = rhsB;
+  bool first = true;
+  if (M <= BVP_CHUNK) {                // the whole problem fits the tail: materialise its level-0 rows
+    if (factor) hipLaunchKernelGGL((k_bvp_rows0<NU>), dim3(M, n_batch), dim3(64), 0, st, a, cur);
+    else hipLaunchKernelGGL((k_bvp_rhs0<NU>), dim3((unsigned)(((long)M * n_batch * 12 + 255) / 256)), dim3(256), 0, st, a, rcur);
+  }
+  while (M > BVP_CHUNK) {
+    const int Mn = (M + BVP_CHUNK - 1) / BVP_CHUNK;
+    int m = M;
+    for (int l = 0; l < BVP_CHUNK_LEVELS; ++l) { Ms[level + l] = m; m = (m + 1) / 2; }
+    if (factor) {
+      if (first) hipLaunchKernelGGL((k_bvp_chunk<NU, true>), dim3(Mn, n_batch), dim3(512), 0, st, a, level, M, cur, nxt);
+      else hipLaunchKernelGGL((k_bvp_chunk<NU, false>), dim3(Mn, n_batch), dim3(512), 0, st, a, level, M, cur, nxt);
     } else {
-      Ms[level] = M;
-      if (Phi) hipLaunchKernelGGL((k_bvp_reduce<NU>), dim3(M1, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
-      else hipLaunchKernelGGL((k_bvp_reduce_rhs<NU>), dim3((M1 + 63) / 64, n_batch), dim3(64), 0, st, a, level, M, cur, nxt);
-      double* t = cur; cur = nxt; nxt = t;
-      M = M1;
-      ++level;
+      if (first) hipLaunchKernelGGL((k_bvp_chunk_rhs<NU, true>), dim3(Mn, n_batch), dim3(256), 0, st, a, level, M, rcur, rnxt);
+      else hipLaunchKernelGGL((k_bvp_chunk_rhs<NU, false>), dim3(Mn, n_batch), dim3(256), 0, st, a, level, M, rcur, rnxt);
     }
+    { double* t = cur; cur = nxt; nxt = t; }
+    { double* t = rcur; rcur = rnxt; rnxt = t; }
+    first = false;
+    M = Mn;
+    level += BVP_CHUNK_LEVELS;
   }
   // remaining levels, final solve and their back-substitution in one launch per trajectory
-  hipLaunchKernelGGL((k_bvp_tail<NU>), dim3(n_batch), dim3(512), 0, st, a, level, M, cur, nxt, Phi ? 1 : 0);
-  int l = level - 1;
-  for (; l >= 1; l -= 2) {             // levels l and l - 1 in one launch
-    const int M1 = Ms[l];
-    const int groups = M1 / 2 + (M1 & 1);
-    hipLaunchKernelGGL((k_bvp_backsub2<NU>), dim3((groups + 3) / 4, n_batch), dim3(64), 0, st, a, l - 1, Ms[l - 1]);
-  }
-  if (l == 0) {
-    const int npairs = Ms[0] / 2;
-    hipLaunchKernelGGL((k_bvp_backsub<NU>), dim3((npairs + 3) / 4, n_batch), dim3(64), 0, st, a, 0, Ms[0]);
+  hipLaunchKernelGGL((k_bvp_tail<NU>), dim3(n_batch), dim3(512), 0, st, a, level, M, cur, nxt, rcur, rnxt, factor ? 1 : 0);
+  for (int l = level - BVP_CHUNK_LEVELS; l >= 0; l -= BVP_CHUNK_LEVELS) {
+    const int groups = (Ms[l] + BVP_CHUNK - 1) / BVP_CHUNK;
+    hipLaunchKernelGGL((k_bvp_backchunk<NU>), dim3(groups, n_batch), dim3(128), 0, st, a, l, Ms[l]);
   }
   return hipGetLastError();
 }
