@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2_defect", "c3", "c4", "c5", "c5_stm", "hbm"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2_defect", "c3", "c4", "c5", "c5_stm", "hbm", "newton"])
     ap.add_argument("--no-rebalance", action="store_true",
                     help="c5: keep the natural segment order (default: lanes ordered by the warm-up sweep's step counts)")
     ap.add_argument("--segments", type=int, default=0, help="segments per GPU (default: the workload's)")
@@ -424,6 +424,215 @@ def leg_12dim(lto, synth, ctx, st, torch, a, reference_integrator=False):
     return out, add_parity
 
 
+NEWTON_ALPHAS = 20      # LinRange(0.1, 1, 20), indirect.jl:227
+
+
+def station_keeping_problem(lto, synth, ctx, S, per_rev=16, pert=1e-7, seed=7):
+    """A CONVERGED shooting problem of S segments for the Newton-iteration leg: S / per_rev revolutions on the reference's first
+    L2 halo orbit (L2_Anderson_1 table), p = 2 with the thrust limit left open at 10 N as in the reference's demo
+    (CRTBP_Multishoot_indirect_demo.jl:178-179), costates ~ 0 -- station keeping.  One revolution's nodes come from the library's own
+    flow from the table's first column (a batch of two-node problems with spans j T / per_rev), repeated period after period (the table
+    closes to 1e-10); the library's Newton loop then converges it, and the interior nodes are perturbed by `pert` so that the measured
+    iteration is a real one (update ~ pert, second-order correction on, tame trial points).  The synthetic stacked-halo guess of the
+    sweep benchmarks is NOT used here: 4 096 segments of it are a 650 TU arc that no Newton iteration converges, its update has norm
+    ~10 and the sweeps at such trial points measure the integrator's reaction to garbage (round 3's 661 us did)."""
+    T1 = 99 * synth.HALO_DT[0]
+    dt = T1 / per_rev
+    x0 = np.concatenate([synth.halo_orbits()[0][:, 0], np.zeros(6)])
+    prm = lto.make_params(lto.MU, lto.DU, lto.TU, 10.0, 1000.0, 1.0, 2.0, 1.0)
+    XCb = np.zeros((12, 2, per_rev - 1), order="F")
+    XCb[:, 0, :] = x0[:, None]
+    Tb = np.zeros((2, per_rev - 1), order="F")
+    Tb[1] = dt * np.arange(1, per_rev)
+    d, _ = lto.indirect_defectCalc(XCb, Tb, prm, lto.integrator(), ctx=ctx)
+    rev = np.concatenate([x0[:, None], d[:, 0, :] + XCb[:, 1, :]], axis=1)           # [12][per_rev]: x(j dt)
+    n = S + 1
+    XC = np.asfortranarray(rev[:, np.arange(n) % per_rev])
+    t = dt * np.arange(n)
+    rng = np.random.default_rng(seed)
+    XC[6:, 1:-1] += 1e-8 * rng.standard_normal((6, n - 2))
+    Xs, ds, status, iters, hist = lto.indirect_solve(XC, t, prm, None, False, 8, ctx=ctx)
+    if status != 0:
+        raise RuntimeError("station-keeping problem of %d segments did not converge: status %d, history %s" % (S, status, hist[:, 0]))
+    Xp = np.array(Xs, order="F")
+    Xp[:, 1:-1] += pert * rng.standard_normal((12, n - 2))
+    return Xp, t, prm, {"segments": S, "revolutions": S / per_rev, "dt_TU": dt, "solve_iterations": int(iters),
+                        "max_defect_converged": float(np.abs(ds).max()), "perturbation": pert}
+
+
+class NewtonIteration:
+    """One iteration of multiShoot_CRTBP_indirect's loop (src/multiShoot_CRTBP_indirect.jl:280-337) as the library's device-resident
+    entry points run it once the line search is on (iteration > 3) -- what a caller of the reference's driver waits for per iteration:
+      STM sweep (jacobianCalc, :290)  ->  block-bidiagonal least-squares step (:149-186)  ->  second-order correction: defect sweep at
+      x + dx and a re-solve with the stored factorisation (:190-214)  ->  line search: the 20 trial trajectories as ONE batched defect
+      sweep + sum(defect.^2) per trial (:221-246)  ->  update (:304)  ->  defect sweep at the new point + max |defect| (:328-331).
+    The reference's integrator setting (adaptive order 8, rtol = atol = 1e-13), 12-dim, about a converged station-keeping trajectory
+    perturbed by 1e-7 (station_keeping_problem).  The point of linearisation stays the same
+    in every repetition (the update goes to a second array), so every repetition does the same work.  `sync` = the host reads its
+    three decision scalars back as the library's own loop (lto_indirect_solve) does: max |dx|, the 20 sums, max |defect|."""
+
+    def __init__(self, lto, synth, ctx, st, torch, S):
+        self.lto, self.ctx, self.st, self.torch, self.S = lto, ctx, st, torch, S
+        n = self.n = S + 1
+        NA = NEWTON_ALPHAS
+        XC, tt, prm, self.problem = station_keeping_problem(lto, synth, ctx, S)
+        self.prm = prm
+        f64 = dict(dtype=torch.float64, device="cuda")
+        self.X = torch.from_numpy(np.ascontiguousarray(XC)).cuda()          # [12][n]: SoA, node-indexed
+        self.t = torch.from_numpy(np.ascontiguousarray(tt)).cuda()
+        self.plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator())
+        self.plan_ls = lto.IndirectPlan(ctx, n, NA, prm, lto.integrator())
+        self.Phi = torch.zeros(144, S, **f64)
+        self.d = torch.zeros(12, S, **f64); self.d2 = torch.zeros(12, S, **f64); self.d3 = torch.zeros(12, S, **f64)
+        self.dt = torch.zeros(12, S * NA, **f64)
+        self.delta = torch.zeros(12, n, **f64); self.delta2 = torch.zeros(12, n, **f64)
+        self.X2 = torch.zeros(12, n, **f64); self.Xn = torch.zeros(12, n, **f64)
+        self.Xt = torch.zeros(12, n * NA, **f64)
+        self.alphas = torch.linspace(0.1, 1.0, NA, **f64)
+        self.ss = torch.zeros(NA, **f64); self.mx = torch.zeros(1, **f64); self.mx2 = torch.zeros(1, **f64)
+        self.host = torch.zeros(NA + 2, dtype=torch.float64).pin_memory()
+
+    def ops(self):
+        """(name, closure) in the order of one iteration; every closure enqueues on the bench's stream."""
+        lto, ctx, st, S, n, NA = self.lto, self.ctx, self.st, self.S, self.n, NEWTON_ALPHAS
+        p, pl = self.plan, self.plan_ls
+        axpy = lambda x, d, a, y: ctx.check(ctx.lib.lto_axpy_dev(ctx.handle, st, x.data_ptr(), d.data_ptr(), a, y.data_ptr(), 12 * n))   # noqa: E731
+        return [
+            ("stm_sweep", lambda: p.jacobian(self.X, n, self.t, 1, self.Phi, S, self.d, S, stream=st)),
+            ("factor_solve", lambda: p.newton_solve(self.Phi, S, self.d, S, self.delta, n, stream=st)),
+            ("max_dx", lambda: lto.defect_norms(ctx, self.delta, n, 12, n, 1, None, self.mx2, stream=st)),
+            ("soc_point", lambda: axpy(self.X, self.delta, 1.0, self.X2)),
+            ("soc_defect_sweep", lambda: p.defect(self.X2, n, self.t, 1, self.d2, S, stream=st)),
+            ("soc_resolve", lambda: p.newton_solve(None, 0, self.d2, S, self.delta2, n, stream=st)),
+            ("soc_add", lambda: axpy(self.delta, self.delta2, 1.0, self.delta)),
+            ("trial_points", lambda: lto.trial_points(ctx, self.X, self.delta, n, 12, n, 1, self.alphas, self.Xt, n * NA, stream=st)),
+            ("line_search_sweep", lambda: pl.defect(self.Xt, n * NA, self.t, 1, self.dt, S * NA, stream=st)),
+            ("line_search_sums", lambda: lto.defect_norms(ctx, self.dt, S * NA, 12, S, NA, self.ss, None, stream=st)),
+            ("update", lambda: axpy(self.X, self.delta, 1.0, self.Xn)),
+            ("defect_sweep", lambda: p.defect(self.Xn, n, self.t, 1, self.d3, S, stream=st)),
+            ("max_defect", lambda: lto.defect_norms(ctx, self.d3, S, 12, S, 1, None, self.mx, stream=st)),
+        ]
+
+    def iteration(self, sync=True):
+        torch = self.torch
+        for name, op in self.ops():
+            op()
+            if sync and name in ("max_dx", "line_search_sums", "max_defect"):
+                src = self.ss if name == "line_search_sums" else (self.mx2 if name == "max_dx" else self.mx)
+                self.host[:src.numel()].copy_(src, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+
+    def measure(self, reps=40, split_reps=20):
+        torch = self.torch
+        for _ in range(5):
+            self.iteration()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.iteration()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / reps * 1e6
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.iteration(sync=False)
+        torch.cuda.synchronize()
+        us_nosync = (time.perf_counter() - t0) / reps * 1e6
+        split = {}
+        for name, op in self.ops():          # every operation alone: a burst of back-to-back calls inside one event pair on the launch stream
+            for _ in range(3):
+                op()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(split_reps):
+                op()
+            e1.record()
+            e1.synchronize()
+            split[name] = e0.elapsed_time(e1) / split_reps * 1e3
+        acc, rej = self.plan.step_counts(stream=self.st)
+        finite = bool(torch.isfinite(self.d3).all() and torch.isfinite(self.dt).all() and torch.isfinite(self.delta).all())
+        return {"segments": self.S, "us_per_iteration": us, "us_per_iteration_without_host_reads": us_nosync,
+                "split_us": {k: round(v, 2) for k, v in split.items()}, "split_sum_us": round(sum(split.values()), 1),
+                "stm_kernel": self.plan.last_kernel(), "finite": finite, "problem": self.problem,
+                "trial_steps_per_segment_stm_sweep": {"mean": float((acc + rej).mean()), "max": int((acc + rej).max())},
+                "max_dx": float(self.mx2.item()), "max_defect_after": float(self.mx.item())}
+
+    def close(self):
+        self.plan_ls.close(); self.plan.close()
+
+
+class _OracleOps:
+    """Propagation back end of the CPU baseline: the oracle's restatement of the reference's closures (checker code, used here only
+    to time the reference's algorithm on the host)."""
+
+    def __init__(self, O):
+        self.O = O
+
+    def _prm(self, params):
+        return [params.MU, params.DU, params.TU, params.thrustLimit, params.mass, params.time_direction, params.p, params.rho]
+
+    def defect(self, XC, t, params):
+        return self.O.indirect_defect(XC, t, self._prm(params), self.O.DOP853_ADAPTIVE)[0]
+
+    def stm(self, XC, t, params):
+        Phi, d, _ = self.O.indirect_jacobian(XC, t, self._prm(params), self.O.DOP853_ADAPTIVE)
+        return Phi, d
+
+    def defect_batch_sumsq(self, XC_batch, t, params):
+        return np.array([np.sum(self.defect(np.asfortranarray(XC_batch[:, :, b]), t, params) ** 2) for b in range(XC_batch.shape[2])])
+
+
+def cpu_newton_baseline(S, seconds, problem=None):
+    """The same iteration the way the reference executes it, on the host: the oracle's closures (adaptive order 8 @ 1e-13, Jacobian by
+    dual numbers) behind the Python mirror of the reference's loop body (drivers.optimizeTraj_OLS: sparse `\\` twice, drivers.lineSearch:
+    20 defect sweeps), one core.  Repeated until `seconds` have passed, at least once."""
+    from oracle import oracle as O
+    import lowthrustopt_amd as lto
+    from lowthrustopt_amd import synth, drivers
+    O.lib(); O.set_threads(1)
+    n = S + 1
+    if problem is not None:                 # the GPU leg's own point of linearisation
+        XC, t, params = problem
+    else:
+        XC, T = synth.indirect_problem(n)
+        XC, t = np.asfortranarray(XC[:, :, 0]), np.ascontiguousarray(T[:, 0])
+        params = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    ops = _OracleOps(O)
+
+    def iteration():
+        Phi, d = ops.stm(XC, t, params)
+        upd = drivers.optimizeTraj_OLS(XC, t, d, Phi, 6, n, params, False, ops)
+        alpha = drivers.lineSearch(XC, upd, t, params, ops)
+        return ops.defect(XC + alpha * upd, t, params)
+    t0 = time.perf_counter()
+    calls = 0
+    while True:
+        iteration()
+        calls += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": el / calls * 1e6, "unit": "us per iteration", "cores": 1, "kind": "port",
+            "sample": "%d iteration(s) of the %d-segment problem in %.1f s: oracle closures (adaptive order 8 @ 1e-13, dual-number Jacobian) + "
+                      "scipy sparse solves + 20 line-search sweeps, as indirect.jl:280-337 does them" % (calls, S, el)}
+
+
+def leg_newton(lto, synth, ctx, st, torch, sizes, cpu_seconds):
+    out = []
+    for S in sizes:
+        it = NewtonIteration(lto, synth, ctx, st, torch, S)
+        r = it.measure()
+        problem = (np.asfortranarray(it.X.cpu().numpy()), it.t.cpu().numpy(), it.prm)
+        it.close()
+        if cpu_seconds > 0:
+            r["cpu_baseline"] = cpu_newton_baseline(S, cpu_seconds, problem)
+        out.append(r)
+    return {"what": "one iteration of multiShoot_CRTBP_indirect's loop (indirect.jl:280-337) with the reference's integrator setting, device-resident: "
+            "STM sweep, block-bidiagonal step, second-order correction (defect sweep + re-solve), 20-trial line search as one batched sweep, "
+            "update, defect sweep; wall time per iteration launch by launch incl. the host's three scalar read-backs; split_us: every operation "
+            "alone, burst of back-to-back calls inside one HIP event pair on the launch stream",
+            "sizes": out}
+
+
 def main():
     a = parse()
     import torch
@@ -448,6 +657,26 @@ def main():
     st = lto.current_stream_ptr()
 
     wl = a.workload
+    if wl == "newton":
+        # measurement aid: the Newton iteration alone -- also what `rocprofv3 --kernel-trace --stats` / `--pmc` runs of
+        # tools/gpu_round.sh profile (`--pmc-child`: iterations only, no output)
+        sizes = [a.segments] if a.segments else [29, 4096]
+        if a.pmc_child:
+            it = NewtonIteration(lto, synth, ctx, st, torch, sizes[-1])
+            for _ in range(a.warmup + a.steps):
+                it.iteration()
+            torch.cuda.synchronize()
+            it.close(); ctx.close()
+            return
+        res = leg_newton(lto, synth, ctx, st, torch, sizes, 0.0 if a.no_cpu_baseline else a.cpu_seconds / 3)
+        big = res["sizes"][-1]
+        print(json.dumps({"metric": "time per iteration of multiShoot_CRTBP_indirect's Newton loop (device-resident)", "value": big["us_per_iteration"],
+                          "unit": "us", "n_gpus": 1, "steps": 40, "warmup": 5, "ms_per_step": big["us_per_iteration"] * 1e-3,
+                          "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": "newton: %d segments, 12-dim, adaptive order 8 @ 1e-13" % big["segments"]},
+                          "newton_iteration": res}), flush=True)
+        ctx.close()
+        return
     if a.ndim == 0:
         a.ndim = 14 if wl in ("c2", "c2_defect", "hbm") else 12
     prm1 = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
@@ -789,6 +1018,9 @@ def main():
                 rf["traffic"], rf["traffic_from"] = live, how
             else:
                 rf["traffic_live"] = "not measured in this run (%s): the stored profile's figure stands" % how
+        if world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
+            # what a user of the reference's driver waits for per iteration
+            out["newton_iteration"] = leg_newton(lto, synth, ctx, st, torch, [29, 4096], 0.0 if a.no_cpu_baseline else max(2.0, a.cpu_seconds / 4))
         if ref12 is not None:
             out["reference_system_12dim"] = ref12[0]
             out["reference_integrator"] = refint[0]

@@ -286,6 +286,13 @@ int lto_indirect_newton_solve_dev(lto_indirect_plan* plan, void* stream, const d
                                   const double* defect, long ldd, int adjoints_only, double* delta, long ldx);
 /* y[i] = x[i] + alpha d[i], i < count (trial points X + alpha dX, update accumulation) */
 int lto_axpy_dev(lto_ctx* ctx, void* stream, const double* x, const double* d, double alpha, double* y, long count);
+/* The n_alpha trial trajectories of lineSearch (src/multiShoot_CRTBP_indirect.jl:227-233) of every trajectory of a batch, one
+ * launch: Xt[c*ldt + (b*n_alpha + a)*n_nodes + k] = X[c*ld + b*n_nodes + k] + alphas[a] * delta[c*ld + b*n_nodes + k] for
+ * c < ndim, b < n_batch, a < n_alpha, k < n_nodes (SoA, node-indexed; alphas is a DEVICE array).  Together with a plan of
+ * n_batch*n_alpha trajectories and lto_defect_norms_dev this is the batched line search for callers that keep their
+ * own loop around the device-resident entry points. */
+int lto_trial_points_dev(lto_ctx* ctx, void* stream, const double* X, const double* delta, long ld, int ndim, int n_nodes,
+                         int n_batch, int n_alpha, const double* alphas, double* Xt, long ldt);
 
 /* Dense output (device): segment s is sampled at t_samples[first[s] .. first[s+1]) (sorted, inside the segment);
  * Y[c*ldy + j] = x_c(t_samples[j]); final_state[c*n_batch + b] (or NULL) = x(t_n) of trajectory b. */

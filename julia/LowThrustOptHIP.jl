@@ -355,6 +355,11 @@ axpy_dev!(ctx::LtoContext, stream, x, d, alpha::Real, y, count::Integer) =
     check(ctx, ccall((:lto_axpy_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, DevPtr, Cdouble, DevPtr, Clong),
                      ctx.handle, devptr(stream), devptr(x), devptr(d), alpha, devptr(y), count))
 
+"The `n_alpha` trial trajectories X + alphas[a] * delta of every trajectory of a batch in one launch (lineSearch, indirect.jl:227-233); `alphas` is a device array."
+trial_points_dev!(ctx::LtoContext, stream, X, delta, ld::Integer, ndim::Integer, n_nodes::Integer, n_batch::Integer, n_alpha::Integer, alphas, Xt, ldt::Integer) =
+    check(ctx, ccall((:lto_trial_points_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, DevPtr, Clong, Cint, Cint, Cint, Cint, DevPtr, DevPtr, Clong),
+                     ctx.handle, devptr(stream), devptr(X), devptr(delta), ld, ndim, n_nodes, n_batch, n_alpha, devptr(alphas), devptr(Xt), ldt))
+
 "Order the lanes of the following adaptive sweeps by the last sweep's step counts (results unchanged)."
 rebalance!(pl::LtoIndirectPlan, stream) = check(pl.ctx, ccall((:lto_indirect_plan_rebalance, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), pl.handle, devptr(stream)))
 "LTO_KERNEL_*: 0 auto, 1 per-lane, 2 cooperative, 3 / 4 / 5 pipeline forms (RK4 plans), 6 cooperative with two lanes per state (12-dim DOP853 plans), 7 pipeline for large batches (RK4 plans)."

@@ -23,6 +23,7 @@
 //
 // Node eliminated at level l by pair j:  mid = (2j+1) 2^l,  left = 2j 2^l,  right = min((2j+2) 2^l, n-1).
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace lto {
 
@@ -128,13 +129,35 @@ __device__ __forceinline__ void bvp_row_from_sweep(const BvpArgs& a, const int b
   }
 }
 
+// x of lane K (a compile-time lane) in every lane: two v_readlane_b32 into a scalar register pair, which the following FMAs read
+// directly.  (HIP's __shfl is an LDS-crossbar ds_bpermute_b32 per dword: 444 of them and their waits per pair reduction.)
+template <int K>
+__device__ __forceinline__ double lane_bcast(const double x) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), K), hi = __builtin_amdgcn_readlane(__double2hiint(x), K);
+  return __hiloint2double(hi, lo);
+}
+// x of lane K of the own 16-lane row (DPP row_newbcast)
+template <int K>
+__device__ __forceinline__ double row_bcast(const double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x150 + K, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x150 + K, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int FIRST, int LAST, class F>
+__device__ __forceinline__ void bvp_static_for(F&& f) {
+  if constexpr (FIRST < LAST) {
+    f(std::integral_constant<int, FIRST>{});
+    bvp_static_for<FIRST + 1, LAST>(f);
+  }
+}
+
 // ---- NK Householder reflections on the stack (one wavefront, lane = column; the reflector of step k is lane k's column,
 // broadcast by v_readlane), then the record of the eliminated node `rec` and the new block row `nr`
 template <int NU>
 __device__ __forceinline__ void bvp_reflect_store(double (&col)[24], const int c, double* rec, double* nr) {
   using D = BvpDims<NU>;
-#pragma unroll
-  for (int k = 0; k < D::NK; ++k) {
+  bvp_static_for<0, D::NK>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     // reflector from column k (computed in every lane, only lane k's is used)
     // (four partial sums: the 23-term chain is otherwise the longest dependent stretch of the reflection; reciprocal and
     // reciprocal square root by Newton refinement of the hardware seeds, ~1 ulp, instead of the IEEE sequences: ~20 against
@@ -160,10 +183,10 @@ __device__ __forceinline__ void bvp_reflect_store(double (&col)[24], const int c
 #pragma unroll
       for (int r = k + 1; r < 24; ++r) col[r] *= scl;
     }
-    const double tau_b = __shfl(tau_k, k);
+    const double tau_b = lane_bcast<k>(tau_k);
     double v[24];
 #pragma unroll
-    for (int r = k + 1; r < 24; ++r) v[r] = __shfl(col[r], k);
+    for (int r = k + 1; r < 24; ++r) v[r] = lane_bcast<k>(col[r]);
     if (c > k && c < D::NLANES) {
       double w0 = col[k], w1 = 0.0, w2 = 0.0, w3 = 0.0;
 #pragma unroll
@@ -179,7 +202,7 @@ __device__ __forceinline__ void bvp_reflect_store(double (&col)[24], const int c
 #pragma unroll
       for (int r = k + 1; r < 24; ++r) col[r] = __builtin_fma(-w, v[r], col[r]);
     }
-  }
+  });
   // rows 0 .. NU-1: the eliminated unknown; rows NU .. NU+11: the new block row (entries below the diagonal of a
   // triangularised column are reflector storage, i.e. structural zeros of the matrix)
   if (c < NU) {
@@ -336,8 +359,8 @@ __device__ __forceinline__ void bvp_final_one(const BvpArgs& a, const double* ro
 #pragma unroll
   for (int c = 0; c < 6; ++c) { m[c] = row[(off + c) * 12 + r]; m[6 + c] = row[12 * NU + (off + c) * 12 + r]; }
   m[12] = rhs ? rhs[r] : row[24 * NU + r];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
+  bvp_static_for<0, 12>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     // partial pivoting: row with the largest |m[.][k]| among rows >= k (ties -> lowest row)
     double best = (lane >= k && lane < 12) ? fabs(m[k]) : -1.0;
     int piv = lane;
@@ -347,25 +370,25 @@ __device__ __forceinline__ void bvp_final_one(const BvpArgs& a, const double* ro
       const int op = __shfl_xor(piv, o);
       if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
     }
-    piv = __shfl(piv, 0);                       // lanes 0..15 agree after the butterfly
+    piv = __builtin_amdgcn_readfirstlane(piv);  // lanes 0..15 agree after the butterfly
     // swap rows k and piv
     const int src = (lane == k) ? piv : (lane == piv ? k : lane);
 #pragma unroll
     for (int c = 0; c < 13; ++c) m[c] = __shfl(m[c], src);
-    const double pk = __shfl(m[k], k);
-    const double f = (lane > k && lane < 12) ? m[k] / pk : 0.0;
+    const double pk = lane_bcast<k>(m[k]);
+    const double f = (lane > k && lane < 12) ? m[k] * rcp_nr(pk) : 0.0;
 #pragma unroll
-    for (int c = k + 1; c < 13; ++c) m[c] = __builtin_fma(-f, __shfl(m[c], k), m[c]);
-  }
+    for (int c = k + 1; c < 13; ++c) m[c] = __builtin_fma(-f, lane_bcast<k>(m[c]), m[c]);
+  });
   // back substitution: x[k] = (m[k][12] - sum_{c>k} m[k][c] x[c]) / m[k][k], broadcast as it is formed
   double x[12];
-#pragma unroll
-  for (int k = 11; k >= 0; --k) {
+  bvp_static_for<0, 12>([&](auto kc) {
+    constexpr int k = 11 - decltype(kc)::value;
     double sacc = m[12];
 #pragma unroll
     for (int c = k + 1; c < 12; ++c) sacc = __builtin_fma(-m[c], x[c], sacc);
-    x[k] = __shfl(sacc / m[k], k);
-  }
+    x[k] = lane_bcast<k>(sacc / m[k]);
+  });
   if (lane == 0) {
     const long n0 = (long)b * a.n_nodes, n1 = n0 + a.n_nodes - 1;
 #pragma unroll
@@ -400,12 +423,12 @@ __device__ __forceinline__ void bvp_backsub_pair16(const BvpArgs& a, int level, 
     s -= rec[D::REC_CA + c * NU + rr] * dl + rec[D::REC_CB + c * NU + rr] * dr;
   }
   double x = 0.0;
-#pragma unroll
-  for (int k = NU - 1; k >= 0; --k) {
-    const double xk = __shfl(s / rec[D::REC_R + k * NU + k], k, 16);      // lane k of the group holds the finished s_k
+  bvp_static_for<0, NU>([&](auto kc) {
+    constexpr int k = NU - 1 - decltype(kc)::value;
+    const double xk = row_bcast<k>(s / rec[D::REC_R + k * NU + k]);       // lane k of the group holds the finished s_k
     if (rr == k) x = xk;
     s = __builtin_fma(-rec[D::REC_R + k * NU + (rr < k ? rr : 0)], (rr < k) ? xk : 0.0, s);
-  }
+  });
   if (r < NU) a.delta[(long)(off + r) * a.ldx + nb + mid] = x;
   if (NU == 6 && r < 6) a.delta[(long)r * a.ldx + nb + mid] = 0.0;       // states are not updated
 }

@@ -632,6 +632,19 @@ int lto_axpy_dev(lto_ctx* c, void* stream, const double* x, const double* d, dou
   return LTO_OK;
 }
 
+int lto_trial_points_dev(lto_ctx* c, void* stream, const double* X, const double* delta, long ld, int ndim, int n_nodes, int n_batch,
+                         int n_alpha, const double* alphas, double* Xt, long ldt) {
+  if (!c) return LTO_ENULL;
+  if (!X || !delta || !alphas || !Xt) return set_err(c, LTO_ENULL, "X, delta, alphas or Xt is NULL");
+  if (ndim < 1 || n_nodes < 1 || n_batch < 1 || n_alpha < 1) return set_err(c, LTO_EINVAL, "ndim, n_nodes, n_batch and n_alpha must be positive");
+  if (ld < (long)n_nodes * n_batch || ldt < (long)n_nodes * n_batch * n_alpha) return set_err(c, LTO_EINVAL, "leading dimension too small");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  hipError_t e = launch_trial_points(X, delta, ld, ndim, n_nodes, n_batch, n_alpha, alphas, Xt, ldt, (hipStream_t)stream);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_trial_points", e);
+  return LTO_OK;
+}
+
 /* Host-pointer API: adopt / refresh the context's cached lane order (see lto_ctx::order_cache).  Below these sizes
  * one round of wavefronts / workgroups covers the chip and the order cannot matter. */
 static const long kOrderMinStm = 8192, kOrderMinDefect = 131072;

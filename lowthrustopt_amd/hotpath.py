@@ -747,3 +747,9 @@ def unpack_soa(ctx, soa, ld, ndim, count, aos, stream=None):
 def defect_norms(ctx, defect, ldd, ndim, seg_per_traj, n_batch, sumsq, maxabs, stream=None):
     ctx.check(ctx.lib.lto_defect_norms_dev(ctx.handle, stream, _dptr(defect), int(ldd), int(ndim), int(seg_per_traj),
                                            int(n_batch), _dptr(sumsq), _dptr(maxabs)))
+
+
+def trial_points(ctx, X, delta, ld, ndim, n_nodes, n_batch, alphas, Xt, ldt, stream=None):
+    """Xt = the len(alphas) trial trajectories X + alpha * delta of every trajectory of the batch (device arrays; lineSearch, indirect.jl:227-233)."""
+    ctx.check(ctx.lib.lto_trial_points_dev(ctx.handle, stream, _dptr(X), _dptr(delta), int(ld), int(ndim), int(n_nodes), int(n_batch),
+                                           int(alphas.numel() if hasattr(alphas, "numel") else len(alphas)), _dptr(alphas), _dptr(Xt), int(ldt)))
