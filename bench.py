@@ -633,8 +633,26 @@ def leg_newton(lto, synth, ctx, st, torch, sizes, cpu_seconds):
             "sizes": out}
 
 
+def self_launch(a):
+    """`bench.py --gpus N` without a launcher: start the contract's launcher as a CHILD process -- before anything in this process
+    has touched the GPU (replacing a process that has initialised HIP takes the node down) -- and leave with its exit code.  Its
+    rank 0 prints the JSON line on the stdout this process was given."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
     import torch
     import lowthrustopt_amd as lto
     from lowthrustopt_amd import synth
@@ -643,17 +661,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or without a launcher: "
+                         "bench.py then starts one itself)" % (a.gpus, world, a.gpus))
     dist = None
-    torch.cuda.set_device(local_rank)
+    # LTO_BENCH_SHARE_DEVICE=1: every local rank uses device 0 and the window transport (which is what exists when ranks share a
+    # device); torch.distributed then runs over gloo -- RCCL refuses two ranks on one device.  This is how the N > 1 path of this
+    # file is exercised on a one-GPU box (tests/test_comm_gpu.py); the timing it prints is of two processes sharing one GPU.
+    share = os.environ.get("LTO_BENCH_SHARE_DEVICE") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
     # LTO_BENCH_FORCE_COLLECTIVE=1 under torchrun exercises the RCCL path (init + all-gather) even at world size 1
     force_coll = os.environ.get("LTO_BENCH_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ
     if world > 1 or force_coll:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    ctx = lto.Context(local_rank)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", dev_index)
+    ctl = torch.device("cpu") if share else dev           # where torch.distributed's control tensors live
+    ctx = lto.Context(dev_index)
     st = lto.current_stream_ptr()
 
     wl = a.workload
@@ -785,11 +813,11 @@ def main():
         #   rccl     lto_comm_create + ncclAllGather
         #   torch    torch.distributed.all_gather_into_tensor (also RCCL)
         # A transport is used only if EVERY rank set it up AND a test gather of rank-stamped slabs came back right everywhere.
-        want = os.environ.get("LTO_BENCH_TRANSPORT", "windows")
+        want = "windows" if share else os.environ.get("LTO_BENCH_TRANSPORT", "windows")
         notes = []
 
         def agreed(ok):
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag.item()) == 1
 
@@ -806,30 +834,55 @@ def main():
                 notes.append("test gather: %s" % ex)
                 return False
 
-        for kind in (["windows", "rccl"] if want == "windows" else ["rccl"] if want == "rccl" else []):
-            cand = None
+        # Every torch.distributed collective below is issued by EVERY rank whatever failed locally (advisor finding, round 3: a rank
+        # that skipped one left its peers hanging in it): a failed step travels as None / an empty blob, the verdict is all-reduced.
+        kinds = ["windows"] if share else (["windows", "rccl"] if want == "windows" else ["rccl"] if want == "rccl" else [])
+        for kind in kinds:
+            cand = half = None
             try:
                 if kind == "windows":
                     def exchange(blob):
                         got = [None] * world
                         dist.all_gather_object(got, blob)
                         return got
+                    if os.environ.get("LTO_BENCH_FAIL_RANK") == str(rank):     # test hook: this rank's set-up fails after the exchange
+                        exchange(b"")
+                        raise RuntimeError("LTO_BENCH_FAIL_RANK")
                     cand = lto.Comm.windows(ctx, world, rank, gather_rows * S, exchange)
                 else:
-                    box = [lto.Comm.unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(box, src=0, device=dev)
+                    box = [None]
+                    if rank == 0:
+                        try:
+                            box[0] = lto.Comm.unique_id()
+                        except Exception as ex:      # noqa: BLE001
+                            notes.append("rccl id: %s" % ex)
+                    dist.broadcast_object_list(box, src=0, device=ctl)
+                    if box[0] is None:
+                        raise RuntimeError("rank 0 could not create an RCCL id")
                     cand = lto.Comm(ctx, world, rank, box[0])
             except Exception as ex:      # noqa: BLE001 -- any failure means "try the next transport"
+                half = getattr(ex, "comm", None)
                 notes.append("%s: %s: %s" % (kind, type(ex).__name__, ex))
-            ok = agreed(cand is not None) and agreed(gather_works(cand))
+            ok = agreed(cand is not None)
+            if ok:
+                ok = agreed(gather_works(cand))
             if ok:
                 native, transport = cand, kind
                 break
-            if cand is not None:
-                dist.barrier()
-                cand.close()
+            dist.barrier()               # nobody closes (unmaps) anything a peer may still be touching
+            for c in (cand, half):
+                if c is not None:
+                    c.close()
             notes.append("%s not usable on every rank" % kind)
         native_note = "; ".join(notes) if notes else None
+        if share and native is None and world > 1:
+            # ranks that share a device have no other transport: every rank leaves the same way (no hang, no half-open windows)
+            if rank == 0:
+                print(json.dumps({"error": "no usable transport for ranks that share a device", "tried": native_note}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            plan.close(); ctx.close()
+            raise SystemExit(3)
     # N > 1: the defect slab of step k is all-gathered (RCCL) on a side stream while step k+1 propagates: two defect /
     # gather buffers alternate, events order producer -> collective -> buffer reuse.  All collectives complete before
     # the closing barrier + synchronize, so every one of the K steps is fully inside the timed region.
@@ -848,6 +901,8 @@ def main():
         with torch.cuda.stream(comm_stream):
             if native is not None:
                 native.allgather(dbufs[b], gathered[b], gather_rows * S, stream=C_void_p(comm_stream.cuda_stream))
+            elif share:
+                raise RuntimeError("ranks share a device and the window transport is not usable: no collective left (gloo does not gather device tensors)")
             else:
                 dist.all_gather_into_tensor(gathered[b], dbufs[b])
             if not serial_coll:
@@ -920,10 +975,12 @@ def main():
     if use_coll:
         for b in range(len(dbufs)):
             assert torch.equal(gathered[b][rank * gather_rows:(rank + 1) * gather_rows], dbufs[b]), "all-gather slab mismatch"
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        slab_ok = agreed(all(bool(torch.isfinite(g).all()) for g in gathered))      # every rank's gathered vector: own slab bit-equal, all slabs finite
+        assert slab_ok, "a gathered defect vector holds non-finite values on some rank"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        kt = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        kt = torch.tensor([kern_ms], dtype=torch.float64, device=ctl)
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
         kern_ms = float(kt.item())
 
@@ -938,6 +995,10 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
+                       "slab_check": ("passed on every rank: own slab of the gathered defect vector bit-equal to the sweep's output, every slab finite"
+                                      if use_coll else "no collective"),
+                       "devices": ("all %d ranks share device 0 (LTO_BENCH_SHARE_DEVICE=1): a functional run of the N > 1 path, not a scaling figure" % world
+                                   if share and world > 1 else "one device per rank"),
                        "collective": ("none" if not use_coll else
                                       "lto_comm_allgather_dev of the defect slabs after every sweep, on the %s; transport: %s%s" % (
                                           "sweep's stream" if serial_coll else "a side stream, overlapping the next sweep",

@@ -391,8 +391,16 @@ int lto_comm_allreduce_dev(lto_comm* comm, void* stream, double* buf, long count
  *   the launcher gathers the world handles in rank order (torch.distributed all_gather, MPI_Allgather, a file)
  *   lto_comm_window_open(comm, all_handles)
  * then lto_comm_allgather_dev / lto_comm_allreduce_dev with count <= max_count, lto_comm_destroy at the end (after a
- * barrier of the launcher: a peer may still be pushing).  One process per rank. */
+ * barrier of the launcher: a peer may still be pushing).  One process per rank.
+ * ONE STREAM: the collectives of a window communicator must all be enqueued on the same stream (the first one it is used on; a
+ * different one returns LTO_EINVAL) -- the reuse of a window half, the push counters and the sequence numbers are ordered by it.
+ * A driver that gathers on a side stream and reduces norms on its main stream uses two communicators.
+ * FAILURE: a wait that runs out (lto_comm_set_wait_limit polls of ~1.5 us each, default 4e6) or a peer found two or more
+ * collectives ahead (the ranks have lost step) sets the communicator's fail word: that collective and every later one of this
+ * rank return NaN -- never a slab of another iteration -- and lto_comm_status reports it to the host. */
 #define LTO_COMM_WINDOW_BYTES 128
+int lto_comm_status(lto_comm* comm, void* stream, int* failed);
+int lto_comm_set_wait_limit(lto_comm* comm, long polls);
 int lto_comm_window_export(lto_ctx* ctx, int world, int rank, long max_count, void* handle_out, lto_comm** out);
 int lto_comm_window_open(lto_comm* comm, const void* all_handles);
 int lto_comm_uses_windows(const lto_comm* comm);

@@ -461,4 +461,13 @@ allgather_dev!(c::LtoComm, stream, send, recv, count::Integer) =
 allreduce_dev!(c::LtoComm, stream, buf, count::Integer, op::Integer) =
     comm_check(c, ccall((:lto_comm_allreduce_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Clong, Cint), c.handle, devptr(stream), devptr(buf), count, op))
 
+"True once a wait of a window communicator has run out or the ranks have lost step (every collective since returned NaN); waits for `stream`."
+function comm_failed(c::LtoComm, stream)
+    f = Ref{Cint}(0)
+    comm_check(c, ccall((:lto_comm_status, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}), c.handle, devptr(stream), f))
+    f[] != 0
+end
+"Polls (~1.5 us each) before a wait for a peer gives up and poisons the result."
+set_wait_limit!(c::LtoComm, polls::Integer) = comm_check(c, ccall((:lto_comm_set_wait_limit, liblto), Cint, (Ptr{Cvoid}, Clong), c.handle, polls))
+
 end # module

@@ -108,15 +108,25 @@ __global__ void k_max_decode(const double* packed, long count, double* buf) {
 
 // windows: wait until every rank's flag has reached `seq` (flags only grow; written by the peers' copy engines, read here at
 // system scope).  One wavefront, lane = rank; bounded: a rank that never arrives raises *fail instead of hanging the stream.
-constexpr long WINDOW_SPIN_LIMIT = 4000000L;     // x (s_sleep 8 + one uncached load) ~ a few seconds
-__global__ void k_window_wait(const unsigned int* flags, int world, unsigned int seq, int* fail) {
-  const int m = threadIdx.x;
-  if (m >= world) return;
+// The limit is per communicator (lto_comm_set_wait_limit; default ~ a few seconds: polls x (s_sleep 8 + one uncached load)).
+// A peer may be at most ONE collective ahead of this rank (it pushes collective k + 1 once it has read k, and needs this rank's push
+// of k + 1 before it can go further): a flag two or more ahead means that the ranks have lost step -- e.g. a peer whose wait ran out
+// and that went on alone, overwriting the half this rank is about to read -- and is a failure too.  The fail word is sticky: every
+// later collective of this rank returns NaN, and lto_comm_status reports it to the host.
+constexpr long WINDOW_SPIN_LIMIT = 4000000L;
+__device__ __forceinline__ bool window_wait_one(const unsigned int* flag, const unsigned int seq, const long limit) {
   long spins = 0;
-  while ((int)(__hip_atomic_load(flags + m, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-    if (++spins > WINDOW_SPIN_LIMIT) { __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+  int d;
+  while ((d = (int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq)) < 0) {
+    if (++spins > limit) return false;
     __builtin_amdgcn_s_sleep(8);
   }
+  return d <= 1;
+}
+__global__ void k_window_wait(const unsigned int* flags, int world, unsigned int seq, int* fail, long limit) {
+  const int m = threadIdx.x;
+  if (m >= world) return;
+  if (!window_wait_one(flags + m, seq, limit)) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // windows: out[i] = sum / NaN-propagating max over the world slabs of the gathered window (poisoned when a wait ran out)
 __global__ void k_window_reduce(const double* slabs, int world, long stride, long count, int op, const int* fail, double* out) {
@@ -166,16 +176,13 @@ __global__ void k_window_push(const double* send, long count, WindowPeers peers,
 }
 // collect: every block waits for all flags, then copies its share of the window's slabs into recv (NaN when a wait ran out)
 __global__ void k_window_collect(const unsigned int* flags, int world, unsigned int seq, int* fail, const double* slabs, long stride,
-                                 long count, double* recv) {
+                                 long count, double* recv, long limit) {
   __shared__ int s_fail;
   if (threadIdx.x == 0) s_fail = 0;
   __syncthreads();
-  if (threadIdx.x < world) {
-    long spins = 0;
-    while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-      if (++spins > WINDOW_SPIN_LIMIT) { s_fail = 1; __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
+  if (threadIdx.x < world && !window_wait_one(flags + threadIdx.x, seq, limit)) {
+    s_fail = 1;
+    __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   const bool bad = s_fail != 0 || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
@@ -187,16 +194,13 @@ __global__ void k_window_collect(const unsigned int* flags, int world, unsigned 
 }
 // the same wait, then the reduction over the slabs
 __global__ void k_window_collect_reduce(const unsigned int* flags, int world, unsigned int seq, int* fail, const double* slabs, long stride,
-                                        long count, int op, double* out) {
+                                        long count, int op, double* out, long limit) {
   __shared__ int s_fail;
   if (threadIdx.x == 0) s_fail = 0;
   __syncthreads();
-  if (threadIdx.x < world) {
-    long spins = 0;
-    while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-      if (++spins > WINDOW_SPIN_LIMIT) { s_fail = 1; __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
+  if (threadIdx.x < world && !window_wait_one(flags + threadIdx.x, seq, limit)) {
+    s_fail = 1;
+    __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   const bool bad = s_fail != 0 || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
@@ -241,6 +245,9 @@ struct lto_comm {
   char* own = nullptr;                 // this rank's window: [flags: world x u32 | fail | push counters: 1024 B in all][2 halves][world][max_count] doubles
   std::vector<char*> peer;             // every rank's window as mapped here (peer[rank] = own)
   unsigned int seq = 0;
+  long wait_limit = 4000000L;          // polls before a wait gives up (lto_comm_set_wait_limit)
+  hipStream_t bound = nullptr;         // the stream of this communicator's collectives (windows: all on ONE stream)
+  bool bound_set = false;
   char err[512] = {0};
 };
 namespace {
@@ -386,6 +393,12 @@ namespace {
 int window_push(lto_comm* c, hipStream_t st, const double* send, long count, unsigned int* seq_out, int* half_out, bool* kernels_out) {
   if (!c->opened) return comm_fail(c, LTO_EINVAL, "lto_comm_window_open has not been called");
   if (count > c->max_count) return comm_fail(c, LTO_EINVAL, "count exceeds the window's max_count");
+  // The window halves, the push counters and the sequence numbers are ordered by ONE stream (a half is reused two collectives
+  // later, a counter by the next push): the communicator belongs to the first stream it is used on.
+  if (!c->bound_set) { c->bound = st; c->bound_set = true; }
+  else if (c->bound != st)
+    return comm_fail(c, LTO_EINVAL, "a window communicator's collectives must all be enqueued on ONE stream (the first one it was used on); "
+                                    "use a second communicator for a second stream");
   const unsigned int seq = ++c->seq;
   const int half = (int)(seq & 1u);
   const bool kernels = sizeof(double) * (size_t)count <= WINDOW_KERNEL_BYTES;
@@ -407,7 +420,7 @@ int window_push(lto_comm* c, hipStream_t st, const double* send, long count, uns
       if (hipMemsetD32Async((hipDeviceptr_t)(c->peer[m] + sizeof(unsigned int) * (size_t)c->rank), (int)seq, 1, st) != hipSuccess)
         return comm_fail(c, LTO_EHIP, "hipMemsetD32Async (flag)");
     }
-    hipLaunchKernelGGL(k_window_wait, dim3(1), dim3(64), 0, st, (const unsigned int*)c->own, c->world, seq, (int*)(c->own + 256));
+    hipLaunchKernelGGL(k_window_wait, dim3(1), dim3(64), 0, st, (const unsigned int*)c->own, c->world, seq, (int*)(c->own + 256), c->wait_limit);
     if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_window_wait");
   }
   *seq_out = seq; *half_out = half; *kernels_out = kernels;
@@ -439,7 +452,7 @@ int lto_comm_allgather_dev(lto_comm* c, void* stream, const double* send, double
     if (kernels) {
       const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
       hipLaunchKernelGGL(k_window_collect, dim3(blocks), dim3(256), 0, st, (const unsigned int*)c->own, c->world, seq, (int*)(c->own + 256), slabs,
-                         c->max_count, count, recv);
+                         c->max_count, count, recv, c->wait_limit);
       if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_window_collect");
       return LTO_OK;
     }
@@ -478,7 +491,7 @@ int lto_comm_allreduce_dev(lto_comm* c, void* stream, double* buf, long count, i
     const unsigned blocks = (unsigned)((count + 255) / 256 > 2048 ? 2048 : (count + 255) / 256);
     if (kernels)
       hipLaunchKernelGGL(k_window_collect_reduce, dim3(blocks), dim3(256), 0, st, (const unsigned int*)c->own, c->world, seq, (int*)(c->own + 256),
-                         slabs, c->max_count, count, op, buf);
+                         slabs, c->max_count, count, op, buf, c->wait_limit);
     else
       hipLaunchKernelGGL(k_window_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, slabs, c->world, c->max_count, count, op,
                          (const int*)(c->own + 256), buf);
@@ -502,6 +515,28 @@ int lto_comm_allreduce_dev(lto_comm* c, void* stream, double* buf, long count, i
   if (r != ncclSuccess) return comm_fail(c, LTO_EHIP, "ncclAllReduce", r);
   hipLaunchKernelGGL(k_max_decode, grid, dim3(256), 0, st, (const double*)c->scratch, count, buf);
   if (hipGetLastError() != hipSuccess) return comm_fail(c, LTO_EHIP, "k_max_decode");
+  return LTO_OK;
+}
+
+/* Has a wait of this communicator run out (a peer never arrived, or the ranks lost step)?  Waits for `stream`, then reads the
+ * window's fail word: *failed = 1 means every collective since has returned NaN and every later one will.  RCCL transport: 0. */
+int lto_comm_status(lto_comm* c, void* stream, int* failed) {
+  if (!c || !failed) return LTO_ENULL;
+  *failed = 0;
+  if (!c->windows || c->world == 1) return LTO_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return comm_fail(c, LTO_EHIP, "hipSetDevice");
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return comm_fail(c, LTO_EHIP, "hipStreamSynchronize");
+  int f = 0;
+  if (hipMemcpy(&f, c->own + 256, sizeof f, hipMemcpyDeviceToHost) != hipSuccess) return comm_fail(c, LTO_EHIP, "hipMemcpy (fail word)");
+  *failed = f ? 1 : 0;
+  return LTO_OK;
+}
+
+/* Polls (each ~ s_sleep 8 + one uncached load, ~1.5 us) before a wait for a peer's flag gives up and poisons the result. */
+int lto_comm_set_wait_limit(lto_comm* c, long polls) {
+  if (!c) return LTO_ENULL;
+  if (polls < 1) return comm_fail(c, LTO_EINVAL, "polls must be positive");
+  c->wait_limit = polls;
   return LTO_OK;
 }
 

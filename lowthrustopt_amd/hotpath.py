@@ -187,19 +187,28 @@ class Comm:
         """The window transport (lto_comm_window_*): device copies into IPC-mapped receive windows, no RCCL, no compute units for
         the payload; also works for ranks that share a device.  `exchange(handle: bytes) -> list of world handles in rank order`
         is the launcher's all-gather of 128-byte blobs (torch.distributed.all_gather_object, MPI, queues)."""
+        # Every rank calls exchange() exactly once, whatever happened before it (a rank that skipped the launcher's collective would
+        # leave its peers hanging in it): a failed export travels as an empty blob, and then EVERY rank raises.
         self = cls.__new__(cls)
         self.ctx, self.lib = ctx, ctx.lib
+        self.handle = None
+        self.world, self.rank = int(world), int(rank)
         h = C.c_void_p()
         blob = C.create_string_buffer(cls.WINDOW_BYTES)
         rc = self.lib.lto_comm_window_export(ctx.handle, int(world), int(rank), int(max_count), blob, C.byref(h))
+        if rc == 0:
+            self.handle = h
+        handles = exchange(blob.raw if rc == 0 else b"")
         if rc != 0:
             raise LtoError(rc, "lto_comm_window_export failed")
-        self.handle = h
-        self.world, self.rank = int(world), int(rank)
-        handles = exchange(blob.raw)
         if len(handles) != self.world or any(len(b) != cls.WINDOW_BYTES for b in handles):
-            raise LtoError(-1, "exchange() must return the world handles in rank order")
-        self.check(self.lib.lto_comm_window_open(self.handle, C.create_string_buffer(b"".join(handles), cls.WINDOW_BYTES * self.world)))
+            self.close()                 # nobody has opened anything yet: every rank sees the same list and raises here
+            raise LtoError(-1, "window export failed on a peer (or exchange() did not return the world handles in rank order)")
+        try:
+            self.check(self.lib.lto_comm_window_open(self.handle, C.create_string_buffer(b"".join(handles), cls.WINDOW_BYTES * self.world)))
+        except LtoError as e:
+            e.comm = self                # peers may have mapped this rank's window already: the caller closes it after a barrier
+            raise
         return self
 
     def uses_windows(self):
@@ -209,6 +218,15 @@ class Comm:
         if rc != 0:
             msg = self.lib.lto_comm_last_error(self.handle)
             raise LtoError(rc, msg.decode() if msg else "")
+
+    def failed(self, stream=None):
+        """True once a wait of this (window) communicator has run out or the ranks have lost step: results are NaN from then on."""
+        f = C.c_int(0)
+        self.check(self.lib.lto_comm_status(self.handle, stream, C.byref(f)))
+        return bool(f.value)
+
+    def set_wait_limit(self, polls):
+        self.check(self.lib.lto_comm_set_wait_limit(self.handle, int(polls)))
 
     def allgather(self, send, recv, count, stream=None):
         """recv [world][count] <- send [count] of every rank."""

@@ -5,6 +5,7 @@ real ncclComm), the single-process group form on a group that repeats device 0 (
 streams, device-resident gather + reduce, bit-equal to an unsharded sweep), and -- only when two GPUs are visible -- two
 ranks running the product callable hip_indirect_defect + the native all-gather.  The driver's 8-GPU scaling run exercises
 the N > 1 RCCL path through bench.py."""
+import ctypes
 import os
 import socket
 
@@ -207,6 +208,23 @@ def _shared_device_rank(rank, world, port, n_nodes, q):
         comm.allreduce(bad, 2, "max", stream=st)
         torch.cuda.synchronize()
         out["ss"], out["mx"], out["bad"] = float(ss), float(mx), bad.cpu().numpy()
+        out["failed"] = comm.failed(stream=st)    # no wait ran out, nobody lost step
+        # one stream per window communicator: a collective on another stream is refused, nothing is enqueued
+        side = torch.cuda.Stream()
+        try:
+            comm.allreduce(ss, 1, "sum", stream=ctypes.c_void_p(side.cuda_stream))
+            out["other_stream"] = "accepted"
+        except lto.LtoError as e:
+            out["other_stream"] = "refused: %s" % e
+        dist.barrier()
+        # A peer that never arrives: rank 0 gathers alone with a short wait limit -- NaN instead of a hang, and the host can see why.
+        if rank == 0:
+            comm.set_wait_limit(2000)
+            lone = torch.full((world, 12, cmax), -7.0, dtype=torch.float64, device="cuda")
+            comm.allgather(slab, lone, 12 * cmax, stream=st)
+            torch.cuda.synchronize()
+            out["lone_all_nan"] = bool(torch.isnan(lone).all())
+            out["lone_failed"] = comm.failed(stream=st)
         dist.barrier()                            # nobody unmaps a window a peer may still be pushing into
         plan.close(); comm.close(); ctx.close()
         dist.destroy_process_group()
@@ -250,6 +268,10 @@ def test_two_processes_share_the_gpu_windows_carry_the_collectives(gpu_ctx):
         assert abs(res[r]["ss"] - float((d_ref ** 2).sum())) <= 1e-12 * float((d_ref ** 2).sum())
         assert res[r]["mx"] == float(np.abs(d_ref).max())
         assert np.isnan(res[r]["bad"][0]) and res[r]["bad"][1] == 2.0          # the NaN of rank 1 reaches every rank
+        assert res[r]["failed"] is False
+        assert res[r]["other_stream"].startswith("refused") and "ONE stream" in res[r]["other_stream"]
+    # a gather whose peer never arrives: NaN, not a hang, and lto_comm_status says so (advisor finding, round 3)
+    assert res[0]["lone_all_nan"] and res[0]["lone_failed"]
 
 
 def test_window_transport_world1_and_misuse(gpu_ctx):
@@ -270,3 +292,40 @@ def test_window_transport_world1_and_misuse(gpu_ctx):
     with pytest.raises(lto._lib.LtoError):
         comm.allgather(send, recv, 501, stream=st)                              # beyond the window
     comm.close()
+
+
+def _run_bench(extra_env, args, timeout=420):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(extra_env)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr[-2000:]
+
+
+def test_bench_multi_rank_path_runs_with_two_ranks_sharing_the_device():
+    """`bench.py --gpus 2` WITHOUT a launcher: it starts torch.distributed.run itself (as a child process, before touching the GPU),
+    both ranks take device 0 (LTO_BENCH_SHARE_DEVICE=1), negotiate the window transport, double-buffer the all-gather of the defect
+    slabs inside the timed steps, check their slabs and reduce the timing over ranks -- the code path the driver's 8-GPU run takes,
+    on the one device this box has."""
+    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, ["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    assert rc == 0 and out is not None, err
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["config"]["global_segments"] == 2 * out["config"]["segments_per_gpu"]
+    assert "IPC receive windows" in out["config"]["collective"]
+    assert out["config"]["slab_check"].startswith("passed on every rank")
+    assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_bench_transport_set_up_failing_on_one_rank_ends_cleanly_on_all():
+    """One rank's window set-up fails (test hook): every rank still issues the same torch.distributed collectives, agrees that the
+    transport is unusable, closes nothing a peer may touch before the barrier, and -- ranks sharing a device have no other transport --
+    leaves with the same exit code instead of hanging (advisor finding, round 3)."""
+    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1", "LTO_BENCH_FAIL_RANK": "1"},
+                              ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], timeout=300)
+    assert rc != 0
+    assert out is not None and "no usable transport" in out["error"] and "windows" in out["tried"], err
