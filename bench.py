@@ -267,20 +267,34 @@ def roofline(wl, ndim, S, kern_ms, work=None, samples=None, burst_n=N_BURST, met
     else:
         traffic_from = ("null: no counter profile of this workload is stored (profiles/%s; tools/gpu_round.sh collects FETCH_SIZE / WRITE_SIZE "
                         "in separate --pmc passes)" % os.path.basename(pmc))
+    model = ("builder-counted on lowthrustopt_amd/csrc/dynamics.hpp with SURVEY 8d's convention (+ - x / sqrt tanh = 1, FMA = 2): "
+             "flops = steps x (stages x F_rhs + C_tab x dim); F_rhs 14-dim + 14x14 variational = 1 490 (116 base + 86 coefficient build + "
+             "14 x 92), 12-dim + 12x12 = 1 070 (SURVEY's figure; the same count gives 1 096)")
+    if wl == "hbm":
+        # the one workload of this path whose arithmetic intensity (4.4 flop/B) is below the machine balance (9.8): HBM is its roof
+        return {
+            "bound": "hbm", "bound_actual": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBS,
+            "traffic": traffic, "traffic_from": traffic_from, "kernel_ms": kern_ms,
+            "kernel_ms_from": "one HIP event pair on the launch stream around %d back-to-back launches right after the timed region, "
+                              "divided by their number (launch period: includes the gap between consecutive launches)" % burst_n,
+            "kernel_ms_isolated": samples, "flops_per_segment": flops, "bytes_per_segment": nbytes, "flops_model": model,
+            "fp64": {"achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP64_TFLOPS},
+            "note": "HBM evidence point: ONE RK4 step per segment with the full STM out; achieved = algorithmic bytes per launch / launch period",
+        }
     return {
         # schema value "mfma" = the compute roof: the dense FP64 matrix peak of MI355X (78.6 TFLOP/s) is numerically the
-        # FP64 vector peak, and the vector pipe is what this kernel runs on (compute_pipe); the HBM roof is in "hbm"
-        "bound": "mfma", "compute_pipe": "fp64_valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+        # FP64 vector peak, and the vector pipe is what this kernel runs on (bound_actual / compute_pipe); the HBM roof is in "hbm"
+        "bound": "mfma", "bound_actual": "fp64_valu", "compute_pipe": "fp64_valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
         "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_from": traffic_from,
         "kernel_ms": kern_ms,
         "kernel_ms_from": "one HIP event pair on the launch stream around %d back-to-back launches right after the timed region, "
                           "divided by their number (launch period: includes the gap between consecutive launches)" % burst_n,
         "kernel_ms_isolated": samples,
-        "flops_per_segment": flops, "bytes_per_segment": nbytes,
+        "flops_per_segment": flops, "bytes_per_segment": nbytes, "flops_model": model,
         "hbm": {"achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gb / PEAK_HBM_GBS},
-        "note": "register-resident fp64 ODE integration: compute-bound on the FP64 vector pipe (no MFMA instruction is "
-                "issued; the MI355X dense FP64 matrix peak equals the vector peak, so the roof is the same number), not "
-                "HBM-bound -- see DESIGN.md 'Roofline'",
+        "note": "register-resident fp64 ODE integration: bound by FP64 vector issue (no MFMA instruction is issued; the schema's "
+                "\"mfma\" names the compute roof, and the MI355X dense FP64 matrix peak equals the vector peak, so the roof is the same "
+                "number), not by HBM -- see DESIGN.md 'Roofline'",
     }
 
 

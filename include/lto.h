@@ -89,6 +89,10 @@ void lto_destroy(lto_ctx* ctx);
  * Phi crossing the link).  Other buffers work too: pageable ones are staged by the HIP runtime (0.31 ms for the same call).
  * Julia: unsafe_wrap the pointer as an Array and free it in a finalizer (julia/LowThrustOptHIP.jl: pinned_array). */
 int lto_host_alloc(lto_ctx* ctx, size_t bytes, void** out);
+/* Lifetime: a block keeps its context alive the way a plan does (lto_destroy only marks a context that still has blocks or
+ * plans; whoever releases the last of them -- from any thread, in any order: finalizers -- frees it, exactly once).
+ * lto_host_free(NULL, ptr) is allowed: the owner of a block is looked up, so a finalizer need not keep the handle.  Freeing a
+ * pointer that is not a live block returns LTO_EINVAL. */
 int lto_host_free(lto_ctx* ctx, void* ptr);
 const char* lto_last_error(const lto_ctx* ctx);
 int lto_version(void);

@@ -234,7 +234,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   // buffer 1, and both evaluations here are consumed before a barrier that precedes it.)
   if (a.warm) {
     const double hw = a.h_first[s];
-    h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
+    h_abs = (hw > 0.0) ? fmin(fmax(hw, 1e-6 * span), span) : 1e-3 * span;      // any positive value is a valid start; a tiny one would cost hundreds of trial steps
     slope(y, K[0], 0);
   } else {
     // Hairer's initial step over all components.  Row r of every column is scaled with the BASE value of row r (a dual

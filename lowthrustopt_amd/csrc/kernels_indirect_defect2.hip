@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
     // which costs an extra RHS evaluation and starts a decade or two low.  Wave-uniform choice; any positive value is a valid start.
     if (a.warm) {
       const double hw = a.h_first[s];
-      h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
+      h_abs = (hw > 0.0) ? fmin(fmax(hw, 1e-6 * span), span) : 1e-3 * span;      // any positive value is a valid start; a tiny one would cost hundreds of trial steps
     } else {   // Hairer's initial step over the 12 components
       double isc[6], p0 = 0.0, p1 = 0.0;
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
     double h_abs;
     if (a.warm) {                // warm start: see k_indirect_defect2
       const double hw = a.h_first[s];
-      h_abs = (hw > 0.0) ? fmin(hw, span) : 1e-3 * span;
+      h_abs = (hw > 0.0) ? fmin(fmax(hw, 1e-6 * span), span) : 1e-3 * span;      // any positive value is a valid start; a tiny one would cost hundreds of trial steps
     } else {                     // Hairer's initial step over the 12 components
       double isc[3], p0 = 0.0, p1 = 0.0;
 #pragma unroll

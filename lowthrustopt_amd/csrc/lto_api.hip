@@ -55,6 +55,7 @@ struct lto_ctx {
   // collector runs finalizers in any order) only marks the context; the last lto_*_plan_destroy frees it.
   int live_plans;
   bool closing;
+  bool free_claimed = false;   // somebody is freeing this context (ctx_release)
   // page-locked blocks handed out by lto_host_alloc.  The GPU addresses them directly, so the host-pointer API reads and
   // writes a caller's buffer that lies inside one of them in place: the AoS <-> SoA kernels are the transfer, and no
   // copy-engine operation (about 10 us of latency each) is queued.
@@ -258,12 +259,26 @@ static std::unordered_map<void*, lto_ctx*> g_blocks;
 static void host_block_forget(void* ptr) { std::lock_guard<std::mutex> lk(g_blocks_mu); g_blocks.erase(ptr); }
 static bool ctx_has_blocks(lto_ctx* c) { std::lock_guard<std::mutex> lk(c->pinned_mu); return !c->pinned.empty(); }
 
+// A context has three kinds of owners: its handle (until lto_destroy), its plans, its page-locked blocks; garbage collectors
+// release them in any order and from any thread (lto_host_free takes no handle).  Who frees the context is decided under ONE
+// lock, and exactly once (advisor finding, round 3: two threads could both see "last owner" and free it twice).
+static std::mutex g_life_mu;
+enum CtxOwner { OWNER_HANDLE, OWNER_PLAN, OWNER_BLOCK };
+static void ctx_plan_added(lto_ctx* c) { std::lock_guard<std::mutex> lk(g_life_mu); ++c->live_plans; }
+static bool ctx_is_closing(lto_ctx* c) { std::lock_guard<std::mutex> lk(g_life_mu); return c->closing; }
+// the caller has given up an owner of kind `what` (a block: already removed from c->pinned); true = the caller frees the context
+static bool ctx_release(lto_ctx* c, CtxOwner what) {
+  std::lock_guard<std::mutex> lk(g_life_mu);
+  if (what == OWNER_HANDLE) c->closing = true;
+  if (what == OWNER_PLAN) --c->live_plans;
+  if (!c->closing || c->live_plans > 0 || c->free_claimed || ctx_has_blocks(c)) return false;
+  c->free_claimed = true;
+  return true;
+}
+
 void lto_destroy(lto_ctx* c) {
   if (!c) return;
-  bool blocks;
-  { std::lock_guard<std::mutex> lk(c->pinned_mu); blocks = !c->pinned.empty(); }
-  if (c->live_plans > 0 || blocks) { c->closing = true; return; }   // freed by the last lto_*_plan_destroy / lto_host_free
-  ctx_free(c);
+  if (ctx_release(c, OWNER_HANDLE)) ctx_free(c);      // otherwise: freed by the last lto_*_plan_destroy / lto_host_free
 }
 
 static void ctx_free(lto_ctx* c) {
@@ -357,7 +372,7 @@ static int plan_build(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_
 int lto_indirect_plan_create(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
                              const lto_integrator* integ, lto_indirect_plan** out) {
   const int rc = plan_build(c, ndim, n_nodes, n_batch, prm, n_prm, integ, out);
-  if (rc == LTO_OK) ++c->live_plans;
+  if (rc == LTO_OK) ctx_plan_added(c);
   return rc;
 }
 
@@ -371,7 +386,7 @@ void lto_indirect_plan_destroy(lto_indirect_plan* p) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   plan_free(p);
-  if (--c->live_plans <= 0 && c->closing && !ctx_has_blocks(c)) ctx_free(c);
+  if (ctx_release(c, OWNER_PLAN)) ctx_free(c);
 }
 
 static void plan_free(lto_indirect_plan* p) {
@@ -459,24 +474,36 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* p, int on) {
   if (!p) return LTO_ENULL;
   if (on && !(p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE))
     return set_err(p->ctx, LTO_EINVAL, "warm start is built for 12-dim DOP853_ADAPTIVE plans (the reference's integrator setting)");
+  if (on) {
+    // Both arrays are allocated and zeroed HERE, not inside the first warm sweep (advisor finding, round 3): a sweep may be part
+    // of a caller's graph capture, where nothing may be allocated, and a segment a sweep skips (zero span, another launch's
+    // control-law class) must leave a value the next sweep recognises as "none" -- 0 -- not whatever the pool handed out.
+    int rc = bind_device(p->ctx);
+    if (rc) return rc;
+    for (int k = 0; k < 2; ++k) {
+      if (p->d_hfirst[k]) continue;
+      hipError_t e = pool_alloc(p->ctx, (void**)&p->d_hfirst[k], sizeof(double) * (size_t)p->S);
+      if (e == hipSuccess) e = hipMemset(p->d_hfirst[k], 0, sizeof(double) * (size_t)p->S);
+      if (e != hipSuccess) { p->d_hfirst[k] = nullptr; return set_err(p->ctx, LTO_EHIP, "warm-start array", e); }
+      p->hfirst_valid[k] = 0;
+    }
+  }
   p->warm_start = on ? 1 : 0;
   if (!on) { p->hfirst_valid[0] = 0; p->hfirst_valid[1] = 0; }
   return LTO_OK;
 }
 
-// The h_first array of sweep kind `which` (0 STM, 1 defect-only), allocated on first use; args get it with the warm flag.
+// The h_first array of sweep kind `which` (0 STM, 1 defect-only); args get it with the warm flag.  The caller marks the array valid
+// (warm_filled) only once the sweep that fills it has been launched successfully.
 static int warm_args(lto_indirect_plan* p, int which, bool kernel_records, IndirectArgs* a) {
   a->h_first = nullptr; a->warm = 0;
-  if (!p->warm_start || !kernel_records) return LTO_OK;
-  if (!p->d_hfirst[which]) {
-    hipError_t e = pool_alloc(p->ctx, (void**)&p->d_hfirst[which], sizeof(double) * (size_t)p->S);
-    if (e != hipSuccess) { p->d_hfirst[which] = nullptr; return set_err(p->ctx, LTO_EHIP, "warm-start array", e); }
-    p->hfirst_valid[which] = 0;
-  }
+  if (!p->warm_start || !kernel_records || !p->d_hfirst[which]) return LTO_OK;
   a->h_first = p->d_hfirst[which];
   a->warm = p->hfirst_valid[which];
-  p->hfirst_valid[which] = 1;          // the sweep about to be launched fills it (stream order)
   return LTO_OK;
+}
+static void warm_filled(lto_indirect_plan* p, int which, const IndirectArgs& a) {
+  if (a.h_first) p->hfirst_valid[which] = 1;          // stream order: the next sweep of this kind reads what this one wrote
 }
 
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
@@ -540,6 +567,7 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
                                    : launch_indirect14_defect(p->pm, p->integ.method, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_defect", e);
+  warm_filled(p, 1, a);
   p->swept = 1;
   return LTO_OK;
 }
@@ -594,6 +622,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
+  warm_filled(p, 0, a);
   p->swept = 1;
   return LTO_OK;
 }
@@ -986,7 +1015,7 @@ static int direct_plan_build(lto_ctx* c, int nstate, int n_nodes, int n_batch, i
 int lto_direct_plan_create(lto_ctx* c, int nstate, int n_nodes, int n_batch, int nsteps, const lto_direct_params* prm,
                            lto_direct_plan** out) {
   const int rc = direct_plan_build(c, nstate, n_nodes, n_batch, nsteps, prm, out);
-  if (rc == LTO_OK) ++c->live_plans;
+  if (rc == LTO_OK) ctx_plan_added(c);
   return rc;
 }
 
@@ -994,7 +1023,7 @@ void lto_direct_plan_destroy(lto_direct_plan* p) {
   if (!p) return;
   lto_ctx* c = p->ctx;
   delete p;
-  if (--c->live_plans <= 0 && c->closing && !ctx_has_blocks(c)) ctx_free(c);
+  if (ctx_release(c, OWNER_PLAN)) ctx_free(c);
 }
 
 int lto_direct_plan_set_kernel(lto_direct_plan* p, int kernel) {
@@ -1247,18 +1276,17 @@ int lto_host_free(lto_ctx* c, void* ptr) {
     if (it != g_blocks.end()) { owner = it->second; g_blocks.erase(it); }
   }
   if (!owner) return c ? set_err(c, LTO_EINVAL, "lto_host_free: not a block from lto_host_alloc (or freed twice)") : LTO_EINVAL;
-  bool last;
+  // device work first, while the block still keeps its context alive; then the block leaves the list and the lifetime decision is taken
+  (void)hipSetDevice(owner->device);
+  if (!ctx_is_closing(owner)) (void)hipStreamSynchronize(owner->stream);   // a sweep may still be writing the block in place
+  else (void)hipDeviceSynchronize();
+  const hipError_t e = hipHostFree(ptr);
   {
     std::lock_guard<std::mutex> lk(owner->pinned_mu);
     for (size_t k = 0; k < owner->pinned.size(); ++k)
       if (owner->pinned[k].host == (char*)ptr) { owner->pinned[k] = owner->pinned.back(); owner->pinned.pop_back(); break; }
-    last = owner->pinned.empty();
   }
-  (void)hipSetDevice(owner->device);
-  if (!owner->closing) (void)hipStreamSynchronize(owner->stream);   // a sweep may still be writing the block in place
-  else (void)hipDeviceSynchronize();
-  const hipError_t e = hipHostFree(ptr);
-  if (last && owner->closing && owner->live_plans <= 0) { ctx_free(owner); return e == hipSuccess ? LTO_OK : LTO_EHIP; }
+  if (ctx_release(owner, OWNER_BLOCK)) { ctx_free(owner); return e == hipSuccess ? LTO_OK : LTO_EHIP; }
   if (e != hipSuccess) return set_err(owner, LTO_EHIP, "hipHostFree", e);
   return LTO_OK;
 }

@@ -126,9 +126,13 @@ def test_indirect_stm_adaptive_vs_oracle(gpu_ctx, oracle, mname, pcase):
     assert rc == 0
     # ode78's simple controller loses accuracy across the sharp thrust switch at rho = 1e-3 (see the defect test);
     # the comparison is against the converged DOP853 oracle, so allow its true error there.
-    tol_d = 1e-8 if (mname == "rkf78_adaptive" and pcase == "p1_rho1e-3") else 1e-10
+    # Tolerances with measured margins (round 4: DOP853 agrees with the oracle's converged dual-number flow to 1.2e-14 of max |Phi|
+    # on every case, ode78 to 4e-13 away from the switch; round 3 accepted 1e-7 everywhere, six orders above what the kernels deliver).
+    switch = (mname == "rkf78_adaptive" and pcase == "p1_rho1e-3")
+    tol_d = 1e-8 if switch else 1e-10
+    tol_p = 1e-5 if switch else (1e-11 if mname == "dop853_adaptive" else 1e-10)
     assert rel_l2(d, d_o, XC[:, 1:]) < tol_d
-    assert np.abs(Phi - Phi_o).max() < (1e-5 if tol_d > 1e-10 else 1e-7) * np.abs(Phi_o).max()
+    assert np.abs(Phi - Phi_o).max() < tol_p * np.abs(Phi_o).max()
 
 
 @pytest.mark.parametrize("pp", [1.0, 2.0, 1.5, 0.0])

@@ -11,13 +11,14 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>
 tail -3 "$OUT/pytest_gpu.log"
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null > "$OUT/bench_c2_driver.json"; last "$OUT/bench_c2_driver.json"
 python bench.py --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_200.json"; last "$OUT/bench_c2_200.json"
-python bench.py --workload hbm --ndim 12 --segments 1048576 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_hbm.json"; last "$OUT/bench_hbm.json"
+python bench.py --workload hbm --ndim 12 --segments 1048576 --no-cpu-baseline --live-traffic on --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_hbm.json"; last "$OUT/bench_hbm.json"
 python bench.py --workload c3 --cpu-seconds 5 2>/dev/null > "$OUT/bench_c3.json"; last "$OUT/bench_c3.json"
 python bench.py --ndim 12 --method dop853 --no-cpu-baseline --steps 50 2>/dev/null > "$OUT/bench_c2_dop853.json"; last "$OUT/bench_c2_dop853.json"
 python bench.py --ndim 12 --method rkf78 --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_rkf78x4.json"; last "$OUT/bench_c2_rkf78x4.json"
 python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_c4.json"; last "$OUT/bench_c4.json"
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_c5.json"; last "$OUT/bench_c5.json"
 python bench.py --workload c5_stm --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null > "$OUT/bench_c5_stm.json"; last "$OUT/bench_c5_stm.json"
+python bench.py --workload newton --cpu-seconds 6 2>/dev/null > "$OUT/bench_newton.json"; last "$OUT/bench_newton.json"
 # kernel traces + stats.  The device ramps its clocks over the first ~300 contract launches (91 -> 79 us per launch): the c2
 # and c3 traces time enough steps (4 000 / 2 000) for the average over ALL launches of the trace to be the ramped duration.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2" -- python bench.py --steps 4000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2.log" 2>&1
@@ -26,6 +27,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c4" -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_dop853" -- python bench.py --ndim 12 --method dop853 --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2_dop853.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5_stm" -- python bench.py --workload c5_stm --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_c5_stm.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5" -- python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_c5.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_newton" -- python bench.py --workload newton --pmc-child --steps 100 --warmup 5 > "$OUT/prof_newton.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_hbm" -- python bench.py --workload hbm --ndim 12 --segments 1048576 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_hbm.log" 2>&1
 # PMC passes for EVERY workload that has a roofline row, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one
 # pass; the program itself right after `--`).  Layout: $OUT/<key>/pmc_{fetch,write,sq}; key = bench.py's pmc_key().
 pmc_passes() {   # pmc_passes <key> <bench.py arguments...>
@@ -41,6 +44,8 @@ pmc_passes c4 --workload c4
 pmc_passes c5 --workload c5
 pmc_passes c5_stm --workload c5_stm
 pmc_passes c2_ndim12_dop853 --ndim 12 --method dop853
+pmc_passes hbm_ndim12 --workload hbm --ndim 12 --segments 1048576
+pmc_passes newton --workload newton --pmc-child      # the Newton iteration's kernels: k_bvp_chunk / _tail / _backchunk, the sweeps, the norms
 find "$OUT" -name "*.csv" | wc -l
 # condense into profiles/ (tag = $1):
 #   python tools/summarize_profile.py $OUT <tag> c2 "k_indirect_pipe8<14"
@@ -50,3 +55,5 @@ find "$OUT" -name "*.csv" | wc -l
 #   python tools/summarize_profile.py $OUT <tag> c5 "k_indirect_defect4"
 #   python tools/summarize_profile.py $OUT <tag> c5_stm "k_indirect_coop2"
 #   python tools/summarize_profile.py $OUT <tag> c2_ndim12_dop853 "k_indirect_coop2" c2_dop853
+#   python tools/summarize_profile.py $OUT <tag> hbm_ndim12 "k_indirect<12"
+#   python tools/summarize_profile.py $OUT <tag> newton_bvp_chunk "k_bvp_chunk<12, true" newton      (likewise _tail, _backchunk, _chunk_rhs)
