@@ -26,7 +26,30 @@ struct IndirectArgs {
   double stm_scale;                // 3^-(steps mod 256): the DPP column lanes of the pipeline kernels carry 3^k Phi (pipe_common.hpp)
   double* h_first;                 // [S] or null: step size of the segment's first ACCEPTED trial step (written by the two-lane adaptive kernels)
   int warm;                        // 1: start every segment from h_first (the previous sweep of this kind) instead of Hairer's rule
+  // Record staging of rebalanced sweeps (round 4; kernels_indirect_coop2.hip, kernels_indirect_defect2.hip): with a balanced lane
+  // order neighbouring lanes hold unrelated segments, and every element of the struct-of-arrays operands is an 8-byte access to
+  // its own cache line (5 - 8 x the algorithmic traffic).  When these are set the kernel reads a node as ONE record
+  //   Xa[node * NODE_REC + c], c < 12;  Xa[node * NODE_REC + 12] = the node's time
+  // and writes a segment's results as records  Da[s * 12 + c],  Pa[s * 144 + col * 12 + row];  the plan converts between the
+  // caller's arrays and the records with coalesced transposes before / after the sweep (lto_api.hip).  Null: the arrays above.
+  const double* Xa;
+  double* Da;
+  double* Pa;
 };
+constexpr int NODE_REC = 16;       // doubles per node record: 12 components, the time, padding to 128 bytes
+// operand access of the kernels that support record staging
+__device__ __forceinline__ double arg_node(const IndirectArgs& a, const int c, const long node) {
+  return a.Xa ? a.Xa[node * NODE_REC + c] : a.X[c * a.ldx + node];
+}
+__device__ __forceinline__ double arg_span(const IndirectArgs& a, const long node, const long tg) {
+  return a.Xa ? a.Xa[(node + 1) * NODE_REC + 12] - a.Xa[node * NODE_REC + 12] : a.t[tg + 1] - a.t[tg];
+}
+__device__ __forceinline__ void put_defect(const IndirectArgs& a, const int c, const int s, const double v) {
+  if (a.Da) a.Da[(long)s * 12 + c] = v; else a.defect[c * a.ldd + s] = v;
+}
+__device__ __forceinline__ void put_phi(const IndirectArgs& a, const int col, const int row, const int s, const double v) {
+  if (a.Pa) a.Pa[(long)s * 144 + col * 12 + row] = v; else a.Phi[(long)(col * 12 + row) * a.ldp + s] = v;
+}
 
 struct DirectArgs {
   const double* X; long ldx;       // [nstate][ldx]
@@ -91,6 +114,8 @@ hipError_t launch_pack_soa2(const double* aos_a, int ndim_a, long count_a, doubl
 hipError_t launch_unpack_soa2(const double* soa_a, long ld_a, int ndim_a, long count_a, double* aos_a, const double* soa_b, long ld_b,
                               int ndim_b, long count_b, double* aos_b, hipStream_t st);
 constexpr int LTO_ORDER_BINS = 1024;   // int workspace launch_segment_order needs
+// node records for the staged sweeps: Xa[j][0..11] = X[c][j], Xa[j][12] = the node's time (t[b * t_stride + k], j = b n_nodes + k)
+hipError_t launch_node_records(const double* X, long ldx, const double* t, int t_stride, int n_nodes, long J, double* Xa, hipStream_t st);
 hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bins, int* order, hipStream_t st);
 hipError_t launch_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, int na, const double* alphas,
                                double* Xt, long ldt, hipStream_t st);

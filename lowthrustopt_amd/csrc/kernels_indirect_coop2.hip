@@ -98,7 +98,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   const int i = s - traj * a.seg_per_traj;
   const long node = (long)traj * a.n_nodes + i;
   const long tg = (long)traj * a.t_stride + i;
-  const double span = a.t[tg + 1] - a.t[tg];
+  const double span = arg_span(a, node, tg);
   const TrajParams tp = a.tp[(long)traj * a.tp_stride];
   const double w2 = 2.0 * tp.omega;
   const bool mine = !a.class_filter || p_class(tp.p) == PM;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   double y[NC], K[13][NC];
   if (BASE) {
 #pragma unroll
-    for (int j = 0; j < NC; ++j) y[j] = a.X[grow[j] * a.ldx + node];
+    for (int j = 0; j < NC; ++j) y[j] = arg_node(a, grow[j], node);
   } else {
 #pragma unroll
     for (int j = 0; j < NC; ++j) y[j] = (grow[j] == col) ? 1.0 : 0.0;
@@ -451,9 +451,9 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
 
   if (in_range && mine) {
     if (BASE) {
-      if (a.defect) {
+      if (a.defect || a.Da) {
 #pragma unroll
-        for (int j = 0; j < NC; ++j) a.defect[grow[j] * a.ldd + s] = y[j] - a.X[grow[j] * a.ldx + node + 1];
+        for (int j = 0; j < NC; ++j) put_defect(a, grow[j], s, y[j] - arg_node(a, grow[j], node + 1));
       }
       if (q4 == 0) {
         if (a.errors) a.errors[s] = 0.0;
@@ -463,7 +463,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NC; ++j) a.Phi[(long)(col * 12 + grow[j]) * a.ldp + s] = y[j];
+      for (int j = 0; j < NC; ++j) put_phi(a, col, grow[j], s, y[j]);
     }
   }
 }

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
   const int i = s - traj * a.seg_per_traj;
   const long node = (long)traj * a.n_nodes + i;
   const long tg = (long)traj * a.t_stride + i;
-  const double span = a.t[tg + 1] - a.t[tg];
+  const double span = arg_span(a, node, tg);
   const TrajParams tp = a.tp[(long)traj * a.tp_stride];
   if (a.class_filter && p_class(tp.p) != PM) return;                   // mixed-class batch: another launch owns this trajectory
   const double w2 = 2.0 * tp.omega;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
 
   double y[6], K[13][6];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) y[j] = a.X[grow[j] * a.ldx + node];
+  for (int j = 0; j < 6; ++j) y[j] = arg_node(a, grow[j], node);
 
   auto rhs = [&](const double (&arg)[6], double (&out)[6]) {
     double R[3], L[3], q[3], kp[3], kq[3];
@@ -178,9 +178,9 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
     for (int j = 0; j < 6; ++j) y[j] = __builtin_nan("");
   }
 
-  if (a.defect) {
+  if (a.defect || a.Da) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) a.defect[grow[j] * a.ldd + s] = y[j] - a.X[grow[j] * a.ldx + node + 1];
+    for (int j = 0; j < 6; ++j) put_defect(a, grow[j], s, y[j] - arg_node(a, grow[j], node + 1));
   }
   if (is_a) {
     if (a.errors) a.errors[s] = 0.0;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
   const int i = s - traj * a.seg_per_traj;
   const long node = (long)traj * a.n_nodes + i;
   const long tg = (long)traj * a.t_stride + i;
-  const double span = a.t[tg + 1] - a.t[tg];
+  const double span = arg_span(a, node, tg);
   const TrajParams tp = a.tp[(long)traj * a.tp_stride];
   if (a.class_filter && p_class(tp.p) != PM) return;                   // mixed-class batch: another launch owns this trajectory
   const QuadLane Q = quad_lane(q4, tp);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
 
   double y[3], K[13][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) y[j] = a.X[(row0 + j) * a.ldx + node];
+  for (int j = 0; j < 3; ++j) y[j] = arg_node(a, row0 + j, node);
 
   auto rhs = [&](const double (&arg)[3], double (&out)[3]) {
     QuadParts bp;
@@ -355,9 +355,9 @@ __global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
     for (int j = 0; j < 3; ++j) y[j] = __builtin_nan("");
   }
 
-  if (a.defect) {
+  if (a.defect || a.Da) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) a.defect[(row0 + j) * a.ldd + s] = y[j] - a.X[(row0 + j) * a.ldx + node + 1];
+    for (int j = 0; j < 3; ++j) put_defect(a, row0 + j, s, y[j] - arg_node(a, row0 + j, node + 1));
   }
   if (q4 == 0) {
     if (a.errors) a.errors[s] = 0.0;

@@ -71,14 +71,19 @@ __device__ __forceinline__ void pipe48_role_base(const IndirectArgs& a, const Pi
     }
     __syncthreads();
   }
+  // (the segment's index and node pass through an empty asm: the compiler otherwise forms the ND addresses of x_{i+1} next to those
+  // of x_i before the loop and parks them across it -- 20 spilled dwords in a kernel that runs at 128 registers per lane)
+  int s_e = L.s;
+  long node_e = L.node;
+  asm volatile("" : "+v"(s_e), "+v"(node_e));
   if (L.in_range && live) {
     if (a.defect) {
 #pragma unroll
-      for (int c = 0; c < ND; ++c) a.defect[c * a.ldd + L.s] = y[c] - a.X[c * a.ldx + L.node + 1];
+      for (int c = 0; c < ND; ++c) a.defect[c * a.ldd + s_e] = y[c] - a.X[c * a.ldx + node_e + 1];
     }
-    if (a.errors) a.errors[L.s] = 0.0;
-    if (a.nacc) a.nacc[L.s] = steps;
-    if (a.nrej) a.nrej[L.s] = 0;
+    if (a.errors) a.errors[s_e] = 0.0;
+    if (a.nacc) a.nacc[s_e] = steps;
+    if (a.nrej) a.nrej[s_e] = 0;
   }
 }
 

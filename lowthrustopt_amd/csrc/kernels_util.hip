@@ -260,6 +260,33 @@ hipError_t launch_end_states(double* X, long ld, int n, int nb, int nrow, double
   return hipGetLastError();
 }
 
+// Node records of the staged (rebalanced) adaptive sweeps: 64 nodes per workgroup through an LDS tile, unit stride on both sides.
+__global__ __launch_bounds__(256) void k_node_records(const double* __restrict__ X, long ldx, const double* __restrict__ t, int t_stride,
+                                                      int n_nodes, long J, double* __restrict__ Xa) {
+  __shared__ double tile[64][NODE_REC + 1];
+  const long j0 = (long)blockIdx.x * 64;
+  for (int q = threadIdx.x; q < 64 * 13; q += 256) {
+    const int c = q >> 6, i = q & 63;
+    const long j = j0 + i;
+    double v = 0.0;
+    if (j < J) {
+      if (c < 12) v = X[c * ldx + j];
+      else { const long b = j / n_nodes; v = t[b * t_stride + (j - b * n_nodes)]; }
+    }
+    tile[i][c] = v;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 64 * NODE_REC; q += 256) {
+    const int i = q / NODE_REC, c = q % NODE_REC;
+    if (j0 + i < J) Xa[(j0 + i) * NODE_REC + c] = (c < 13) ? tile[i][c] : 0.0;
+  }
+}
+hipError_t launch_node_records(const double* X, long ldx, const double* t, int t_stride, int n_nodes, long J, double* Xa, hipStream_t st) {
+  if (J <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_node_records, dim3((unsigned)((J + 63) / 64)), dim3(256), 0, st, X, ldx, t, t_stride, n_nodes, J, Xa);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_soa(const double* aos, int ndim, long count, double* soa, long ld, hipStream_t st) {
   if (count <= 0) return hipSuccess;
   if (ndim < 1 || ndim > MAXDIM) return hipErrorInvalidValue;

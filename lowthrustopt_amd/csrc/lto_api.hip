@@ -94,6 +94,10 @@ struct lto_indirect_plan {
   int defect_lanes;         // lanes per segment of the defect-only sweep with the reference's setting: 0 = choose, 1, 2, 4
   double* d_hfirst[2];      // [0] STM sweeps, [1] defect-only sweeps
   int hfirst_valid[2];
+  // record staging of rebalanced sweeps (kernels.hpp, IndirectArgs::Xa / Da / Pa): allocated with the lane order
+  double* d_xa;             // [n_nodes n_batch][NODE_REC]
+  double* d_da;             // [S][12]
+  double* d_pa;             // [S][144], on the first staged STM sweep
 };
 
 struct lto_direct_plan {
@@ -398,6 +402,9 @@ static void plan_free(lto_indirect_plan* p) {
   if (!p->order_borrowed) pool_free(p->ctx, p->d_order, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS));
   pool_free(p->ctx, p->d_bvp, p->bvp_bytes);
   for (int k = 0; k < 2; ++k) pool_free(p->ctx, p->d_hfirst[k], sizeof(double) * (size_t)p->S);
+  pool_free(p->ctx, p->d_xa, sizeof(double) * NODE_REC * (size_t)p->n_nodes * p->n_batch);
+  pool_free(p->ctx, p->d_da, sizeof(double) * 12 * (size_t)p->S);
+  pool_free(p->ctx, p->d_pa, sizeof(double) * 144 * (size_t)p->S);
   delete p;
 }
 
@@ -419,6 +426,20 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* p, void* stream, int* accept
   return LTO_OK;
 }
 
+// Record staging (12-dim plans with the reference's integrator setting): the buffers come with the lane order, outside any sweep.
+static bool stage_capable(const lto_indirect_plan* p) { return p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE; }
+static int stage_alloc(lto_indirect_plan* p) {
+  if (!stage_capable(p)) return LTO_OK;
+  lto_ctx* c = p->ctx;
+  struct { double** ptr; size_t n; } want[3] = {{&p->d_xa, (size_t)NODE_REC * p->n_nodes * p->n_batch}, {&p->d_da, (size_t)12 * p->S}, {&p->d_pa, (size_t)144 * p->S}};
+  for (auto& w : want) {
+    if (*w.ptr) continue;
+    hipError_t e = pool_alloc(c, (void**)w.ptr, sizeof(double) * w.n);
+    if (e != hipSuccess) { *w.ptr = nullptr; (void)hipGetLastError(); return LTO_OK; }     // no staging: the sweeps gather from the caller's arrays as before
+  }
+  return LTO_OK;
+}
+
 int lto_indirect_plan_rebalance(lto_indirect_plan* p, void* stream) {
   if (!p) return LTO_ENULL;
   lto_ctx* c = p->ctx;
@@ -433,7 +454,7 @@ int lto_indirect_plan_rebalance(lto_indirect_plan* p, void* stream) {
   hipError_t e = launch_segment_order(p->d_nacc, p->d_nrej, p->S, p->d_order + p->S, p->d_order, (hipStream_t)stream);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_segment_order", e);
   p->use_order = 1;
-  return LTO_OK;
+  return stage_alloc(p);
 }
 
 int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
@@ -561,10 +582,18 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   }
   rc = warm_args(p, 1, lanes > 1, &a);
   if (rc) return rc;
+  // balanced lane order: nodes in, defects out as records (IndirectArgs::Xa / Da), coalesced transposes either side of the sweep
+  const bool staged = a.order && lanes > 1 && p->d_xa && p->d_da;
+  if (staged) {
+    hipError_t q = launch_node_records(X, ldx, t, a.t_stride, p->n_nodes, (long)p->n_nodes * p->n_batch, p->d_xa, st);
+    if (q != hipSuccess) return set_err(c, LTO_EHIP, "launch_node_records", q);
+    a.Xa = p->d_xa; a.Da = p->d_da;
+  }
   hipError_t e = lanes == 4        ? launch_indirect_defect4(p->pm, a, st)
                  : lanes == 2      ? launch_indirect_defect2(p->pm, a, st)
                  : (p->ndim == 12) ? launch_indirect_defect(p->pm, p->integ.method, a, st)
                                    : launch_indirect14_defect(p->pm, p->integ.method, a, st);
+  if (e == hipSuccess && staged) e = launch_pack_soa(p->d_da, 12, p->S, defect, ldd, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_defect", e);
   warm_filled(p, 1, a);
@@ -613,6 +642,13 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   p->last_kernel = kern;
   rc = warm_args(p, 0, kern == LTO_KERNEL_COOP2, &a);
   if (rc) return rc;
+  const bool staged = a.order && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && p->d_pa;
+  if (staged) {
+    hipError_t q = launch_node_records(X, ldx, t, a.t_stride, p->n_nodes, (long)p->n_nodes * p->n_batch, p->d_xa, st);
+    if (q != hipSuccess) return set_err(c, LTO_EHIP, "launch_node_records", q);
+    a.Xa = p->d_xa; a.Pa = p->d_pa;
+    if (a.defect) a.Da = p->d_da;
+  }
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
   else if (kern == LTO_KERNEL_COOP2) e = launch_indirect_stm_coop2(p->pm, a, st);
@@ -620,6 +656,8 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, st);
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
+  if (e == hipSuccess && staged) e = launch_pack_soa(p->d_pa, 144, p->S, a.Phi, a.ldp, st);
+  if (e == hipSuccess && staged && a.Da) e = launch_pack_soa(p->d_da, 12, p->S, a.defect, a.ldd, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
   warm_filled(p, 0, a);
@@ -686,6 +724,7 @@ static void host_order_adopt(lto_ctx* c, lto_indirect_plan* p, bool stm) {
   if (p->order_borrowed) { p->d_order = nullptr; p->use_order = 0; p->order_borrowed = 0; }   // cached plan: the context's order may have moved
   if (!host_order_wanted(p, stm) || !c->order_cache || c->order_S != p->S || c->order_ndim != p->ndim) return;
   p->d_order = c->order_cache; p->order_borrowed = 1; p->use_order = 1;
+  (void)stage_alloc(p);
 }
 
 static void host_order_refresh(lto_ctx* c, lto_indirect_plan* p, bool stm, hipStream_t st) {
