@@ -1,11 +1,14 @@
 #!/bin/bash
 # Standard GPU-box series: parity tests, bench lines, rocprof kernel traces + PMC passes.  Outputs -> gpurun_out/<tag>/.
+# usage: tools/gpu_round.sh <tag> [bench|prof|pmc|all]   (one gpurun call holds 20 minutes: bench + prof in one call, pmc in another)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/${1:-run}
+PART=${2:-all}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 last() { tail -1 "$1" | cut -c1-400; }
+if [ "$PART" = all ] || [ "$PART" = bench ]; then
 # progress goes straight into the log (a pipe into tail would hold it back until the end: the GPU box kills a run that stays silent for 7 minutes)
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
 tail -3 "$OUT/pytest_gpu.log"
@@ -19,6 +22,8 @@ python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/nul
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_c5.json"; last "$OUT/bench_c5.json"
 python bench.py --workload c5_stm --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null > "$OUT/bench_c5_stm.json"; last "$OUT/bench_c5_stm.json"
 python bench.py --workload newton --cpu-seconds 6 2>/dev/null > "$OUT/bench_newton.json"; last "$OUT/bench_newton.json"
+fi
+if [ "$PART" = all ] || [ "$PART" = prof ]; then
 # kernel traces + stats.  The device ramps its clocks over the first ~300 contract launches (91 -> 79 us per launch): the c2
 # and c3 traces time enough steps (4 000 / 2 000) for the average over ALL launches of the trace to be the ramped duration.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2" -- python bench.py --steps 4000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2.log" 2>&1
@@ -29,6 +34,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5_stm" -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5" -- python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_c5.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_newton" -- python bench.py --workload newton --pmc-child --steps 100 --warmup 5 > "$OUT/prof_newton.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_hbm" -- python bench.py --workload hbm --ndim 12 --segments 1048576 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_hbm.log" 2>&1
+fi
+if [ "$PART" = all ] || [ "$PART" = pmc ]; then
 # PMC passes for EVERY workload that has a roofline row, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one
 # pass; the program itself right after `--`).  Layout: $OUT/<key>/pmc_{fetch,write,sq}; key = bench.py's pmc_key().
 pmc_passes() {   # pmc_passes <key> <bench.py arguments...>
@@ -46,6 +53,7 @@ pmc_passes c5_stm --workload c5_stm
 pmc_passes c2_ndim12_dop853 --ndim 12 --method dop853
 pmc_passes hbm_ndim12 --workload hbm --ndim 12 --segments 1048576
 pmc_passes newton --workload newton --pmc-child      # the Newton iteration's kernels: k_bvp_chunk / _tail / _backchunk, the sweeps, the norms
+fi
 find "$OUT" -name "*.csv" | wc -l
 # condense into profiles/ (tag = $1):
 #   python tools/summarize_profile.py $OUT <tag> c2 "k_indirect_pipe8<14"
