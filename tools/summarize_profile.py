@@ -30,7 +30,7 @@ def rows(pattern):
 
 def main():
     run, tag, workload, kname = sys.argv[1:5]
-    src = sys.argv[5] if len(sys.argv) > 5 else workload      # prof_<src>/ holds the kernel trace (one trace, several kernels)
+    src = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else workload      # prof_<src>/ holds the kernel trace (one trace, several kernels)
     pmc_src = src if os.path.isdir(os.path.join(run, src)) else workload   # <run>/<pmc_src>/pmc_* hold the counter passes
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     # kernel stats
@@ -61,6 +61,31 @@ def main():
             summary["pmc"][k] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
     fetch_kib = summary["pmc"].get("FETCH_SIZE", {}).get("per_launch_mean")
     write_kib = summary["pmc"].get("WRITE_SIZE", {}).get("per_launch_mean")
+    # helper kernels that belong to the same sweep (argument 6: "k_node_records+k_pack"): their bytes per launch of the dominant
+    # kernel (launch counts of the same counter pass) are added -- the staged sweeps of round 4 are three kernels, not one
+    helpers = sys.argv[6].split("+") if len(sys.argv) > 6 else []
+    if helpers and fetch_kib is not None and write_kib is not None:
+        summary["helpers"] = {}
+        for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+            per = {}
+            n_dom = 0
+            for r in list(rows(os.path.join(run, sub, "**", "*_counter_collection.csv"))) + list(rows(os.path.join(run, pmc_src, sub, "**", "*_counter_collection.csv"))):
+                if r["Counter_Name"] != counter:
+                    continue
+                if kname in r["Kernel_Name"]:
+                    n_dom += 1
+                for h in helpers:
+                    if h in r["Kernel_Name"]:
+                        per.setdefault(h, []).append(float(r["Counter_Value"]))
+            for h, v in per.items():
+                add = sum(v) / max(n_dom, 1)
+                summary["helpers"].setdefault(h, {})[counter + "_kib_per_sweep"] = add
+                if counter == "FETCH_SIZE":
+                    fetch_kib += add
+                else:
+                    write_kib += add
+        summary["pmc"]["FETCH_SIZE"]["per_sweep_with_helpers"] = fetch_kib
+        summary["pmc"]["WRITE_SIZE"]["per_sweep_with_helpers"] = write_kib
     if fetch_kib is not None and write_kib is not None:
         summary["hbm_bytes_per_launch_raw"] = (fetch_kib + write_kib) * 1024.0
         summary["hbm_bytes_per_launch"] = (2.0 * fetch_kib + write_kib) * 1024.0
