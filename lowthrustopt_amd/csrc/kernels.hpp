@@ -116,6 +116,7 @@ hipError_t launch_unpack_soa2(const double* soa_a, long ld_a, int ndim_a, long c
 constexpr int LTO_ORDER_BINS = 1024;   // int workspace launch_segment_order needs
 // node records for the staged sweeps: Xa[j][0..11] = X[c][j], Xa[j][12] = the node's time (t[b * t_stride + k], j = b n_nodes + k)
 hipError_t launch_node_records(const double* X, long ldx, const double* t, int t_stride, int n_nodes, long J, double* Xa, hipStream_t st);
+hipError_t launch_step_stats(const int* nacc, const int* nrej, int S, unsigned long long* acc, long long* host_out, hipStream_t st);
 hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bins, int* order, hipStream_t st);
 hipError_t launch_trial_points(const double* X, const double* d, long ld, int ndim, int n, int nb, int na, const double* alphas,
                                double* Xt, long ldt, hipStream_t st);

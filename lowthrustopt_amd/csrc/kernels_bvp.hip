@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_bvp_chunk_rhs(BvpArgs a, const int leve
 // Last level: one row  A d_first + B d_last = r.  NU = 12: the end states are fixed, 12 x 12 system for the two
 // end-node costate updates.  NU = 6: 12 x 12 system for the costates of the first and last node.  Gaussian elimination
 // with partial pivoting: one wavefront per trajectory, lane r < 12 holds row r of the augmented 12 x 13 system in registers;
-// pivot search, row swap and elimination go through cross-lane shuffles (no scratch arrays).  `rhs` != null: the row's
+// pivot search by DPP, elimination through v_readlane (no scratch arrays, no LDS crossbar).  `rhs` != null: the row's
 // right-hand side comes from there (re-solve).
 template <int NU>
 __device__ __forceinline__ void bvp_final_one(const BvpArgs& a, const double* row, const double* rhs, const int b, const int lane) {
@@ -359,35 +359,45 @@ __device__ __forceinline__ void bvp_final_one(const BvpArgs& a, const double* ro
 #pragma unroll
   for (int c = 0; c < 6; ++c) { m[c] = row[(off + c) * 12 + r]; m[6 + c] = row[12 * NU + (off + c) * 12 + r]; }
   m[12] = rhs ? rhs[r] : row[24 * NU + r];
+  // No row ever moves (round 3 swapped rows through 13 ds_bpermute per step): a lane remembers that its row has been a pivot,
+  // the pivot row of step k is read where it sits (v_readlane with a scalar lane), and the back-substitution visits the rows
+  // in pivot order.  Pivot search: all-reduce over the 16-lane row by DPP rotations (max is idempotent), ties to the lowest row.
+  bool used = lane >= 12;
+  int pivs[12];
   bvp_static_for<0, 12>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    // partial pivoting: row with the largest |m[.][k]| among rows >= k (ties -> lowest row)
-    double best = (lane >= k && lane < 12) ? fabs(m[k]) : -1.0;
-    int piv = lane;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const double ob = __shfl_xor(best, o);
-      const int op = __shfl_xor(piv, o);
+    double best = used ? -1.0 : fabs(m[k]);
+    int piv = lane & 15;
+    auto step = [&](auto rot_c) {
+      constexpr int ctrl = 0x120 + decltype(rot_c)::value;            // row_ror:n
+      const int lo = __builtin_amdgcn_mov_dpp(__double2loint(best), ctrl, 0xF, 0xF, false);
+      const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(best), ctrl, 0xF, 0xF, false);
+      const double ob = __hiloint2double(hi, lo);
+      const int op = __builtin_amdgcn_mov_dpp(piv, ctrl, 0xF, 0xF, false);
       if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
-    }
-    piv = __builtin_amdgcn_readfirstlane(piv);  // lanes 0..15 agree after the butterfly
-    // swap rows k and piv
-    const int src = (lane == k) ? piv : (lane == piv ? k : lane);
+    };
+    step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 1>{});
+    const int pv = __builtin_amdgcn_readfirstlane(piv);               // every lane of row 0 holds the same answer
+    pivs[k] = pv;
+    auto from_piv = [&](const double x) {
+      return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), pv), __builtin_amdgcn_readlane(__double2loint(x), pv));
+    };
+    const double pk = from_piv(m[k]);
+    const double f = (!used && lane != pv) ? m[k] * rcp_nr(pk) : 0.0;
 #pragma unroll
-    for (int c = 0; c < 13; ++c) m[c] = __shfl(m[c], src);
-    const double pk = lane_bcast<k>(m[k]);
-    const double f = (lane > k && lane < 12) ? m[k] * rcp_nr(pk) : 0.0;
-#pragma unroll
-    for (int c = k + 1; c < 13; ++c) m[c] = __builtin_fma(-f, lane_bcast<k>(m[c]), m[c]);
+    for (int c = k + 1; c < 13; ++c) m[c] = __builtin_fma(-f, from_piv(m[c]), m[c]);
+    used = used || (lane == pv);
   });
-  // back substitution: x[k] = (m[k][12] - sum_{c>k} m[k][c] x[c]) / m[k][k], broadcast as it is formed
+  // back substitution in pivot order: x[k] from the row that was the pivot of column k, broadcast as it is formed
   double x[12];
   bvp_static_for<0, 12>([&](auto kc) {
     constexpr int k = 11 - decltype(kc)::value;
     double sacc = m[12];
 #pragma unroll
     for (int c = k + 1; c < 12; ++c) sacc = __builtin_fma(-m[c], x[c], sacc);
-    x[k] = lane_bcast<k>(sacc / m[k]);
+    const double q = sacc / m[k];
+    x[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), pivs[k]), __builtin_amdgcn_readlane(__double2loint(q), pivs[k]));
   });
   if (lane == 0) {
     const long n0 = (long)b * a.n_nodes, n1 = n0 + a.n_nodes - 1;

@@ -260,6 +260,54 @@ hipError_t launch_end_states(double* X, long ld, int n, int nb, int nrow, double
   return hipGetLastError();
 }
 
+// Sum and maximum of the trial steps of the last adaptive sweep, straight into page-locked host memory (no copy, no
+// synchronisation): the plan's NEXT defect sweep reads them -- whatever has arrived by then -- to tell a workload whose segments
+// all take about the same number of steps (throughput-bound: fewer lanes per segment) from one with a long tail (the slowest
+// segment sets the time: more lanes per segment).  acc[0] = sum, acc[1] = max, acc[2] = blocks done (device scratch, left zeroed).
+__global__ __launch_bounds__(1024) void k_step_stats(const int* __restrict__ nacc, const int* __restrict__ nrej, int S, unsigned long long* acc,
+                                                     volatile long long* host_out) {
+  long long sum = 0;
+  int mx = 0;
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < S; i += gridDim.x * 1024) {
+    const int k = nacc[i] + nrej[i];
+    sum += k;
+    mx = k > mx ? k : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o);
+    const int om = __shfl_xor(mx, o);
+    mx = om > mx ? om : mx;
+  }
+  __shared__ long long s_sum[16];
+  __shared__ int s_mx[16];
+  if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_mx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {               // one pair of atomics per block (1 024 contended atomics on two addresses took ~30 us)
+    long long bs = 0;
+    int bm = 0;
+    for (int k = 0; k < 16; ++k) { bs += s_sum[k]; bm = s_mx[k] > bm ? s_mx[k] : bm; }
+    atomicAdd(&acc[0], (unsigned long long)bs);
+    atomicMax(&acc[1], (unsigned long long)bm);
+    __threadfence();
+    if (atomicAdd(&acc[2], 1ull) + 1ull == gridDim.x) {            // last block: publish and reset
+      __threadfence();
+      const unsigned long long s = atomicExch(&acc[0], 0ull), m = atomicExch(&acc[1], 0ull);
+      acc[2] = 0ull;
+      host_out[1] = (long long)m;
+      host_out[2] = (long long)S;
+      __threadfence_system();
+      host_out[0] = (long long)s;                                   // the sum last: a reader that sees it sees a whole record
+    }
+  }
+}
+hipError_t launch_step_stats(const int* nacc, const int* nrej, int S, unsigned long long* acc, long long* host_out, hipStream_t st) {
+  if (S <= 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((S + 4095) / 4096 > 64 ? 64 : (S + 4095) / 4096);
+  hipLaunchKernelGGL(k_step_stats, dim3(blocks), dim3(1024), 0, st, nacc, nrej, S, acc, (volatile long long*)host_out);
+  return hipGetLastError();
+}
+
 // Node records of the staged (rebalanced) adaptive sweeps: 64 nodes per workgroup through an LDS tile, unit stride on both sides.
 __global__ __launch_bounds__(256) void k_node_records(const double* __restrict__ X, long ldx, const double* __restrict__ t, int t_stride,
                                                       int n_nodes, long J, double* __restrict__ Xa) {

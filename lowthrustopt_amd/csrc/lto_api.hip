@@ -95,6 +95,11 @@ struct lto_indirect_plan {
   double* d_hfirst[2];      // [0] STM sweeps, [1] defect-only sweeps
   int hfirst_valid[2];
   // record staging of rebalanced sweeps (kernels.hpp, IndirectArgs::Xa / Da / Pa): allocated with the lane order
+  // trial-step statistics of the last defect-only sweep (k_step_stats): [sum, max, S] in page-locked host memory the kernel writes
+  long long* h_stats;       // host view (nullptr: not available)
+  long long* h_stats_dev;   // device view of the same block
+  unsigned long long* d_stats_acc;   // [3] device scratch
+  int stats_age;            // qualifying sweeps so far
   double* d_xa;             // [n_nodes n_batch][NODE_REC]
   double* d_da;             // [S][12]
   double* d_pa;             // [S][144], on the first staged STM sweep
@@ -402,6 +407,8 @@ static void plan_free(lto_indirect_plan* p) {
   if (!p->order_borrowed) pool_free(p->ctx, p->d_order, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS));
   pool_free(p->ctx, p->d_bvp, p->bvp_bytes);
   for (int k = 0; k < 2; ++k) pool_free(p->ctx, p->d_hfirst[k], sizeof(double) * (size_t)p->S);
+  if (p->h_stats) (void)hipHostFree(p->h_stats);
+  pool_free(p->ctx, p->d_stats_acc, sizeof(unsigned long long) * 4);
   pool_free(p->ctx, p->d_xa, sizeof(double) * NODE_REC * (size_t)p->n_nodes * p->n_batch);
   pool_free(p->ctx, p->d_da, sizeof(double) * 12 * (size_t)p->S);
   pool_free(p->ctx, p->d_pa, sizeof(double) * 144 * (size_t)p->S);
@@ -578,7 +585,19 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   if (ref_setting) {
     if (p->defect_lanes) lanes = p->defect_lanes;
     else if (p->kernel == LTO_KERNEL_COOP2) lanes = 2;
-    else if (p->kernel == LTO_KERNEL_AUTO) lanes = ((long)(p->S + 15) / 16 <= 32L * c->cu_count) ? 4 : (p->S <= 262144 ? 2 : 1);
+    else if (p->kernel == LTO_KERNEL_AUTO) {
+      lanes = ((long)(p->S + 15) / 16 <= 32L * c->cu_count) ? 4 : (p->S <= 262144 ? 2 : 1);
+      // Those thresholds come from the C5 study, where the slowest segment takes 8 x the mean number of trial steps and sets the
+      // sweep's time: more lanes per segment = a shorter stream for it.  A sweep whose segments all take about the same number
+      // of steps (the 20 trial trajectories of a line search) is throughput-bound once the chip is full, and fewer lanes per
+      // segment issue fewer instructions per segment (tools/probe_linesearch_lanes.py, 20 x 4 096 segments: 166 / 147 / 124 us
+      // with 4 / 2 / 1 lanes; 20 x 1 024: 73 / 61 / 94).  The previous sweep's statistics say which case this is.
+      if (p->h_stats && p->S >= 64L * c->cu_count) {
+        const long long sum = ((volatile long long*)p->h_stats)[0], mx = ((volatile long long*)p->h_stats)[1], cnt = ((volatile long long*)p->h_stats)[2];
+        if (cnt == p->S && sum > 0 && mx * (long long)p->S <= 3 * sum)        // max <= 3 x mean: no tail worth shortening
+          lanes = (p->S <= 160L * c->cu_count) ? 2 : 1;
+      }
+    }
   }
   rc = warm_args(p, 1, lanes > 1, &a);
   if (rc) return rc;
@@ -597,6 +616,25 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_defect", e);
   warm_filled(p, 1, a);
+  if (ref_setting && p->kernel == LTO_KERNEL_AUTO && !p->defect_lanes && p->S >= 64L * c->cu_count) {
+    // statistics for the next sweep's choice (a few us, stream-ordered, written by the kernel itself into page-locked memory)
+    if (!p->h_stats) {
+      void* hp = nullptr; void* dp = nullptr;
+      if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess &&
+          pool_alloc(c, (void**)&p->d_stats_acc, sizeof(unsigned long long) * 4) == hipSuccess &&
+          hipMemset(p->d_stats_acc, 0, sizeof(unsigned long long) * 4) == hipSuccess) {
+        std::memset(hp, 0, 64);
+        p->h_stats = (long long*)hp; p->h_stats_dev = (long long*)dp;
+      } else {
+        (void)hipGetLastError();
+        if (hp) (void)hipHostFree(hp);
+        p->h_stats = nullptr;
+      }
+    }
+    // not after every sweep (the extra launch and its host write cost ~10 us): after the first two, then every sixteenth
+    const int age = p->stats_age++;
+    if (p->h_stats && (age < 2 || (age & 15) == 0)) (void)launch_step_stats(p->d_nacc, p->d_nrej, p->S, p->d_stats_acc, p->h_stats_dev, st);
+  }
   p->swept = 1;
   return LTO_OK;
 }
