@@ -562,12 +562,16 @@ class NewtonIteration:
             e1.record()
             e1.synchronize()
             split[name] = e0.elapsed_time(e1) / split_reps * 1e3
+        self.plan.jacobian(self.X, self.n, self.t, 1, self.Phi, self.S, self.d, self.S, stream=self.st)      # the counters hold the LAST sweep's steps
         acc, rej = self.plan.step_counts(stream=self.st)
+        self.plan.defect(self.X, self.n, self.t, 1, self.d2, self.S, stream=self.st)
+        acc_d, rej_d = self.plan.step_counts(stream=self.st)
         finite = bool(torch.isfinite(self.d3).all() and torch.isfinite(self.dt).all() and torch.isfinite(self.delta).all())
         return {"segments": self.S, "us_per_iteration": us, "us_per_iteration_without_host_reads": us_nosync,
                 "split_us": {k: round(v, 2) for k, v in split.items()}, "split_sum_us": round(sum(split.values()), 1),
                 "stm_kernel": self.plan.last_kernel(), "finite": finite, "problem": self.problem,
                 "trial_steps_per_segment_stm_sweep": {"mean": float((acc + rej).mean()), "max": int((acc + rej).max())},
+                "trial_steps_per_segment_defect_sweep": {"mean": float((acc_d + rej_d).mean()), "max": int((acc_d + rej_d).max())},
                 "max_dx": float(self.mx2.item()), "max_defect_after": float(self.mx.item())}
 
     def close(self):

@@ -158,49 +158,45 @@ __device__ __forceinline__ void bvp_reflect_store(double (&col)[24], const int c
   using D = BvpDims<NU>;
   bvp_static_for<0, D::NK>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    // reflector from column k (computed in every lane, only lane k's is used)
-    // (four partial sums: the 23-term chain is otherwise the longest dependent stretch of the reflection; reciprocal and
-    // reciprocal square root by Newton refinement of the hardware seeds, ~1 ulp, instead of the IEEE sequences: ~20 against
-    // ~100 dependent instructions per reflection, twelve reflections per pair)
+    // Reflection k: H = I - g v v^T with v = (alpha - beta, x_{k+1}, ..., x_23) taken from lane k's column AS IT IS, beta =
+    // -sign(alpha) |(alpha, x)|, g = 1 / (beta (beta - alpha)).  Round 4: the reflector is not normalised (nobody stores it any
+    // more -- the record keeps R and the explicit Q^T), so lane k's column is broadcast first (v_readlane, overlapping the norm's
+    // chain), every lane forms the same norm and g from the broadcast values (one reciprocal square root and ONE reciprocal by
+    // Newton refinement of the hardware seeds, ~1 ulp), and the 23 scaling multiplications and the broadcast of tau are gone:
+    // ~130 instead of ~165 instructions per reflection, twelve (eighteen) reflections per pair.
+    double x[24];
+#pragma unroll
+    for (int r = k + 1; r < 24; ++r) x[r] = lane_bcast<k>(col[r]);
+    const double alpha = lane_bcast<k>(col[k]);
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
 #pragma unroll
     for (int r = k + 1; r < 24; ++r) {
-      if (((r - k - 1) & 3) == 0) q0 = __builtin_fma(col[r], col[r], q0);
-      else if (((r - k - 1) & 3) == 1) q1 = __builtin_fma(col[r], col[r], q1);
-      else if (((r - k - 1) & 3) == 2) q2 = __builtin_fma(col[r], col[r], q2);
-      else q3 = __builtin_fma(col[r], col[r], q3);
+      if (((r - k - 1) & 3) == 0) q0 = __builtin_fma(x[r], x[r], q0);
+      else if (((r - k - 1) & 3) == 1) q1 = __builtin_fma(x[r], x[r], q1);
+      else if (((r - k - 1) & 3) == 2) q2 = __builtin_fma(x[r], x[r], q2);
+      else q3 = __builtin_fma(x[r], x[r], q3);
     }
     const double xn2 = (q0 + q1) + (q2 + q3);
-    const double alpha = col[k];
+    const bool trivial = (xn2 == 0.0);                 // nothing below the diagonal: H = I
     const double n2 = __builtin_fma(alpha, alpha, xn2);
-    const bool trivial = (xn2 == 0.0);
-    const double nrm = trivial ? fabs(alpha) : n2 * rsqrt_nr(n2);
+    const double nrm = n2 * rsqrt_nr(n2);
     const double beta = (alpha >= 0.0) ? -nrm : nrm;
-    const double tau_k = trivial ? 0.0 : (beta - alpha) * rcp_nr(beta);
-    const double scl = trivial ? 0.0 : rcp_nr(alpha - beta);
-    if (c == k && !trivial) {
-      col[k] = beta;
-#pragma unroll
-      for (int r = k + 1; r < 24; ++r) col[r] *= scl;
-    }
-    const double tau_b = lane_bcast<k>(tau_k);
-    double v[24];
-#pragma unroll
-    for (int r = k + 1; r < 24; ++r) v[r] = lane_bcast<k>(col[r]);
+    const double vk = alpha - beta;
+    const double g = trivial ? 0.0 : rcp_nr(beta * (beta - alpha));
+    if (c == k && !trivial) col[k] = beta;
     if (c > k && c < D::NLANES) {
-      double w0 = col[k], w1 = 0.0, w2 = 0.0, w3 = 0.0;
+      double w0 = vk * col[k], w1 = 0.0, w2 = 0.0, w3 = 0.0;
 #pragma unroll
       for (int r = k + 1; r < 24; ++r) {
-        if (((r - k - 1) & 3) == 0) w0 = __builtin_fma(v[r], col[r], w0);
-        else if (((r - k - 1) & 3) == 1) w1 = __builtin_fma(v[r], col[r], w1);
-        else if (((r - k - 1) & 3) == 2) w2 = __builtin_fma(v[r], col[r], w2);
-        else w3 = __builtin_fma(v[r], col[r], w3);
+        if (((r - k - 1) & 3) == 0) w0 = __builtin_fma(x[r], col[r], w0);
+        else if (((r - k - 1) & 3) == 1) w1 = __builtin_fma(x[r], col[r], w1);
+        else if (((r - k - 1) & 3) == 2) w2 = __builtin_fma(x[r], col[r], w2);
+        else w3 = __builtin_fma(x[r], col[r], w3);
       }
-      double w = (w0 + w1) + (w2 + w3);
-      w *= tau_b;
-      col[k] -= w;
+      const double w = ((w0 + w1) + (w2 + w3)) * g;
+      col[k] = __builtin_fma(-w, vk, col[k]);
 #pragma unroll
-      for (int r = k + 1; r < 24; ++r) col[r] = __builtin_fma(-w, v[r], col[r]);
+      for (int r = k + 1; r < 24; ++r) col[r] = __builtin_fma(-w, x[r], col[r]);
     }
   });
   // rows 0 .. NU-1: the eliminated unknown; rows NU .. NU+11: the new block row (entries below the diagonal of a
@@ -432,10 +428,13 @@ __device__ __forceinline__ void bvp_backsub_pair16(const BvpArgs& a, int level, 
     const double dl = a.delta[(long)(off + c) * a.ldx + nb + left], dr = a.delta[(long)(off + c) * a.ldx + nb + right];
     s -= rec[D::REC_CA + c * NU + rr] * dl + rec[D::REC_CB + c * NU + rr] * dr;
   }
+  // the reciprocal of this lane's diagonal entry up front (hardware seed + Newton step, ~1 ulp), so that a step of the dependent
+  // chain is one multiplication, one broadcast and one FMA instead of an IEEE division sequence of ~30 instructions
+  const double rdiag = rcp_nr(rec[D::REC_R + rr * NU + rr]);
   double x = 0.0;
   bvp_static_for<0, NU>([&](auto kc) {
     constexpr int k = NU - 1 - decltype(kc)::value;
-    const double xk = row_bcast<k>(s / rec[D::REC_R + k * NU + k]);       // lane k of the group holds the finished s_k
+    const double xk = row_bcast<k>(s * rdiag);                            // lane k of the group holds the finished s_k
     if (rr == k) x = xk;
     s = __builtin_fma(-rec[D::REC_R + k * NU + (rr < k ? rr : 0)], (rr < k) ? xk : 0.0, s);
   });
