@@ -374,6 +374,21 @@ static int plan_build(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_
     plan_free(p);
     return set_err(c, LTO_EHIP, "plan allocation", e);
   }
+  // Page-locked landing place of the trial-step statistics that steer AUTO's lanes per segment (lto_indirect_defect_dev): here, not
+  // in the first sweep that wants it -- a sweep may be inside a caller's graph capture, where nothing may be allocated.
+  if (ndim == 12 && integ->method == LTO_DOP853_ADAPTIVE && p->S >= 64L * c->cu_count) {
+    void* hp = nullptr; void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess &&
+        pool_alloc(c, (void**)&p->d_stats_acc, sizeof(unsigned long long) * 4) == hipSuccess &&
+        hipMemset(p->d_stats_acc, 0, sizeof(unsigned long long) * 4) == hipSuccess) {
+      std::memset(hp, 0, 64);
+      p->h_stats = (long long*)hp; p->h_stats_dev = (long long*)dp;
+    } else {                       // no statistics: AUTO keeps its size thresholds
+      (void)hipGetLastError();
+      if (hp) (void)hipHostFree(hp);
+      p->h_stats = nullptr;
+    }
+  }
   *out = p;
   return LTO_OK;
 }
@@ -618,19 +633,6 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   warm_filled(p, 1, a);
   if (ref_setting && p->kernel == LTO_KERNEL_AUTO && !p->defect_lanes && p->S >= 64L * c->cu_count) {
     // statistics for the next sweep's choice (a few us, stream-ordered, written by the kernel itself into page-locked memory)
-    if (!p->h_stats) {
-      void* hp = nullptr; void* dp = nullptr;
-      if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess &&
-          pool_alloc(c, (void**)&p->d_stats_acc, sizeof(unsigned long long) * 4) == hipSuccess &&
-          hipMemset(p->d_stats_acc, 0, sizeof(unsigned long long) * 4) == hipSuccess) {
-        std::memset(hp, 0, 64);
-        p->h_stats = (long long*)hp; p->h_stats_dev = (long long*)dp;
-      } else {
-        (void)hipGetLastError();
-        if (hp) (void)hipHostFree(hp);
-        p->h_stats = nullptr;
-      }
-    }
     // not after every sweep (the extra launch and its host write cost ~10 us): after the first two, then every sixteenth
     const int age = p->stats_age++;
     if (p->h_stats && (age < 2 || (age & 15) == 0)) (void)launch_step_stats(p->d_nacc, p->d_nrej, p->S, p->d_stats_acc, p->h_stats_dev, st);
