@@ -1452,3 +1452,46 @@ def test_indirect_auto_kernel_choice(gpu_ctx):
         torch.cuda.synchronize()
         assert plan.last_kernel() == want, (ndim, n, method, steps, plan.last_kernel())
         assert bool(torch.isfinite(Phi).all())
+
+
+def test_rebalanced_auto_sweeps_with_record_staging_are_bit_identical(gpu_ctx):
+    """AUTO on a 12-dim DOP853 plan after lto_indirect_plan_rebalance: the two- / four-lane defect kernels and the two-lane
+    cooperative STM kernel then read node RECORDS and write defect / STM records (IndirectArgs::Xa / Da / Pa) with coalesced
+    transposes either side.  Defect, STM and step counters equal the natural-order sweeps bit for bit -- ragged sizes, three
+    trajectories with their own grids, two control-law classes (one launch per class writes its own segments' records)."""
+    import torch
+    n, B = 203, 3                                              # 606 segments: ragged against 16 and 64
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=43, dt_range=(0.02, 0.5))
+    prms = [lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0 if b != 1 else 2.0, 10.0 ** -b) for b in range(B)]
+    Xd = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    S = (n - 1) * B
+    for lanes in (0, 2):
+        plan = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator())
+        plan.set_defect_lanes(lanes)
+
+        def sweep():
+            Phi = torch.full((144, S), -3.0, dtype=torch.float64, device="cuda")
+            d = torch.full((12, S), -3.0, dtype=torch.float64, device="cuda")
+            d0 = torch.full((12, S), -3.0, dtype=torch.float64, device="cuda")
+            plan.jacobian(Xd, n * B, td, B, Phi, S, d, S)
+            cj = plan.step_counts()
+            assert plan.last_kernel() == "cooperative2"
+            plan.defect(Xd, n * B, td, B, d0, S)
+            cd = plan.step_counts()
+            torch.cuda.synchronize()
+            return Phi.cpu().numpy(), d.cpu().numpy(), d0.cpu().numpy(), cj, cd
+
+        ref = sweep()
+        assert np.all(np.isfinite(ref[0])) and ref[4][0].max() > 2 * ref[4][0].min()
+        for _ in range(2):
+            plan.rebalance()
+            out = sweep()
+            for a, b in zip(out[:3], ref[:3]):
+                assert np.array_equal(a, b)
+            for a, b in zip(out[3] + out[4], ref[3] + ref[4]):
+                assert np.array_equal(a, b)
+        plan.reset_order()
+        out = sweep()
+        assert all(np.array_equal(a, b) for a, b in zip(out[:3], ref[:3]))
+        plan.close()
