@@ -476,16 +476,22 @@ __device__ __forceinline__ void pipe8_role_columns_alt(const IndirectArgs& a, co
   double y[ND];
 #pragma unroll
   for (int r = 0; r < ND; ++r) y[r] = (r == col) ? 1.0 : 0.0;
+  // the state travels as 16-byte pairs (rows 2q, 2q + 1 of a lane side by side): seven 128-bit LDS instructions each way instead
+  // of fourteen 64-bit ones (round 4, tools/micro/lds_probe.hip: a 128-bit store costs 31 ticks of issue against 2 x 22.5, a load 18
+  // against 2 x 17.5) -- the hand-over is 10 % of a step on the two SIMDs that share this job
+  typedef double p8_d2 __attribute__((ext_vector_type(2)));
+  static_assert(ND % 2 == 0, "pairs of rows");
+  p8_d2* hand2 = reinterpret_cast<p8_d2*>(s_hand);
   auto load = [&]() {
     if (on) {
 #pragma unroll
-      for (int r = 0; r < ND; ++r) y[r] = s_hand[r * 64 + lane];
+      for (int q = 0; q < ND / 2; ++q) { const p8_d2 v = hand2[q * 64 + lane]; y[2 * q] = v.x; y[2 * q + 1] = v.y; }
     }
   };
   auto store = [&]() {
     if (on) {
 #pragma unroll
-      for (int r = 0; r < ND; ++r) s_hand[r * 64 + lane] = y[r];
+      for (int q = 0; q < ND / 2; ++q) hand2[q * 64 + lane] = p8_d2{y[2 * q], y[2 * q + 1]};
     }
   };
   if (!ODD) __builtin_amdgcn_s_setprio(2);
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   using P = Pipe8<ND, PM>;
   __shared__ double s_int[P::INT_DOUBLES];
   __shared__ double s_coef[P::COEF_DOUBLES];
-  __shared__ double s_hand[P::HAND_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double s_hand[P::HAND_DOUBLES];
   __shared__ double s_lm[4 * PIPE_SEG];
   __shared__ Pipe8Flags s_fl;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

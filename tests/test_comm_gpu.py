@@ -307,15 +307,16 @@ def _run_bench(extra_env, args, timeout=420):
     return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr[-2000:]
 
 
-def test_bench_multi_rank_path_runs_with_two_ranks_sharing_the_device():
-    """`bench.py --gpus 2` WITHOUT a launcher: it starts torch.distributed.run itself (as a child process, before touching the GPU),
-    both ranks take device 0 (LTO_BENCH_SHARE_DEVICE=1), negotiate the window transport, double-buffer the all-gather of the defect
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_path_runs_with_ranks_sharing_the_device(world):
+    """`bench.py --gpus N` WITHOUT a launcher (N = 2 and 4: the window transport with more than one peer): it starts
+    torch.distributed.run itself (as a child process, before touching the GPU), all ranks take device 0 (LTO_BENCH_SHARE_DEVICE=1), negotiate the window transport, double-buffer the all-gather of the defect
     slabs inside the timed steps, check their slabs and reduce the timing over ranks -- the code path the driver's 8-GPU run takes,
     on the one device this box has."""
-    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, ["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, ["--gpus", str(world), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
     assert rc == 0 and out is not None, err
-    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
-    assert out["config"]["global_segments"] == 2 * out["config"]["segments_per_gpu"]
+    assert out["n_gpus"] == world and out["steps"] == 5 and out["warmup"] == 2
+    assert out["config"]["global_segments"] == world * out["config"]["segments_per_gpu"]
     assert "IPC receive windows" in out["config"]["collective"]
     assert out["config"]["slab_check"].startswith("passed on every rank")
     assert out["value"] > 0 and out["scaling"] == "weak"
