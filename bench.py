@@ -482,8 +482,9 @@ class NewtonIteration:
       sweep + sum(defect.^2) per trial (:221-246)  ->  update (:304)  ->  defect sweep at the new point + max |defect| (:328-331).
     The reference's integrator setting (adaptive order 8, rtol = atol = 1e-13), 12-dim, about a converged station-keeping trajectory
     perturbed by 1e-7 (station_keeping_problem).  The point of linearisation stays the same
-    in every repetition (the update goes to a second array), so every repetition does the same work.  `sync` = the host reads its
-    three decision scalars back as the library's own loop (lto_indirect_solve) does: max |dx|, the 20 sums, max |defect|."""
+    in every repetition (the update goes to a second array), so every repetition does the same work.  `sync` = the host reads back
+    once per iteration as the library's own loop (lto_indirect_solve) does since round 4 (max |defect|, max |dx|; the correction mask
+    and the line search's minimiser are taken on the device)."""
 
     def __init__(self, lto, synth, ctx, st, torch, S):
         self.lto, self.ctx, self.st, self.torch, self.S = lto, ctx, st, torch, S
@@ -531,9 +532,9 @@ class NewtonIteration:
         torch = self.torch
         for name, op in self.ops():
             op()
-            if sync and name in ("max_dx", "line_search_sums", "max_defect"):
-                src = self.ss if name == "line_search_sums" else (self.mx2 if name == "max_dx" else self.mx)
-                self.host[:src.numel()].copy_(src, non_blocking=True)
+            if sync and name == "max_defect":      # the library's loop reads back once per iteration (max |defect|, step lengths, max |dx|)
+                self.host[:1].copy_(self.mx, non_blocking=True)
+                self.host[1:2].copy_(self.mx2, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
 
     def measure(self, reps=40, split_reps=20):
@@ -646,7 +647,7 @@ def leg_newton(lto, synth, ctx, st, torch, sizes, cpu_seconds):
         out.append(r)
     return {"what": "one iteration of multiShoot_CRTBP_indirect's loop (indirect.jl:280-337) with the reference's integrator setting, device-resident: "
             "STM sweep, block-bidiagonal step, second-order correction (defect sweep + re-solve), 20-trial line search as one batched sweep, "
-            "update, defect sweep; wall time per iteration launch by launch incl. the host's three scalar read-backs; split_us: every operation "
+            "update, defect sweep; wall time per iteration launch by launch incl. the host's read-back of the iteration's scalars (once per iteration, as lto_indirect_solve does); split_us: every operation "
             "alone, burst of back-to-back calls inside one HIP event pair on the launch stream",
             "sizes": out}
 

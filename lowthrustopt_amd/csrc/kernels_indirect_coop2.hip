@@ -76,7 +76,6 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   // ---- who is this lane
   int seg, col = 0;
   const int q4 = lane & 3;               // base wave: the quad's lane (r, v, lambda_v, lambda_r)
-  constexpr bool shadow = false;
   if (BASE) {
     seg = lane >> 2;
   } else {

@@ -219,8 +219,40 @@ __global__ __launch_bounds__(256) void k_axpy_traj(const double* x, const double
     const long j = q % per;
     const int c = (int)(q / per);
     const long idx = c * ld + j;
-    y[idx] = __builtin_fma(alpha[j / n], d[idx], x[idx]);
+    const double al = alpha[j / n];
+    y[idx] = (al == 0.0) ? x[idx] : __builtin_fma(al, d[idx], x[idx]);      // a frozen trajectory keeps its values whatever d holds (NaN x 0 is NaN)
   }
+}
+
+// Decisions of the Newton loop taken on the device (lto_indirect_solve_batch), so that the host reads back once per iteration:
+// second-order-correction mask  step[b] = 1 if trajectory b is active and max |xc_update| < thr (indirect.jl:190), else 0
+__global__ void k_soc_mask(const double* mx, const double* act, double thr, double* step, int nb) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) step[b] = (act[b] != 0.0 && mx[b] == mx[b] && mx[b] < thr) ? 1.0 : 0.0;
+}
+// step length  step[b] = alphas[first minimiser of ss[b*na .. ]] where the line search is on (lineSearch, :244-245: `alpha[er .==
+// minimum(er)][1]`, the comparison `<` skips NaN trials exactly as the host loop did), 1 for the other active trajectories, 0 for frozen ones
+__global__ void k_pick_alpha(const double* ss, const double* alphas, int na, const double* act, const double* search, double* step, int nb) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  double s = act[b] != 0.0 ? 1.0 : 0.0;
+  if (act[b] != 0.0 && search[b] != 0.0) {
+    const double* e = ss + (long)b * na;
+    int best = 0;
+    for (int a = 1; a < na; ++a) if (e[a] < e[best]) best = a;
+    s = alphas[best];
+  }
+  step[b] = s;
+}
+hipError_t launch_soc_mask(const double* mx, const double* act, double thr, double* step, int nb, hipStream_t st) {
+  if (nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_soc_mask, dim3((nb + 255) / 256), dim3(256), 0, st, mx, act, thr, step, nb);
+  return hipGetLastError();
+}
+hipError_t launch_pick_alpha(const double* ss, const double* alphas, int na, const double* act, const double* search, double* step, int nb, hipStream_t st) {
+  if (nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pick_alpha, dim3((nb + 255) / 256), dim3(256), 0, st, ss, alphas, na, act, search, step, nb);
+  return hipGetLastError();
 }
 
 // save (dir = 0) or restore (dir = 1) the first `nrow` rows of node 0 and node n-1 of every trajectory

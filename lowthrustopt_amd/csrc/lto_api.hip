@@ -900,7 +900,7 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (rc) { plan_free(p); return rc; }
   const long n = n_nodes, J = n * B, S = (n - 1) * B;
   const int ntl = (n_tgrids == 1) ? 1 : B * NA;
-  const size_t n_small = (size_t)12 * B + NA + 3 * (size_t)B + (size_t)NA * B + 64;
+  const size_t n_small = (size_t)12 * B + NA + 6 * (size_t)B + (size_t)NA * B + 64;
   const size_t need = al256(sizeof(double) * 12 * J) * 5 + al256(sizeof(double) * 12 * J * NA) + al256(sizeof(double) * n * n_tgrids) +
                       al256(sizeof(double) * n * ntl) + al256(sizeof(double) * 12 * S) * 3 + al256(sizeof(double) * 12 * S * NA) +
                       al256(sizeof(double) * 144 * S) + al256(sizeof(double) * n_small) + 65536;
@@ -926,11 +926,15 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   double* d_step = d_alphas + NA;                          // [B]    step length / SOC mask per trajectory
   double* d_mx = d_step + B;                               // [B]    per-trajectory max norms
   double* d_ss = d_mx + B;                                 // [NA*B] per-trial sums of squares
+  double* d_act = d_ss + (size_t)NA * B;                   // [B]    1 = trajectory still in its loop
+  double* d_search = d_act + B;                            // [B]    1 = line search on (iteration > 3)
+  double* d_mxdel = d_search + B;                          // [B]    max |xc_update| of the iteration
   hipStream_t st = c->stream;
   double alphas[NA];
   for (int a = 0; a < NA; ++a) alphas[a] = 0.1 + (1.0 - 0.1) / (NA - 1) * a;
   alphas[NA - 1] = 1.0;
-  std::vector<double> h_mx(B), h_er(B, 1.0), h_step(B), h_ss((size_t)NA * B);   // er = 1.0: :279
+  std::vector<double> h_mx(B), h_er(B, 1.0), h_step(B), h_back((size_t)3 * B), h_act(B, -1.0), h_search(B, -1.0);   // er = 1.0: :279
+  bool soc_speculative = false;
   std::vector<int> it(B, 0), status(B, 0);
   std::vector<char> active(B, 1);
 
@@ -949,10 +953,6 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
     if (q == hipSuccess) q = hipStreamSynchronize(st);
     return q == hipSuccess ? LTO_OK : set_err(c, LTO_EHIP, "norm", q);
   };
-  auto upload_step = [&]() -> int {
-    hipError_t q = hipMemcpyAsync(d_step, h_step.data(), sizeof(double) * B, hipMemcpyHostToDevice, st);
-    return q == hipSuccess ? LTO_OK : set_err(c, LTO_EHIP, "step upload", q);
-  };
   auto any_active = [&]() { for (int b = 0; b < B; ++b) if (active[b]) return true; return false; };
 
   if (rc == LTO_OK) rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, nullptr);      // :274
@@ -964,26 +964,48 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
       if (++it[b] > maxIter) { status[b] = 1; active[b] = 0; }
     }
     if (!any_active()) break;
+    // Round 4: the loop's decisions are taken on the device -- the second-order-correction mask from max |xc_update| (:190) and the
+    // line search's first minimiser (:244-245) -- so the host reads back ONCE per iteration (max |defect|, the step lengths and
+    // max |xc_update| together) instead of three times.  While the last known max |xc_update| of some active trajectory is
+    // >= 0.1 the correction is still decided on the host (one more read-back, but a defect sweep and a re-solve whose result would
+    // be discarded are not launched); once every active trajectory has been below, it is computed for all and applied by mask.
+    bool flags_changed = false;
+    for (int b = 0; b < B; ++b) {
+      const double fa = active[b] ? 1.0 : 0.0, fs = (active[b] && it[b] > 3) ? 1.0 : 0.0;
+      if (fa != h_act[b] || fs != h_search[b]) { h_act[b] = fa; h_search[b] = fs; flags_changed = true; }
+    }
+    if (flags_changed) {
+      e = hipMemcpyAsync(d_act, h_act.data(), sizeof(double) * B, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_search, h_search.data(), sizeof(double) * B, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "flag upload", e); break; }
+    }
     rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);              // :290
     // large adaptive problems: the next sweeps of this plan run with the lanes ordered by this sweep's step counts
     if (rc == LTO_OK && host_order_wanted(p, true)) rc = lto_indirect_plan_rebalance(p, st);
     if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, flag_adjointsOnly, d_del, J);   // :182
-    if (rc == LTO_OK) rc = max_abs(d_del, J, n, h_mx.data());
     if (rc != LTO_OK) break;
-    bool soc = false;                                      // second-order correction, :190-214
-    for (int b = 0; b < B; ++b) { h_step[b] = (active[b] && h_mx[b] == h_mx[b] && h_mx[b] < 1e-1) ? 1.0 : 0.0; soc |= h_step[b] != 0.0; }
+    e = launch_defect_norms(d_del, J, 12, (int)n, B, nullptr, d_mxdel, st);                          // max |xc_update| per trajectory
+    if (e == hipSuccess) e = launch_soc_mask(d_mxdel, d_act, 1e-1, d_step, B, st);                   // second-order correction, :190-214
+    if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "soc mask", e); break; }
+    bool soc = true;
+    if (!soc_speculative) {                                // early iterations: read max |xc_update| and skip the work if nobody needs it
+      e = hipMemcpyAsync(h_mx.data(), d_mxdel, sizeof(double) * B, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "norm", e); break; }
+      soc = false;
+      for (int b = 0; b < B; ++b) soc |= (active[b] && h_mx[b] == h_mx[b] && h_mx[b] < 1e-1);
+    }
     if (soc) {
       e = launch_axpy(d_X, d_del, 1.0, d_X2, 12 * J, st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "axpy", e); break; }
       rc = lto_indirect_defect_dev(p, st, d_X2, J, d_t, n_tgrids, d_def2, S, nullptr);
       if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, nullptr, 0, d_def2, S, flag_adjointsOnly, d_del2, J);
-      if (rc == LTO_OK) rc = upload_step();
       if (rc != LTO_OK) break;
-      e = launch_axpy_traj(d_del, d_del2, d_step, d_del, J, 12, n_nodes, B, st);
+      e = launch_axpy_traj(d_del, d_del2, d_step, d_del, J, 12, n_nodes, B, st);                      // masked: step = 0 keeps d_del
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "axpy", e); break; }
     }
     bool search = false;
-    for (int b = 0; b < B; ++b) { h_step[b] = active[b] ? 1.0 : 0.0; search |= active[b] && it[b] > 3; }
+    for (int b = 0; b < B; ++b) search |= active[b] && it[b] > 3;
     if (search) {                                          // :300-302: the 20 trial trajectories of every problem, one sweep
       e = launch_trial_points(d_X, d_del, J, 12, n_nodes, B, NA, d_alphas, d_Xt, J * NA, st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "trial points", e); break; }
@@ -991,25 +1013,26 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
       if (rc == LTO_OK && host_order_wanted(pl, false)) rc = lto_indirect_plan_rebalance(pl, st);
       if (rc != LTO_OK) break;
       e = launch_defect_norms(d_deft, S * NA, 12, n_nodes - 1, B * NA, d_ss, nullptr, st);         // sum(defect.^2), :240
-      if (e == hipSuccess) e = hipMemcpyAsync(h_ss.data(), d_ss, sizeof(double) * NA * B, hipMemcpyDeviceToHost, st);
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "line search", e); break; }
-      for (int b = 0; b < B; ++b) {
-        if (!active[b] || it[b] <= 3) continue;
-        const double* ss = &h_ss[(size_t)b * NA];
-        int best = 0;                                      // alpha[er .== minimum(er)][1]: first minimiser (:244-245)
-        for (int a = 1; a < NA; ++a) if (ss[a] < ss[best]) best = a;
-        h_step[b] = alphas[best];
-      }
     }
-    rc = upload_step();
-    if (rc != LTO_OK) break;
-    e = launch_axpy_traj(d_X, d_del, d_step, d_X, J, 12, n_nodes, B, st);                           // :304
+    e = launch_pick_alpha(d_ss, d_alphas, NA, d_act, d_search, d_step, B, st);                       // alpha (:244-245), 1, or 0 (frozen)
+    if (e == hipSuccess) e = launch_axpy_traj(d_X, d_del, d_step, d_X, J, 12, n_nodes, B, st);      // :304
     if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, B, 6, d_saved, 1, st);             // :324-325
     if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "update", e); break; }
     rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, nullptr);                 // :328
-    if (rc == LTO_OK) rc = max_abs(d_def, S, n - 1, h_mx.data());                                  // :331
     if (rc != LTO_OK) break;
+    e = launch_defect_norms(d_def, S, 12, (int)(n - 1), B, nullptr, d_mx, st);                       // :331
+    // one read-back: [step | max |defect|] are adjacent in the small block, max |xc_update| follows the flags
+    if (e == hipSuccess) e = hipMemcpyAsync(h_back.data(), d_step, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_back.data() + 2 * B, d_mxdel, sizeof(double) * B, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "norm", e); break; }
+    soc_speculative = true;
+    for (int b = 0; b < B; ++b) {
+      h_step[b] = h_back[b]; h_mx[b] = h_back[B + b];
+      const double md = h_back[2 * B + b];
+      if (active[b] && !(md < 1e-1)) soc_speculative = false;        // somebody is still taking big steps (or NaN): decide on the host next time
+    }
     for (int b = 0; b < B; ++b) {
       if (!active[b]) continue;
       h_er[b] = h_mx[b];

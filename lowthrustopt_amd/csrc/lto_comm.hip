@@ -113,7 +113,6 @@ __global__ void k_max_decode(const double* packed, long count, double* buf) {
 // of k + 1 before it can go further): a flag two or more ahead means that the ranks have lost step -- e.g. a peer whose wait ran out
 // and that went on alone, overwriting the half this rank is about to read -- and is a failure too.  The fail word is sticky: every
 // later collective of this rank returns NaN, and lto_comm_status reports it to the host.
-constexpr long WINDOW_SPIN_LIMIT = 4000000L;
 __device__ __forceinline__ bool window_wait_one(const unsigned int* flag, const unsigned int seq, const long limit) {
   long spins = 0;
   int d;
@@ -245,7 +244,7 @@ struct lto_comm {
   char* own = nullptr;                 // this rank's window: [flags: world x u32 | fail | push counters: 1024 B in all][2 halves][world][max_count] doubles
   std::vector<char*> peer;             // every rank's window as mapped here (peer[rank] = own)
   unsigned int seq = 0;
-  long wait_limit = 4000000L;          // polls before a wait gives up (lto_comm_set_wait_limit)
+  long wait_limit = 4000000L;          // polls before a wait gives up (lto_comm_set_wait_limit): ~ a few seconds
   hipStream_t bound = nullptr;         // the stream of this communicator's collectives (windows: all on ONE stream)
   bool bound_set = false;
   char err[512] = {0};

@@ -313,7 +313,10 @@ def test_bench_multi_rank_path_runs_with_ranks_sharing_the_device(world):
     torch.distributed.run itself (as a child process, before touching the GPU), all ranks take device 0 (LTO_BENCH_SHARE_DEVICE=1), negotiate the window transport, double-buffer the all-gather of the defect
     slabs inside the timed steps, check their slabs and reduce the timing over ranks -- the code path the driver's 8-GPU run takes,
     on the one device this box has."""
-    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, ["--gpus", str(world), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    # (1 024 segments per rank: the ranks' kernels share ONE device here, and a rank's collect kernel polls for flags that its
+    # peers' push kernels can only raise if they get compute units at the same time; at the contract size four ranks starve one another)
+    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, ["--gpus", str(world), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                                                                "--segments", "1024"])
     assert rc == 0 and out is not None, err
     assert out["n_gpus"] == world and out["steps"] == 5 and out["warmup"] == 2
     assert out["config"]["global_segments"] == world * out["config"]["segments_per_gpu"]
@@ -327,6 +330,6 @@ def test_bench_transport_set_up_failing_on_one_rank_ends_cleanly_on_all():
     transport is unusable, closes nothing a peer may touch before the barrier, and -- ranks sharing a device have no other transport --
     leaves with the same exit code instead of hanging (advisor finding, round 3)."""
     rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1", "LTO_BENCH_FAIL_RANK": "1"},
-                              ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], timeout=300)
+                              ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--segments", "1024"], timeout=300)
     assert rc != 0
     assert out is not None and "no usable transport" in out["error"] and "windows" in out["tried"], err
