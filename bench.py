@@ -479,12 +479,13 @@ class NewtonIteration:
     entry points run it once the line search is on (iteration > 3) -- what a caller of the reference's driver waits for per iteration:
       STM sweep (jacobianCalc, :290)  ->  block-bidiagonal least-squares step (:149-186)  ->  second-order correction: defect sweep at
       x + dx and a re-solve with the stored factorisation (:190-214)  ->  line search: the 20 trial trajectories as ONE batched defect
-      sweep + sum(defect.^2) per trial (:221-246)  ->  update (:304)  ->  defect sweep at the new point + max |defect| (:328-331).
+      sweep + sum(defect.^2) per trial (:221-246)  ->  update (:304)  ->  the defect check at the new point (:328-331), which is the
+      chosen trial point bit for bit: its defect block and max |defect| are taken from the line search's sweep, not swept again.
     The reference's integrator setting (adaptive order 8, rtol = atol = 1e-13), 12-dim, about a converged station-keeping trajectory
     perturbed by 1e-7 (station_keeping_problem).  The point of linearisation stays the same
     in every repetition (the update goes to a second array), so every repetition does the same work.  `sync` = the host reads back
-    once per iteration as the library's own loop (lto_indirect_solve) does since round 4 (max |defect|, max |dx|; the correction mask
-    and the line search's minimiser are taken on the device)."""
+    once per iteration as the library's own loop (lto_indirect_solve) does since round 4 (step length, max |defect|, max |dx| through
+    lto_read_scalars_dev; the correction mask and the line search's minimiser are taken on the device)."""
 
     def __init__(self, lto, synth, ctx, st, torch, S):
         self.lto, self.ctx, self.st, self.torch, self.S = lto, ctx, st, torch, S
@@ -504,8 +505,10 @@ class NewtonIteration:
         self.X2 = torch.zeros(12, n, **f64); self.Xn = torch.zeros(12, n, **f64)
         self.Xt = torch.zeros(12, n * NA, **f64)
         self.alphas = torch.linspace(0.1, 1.0, NA, **f64)
-        self.ss = torch.zeros(NA, **f64); self.mx = torch.zeros(1, **f64); self.mx2 = torch.zeros(1, **f64)
-        self.host = torch.zeros(NA + 2, dtype=torch.float64).pin_memory()
+        self.ss = torch.zeros(NA, **f64); self.mxt = torch.zeros(NA, **f64)
+        self.scal = torch.zeros(3, **f64)                                       # [step | max |defect| | max |dx|]: one read-back
+        self.step, self.mx, self.mx2 = self.scal[0:1], self.scal[1:2], self.scal[2:3]
+        self.host = np.zeros(3)
 
     def ops(self):
         """(name, closure) in the order of one iteration; every closure enqueues on the bench's stream."""
@@ -522,20 +525,18 @@ class NewtonIteration:
             ("soc_add", lambda: axpy(self.delta, self.delta2, 1.0, self.delta)),
             ("trial_points", lambda: lto.trial_points(ctx, self.X, self.delta, n, 12, n, 1, self.alphas, self.Xt, n * NA, stream=st)),
             ("line_search_sweep", lambda: pl.defect(self.Xt, n * NA, self.t, 1, self.dt, S * NA, stream=st)),
-            ("line_search_sums", lambda: lto.defect_norms(ctx, self.dt, S * NA, 12, S, NA, self.ss, None, stream=st)),
+            ("line_search_norms", lambda: lto.defect_norms(ctx, self.dt, S * NA, 12, S, NA, self.ss, self.mxt, stream=st)),
+            # lineSearch's minimiser and the check of :328-331 without another sweep: the updated trajectory IS the chosen trial point
+            ("pick_and_take", lambda: lto.line_search_pick(ctx, self.ss, self.mxt, self.alphas, self.dt, S * NA, 12, S, 1, self.step, self.mx,
+                                                           self.d3, S, stream=st)),
             ("update", lambda: axpy(self.X, self.delta, 1.0, self.Xn)),
-            ("defect_sweep", lambda: p.defect(self.Xn, n, self.t, 1, self.d3, S, stream=st)),
-            ("max_defect", lambda: lto.defect_norms(ctx, self.d3, S, 12, S, 1, None, self.mx, stream=st)),
         ]
 
     def iteration(self, sync=True):
-        torch = self.torch
         for name, op in self.ops():
             op()
-            if sync and name == "max_defect":      # the library's loop reads back once per iteration (max |defect|, step lengths, max |dx|)
-                self.host[:1].copy_(self.mx, non_blocking=True)
-                self.host[1:2].copy_(self.mx2, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
+            if sync and name == "update":          # the library's loop reads back once per iteration (step length, max |defect|, max |dx|)
+                self.lto.read_scalars(self.ctx, self.scal, 3, None, 0, self.host, stream=self.st)
 
     def measure(self, reps=40, split_reps=20):
         torch = self.torch
@@ -647,7 +648,8 @@ def leg_newton(lto, synth, ctx, st, torch, sizes, cpu_seconds):
         out.append(r)
     return {"what": "one iteration of multiShoot_CRTBP_indirect's loop (indirect.jl:280-337) with the reference's integrator setting, device-resident: "
             "STM sweep, block-bidiagonal step, second-order correction (defect sweep + re-solve), 20-trial line search as one batched sweep, "
-            "update, defect sweep; wall time per iteration launch by launch incl. the host's read-back of the iteration's scalars (once per iteration, as lto_indirect_solve does); split_us: every operation "
+            "the minimiser's defect block taken from that sweep as the check of :328-331 (the updated trajectory is that trial point), update; wall time per iteration launch by launch "
+            "incl. the host's read-back of the iteration's scalars (once per iteration, lto_read_scalars_dev, as lto_indirect_solve does); split_us: every operation "
             "alone, burst of back-to-back calls inside one HIP event pair on the launch stream",
             "sizes": out}
 

@@ -297,6 +297,22 @@ int lto_axpy_dev(lto_ctx* ctx, void* stream, const double* x, const double* d, d
  * own loop around the device-resident entry points. */
 int lto_trial_points_dev(lto_ctx* ctx, void* stream, const double* X, const double* delta, long ld, int ndim, int n_nodes,
                          int n_batch, int n_alpha, const double* alphas, double* Xt, long ldt);
+/* The per-iteration read-back of a Newton loop kept around the device-resident entry points: out[0..na) = a[..], out[na..na+nb) =
+ * b[..] (device arrays; b may be NULL with nb = 0), returning when the values have arrived.  One small kernel writes them into a
+ * page-locked block of the context behind everything queued on `stream`, and the host polls a sequence word -- no copy-engine
+ * operation and no stream synchronisation; falls back to copies + synchronisation when the block cannot be mapped.  Not
+ * thread-safe per context; `stream` must not be capturing. */
+int lto_read_scalars_dev(lto_ctx* ctx, void* stream, const double* a, int na, const double* b, int nb, double* out);
+/* lineSearch's decision (indirect.jl:244-245) and the defect check that follows the update (:328-331), without another sweep.  For
+ * every trajectory b < n_batch: a* = first minimiser of sumsq[b*n_alpha .. ) (NaN trials never win), step[b] = alphas[a*];
+ * maxabs_out[b] = maxabs[b*n_alpha + a*]; defect[c*ldd + b*seg + i] = trial_defect[c*ldt + (b*n_alpha + a*)*seg + i].  The updated
+ * trajectory XC_all + xc_update*alpha with its end states pinned (:304, :324-325) is the chosen trial point bit for bit (one fma
+ * each, the update's end-state rows are zero), so `defectCalc` at it is the part of the line search's own sweep that integrated it.
+ * sumsq / maxabs as lto_defect_norms_dev leaves them for the n_batch*n_alpha trial trajectories; alphas is a DEVICE array.
+ * maxabs with maxabs_out and trial_defect with defect may be NULL in pairs. */
+int lto_line_search_pick_dev(lto_ctx* ctx, void* stream, const double* sumsq, const double* maxabs, const double* alphas, int n_alpha,
+                             const double* trial_defect, long ldt, int ndim, int seg_per_traj, int n_batch, double* step,
+                             double* maxabs_out, double* defect, long ldd);
 
 /* Dense output (device): segment s is sampled at t_samples[first[s] .. first[s+1]) (sorted, inside the segment);
  * Y[c*ldy + j] = x_c(t_samples[j]); final_state[c*n_batch + b] (or NULL) = x(t_n) of trajectory b. */

@@ -360,6 +360,16 @@ trial_points_dev!(ctx::LtoContext, stream, X, delta, ld::Integer, ndim::Integer,
     check(ctx, ccall((:lto_trial_points_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, DevPtr, Clong, Cint, Cint, Cint, Cint, DevPtr, DevPtr, Clong),
                      ctx.handle, devptr(stream), devptr(X), devptr(delta), ld, ndim, n_nodes, n_batch, n_alpha, devptr(alphas), devptr(Xt), ldt))
 
+"A few device scalars to a host `Vector{Float64}` (`out[1:na] <- a`, `out[na+1:na+nb] <- b`), back when they have arrived: the per-iteration read-back of a Newton loop."
+read_scalars_dev!(ctx::LtoContext, stream, a, na::Integer, b, nb::Integer, out::Vector{Float64}) =
+    check(ctx, ccall((:lto_read_scalars_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Cint, DevPtr, Cint, Ptr{Cdouble}),
+                     ctx.handle, devptr(stream), devptr(a), na, devptr(b), nb, out))
+
+"lineSearch's first minimiser per trajectory on the device (indirect.jl:244-245): step <- alpha, maxabs_out <- the chosen trial's max |defect|, defect <- its defect block (the check of :328-331 without another sweep)."
+line_search_pick_dev!(ctx::LtoContext, stream, sumsq, maxabs, alphas, n_alpha::Integer, trial_defect, ldt::Integer, ndim::Integer, seg_per_traj::Integer, n_batch::Integer, step, maxabs_out, defect, ldd::Integer) =
+    check(ctx, ccall((:lto_line_search_pick_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, DevPtr, DevPtr, Cint, DevPtr, Clong, Cint, Cint, Cint, DevPtr, DevPtr, DevPtr, Clong),
+                     ctx.handle, devptr(stream), devptr(sumsq), devptr(maxabs), devptr(alphas), n_alpha, devptr(trial_defect), ldt, ndim, seg_per_traj, n_batch, devptr(step), devptr(maxabs_out), devptr(defect), ldd))
+
 "Order the lanes of the following adaptive sweeps by the last sweep's step counts (results unchanged)."
 rebalance!(pl::LtoIndirectPlan, stream) = check(pl.ctx, ccall((:lto_indirect_plan_rebalance, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), pl.handle, devptr(stream)))
 "LTO_KERNEL_*: 0 auto, 1 per-lane, 2 cooperative, 3 / 4 / 5 pipeline forms (RK4 plans), 6 cooperative with two lanes per state (12-dim DOP853 plans), 7 pipeline for large batches (RK4 plans)."

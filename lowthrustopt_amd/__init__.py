@@ -6,7 +6,7 @@ from ._lib import LtoError, LtoParams, LtoIntegrator, LtoDirectParams, load_libr
 from .hotpath import (Context, Group, Comm, GroupComm, default_context, integrator, make_params, indirect_defectCalc, indirect_stm,  # noqa: F401
                       indirect_scatter, indirect_jacobianCalc, direct_defectCalc, direct_jacobian_blocks,
                       direct_scatter, direct_jacobianCalc, direct_endpoint_partials, direct_midpoints, densify, indirect_newton_step, indirect_solve, indirect_solve_batch, IndirectPlan, DirectPlan, pack_soa, unpack_soa,
-                      defect_norms, trial_points, current_stream_ptr)
+                      defect_norms, trial_points, line_search_pick, read_scalars, current_stream_ptr)
 from . import synth  # noqa: F401
 
 __version__ = "0.1.0"

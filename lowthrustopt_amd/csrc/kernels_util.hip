@@ -231,27 +231,77 @@ __global__ void k_soc_mask(const double* mx, const double* act, double thr, doub
   if (b < nb) step[b] = (act[b] != 0.0 && mx[b] == mx[b] && mx[b] < thr) ? 1.0 : 0.0;
 }
 // step length  step[b] = alphas[first minimiser of ss[b*na .. ]] where the line search is on (lineSearch, :244-245: `alpha[er .==
-// minimum(er)][1]`, the comparison `<` skips NaN trials exactly as the host loop did), 1 for the other active trajectories, 0 for frozen ones
-__global__ void k_pick_alpha(const double* ss, const double* alphas, int na, const double* act, const double* search, double* step, int nb) {
+// minimum(er)][1]`, the comparison `<` skips NaN trials exactly as the host loop did), 1 for the other active trajectories, 0 for frozen ones.
+// act / search == nullptr: every trajectory searches.  With `mxt` (max |defect| of every trial trajectory) the chosen trial's maximum
+// goes to mx[b]: the defect check after the update (:328-331) is the line search's own sweep at that trial point (k_take_trial).
+__device__ inline int first_minimiser(const double* e, int na) {
+  int best = 0;
+  for (int a = 1; a < na; ++a) if (e[a] < e[best]) best = a;
+  return best;
+}
+__global__ void k_pick_alpha(const double* ss, const double* alphas, int na, const double* act, const double* search, double* step, int nb,
+                             const double* mxt, double* mx) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
-  double s = act[b] != 0.0 ? 1.0 : 0.0;
-  if (act[b] != 0.0 && search[b] != 0.0) {
-    const double* e = ss + (long)b * na;
-    int best = 0;
-    for (int a = 1; a < na; ++a) if (e[a] < e[best]) best = a;
-    s = alphas[best];
+  const bool on = !act || act[b] != 0.0;
+  double s = on ? 1.0 : 0.0;
+  int chosen = -1;
+  if (on && (!search || search[b] != 0.0)) {
+    chosen = first_minimiser(ss + (long)b * na, na);
+    s = alphas[chosen];
   }
   step[b] = s;
+  if (mxt && mx && chosen >= 0) mx[b] = mxt[(long)b * na + chosen];
+}
+// defect[c][b*seg + i] = trial[c][(b*na + chosen)*seg + i] for the trajectories whose line search chose a trial point: XC_all +
+// xc_update*alpha pinned at its end states (:304, :324-325) IS that trial point (the update's end-state rows are zero and both are one
+// fma), so its defect sweep (:328) would repeat the trial's lane for lane.
+__global__ __launch_bounds__(256) void k_take_trial(const double* __restrict__ trial, long ldt, const double* __restrict__ ss,
+                                                    const double* __restrict__ act, const double* __restrict__ search, int na, int seg,
+                                                    int ndim, int nb, double* __restrict__ defect, long ldd) {
+  for (int b = blockIdx.y; b < nb; b += gridDim.y) {
+    if ((act && act[b] == 0.0) || (search && search[b] == 0.0)) continue;
+    const int a = first_minimiser(ss + (long)b * na, na);
+    const long src = ((long)b * na + a) * seg, dst = (long)b * seg;
+    const long total = (long)ndim * seg;
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += gridDim.x * 256L) {
+      const int c = (int)(q / seg);
+      const int i = (int)(q % seg);
+      defect[c * ldd + dst + i] = trial[c * ldt + src + i];
+    }
+  }
+}
+// The iteration's scalars straight into page-locked host memory (no copy-engine operation, no stream synchronisation): the host
+// polls the sequence word, which is written last behind a system-scope fence.
+__global__ void k_iter_report(const double* a, int na_, const double* b, int nb_, volatile double* host, volatile long long* seq_word, long long seq) {
+  const int i = threadIdx.x;
+  for (int k = i; k < na_; k += blockDim.x) host[k] = a[k];
+  for (int k = i; k < nb_; k += blockDim.x) host[na_ + k] = b[k];
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) *seq_word = seq;
 }
 hipError_t launch_soc_mask(const double* mx, const double* act, double thr, double* step, int nb, hipStream_t st) {
   if (nb <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_soc_mask, dim3((nb + 255) / 256), dim3(256), 0, st, mx, act, thr, step, nb);
   return hipGetLastError();
 }
-hipError_t launch_pick_alpha(const double* ss, const double* alphas, int na, const double* act, const double* search, double* step, int nb, hipStream_t st) {
+hipError_t launch_pick_alpha(const double* ss, const double* alphas, int na, const double* act, const double* search, double* step, int nb,
+                             const double* mxt, double* mx, hipStream_t st) {
   if (nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_pick_alpha, dim3((nb + 255) / 256), dim3(256), 0, st, ss, alphas, na, act, search, step, nb);
+  hipLaunchKernelGGL(k_pick_alpha, dim3((nb + 255) / 256), dim3(256), 0, st, ss, alphas, na, act, search, step, nb, mxt, mx);
+  return hipGetLastError();
+}
+hipError_t launch_take_trial(const double* trial, long ldt, const double* ss, const double* act, const double* search, int na, int seg,
+                             int ndim, int nb, double* defect, long ldd, hipStream_t st) {
+  if (nb <= 0 || seg <= 0) return hipSuccess;
+  long blocks = ((long)ndim * seg + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(k_take_trial, dim3((unsigned)blocks, (unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, trial, ldt, ss, act, search, na, seg, ndim, nb, defect, ldd);
+  return hipGetLastError();
+}
+hipError_t launch_iter_report(const double* a, int na, const double* b, int nb, double* host_dev, long long* seq_dev, long long seq, hipStream_t st) {
+  hipLaunchKernelGGL(k_iter_report, dim3(1), dim3(256), 0, st, a, na, b, nb, (volatile double*)host_dev, (volatile long long*)seq_dev, seq);
   return hipGetLastError();
 }
 

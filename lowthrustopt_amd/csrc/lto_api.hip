@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -66,6 +67,12 @@ struct lto_ctx {
   std::vector<Pinned> pinned;
   std::mutex pinned_mu;
   double last_call_ms;     // wall time of the last host-pointer call, entry to return (lto_last_call_ms)
+  // landing block of the Newton loop's per-iteration scalars (lto_indirect_solve_batch): page-locked, mapped, written by
+  // k_iter_report; word 0 is the sequence number the host polls, the values follow.  Grow-only; absent = copy + synchronise.
+  double* rep_host;
+  double* rep_dev;
+  size_t rep_doubles;
+  long long rep_seq;
   char err[512];
 };
 
@@ -298,6 +305,7 @@ static void ctx_free(lto_ctx* c) {
   c->pinned.clear();
   if (c->arena) (void)hipFree(c->arena);
   if (c->order_cache) (void)hipFree(c->order_cache);
+  if (c->rep_host) (void)hipHostFree(c->rep_host);
   for (int i = 0; i < 8; ++i) if (c->pool[i].ptr) (void)hipFree(c->pool[i].ptr);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
@@ -752,6 +760,77 @@ int lto_trial_points_dev(lto_ctx* c, void* stream, const double* X, const double
   return LTO_OK;
 }
 
+// Scalars of the Newton loop to the host: a[0..na) then b[0..nb) into out.  With the mapped landing block one small kernel
+// writes them and the host polls the sequence word (a few microseconds after the kernel); a stream that has drained without
+// the word arriving is an error.  Without the block: two copies and a stream synchronisation (about 30 us).
+static bool report_reserve(lto_ctx* c, size_t doubles) {
+  if (c->rep_host && c->rep_doubles >= doubles) return true;
+  if (c->rep_host) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->rep_host); c->rep_host = nullptr; c->rep_doubles = 0; }
+  void* hp = nullptr; void* dp = nullptr;
+  const size_t want = doubles + 64;
+  if (hipHostMalloc(&hp, sizeof(double) * (want + 1), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hp) (void)hipHostFree(hp);
+    return false;
+  }
+  std::memset(hp, 0, sizeof(double) * (want + 1));
+  c->rep_host = (double*)hp; c->rep_dev = (double*)dp; c->rep_doubles = want; c->rep_seq = 0;
+  return true;
+}
+static int read_scalars(lto_ctx* c, hipStream_t st, const double* a, int na, const double* b, int nb, double* out) {
+  hipError_t e;
+  if (c->rep_host && c->rep_doubles >= (size_t)(na + nb)) {
+    const long long seq = ++c->rep_seq;
+    e = launch_iter_report(a, na, b, nb, c->rep_dev + 1, (long long*)c->rep_dev, seq, st);
+    if (e != hipSuccess) return set_err(c, LTO_EHIP, "report", e);
+    volatile long long* w = (volatile long long*)c->rep_host;
+    for (unsigned long spin = 1;; ++spin) {
+      if (*w == seq) break;
+      if ((spin & 0x3fff) == 0) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipErrorNotReady) continue;
+        if (q == hipSuccess && *w == seq) break;
+        return set_err(c, LTO_EHIP, "report: the stream drained without the iteration's scalars", q);
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    std::memcpy(out, c->rep_host + 1, sizeof(double) * (size_t)(na + nb));
+    return LTO_OK;
+  }
+  e = hipMemcpyAsync(out, a, sizeof(double) * (size_t)na, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && nb > 0) e = hipMemcpyAsync(out + na, b, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return e == hipSuccess ? LTO_OK : set_err(c, LTO_EHIP, "norm", e);
+}
+
+int lto_line_search_pick_dev(lto_ctx* c, void* stream, const double* sumsq, const double* maxabs, const double* alphas, int n_alpha,
+                             const double* trial_defect, long ldt, int ndim, int seg_per_traj, int n_batch, double* step,
+                             double* maxabs_out, double* defect, long ldd) {
+  if (!c) return LTO_ENULL;
+  if (!sumsq || !alphas || !step) return set_err(c, LTO_ENULL, "sumsq, alphas or step is NULL");
+  if ((maxabs == nullptr) != (maxabs_out == nullptr) || (trial_defect == nullptr) != (defect == nullptr))
+    return set_err(c, LTO_ENULL, "maxabs / maxabs_out and trial_defect / defect come in pairs");
+  if (n_alpha < 1 || n_batch < 1 || ndim < 1 || seg_per_traj < 1) return set_err(c, LTO_EINVAL, "n_alpha, n_batch, ndim and seg_per_traj must be positive");
+  if (defect && (ldt < (long)seg_per_traj * n_batch * n_alpha || ldd < (long)seg_per_traj * n_batch)) return set_err(c, LTO_EINVAL, "leading dimension too small");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = launch_pick_alpha(sumsq, alphas, n_alpha, nullptr, nullptr, step, n_batch, maxabs, maxabs_out, st);
+  if (e == hipSuccess && defect) e = launch_take_trial(trial_defect, ldt, sumsq, nullptr, nullptr, n_alpha, seg_per_traj, ndim, n_batch, defect, ldd, st);
+  if (e != hipSuccess) return set_err(c, LTO_EHIP, "line search pick", e);
+  return LTO_OK;
+}
+
+int lto_read_scalars_dev(lto_ctx* c, void* stream, const double* a, int na, const double* b, int nb, double* out) {
+  if (!c) return LTO_ENULL;
+  if (!a || !out || (nb > 0 && !b)) return set_err(c, LTO_ENULL, "a, b or out is NULL");
+  if (na < 1 || nb < 0 || (long)na + nb > (1L << 20)) return set_err(c, LTO_EINVAL, "need 1 <= na, 0 <= nb, na + nb <= 2^20");
+  int rc = bind_device(c);
+  if (rc) return rc;
+  (void)report_reserve(c, (size_t)na + nb);
+  return read_scalars(c, (hipStream_t)stream, a, na, b, nb, out);
+}
+
 /* Host-pointer API: adopt / refresh the context's cached lane order (see lto_ctx::order_cache).  Below these sizes
  * one round of wavefronts / workgroups covers the chip and the order cannot matter. */
 static const long kOrderMinStm = 8192, kOrderMinDefect = 131072;
@@ -900,9 +979,9 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   if (rc) { plan_free(p); return rc; }
   const long n = n_nodes, J = n * B, S = (n - 1) * B;
   const int ntl = (n_tgrids == 1) ? 1 : B * NA;
-  const size_t n_small = (size_t)12 * B + NA + 6 * (size_t)B + (size_t)NA * B + 64;
+  const size_t n_small = (size_t)12 * B + NA + 6 * (size_t)B + 2 * (size_t)NA * B + 64;
   const size_t need = al256(sizeof(double) * 12 * J) * 5 + al256(sizeof(double) * 12 * J * NA) + al256(sizeof(double) * n * n_tgrids) +
-                      al256(sizeof(double) * n * ntl) + al256(sizeof(double) * 12 * S) * 3 + al256(sizeof(double) * 12 * S * NA) +
+                      al256(sizeof(double) * n * ntl) + al256(sizeof(double) * 12 * S) * 4 + al256(sizeof(double) * 12 * S * NA) +
                       al256(sizeof(double) * 144 * S) + al256(sizeof(double) * n_small) + 65536;
   rc = arena_reserve(c, need);
   if (rc) { plan_free(pl); plan_free(p); return rc; }
@@ -917,6 +996,7 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   double* d_tl = (n_tgrids == 1) ? d_t : arena_take<double>(c, (size_t)n * ntl);
   double* d_def = arena_take<double>(c, (size_t)12 * S);
   double* d_def2 = arena_take<double>(c, (size_t)12 * S);
+  double* d_defj = arena_take<double>(c, (size_t)12 * S);   // the STM sweep's own defect (right-hand side of the step); d_def stays defectCalc's
   double* d_def_aos = arena_take<double>(c, (size_t)12 * S);
   double* d_deft = arena_take<double>(c, (size_t)12 * S * NA);
   double* d_phi = arena_take<double>(c, (size_t)144 * S);
@@ -929,6 +1009,8 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   double* d_act = d_ss + (size_t)NA * B;                   // [B]    1 = trajectory still in its loop
   double* d_search = d_act + B;                            // [B]    1 = line search on (iteration > 3)
   double* d_mxdel = d_search + B;                          // [B]    max |xc_update| of the iteration
+  double* d_mxt = d_mxdel + B;                             // [NA*B] per-trial max |defect|
+  (void)report_reserve(c, (size_t)3 * B);
   hipStream_t st = c->stream;
   double alphas[NA];
   for (int a = 0; a < NA; ++a) alphas[a] = 0.1 + (1.0 - 0.1) / (NA - 1) * a;
@@ -979,19 +1061,18 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
       if (e == hipSuccess) e = hipMemcpyAsync(d_search, h_search.data(), sizeof(double) * B, hipMemcpyHostToDevice, st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "flag upload", e); break; }
     }
-    rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_def, S);              // :290
+    rc = lto_indirect_jacobian_dev(p, st, d_X, J, d_t, n_tgrids, d_phi, S, d_defj, S);             // :290
     // large adaptive problems: the next sweeps of this plan run with the lanes ordered by this sweep's step counts
     if (rc == LTO_OK && host_order_wanted(p, true)) rc = lto_indirect_plan_rebalance(p, st);
-    if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_def, S, flag_adjointsOnly, d_del, J);   // :182
+    if (rc == LTO_OK) rc = lto_indirect_newton_solve_dev(p, st, d_phi, S, d_defj, S, flag_adjointsOnly, d_del, J);  // :182
     if (rc != LTO_OK) break;
     e = launch_defect_norms(d_del, J, 12, (int)n, B, nullptr, d_mxdel, st);                          // max |xc_update| per trajectory
     if (e == hipSuccess) e = launch_soc_mask(d_mxdel, d_act, 1e-1, d_step, B, st);                   // second-order correction, :190-214
     if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "soc mask", e); break; }
     bool soc = true;
     if (!soc_speculative) {                                // early iterations: read max |xc_update| and skip the work if nobody needs it
-      e = hipMemcpyAsync(h_mx.data(), d_mxdel, sizeof(double) * B, hipMemcpyDeviceToHost, st);
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
-      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "norm", e); break; }
+      rc = read_scalars(c, st, d_mxdel, B, nullptr, 0, h_mx.data());
+      if (rc != LTO_OK) break;
       soc = false;
       for (int b = 0; b < B; ++b) soc |= (active[b] && h_mx[b] == h_mx[b] && h_mx[b] < 1e-1);
     }
@@ -1004,29 +1085,36 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
       e = launch_axpy_traj(d_del, d_del2, d_step, d_del, J, 12, n_nodes, B, st);                      // masked: step = 0 keeps d_del
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "axpy", e); break; }
     }
-    bool search = false;
-    for (int b = 0; b < B; ++b) search |= active[b] && it[b] > 3;
+    bool search = false, all_search = true;
+    for (int b = 0; b < B; ++b) if (active[b]) { search |= it[b] > 3; all_search &= it[b] > 3; }
     if (search) {                                          // :300-302: the 20 trial trajectories of every problem, one sweep
       e = launch_trial_points(d_X, d_del, J, 12, n_nodes, B, NA, d_alphas, d_Xt, J * NA, st);
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "trial points", e); break; }
       rc = lto_indirect_defect_dev(pl, st, d_Xt, J * NA, d_tl, ntl, d_deft, S * NA, nullptr);
       if (rc == LTO_OK && host_order_wanted(pl, false)) rc = lto_indirect_plan_rebalance(pl, st);
       if (rc != LTO_OK) break;
-      e = launch_defect_norms(d_deft, S * NA, 12, n_nodes - 1, B * NA, d_ss, nullptr, st);         // sum(defect.^2), :240
+      e = launch_defect_norms(d_deft, S * NA, 12, n_nodes - 1, B * NA, d_ss, d_mxt, st);           // sum(defect.^2), :240 (+ max |defect|)
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "line search", e); break; }
     }
-    e = launch_pick_alpha(d_ss, d_alphas, NA, d_act, d_search, d_step, B, st);                       // alpha (:244-245), 1, or 0 (frozen)
+    // alpha (:244-245), 1, or 0 (frozen); where the line search ran, the chosen trial's max |defect| and its index as well
+    e = launch_pick_alpha(d_ss, d_alphas, NA, d_act, d_search, d_step, B, search ? d_mxt : nullptr, d_mx, st);
     if (e == hipSuccess) e = launch_axpy_traj(d_X, d_del, d_step, d_X, J, 12, n_nodes, B, st);      // :304
     if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, B, 6, d_saved, 1, st);             // :324-325
     if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "update", e); break; }
-    rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, nullptr);                 // :328
-    if (rc != LTO_OK) break;
-    e = launch_defect_norms(d_def, S, 12, (int)(n - 1), B, nullptr, d_mx, st);                       // :331
+    if (search && all_search) {
+      // CHECK UPDATE (:328-331) without a sweep: the new XC_all is the chosen trial point bit for bit (same fma, the update's
+      // end-state rows are zero), so defectCalc there is the lanes of the line search's sweep that integrated it.
+      e = launch_take_trial(d_deft, S * NA, d_ss, d_act, d_search, NA, n_nodes - 1, 12, B, d_def, S, st);
+      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "take trial", e); break; }
+    } else {
+      rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, nullptr);               // :328
+      if (rc != LTO_OK) break;
+      e = launch_defect_norms(d_def, S, 12, (int)(n - 1), B, nullptr, d_mx, st);                     // :331
+      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "norm", e); break; }
+    }
     // one read-back: [step | max |defect|] are adjacent in the small block, max |xc_update| follows the flags
-    if (e == hipSuccess) e = hipMemcpyAsync(h_back.data(), d_step, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_back.data() + 2 * B, d_mxdel, sizeof(double) * B, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "norm", e); break; }
+    rc = read_scalars(c, st, d_step, 2 * B, d_mxdel, B, h_back.data());
+    if (rc != LTO_OK) break;
     soc_speculative = true;
     for (int b = 0; b < B; ++b) {
       h_step[b] = h_back[b]; h_mx[b] = h_back[B + b];

@@ -771,3 +771,18 @@ def trial_points(ctx, X, delta, ld, ndim, n_nodes, n_batch, alphas, Xt, ldt, str
     """Xt = the len(alphas) trial trajectories X + alpha * delta of every trajectory of the batch (device arrays; lineSearch, indirect.jl:227-233)."""
     ctx.check(ctx.lib.lto_trial_points_dev(ctx.handle, stream, _dptr(X), _dptr(delta), int(ld), int(ndim), int(n_nodes), int(n_batch),
                                            int(alphas.numel() if hasattr(alphas, "numel") else len(alphas)), _dptr(alphas), _dptr(Xt), int(ldt)))
+
+
+def line_search_pick(ctx, sumsq, maxabs, alphas, trial_defect, ldt, ndim, seg_per_traj, n_batch, step, maxabs_out, defect, ldd, stream=None):
+    """lineSearch's first minimiser per trajectory (indirect.jl:244-245) taken on the device: step <- alpha, maxabs_out <- the chosen trial's
+    max |defect|, defect <- its defect block (the check of :328-331 without another sweep).  Device arrays."""
+    na = int(alphas.numel() if hasattr(alphas, "numel") else len(alphas))
+    ctx.check(ctx.lib.lto_line_search_pick_dev(ctx.handle, stream, _dptr(sumsq), _dptr(maxabs), _dptr(alphas), na, _dptr(trial_defect), int(ldt),
+                                               int(ndim), int(seg_per_traj), int(n_batch), _dptr(step), _dptr(maxabs_out), _dptr(defect), int(ldd)))
+
+
+def read_scalars(ctx, a, na, b, nb, out, stream=None):
+    """out[:na] <- device a, out[na:na+nb] <- device b (or None), back when they have arrived (lto_read_scalars_dev): the per-iteration
+    read-back of a Newton loop.  `out`: a C-contiguous float64 numpy array."""
+    ctx.check(ctx.lib.lto_read_scalars_dev(ctx.handle, stream, _dptr(a), int(na), _dptr(b), int(nb), out.ctypes.data_as(C.c_void_p)))
+    return out

@@ -304,6 +304,10 @@ def test_device_newton_loop_equals_python_loop(gpu_ctx, oracle, adjoints_only):
         if not adjoints_only:
             assert np.abs(XC_d - exact).max() < 1e-6
     assert len(hist) >= 1 and np.all(hist[:3, 1] == 1.0)     # no line search before iteration 4 (indirect.jl:300)
+    # the returned defect is defectCalc at the returned trajectory, bit for bit -- also when the last iteration took it from the
+    # line search's sweep at the chosen trial point instead of sweeping again (:328), and the history holds its maximum
+    d_again, _ = lto.indirect_defectCalc(XC_d, t, prm, None, ctx=gpu_ctx)
+    assert np.array_equal(d_again, def_d) and hist[-1, 0] == np.abs(def_d).max()
     # a step that blows the defect up past 1e3 aborts the way the reference does: iterCount += 100 -> status 1 (:333-336)
     XCb, _, _ = consistent_problem(oracle, n_nodes=20, pert=3e-3, seed=5)
     _, _, stb, itb, hb = lto.indirect_solve(XCb, t, prm, None, False, 25, ctx=gpu_ctx)

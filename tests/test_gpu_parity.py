@@ -1044,6 +1044,59 @@ def test_pack_unpack_and_norms(gpu_ctx):
     assert bool(torch.isnan(mx[2])) and bool(torch.isfinite(mx[[0, 1, 3, 4, 5, 6]]).all())
 
 
+def test_line_search_pick_and_scalar_read_back(gpu_ctx):
+    """lto_line_search_pick_dev: lineSearch's `alpha[er .== minimum(er)][1]` (indirect.jl:244-245) per trajectory -- the first
+    minimiser, NaN trials never win -- with the chosen trial's max |defect| and defect block; lto_read_scalars_dev returns the
+    values the device holds."""
+    import torch
+    f64 = dict(dtype=torch.float64, device="cuda")
+    B, NA, seg = 5, 20, 37
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    dt = torch.randn(12, B * NA * seg + 3, generator=g, **f64)
+    dt[:, (1 * NA + 4) * seg:(1 * NA + 5) * seg] *= 1e-3                 # trajectory 1: trial 4 is the minimum
+    dt[:, (2 * NA + 0) * seg:(2 * NA + 1) * seg] = float("nan")           # trajectory 2: the first trial is NaN
+    dt[:, (3 * NA + 7) * seg:(3 * NA + 8) * seg] = 0.0                    # trajectory 3: trials 7 and 9 tie -> the first
+    dt[:, (3 * NA + 9) * seg:(3 * NA + 10) * seg] = 0.0
+    ss = torch.zeros(B * NA, **f64); mxt = torch.zeros(B * NA, **f64)
+    lto.defect_norms(gpu_ctx, dt, dt.shape[1], 12, seg, B * NA, ss, mxt)
+    alphas = torch.linspace(0.1, 1.0, NA, **f64)
+    step = torch.zeros(B, **f64); mx = torch.full((B,), -1.0, **f64)
+    d = torch.full((12, B * seg + 2), 7.0, **f64)
+    lto.line_search_pick(gpu_ctx, ss, mxt, alphas, dt, dt.shape[1], 12, seg, B, step, mx, d, d.shape[1])
+    torch.cuda.synchronize()
+    ssh = ss.cpu().numpy().reshape(B, NA)
+    for b in range(B):
+        e = ssh[b]
+        best = 0
+        for a in range(1, NA):
+            if e[a] < e[best]:
+                best = a
+        if b == 1: assert best == 4
+        if b == 3: assert best == 7
+        if b == 2:
+            assert best == 0
+            continue
+        assert float(step[b]) == float(alphas[best]) and float(mx[b]) == float(mxt[b * NA + best])
+        assert torch.equal(d[:, b * seg:(b + 1) * seg], dt[:, (b * NA + best) * seg:(b * NA + best + 1) * seg])
+    assert bool((d[:, B * seg:] == 7.0).all())
+    # trajectory 2: every comparison against the NaN first trial is false, so it stays the "minimum" -- as `minimum` of a vector with NaN
+    # is NaN in the reference and the loop leaves with status 2
+    assert float(step[2]) == 0.1 and bool(torch.isnan(mx[2]))
+    out = np.zeros(2 * B + 3)
+    three = torch.tensor([1.5, -2.0, float("inf")], **f64)
+    for _ in range(3):                                                      # the sequence word advances per call
+        lto.read_scalars(gpu_ctx, torch.cat([step, mx]), 2 * B, three, 3, out)
+        assert np.array_equal(out[:B], step.cpu().numpy()) and np.array_equal(out[B:2 * B], mx.cpu().numpy(), equal_nan=True)
+        assert out[2 * B] == 1.5 and out[2 * B + 1] == -2.0 and np.isinf(out[2 * B + 2])
+        three = three * 1.0
+    big = torch.arange(5000, **f64)                                         # larger than the block of the calls before: it grows
+    outb = np.zeros(5000)
+    lto.read_scalars(gpu_ctx, big, 5000, None, 0, outb)
+    assert np.array_equal(outb, np.arange(5000.0))
+    with pytest.raises(lto.LtoError):
+        lto.read_scalars(gpu_ctx, big, 0, None, 0, outb)
+
+
 @pytest.mark.parametrize("pcase", ["p1_rho1", "p2_clamped", "p1.5", "p0"])
 @pytest.mark.parametrize("ndim", [12, 14])
 @pytest.mark.parametrize("kernel,mname", KERNEL_METHODS)
