@@ -509,6 +509,7 @@ class NewtonIteration:
         self.scal = torch.zeros(3, **f64)                                       # [step | max |defect| | max |dx|]: one read-back
         self.step, self.mx, self.mx2 = self.scal[0:1], self.scal[1:2], self.scal[2:3]
         self.host = np.zeros(3)
+        self.count = 0
 
     def ops(self):
         """(name, closure) in the order of one iteration; every closure enqueues on the bench's stream."""
@@ -535,6 +536,12 @@ class NewtonIteration:
     def iteration(self, sync=True):
         for name, op in self.ops():
             op()
+            if name == "line_search_sweep" and self.S * NEWTON_ALPHAS >= 16384:
+                # as lto_indirect_solve: trial sweeps of this size run with the lanes ordered by an earlier sweep's step counts, the
+                # order renewed every fourth iteration
+                if self.count % 4 == 0:
+                    self.plan_ls.rebalance(stream=self.st)
+                self.count += 1
             if sync and name == "update":          # the library's loop reads back once per iteration (step length, max |defect|, max |dx|)
                 self.lto.read_scalars(self.ctx, self.scal, 3, None, 0, self.host, stream=self.st)
 

@@ -33,6 +33,21 @@ def main():
             us = (time.perf_counter() - t0) / 50 * 1e6
             acc, rej = it.plan_ls.step_counts(stream=st)
             print("S=%5d x 20 trial trajectories, lanes %d: %.1f us per sweep; trial steps mean %.2f max %d" % (S, lanes, us, (acc + rej).mean(), (acc + rej).max()), flush=True)
+        it.plan_ls.set_defect_lanes(0)
+        if S * NA >= 16384:                    # the same sweep with the lanes ordered by the previous sweep's step counts
+            it.plan_ls.defect(it.Xt, n * NA, it.t, 1, it.dt, S * NA, stream=st)
+            ref = it.dt.clone()
+            it.plan_ls.rebalance(stream=st)
+            for lanes in (0, 4, 2, 1):
+                it.plan_ls.set_defect_lanes(lanes)
+                for _ in range(5):
+                    it.plan_ls.defect(it.Xt, n * NA, it.t, 1, it.dt, S * NA, stream=st)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(50):
+                    it.plan_ls.defect(it.Xt, n * NA, it.t, 1, it.dt, S * NA, stream=st)
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t0) / 50 * 1e6
+                print("S=%5d x 20 REBALANCED, lanes %d: %.1f us per sweep; max |d - natural order| %.2e" % (S, lanes, us, float((it.dt - ref).abs().max())), flush=True)
         for lanes in (0, 4, 2, 1):
             it.plan.set_defect_lanes(lanes)
             for _ in range(5):
