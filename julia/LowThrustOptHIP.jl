@@ -297,6 +297,17 @@ ctx_stream(ctx::LtoContext) = ccall((:lto_ctx_stream, liblto), Ptr{Cvoid}, (Ptr{
 "Wall time [ms] of the last host-pointer call on `ctx`, entry to return, as measured inside the library."
 last_call_ms(ctx::LtoContext) = ccall((:lto_last_call_ms, liblto), Cdouble, (Ptr{Cvoid},), ctx.handle)
 
+"Measure the cost table LTO_KERNEL_AUTO chooses the RK4 STM kernel family by (microseconds per round) on this context's device."
+calibrate_kernels!(ctx::LtoContext) = check(ctx, ccall((:lto_calibrate_kernels, liblto), Cint, (Ptr{Cvoid},), ctx.handle))
+
+"(`[pipeline8, pipeline48, per-lane]` microseconds per round at 64 steps, calibrated?) for `ndim` = 12 or 14."
+function kernel_round_costs(ctx::LtoContext, ndim::Integer)
+    us = zeros(Float64, 3)
+    cal = Ref{Cint}(0)
+    check(ctx, ccall((:lto_kernel_round_costs, liblto), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cint}), ctx.handle, ndim, us, cal))
+    return us, cal[] != 0
+end
+
 """`Array{Float64}` of the given size in page-locked host memory (lto_host_alloc): the GPU reads and writes such arrays (and
 contiguous views into them) in place during a host-pointer call -- no copy is queued (Jacobian call at 4 096 segments: 0.20 ms
 instead of 0.29 ms with ordinary arrays).  Freed by a finalizer, which may run before or after the context's: the library finds

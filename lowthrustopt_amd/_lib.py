@@ -87,6 +87,8 @@ SIGNATURES = {
     "lto_indirect_newton_solve_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_long, C.c_int, _vp, C.c_long]),
     "lto_axpy_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, _vp, C.c_long]),
     "lto_trial_points_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_long]),
+    "lto_calibrate_kernels": (C.c_int, [_vp]),
+    "lto_kernel_round_costs": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "lto_read_scalars_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "lto_line_search_pick_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_long]),
     "lto_indirect_dense_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),

@@ -126,7 +126,8 @@ hipError_t launch_soc_mask(const double* mx, const double* act, double thr, doub
 hipError_t launch_pick_alpha(const double* ss, const double* alphas, int na, const double* act, const double* search, double* step, int nb,
                              const double* mxt, double* mx, hipStream_t st);
 hipError_t launch_take_trial(const double* trial, long ldt, const double* ss, const double* act, const double* search, int na, int seg,
-                             int ndim, int nb, double* defect, long ldd, hipStream_t st);
+                             int ndim, int nb, double* defect, long ldd, const double* alphas, double* step, const double* mxt, double* mx,
+                             hipStream_t st);   // step != nullptr: also k_pick_alpha's outputs (one launch for both)
 hipError_t launch_iter_report(const double* a, int na, const double* b, int nb, double* host_dev, long long* seq_dev, long long seq, hipStream_t st);
 hipError_t launch_end_states(double* X, long ld, int n, int nb, int nrow, double* saved, int restore, hipStream_t st);
 hipError_t launch_defect_norms(const double* defect, long ldd, int ndim, int seg_per_traj, int n_batch, double* sumsq,

@@ -276,10 +276,17 @@ __global__ void k_pick_alpha(const double* ss, const double* alphas, int na, con
 // fma), so its defect sweep (:328) would repeat the trial's lane for lane.
 __global__ __launch_bounds__(256) void k_take_trial(const double* __restrict__ trial, long ldt, const double* __restrict__ ss,
                                                     const double* __restrict__ act, const double* __restrict__ search, int na, int seg,
-                                                    int ndim, int nb, double* __restrict__ defect, long ldd) {
+                                                    int ndim, int nb, double* __restrict__ defect, long ldd, const double* __restrict__ alphas,
+                                                    double* __restrict__ step, const double* __restrict__ mxt, double* __restrict__ mx) {
   for (int b = blockIdx.y; b < nb; b += gridDim.y) {
-    if ((act && act[b] == 0.0) || (search && search[b] == 0.0)) continue;
-    const int a = first_minimiser(ss + (long)b * na, na);
+    const bool on = !act || act[b] != 0.0;
+    const bool chosen = on && (!search || search[b] != 0.0);
+    const int a = chosen ? first_minimiser(ss + (long)b * na, na) : 0;
+    if (step && blockIdx.x == 0 && threadIdx.x == 0) {      // k_pick_alpha's part, when this launch stands for both
+      step[b] = chosen ? alphas[a] : (on ? 1.0 : 0.0);
+      if (mxt && mx && chosen) mx[b] = mxt[(long)b * na + a];
+    }
+    if (!chosen) continue;
     const long src = ((long)b * na + a) * seg, dst = (long)b * seg;
     const long total = (long)ndim * seg;
     for (long q = blockIdx.x * 256L + threadIdx.x; q < total; q += gridDim.x * 256L) {
@@ -311,11 +318,12 @@ hipError_t launch_pick_alpha(const double* ss, const double* alphas, int na, con
   return hipGetLastError();
 }
 hipError_t launch_take_trial(const double* trial, long ldt, const double* ss, const double* act, const double* search, int na, int seg,
-                             int ndim, int nb, double* defect, long ldd, hipStream_t st) {
+                             int ndim, int nb, double* defect, long ldd, const double* alphas, double* step, const double* mxt, double* mx,
+                             hipStream_t st) {
   if (nb <= 0 || seg <= 0) return hipSuccess;
   long blocks = ((long)ndim * seg + 255) / 256;
   if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(k_take_trial, dim3((unsigned)blocks, (unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, trial, ldt, ss, act, search, na, seg, ndim, nb, defect, ldd);
+  hipLaunchKernelGGL(k_take_trial, dim3((unsigned)blocks, (unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, trial, ldt, ss, act, search, na, seg, ndim, nb, defect, ldd, alphas, step, mxt, mx);
   return hipGetLastError();
 }
 hipError_t launch_iter_report(const double* a, int na, const double* b, int nb, double* host_dev, long long* seq_dev, long long seq, hipStream_t st) {

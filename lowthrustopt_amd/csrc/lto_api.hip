@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -69,6 +70,11 @@ struct lto_ctx {
   double last_call_ms;     // wall time of the last host-pointer call, entry to return (lto_last_call_ms)
   // landing block of the Newton loop's per-iteration scalars (lto_indirect_solve_batch): page-locked, mapped, written by
   // k_iter_report; word 0 is the sequence number the host polls, the values follow.  Grow-only; absent = copy + synchronise.
+  // AUTO's cost table: microseconds per ROUND of each RK4 STM family at 64 steps, [ndim == 14][family] with family 0 = eight-wave
+  // pipeline (rounds of 16 x CUs segments), 1 = 48-segment pipeline (48 x CUs), 2 = per-lane with three columns (64 x CUs; 12-dim only).
+  // Defaults: MI355X, profiles/r04z; lto_calibrate_kernels replaces them with this device's own.
+  double round_cost[2][3];
+  bool calibrated;
   double* rep_host;
   double* rep_dev;
   size_t rep_doubles;
@@ -255,6 +261,7 @@ int lto_create(lto_ctx** out, int device_id) {
   if (!c) return LTO_EHIP;
   c->device = device_id;
   c->cu_count = 0;
+  { const double dflt[2][3] = {{66.0, 163.0, 249.0}, {76.0, 190.0, 1e300}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
   if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) { c->cu_count = 0; (void)hipGetLastError(); }
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -668,7 +675,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   // CU holds one (91 KB of LDS), so up to 16 x CUs segments (4 096 on MI355X) the sweep is one round -- 14-dim 76 us, 12-dim 66 us
   // against 106 / 89 us (four-wave form, removed), 173 / 136 us per-lane, 238 / 116 us cooperative -- and above that every family
   // runs in rounds of the segments the chip holds at once, a partly filled round costing a whole one: the family with the
-  // cheapest rounds for THIS segment count wins (us per round at 64 steps; the ratios do not depend on the step count): the
+  // cheapest rounds for THIS segment count wins (lto_ctx::round_cost: us per round at 64 steps; the ratios do not depend on the step count): the
   // eight-wave form in rounds of 16 x CUs, the 48-segment / 16-wave form in rounds of 48 x CUs, for 12-dim also the per-lane
   // kernel with 3 columns per lane in rounds of 64 x CUs.  13-stage methods: the wave-specialised kernel (DOP853 @1e-13,
   // 4 096 segments: 0.32 ms vs 1.9 ms per-lane), for the reference's setting (12-dim, DOP853) its two-lanes-per-state form.
@@ -681,9 +688,10 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
     else if (p->S <= 16 * cus) kern = LTO_KERNEL_PIPE8;
     else {
       const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };
-      const double t8 = rounds(16 * cus) * (p->ndim == 14 ? 76.0 : 66.0);
-      const double t48 = rounds(48 * cus) * (p->ndim == 14 ? 190.0 : 163.0);
-      const double tl = (p->ndim == 12) ? rounds(64 * cus) * 249.0 : 1e300;
+      const double* cost = c->round_cost[p->ndim == 14 ? 1 : 0];     // us per round: defaults or this device's (lto_calibrate_kernels)
+      const double t8 = rounds(16 * cus) * cost[0];
+      const double t48 = rounds(48 * cus) * cost[1];
+      const double tl = (p->ndim == 12) ? rounds(64 * cus) * cost[2] : 1e300;
       kern = (t48 <= t8 && t48 <= tl) ? LTO_KERNEL_PIPE48 : (t8 <= tl ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PER_LANE);
     }
   }
@@ -815,8 +823,9 @@ int lto_line_search_pick_dev(lto_ctx* c, void* stream, const double* sumsq, cons
   int rc = bind_device(c);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = launch_pick_alpha(sumsq, alphas, n_alpha, nullptr, nullptr, step, n_batch, maxabs, maxabs_out, st);
-  if (e == hipSuccess && defect) e = launch_take_trial(trial_defect, ldt, sumsq, nullptr, nullptr, n_alpha, seg_per_traj, ndim, n_batch, defect, ldd, st);
+  hipError_t e = defect ? launch_take_trial(trial_defect, ldt, sumsq, nullptr, nullptr, n_alpha, seg_per_traj, ndim, n_batch, defect, ldd, alphas,
+                                            step, maxabs, maxabs_out, st)
+                        : launch_pick_alpha(sumsq, alphas, n_alpha, nullptr, nullptr, step, n_batch, maxabs, maxabs_out, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "line search pick", e);
   return LTO_OK;
 }
@@ -829,6 +838,104 @@ int lto_read_scalars_dev(lto_ctx* c, void* stream, const double* a, int na, cons
   if (rc) return rc;
   (void)report_reserve(c, (size_t)na + nb);
   return read_scalars(c, (hipStream_t)stream, a, na, b, nb, out);
+}
+
+/* AUTO's cost table measured on this device: one full round of every RK4 STM family and dimension (16 / 48 / 64 x CUs segments,
+ * 16 RK4 steps, one state near the L2 halo orbits in every segment -- fixed-step kernels do the same work whatever the data), after 30 ms of
+ * sweeps so that the clocks have settled; the median of five launches, scaled to 64 steps. */
+int lto_calibrate_kernels(lto_ctx* c) {
+  if (!c) return LTO_ENULL;
+  int rc = bind_device(c);
+  if (rc) return rc;
+  const long cus = c->cu_count > 0 ? c->cu_count : 256;
+  const long per_round[3] = {16 * cus, 48 * cus, 64 * cus};
+  const int family_kernel[3] = {LTO_KERNEL_PIPE8, LTO_KERNEL_PIPE48, LTO_KERNEL_PER_LANE};
+  const long Smax = per_round[2], nmax = Smax + 1;
+  hipStream_t st = c->stream;
+  LTO_HIP(c, hipStreamSynchronize(st));
+  rc = arena_reserve(c, al256(sizeof(double) * 14 * nmax) + al256(sizeof(double) * nmax) + al256(sizeof(double) * 196 * Smax) + al256(sizeof(double) * 14 * Smax) + 4096);
+  if (rc) return rc;
+  c->arena_top = 0;
+  double* d_X = arena_take<double>(c, (size_t)14 * nmax);
+  double* d_t = arena_take<double>(c, (size_t)nmax);
+  double* d_phi = arena_take<double>(c, (size_t)196 * Smax);
+  double* d_def = arena_take<double>(c, (size_t)14 * Smax);
+  // a state near the Earth-Moon L2 halo family (0.17 DU from the Moon), small costates; 1 000 kg / lambda_m = 0.1 for the 14-row layout
+  const double x12[12] = {1.1599795702248494, 0.0097200000000000, -0.1240184140575570, 0.0087153964800000, -0.2085329310256100, 0.0105833000000000,
+                          0.01, -0.02, 0.015, 0.02, 0.01, -0.01};
+  std::vector<double> hX((size_t)14 * nmax), ht((size_t)nmax);
+  for (long k = 0; k < nmax; ++k) ht[k] = 0.02 * (double)k;
+  hipEvent_t e0, e1;
+  LTO_HIP(c, hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return set_err(c, LTO_EHIP, "hipEventCreate"); }
+  lto_params prm = {0.012150585609624, 384400.0, 375190.25852, 0.05, 1000.0, 1.0, 1.0, 1.0};
+  lto_integrator integ; std::memset(&integ, 0, sizeof integ);
+  integ.method = LTO_RK4; integ.steps = 16;
+  double measured[2][3] = {{0, 0, 1e300}, {0, 0, 1e300}};
+  for (int di = 0; di < 2 && rc == LTO_OK; ++di) {
+    const int nd = di ? 14 : 12;
+    for (long k = 0; k < nmax; ++k)
+      for (int r = 0; r < nd; ++r) {
+        double v;
+        if (nd == 12) v = x12[r];
+        else v = (r < 6) ? x12[r] : (r == 6) ? 1000.0 : (r < 13) ? x12[r - 1] : 0.1;
+        hX[(size_t)r * nmax + k] = v;
+      }
+    prm.mass = di ? 3000.0 : 1000.0;                 // 14-row layout: the slot carries Isp
+    hipError_t e = hipMemcpyAsync(d_X, hX.data(), sizeof(double) * nd * nmax, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_t, ht.data(), sizeof(double) * nmax, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "calibration upload", e); break; }
+    for (int f = 0; f < 3 && rc == LTO_OK; ++f) {
+      if (nd == 14 && f == 2) continue;
+      const long S = per_round[f];
+      lto_indirect_plan* p = nullptr;
+      rc = plan_build(c, nd, (int)(S + 1), 1, &prm, 1, &integ, &p);
+      if (rc) break;
+      p->kernel = family_kernel[f];
+      if (f == 2) p->cols_per_lane = 3;
+      auto sweep = [&]() { return lto_indirect_jacobian_dev(p, st, d_X, nmax, d_t, 1, d_phi, S, d_def, S); };
+      if (di == 0 && f == 0) {                      // let the clocks settle: ~30 ms of sweeps
+        const auto t0 = std::chrono::steady_clock::now();
+        while (rc == LTO_OK && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.03) {
+          for (int q = 0; q < 16 && rc == LTO_OK; ++q) rc = sweep();
+          if (rc == LTO_OK && hipStreamSynchronize(st) != hipSuccess) rc = set_err(c, LTO_EHIP, "calibration warm-up");
+        }
+      }
+      double ms[5];
+      for (int q = 0; q < 2 && rc == LTO_OK; ++q) rc = sweep();
+      for (int q = 0; q < 5 && rc == LTO_OK; ++q) {
+        float m = 0.0f;
+        if (hipEventRecord(e0, st) != hipSuccess) { rc = set_err(c, LTO_EHIP, "hipEventRecord"); break; }
+        rc = sweep();
+        if (rc == LTO_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&m, e0, e1) != hipSuccess))
+          rc = set_err(c, LTO_EHIP, "calibration timing");
+        ms[q] = m;
+      }
+      plan_free(p);
+      if (rc == LTO_OK) {
+        std::sort(ms, ms + 5);
+        measured[di][f] = ms[2] * 1e3 * (64.0 / integ.steps);
+      }
+    }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc != LTO_OK) return rc;
+  for (int di = 0; di < 2; ++di)
+    for (int f = 0; f < 3; ++f)
+      if (!(measured[di][f] > 0.0)) return set_err(c, LTO_EHIP, "calibration returned a non-positive time");
+  std::memcpy(c->round_cost, measured, sizeof measured);
+  c->calibrated = true;
+  return LTO_OK;
+}
+
+int lto_kernel_round_costs(const lto_ctx* c, int ndim, double* us_per_round, int* calibrated) {
+  if (!c || !us_per_round) return LTO_ENULL;
+  if (ndim != 12 && ndim != 14) return LTO_EINVAL;
+  for (int f = 0; f < 3; ++f) us_per_round[f] = c->round_cost[ndim == 14 ? 1 : 0][f];
+  if (ndim == 14) us_per_round[2] = -1.0;           // not a candidate
+  if (calibrated) *calibrated = c->calibrated ? 1 : 0;
+  return LTO_OK;
 }
 
 /* Host-pointer API: adopt / refresh the context's cached lane order (see lto_ctx::order_cache).  Below these sizes
@@ -1102,17 +1209,16 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
       e = launch_defect_norms(d_deft, S * NA, 12, n_nodes - 1, B * NA, d_ss, d_mxt, st);           // sum(defect.^2), :240 (+ max |defect|)
       if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "line search", e); break; }
     }
-    // alpha (:244-245), 1, or 0 (frozen); where the line search ran, the chosen trial's max |defect| and its index as well
-    e = launch_pick_alpha(d_ss, d_alphas, NA, d_act, d_search, d_step, B, search ? d_mxt : nullptr, d_mx, st);
+    // alpha (:244-245), 1, or 0 (frozen).  When every active trajectory searched, the same launch takes the chosen trial's max
+    // |defect| and defect block: CHECK UPDATE (:328-331) without a sweep -- the new XC_all is the chosen trial point bit for bit
+    // (same fma, the update's end-state rows are zero), so defectCalc there is the lanes of the line search's sweep that integrated it.
+    const bool reuse = search && all_search;
+    e = reuse ? launch_take_trial(d_deft, S * NA, d_ss, d_act, d_search, NA, n_nodes - 1, 12, B, d_def, S, d_alphas, d_step, d_mxt, d_mx, st)
+              : launch_pick_alpha(d_ss, d_alphas, NA, d_act, d_search, d_step, B, nullptr, nullptr, st);
     if (e == hipSuccess) e = launch_axpy_traj(d_X, d_del, d_step, d_X, J, 12, n_nodes, B, st);      // :304
     if (e == hipSuccess) e = launch_end_states(d_X, J, n_nodes, B, 6, d_saved, 1, st);             // :324-325
     if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "update", e); break; }
-    if (search && all_search) {
-      // CHECK UPDATE (:328-331) without a sweep: the new XC_all is the chosen trial point bit for bit (same fma, the update's
-      // end-state rows are zero), so defectCalc there is the lanes of the line search's sweep that integrated it.
-      e = launch_take_trial(d_deft, S * NA, d_ss, d_act, d_search, NA, n_nodes - 1, 12, B, d_def, S, st);
-      if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "take trial", e); break; }
-    } else {
+    if (!reuse) {
       rc = lto_indirect_defect_dev(p, st, d_X, J, d_t, n_tgrids, d_def, S, nullptr);               // :328
       if (rc != LTO_OK) break;
       e = launch_defect_norms(d_def, S, 12, (int)(n - 1), B, nullptr, d_mx, st);                     // :331

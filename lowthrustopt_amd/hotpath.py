@@ -111,6 +111,18 @@ class Context:
         """Wall time of the last host-pointer call as measured inside the library (entry to return)."""
         return float(self.lib.lto_last_call_ms(self.handle))
 
+    def calibrate_kernels(self):
+        """Measure AUTO's cost table (us per round of every RK4 STM family) on this context's device (lto_calibrate_kernels)."""
+        self.check(self.lib.lto_calibrate_kernels(self.handle))
+        return {nd: self.kernel_round_costs(nd)[0] for nd in (12, 14)}
+
+    def kernel_round_costs(self, ndim):
+        """([pipeline8, pipeline48, per-lane] us per round at 64 steps, calibrated?) -- what LTO_KERNEL_AUTO chooses by."""
+        out = (C.c_double * 3)()
+        cal = C.c_int(0)
+        self.check(self.lib.lto_kernel_round_costs(self.handle, int(ndim), out, C.byref(cal)))
+        return [float(v) for v in out], bool(cal.value)
+
 
 class Group:
     """Several GPUs behind this one process (lto_group_*): pass as `ctx=` to indirect_defectCalc, indirect_stm,

@@ -1507,6 +1507,44 @@ def test_indirect_auto_kernel_choice(gpu_ctx):
         assert bool(torch.isfinite(Phi).all())
 
 
+def test_kernel_cost_table_calibration():
+    """lto_calibrate_kernels: AUTO's cost table (us per round of every RK4 STM family) measured on the device itself replaces
+    the MI355X defaults a new context holds; the measured figures are of the defaults' size, keep the families' order, and leave
+    the choices at the round boundaries where test_indirect_auto_kernel_choice pins them."""
+    import torch
+    ctx = lto.Context(0)
+    try:
+        d12, cal = ctx.kernel_round_costs(12)
+        d14, _ = ctx.kernel_round_costs(14)
+        assert not cal and d12 == [66.0, 163.0, 249.0] and d14[:2] == [76.0, 190.0] and d14[2] == -1.0
+        got = ctx.calibrate_kernels()
+        m12, cal = ctx.kernel_round_costs(12)
+        m14, _ = ctx.kernel_round_costs(14)
+        assert cal and got[12] == m12 and got[14] == m14
+        for meas, dflt in ((m12, d12), (m14[:2], d14[:2])):
+            for a, b in zip(meas, dflt):
+                assert 0.6 * b < a < 1.6 * b, (meas, dflt)               # same device class: same size (clocks differ run to run)
+            assert all(x < y for x, y in zip(meas, meas[1:]))           # a round of 16 / 48 / 64 x CUs segments: dearer as it grows
+        if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+            for ndim, n, want in ((14, 8193, "pipeline8"), (12, 8193, "pipeline8"), (14, 12289, "pipeline48"), (12, 12289, "pipeline48")):
+                XC, T = synth.indirect_problem(n, seed=2)
+                X = XC
+                if ndim == 14:
+                    X = np.zeros((14, n, 1), order="F")
+                    X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+                prm = lto.make_params(MU, DU, TU, 0.05, 2000.0 if ndim == 14 else 1000.0, 1.0, 1.0, 1.0)
+                plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=8), ndim=ndim)
+                S = n - 1
+                Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
+                d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+                plan.jacobian(torch.from_numpy(synth.to_soa_nodes(X)).cuda(), n, torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda(), 1, Phi, S, d, S)
+                torch.cuda.synchronize()
+                assert plan.last_kernel() == want, (ndim, n, plan.last_kernel(), m12, m14)
+                plan.close()
+    finally:
+        ctx.close()
+
+
 def test_rebalanced_auto_sweeps_with_record_staging_are_bit_identical(gpu_ctx):
     """AUTO on a 12-dim DOP853 plan after lto_indirect_plan_rebalance: the two- / four-lane defect kernels and the two-lane
     cooperative STM kernel then read node RECORDS and write defect / STM records (IndirectArgs::Xa / Da / Pa) with coalesced
