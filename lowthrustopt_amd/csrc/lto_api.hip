@@ -71,9 +71,10 @@ struct lto_ctx {
   // landing block of the Newton loop's per-iteration scalars (lto_indirect_solve_batch): page-locked, mapped, written by
   // k_iter_report; word 0 is the sequence number the host polls, the values follow.  Grow-only; absent = copy + synchronise.
   // AUTO's cost table: microseconds per ROUND of each RK4 STM family at 64 steps, [ndim == 14][family] with family 0 = eight-wave
-  // pipeline (rounds of 16 x CUs segments), 1 = 48-segment pipeline (48 x CUs), 2 = per-lane with three columns (64 x CUs; 12-dim only).
+  // pipeline (rounds of 16 x CUs segments), 1 = 48-segment pipeline (48 x CUs), 2 = per-lane with three columns (64 x CUs; 12-dim
+  // only), 3 = 44-segment form of the large-batch pipeline (44 x CUs; 12-dim only).
   // Defaults: MI355X, profiles/r04z; lto_calibrate_kernels replaces them with this device's own.
-  double round_cost[2][3];
+  double round_cost[2][4];
   bool calibrated;
   double* rep_host;
   double* rep_dev;
@@ -98,6 +99,7 @@ struct lto_indirect_plan {
   int cols_per_lane;
   int kernel;       // LTO_KERNEL_*
   int last_kernel;  // family the last STM sweep ran (AUTO resolved)
+  int p48_form;     // large-batch pipeline, 12-dim: 0 = the form with the cheaper rounds, 44 / 48 = that form (calibration)
   double* d_bvp;    // workspace of the device Newton solve (lazily allocated)
   size_t bvp_bytes;
   int bvp_variant;  // -1 none, 0 square system, 1 adjoints-only least squares: what the stored factorisation is
@@ -261,7 +263,7 @@ int lto_create(lto_ctx** out, int device_id) {
   if (!c) return LTO_EHIP;
   c->device = device_id;
   c->cu_count = 0;
-  { const double dflt[2][3] = {{66.0, 163.0, 249.0}, {76.0, 190.0, 1e300}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
+  { const double dflt[2][4] = {{66.0, 163.0, 249.0, 139.0}, {76.0, 190.0, 1e300, 1e300}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
   if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) { c->cu_count = 0; (void)hipGetLastError(); }
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -676,7 +678,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   // against 106 / 89 us (four-wave form, removed), 173 / 136 us per-lane, 238 / 116 us cooperative -- and above that every family
   // runs in rounds of the segments the chip holds at once, a partly filled round costing a whole one: the family with the
   // cheapest rounds for THIS segment count wins (lto_ctx::round_cost: us per round at 64 steps; the ratios do not depend on the step count): the
-  // eight-wave form in rounds of 16 x CUs, the 48-segment / 16-wave form in rounds of 48 x CUs, for 12-dim also the per-lane
+  // eight-wave form in rounds of 16 x CUs, the 48-segment / 16-wave form in rounds of 48 x CUs (12-dim: 44 x CUs), for 12-dim also the per-lane
   // kernel with 3 columns per lane in rounds of 64 x CUs.  13-stage methods: the wave-specialised kernel (DOP853 @1e-13,
   // 4 096 segments: 0.32 ms vs 1.9 ms per-lane), for the reference's setting (12-dim, DOP853) its two-lanes-per-state form.
   int kern = p->kernel;
@@ -690,10 +692,19 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
       const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };
       const double* cost = c->round_cost[p->ndim == 14 ? 1 : 0];     // us per round: defaults or this device's (lto_calibrate_kernels)
       const double t8 = rounds(16 * cus) * cost[0];
-      const double t48 = rounds(48 * cus) * cost[1];
+      const double t48 = std::min(rounds(48 * cus) * cost[1], p->ndim == 12 ? rounds(44 * cus) * cost[3] : 1e300);
       const double tl = (p->ndim == 12) ? rounds(64 * cus) * cost[2] : 1e300;
       kern = (t48 <= t8 && t48 <= tl) ? LTO_KERNEL_PIPE48 : (t8 <= tl ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PER_LANE);
     }
+  }
+  // the large-batch pipeline has two forms for 12-dim (48 or 44 segments per workgroup, kernels_indirect_pipe48.hip): the cheaper
+  // rounds for this segment count, whether AUTO or the caller chose the family
+  bool seg44 = false;
+  if (kern == LTO_KERNEL_PIPE48 && p->ndim == 12) {
+    const long cus = c->cu_count > 0 ? c->cu_count : 256;
+    const double* cost = c->round_cost[0];
+    const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };
+    seg44 = p->p48_form ? p->p48_form == 44 : rounds(44 * cus) * cost[3] < rounds(48 * cus) * cost[1];
   }
   p->last_kernel = kern;
   rc = warm_args(p, 0, kern == LTO_KERNEL_COOP2, &a);
@@ -709,7 +720,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
   else if (kern == LTO_KERNEL_COOP2) e = launch_indirect_stm_coop2(p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);
-  else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, st);
+  else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, seg44, st);
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   if (e == hipSuccess && staged) e = launch_pack_soa(p->d_pa, 144, p->S, a.Phi, a.ldp, st);
@@ -841,15 +852,15 @@ int lto_read_scalars_dev(lto_ctx* c, void* stream, const double* a, int na, cons
 }
 
 /* AUTO's cost table measured on this device: one full round of every RK4 STM family and dimension (16 / 48 / 64 x CUs segments,
- * 16 RK4 steps, one state near the L2 halo orbits in every segment -- fixed-step kernels do the same work whatever the data), after 30 ms of
- * sweeps so that the clocks have settled; the median of five launches, scaled to 64 steps. */
+ * 64 RK4 steps, one state near the L2 halo orbits in every segment -- fixed-step kernels do the same work whatever the data), after 30 ms of
+ * sweeps so that the clocks have settled; the median of five launches. */
 int lto_calibrate_kernels(lto_ctx* c) {
   if (!c) return LTO_ENULL;
   int rc = bind_device(c);
   if (rc) return rc;
   const long cus = c->cu_count > 0 ? c->cu_count : 256;
-  const long per_round[3] = {16 * cus, 48 * cus, 64 * cus};
-  const int family_kernel[3] = {LTO_KERNEL_PIPE8, LTO_KERNEL_PIPE48, LTO_KERNEL_PER_LANE};
+  const long per_round[4] = {16 * cus, 48 * cus, 64 * cus, 44 * cus};
+  const int family_kernel[4] = {LTO_KERNEL_PIPE8, LTO_KERNEL_PIPE48, LTO_KERNEL_PER_LANE, LTO_KERNEL_PIPE48};
   const long Smax = per_round[2], nmax = Smax + 1;
   hipStream_t st = c->stream;
   LTO_HIP(c, hipStreamSynchronize(st));
@@ -870,8 +881,8 @@ int lto_calibrate_kernels(lto_ctx* c) {
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return set_err(c, LTO_EHIP, "hipEventCreate"); }
   lto_params prm = {0.012150585609624, 384400.0, 375190.25852, 0.05, 1000.0, 1.0, 1.0, 1.0};
   lto_integrator integ; std::memset(&integ, 0, sizeof integ);
-  integ.method = LTO_RK4; integ.steps = 16;
-  double measured[2][3] = {{0, 0, 1e300}, {0, 0, 1e300}};
+  integ.method = LTO_RK4; integ.steps = 64;
+  double measured[2][4] = {{0, 0, 0, 0}, {0, 0, 1e300, 1e300}};
   for (int di = 0; di < 2 && rc == LTO_OK; ++di) {
     const int nd = di ? 14 : 12;
     for (long k = 0; k < nmax; ++k)
@@ -886,13 +897,14 @@ int lto_calibrate_kernels(lto_ctx* c) {
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, ht.data(), sizeof(double) * nmax, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "calibration upload", e); break; }
-    for (int f = 0; f < 3 && rc == LTO_OK; ++f) {
-      if (nd == 14 && f == 2) continue;
-      const long S = per_round[f];
+    for (int f = 0; f < 4 && rc == LTO_OK; ++f) {
+      if (nd == 14 && f >= 2) continue;
+      const long S = per_round[f];      // one full round: with 44 x CUs segments the 44-form is the cheaper one, with 48 x CUs the 48-form
       lto_indirect_plan* p = nullptr;
       rc = plan_build(c, nd, (int)(S + 1), 1, &prm, 1, &integ, &p);
       if (rc) break;
       p->kernel = family_kernel[f];
+      p->p48_form = (f == 3) ? 44 : 48;
       if (f == 2) p->cols_per_lane = 3;
       auto sweep = [&]() { return lto_indirect_jacobian_dev(p, st, d_X, nmax, d_t, 1, d_phi, S, d_def, S); };
       if (di == 0 && f == 0) {                      // let the clocks settle: ~30 ms of sweeps
@@ -922,7 +934,7 @@ int lto_calibrate_kernels(lto_ctx* c) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (rc != LTO_OK) return rc;
   for (int di = 0; di < 2; ++di)
-    for (int f = 0; f < 3; ++f)
+    for (int f = 0; f < 4; ++f)
       if (!(measured[di][f] > 0.0)) return set_err(c, LTO_EHIP, "calibration returned a non-positive time");
   std::memcpy(c->round_cost, measured, sizeof measured);
   c->calibrated = true;
@@ -932,8 +944,8 @@ int lto_calibrate_kernels(lto_ctx* c) {
 int lto_kernel_round_costs(const lto_ctx* c, int ndim, double* us_per_round, int* calibrated) {
   if (!c || !us_per_round) return LTO_ENULL;
   if (ndim != 12 && ndim != 14) return LTO_EINVAL;
-  for (int f = 0; f < 3; ++f) us_per_round[f] = c->round_cost[ndim == 14 ? 1 : 0][f];
-  if (ndim == 14) us_per_round[2] = -1.0;           // not a candidate
+  for (int f = 0; f < 4; ++f) us_per_round[f] = c->round_cost[ndim == 14 ? 1 : 0][f];
+  if (ndim == 14) us_per_round[2] = us_per_round[3] = -1.0;           // not candidates
   if (calibrated) *calibrated = c->calibrated ? 1 : 0;
   return LTO_OK;
 }

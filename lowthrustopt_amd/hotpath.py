@@ -117,8 +117,9 @@ class Context:
         return {nd: self.kernel_round_costs(nd)[0] for nd in (12, 14)}
 
     def kernel_round_costs(self, ndim):
-        """([pipeline8, pipeline48, per-lane] us per round at 64 steps, calibrated?) -- what LTO_KERNEL_AUTO chooses by."""
-        out = (C.c_double * 3)()
+        """([pipeline8, pipeline48 (48 segments per workgroup), per-lane, pipeline48 (44 segments)] us per round at 64 steps,
+        calibrated?) -- what LTO_KERNEL_AUTO chooses by."""
+        out = (C.c_double * 4)()
         cal = C.c_int(0)
         self.check(self.lib.lto_kernel_round_costs(self.handle, int(ndim), out, C.byref(cal)))
         return [float(v) for v in out], bool(cal.value)

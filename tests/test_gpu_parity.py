@@ -1410,6 +1410,34 @@ def test_indirect_pipeline_kernel_equals_per_lane_at_full_size(gpu_ctx, ndim, st
             assert np.abs(P1 - P2).max() < 1e-11 * np.abs(P1).max(), kernel
 
 
+def test_large_batch_pipeline_forms_agree_bitwise(gpu_ctx):
+    """12-dim, LTO_KERNEL_PIPE48: 12 288 segments run in the form with 48 segments per workgroup (one round), their first 11 261 as
+    a problem of their own in the form with 44 (wave 12 leaves, the last workgroup is ragged): the same bits segment by segment,
+    and the per-lane kernel within rounding."""
+    import torch
+    n = 12289
+    XC, T = synth.indirect_problem(n, seed=9)
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    Xd = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    res = {}
+    for name, nn, kernel in (("48", n, "pipe48"), ("44", 11262, "pipe48"), ("lane", 11262, "per_lane")):
+        S = nn - 1
+        plan = lto.IndirectPlan(gpu_ctx, nn, 1, prm, lto.integrator(lto.RK4, steps=9), ndim=12)
+        pick_kernel(plan, kernel)
+        Phi = torch.full((144, S), 7.0, dtype=torch.float64, device="cuda")
+        d = torch.full((12, S), 7.0, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+        torch.cuda.synchronize()
+        assert plan.last_kernel() == ("per-lane" if kernel == "per_lane" else "pipeline48")
+        res[name] = (Phi, d)
+        plan.close()
+    S44 = 11261
+    assert torch.equal(res["48"][0][:, :S44], res["44"][0]) and torch.equal(res["48"][1][:, :S44], res["44"][1])
+    assert float((res["44"][0] - res["lane"][0]).abs().max()) < 1e-11 * float(res["lane"][0].abs().max())
+    assert float((res["44"][1] - res["lane"][1]).abs().max()) < 1e-12
+
+
 @pytest.mark.parametrize("ndim", [12, 14])
 @pytest.mark.parametrize("steps", [255, 256, 257, 600])
 def test_indirect_pipeline_column_rescaling_at_many_steps(gpu_ctx, oracle, ndim, steps):
@@ -1516,7 +1544,7 @@ def test_kernel_cost_table_calibration():
     try:
         d12, cal = ctx.kernel_round_costs(12)
         d14, _ = ctx.kernel_round_costs(14)
-        assert not cal and d12 == [66.0, 163.0, 249.0] and d14[:2] == [76.0, 190.0] and d14[2] == -1.0
+        assert not cal and d12 == [66.0, 163.0, 249.0, 139.0] and d14 == [76.0, 190.0, -1.0, -1.0]
         got = ctx.calibrate_kernels()
         m12, cal = ctx.kernel_round_costs(12)
         m14, _ = ctx.kernel_round_costs(14)
@@ -1524,9 +1552,11 @@ def test_kernel_cost_table_calibration():
         for meas, dflt in ((m12, d12), (m14[:2], d14[:2])):
             for a, b in zip(meas, dflt):
                 assert 0.6 * b < a < 1.6 * b, (meas, dflt)               # same device class: same size (clocks differ run to run)
-            assert all(x < y for x, y in zip(meas, meas[1:]))           # a round of 16 / 48 / 64 x CUs segments: dearer as it grows
+            assert all(x < y for x, y in zip(meas[:3], meas[1:3]))      # a round of 16 / 48 / 64 x CUs segments: dearer as it grows
+        assert m12[0] < m12[3] < m12[1]                                 # 44 x CUs segments in the 44-segment form: between the two
         if torch.cuda.get_device_properties(0).multi_processor_count == 256:
-            for ndim, n, want in ((14, 8193, "pipeline8"), (12, 8193, "pipeline8"), (14, 12289, "pipeline48"), (12, 12289, "pipeline48")):
+            for ndim, n, want in ((14, 8193, "pipeline8"), (12, 8193, "pipeline8"), (14, 12289, "pipeline48"), (12, 12289, "pipeline48"),
+                                  (12, 11265, "pipeline48"), (12, 22529, "pipeline48")):
                 XC, T = synth.indirect_problem(n, seed=2)
                 X = XC
                 if ndim == 14:
