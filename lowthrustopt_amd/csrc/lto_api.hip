@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <unordered_map>
 
 #include <vector>
@@ -803,11 +804,14 @@ static int read_scalars(lto_ctx* c, hipStream_t st, const double* a, int na, con
     e = launch_iter_report(a, na, b, nb, c->rep_dev + 1, (long long*)c->rep_dev, seq, st);
     if (e != hipSuccess) return set_err(c, LTO_EHIP, "report", e);
     volatile long long* w = (volatile long long*)c->rep_host;
+    // busy poll for the first ~260 k reads (the usual case: microseconds behind the last kernel) with a look at the stream every 16 k,
+    // then a look and a short sleep per read, so that a sweep that takes seconds does not hold a core at 100 %
     for (unsigned long spin = 1;; ++spin) {
       if (*w == seq) break;
-      if ((spin & 0x3fff) == 0) {
+      const bool slow = spin > 0x40000;
+      if (slow || (spin & 0x3fff) == 0) {
         const hipError_t q = hipStreamQuery(st);
-        if (q == hipErrorNotReady) continue;
+        if (q == hipErrorNotReady) { if (slow) std::this_thread::sleep_for(std::chrono::microseconds(20)); continue; }
         if (q == hipSuccess && *w == seq) break;
         return set_err(c, LTO_EHIP, "report: the stream drained without the iteration's scalars", q);
       }
