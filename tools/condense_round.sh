@@ -8,6 +8,7 @@ RUN=gpurun_out/$1
 TAG=$2
 for f in "$RUN"/bench_*.json; do cp "$f" "profiles/${TAG}_$(basename "$f")"; done
 cp "$RUN/pytest_gpu.log" "profiles/${TAG}_pytest_gpu.log"
+[ -f "$RUN/probe_calibration.txt" ] && cp "$RUN/probe_calibration.txt" "profiles/${TAG}_probe_calibration.txt"
 S="python tools/summarize_profile.py $RUN $TAG"
 q() { "$@" > /dev/null; }
 q $S c2 "k_indirect_pipe8<14"

@@ -22,6 +22,7 @@ python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/nul
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_c5.json"; last "$OUT/bench_c5.json"
 python bench.py --workload c5_stm --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null > "$OUT/bench_c5_stm.json"; last "$OUT/bench_c5_stm.json"
 python bench.py --workload newton --cpu-seconds 6 2>/dev/null > "$OUT/bench_newton.json"; last "$OUT/bench_newton.json"
+python tools/probe_calibration.py 2>/dev/null > "$OUT/probe_calibration.txt"; cat "$OUT/probe_calibration.txt"
 fi
 if [ "$PART" = all ] || [ "$PART" = prof ]; then
 # kernel traces + stats.  The device ramps its clocks over the first ~300 contract launches (91 -> 79 us per launch): the c2
