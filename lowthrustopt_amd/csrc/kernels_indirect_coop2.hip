@@ -170,14 +170,12 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     if constexpr (ROLE == C2_TOP) { qo.x = 0.0; qo.y = r[9]; } else qo = pair(8);
     const c2_d2 o01 = sh.xa[buf][1 - ROLE][col][seg];
     const double o2v = sh.xb[buf][1 - ROLE][col][seg];
-    // (scheduling fences: left alone, the compiler waits for all nine loads at once, two instructions behind them, and lets the
-    // hand-over's stores drift to the end of the stage, in front of the barrier)
-    __builtin_amdgcn_sched_barrier(0);
+    // (no scheduling fences: two __builtin_amdgcn_sched_barrier(0) stood here and behind early() until the end of round 4; without
+    // them the sweep takes 159.0 instead of 162.6 us at 4 096 segments -- profiles/r04_sched_strategy.txt)
     sums();
     if constexpr (ROLE == C2_TOP) { out[0] = arg[3]; out[1] = arg[4]; out[2] = arg[5]; }
     else { out[0] = __builtin_fma(w2, arg[1], -arg[3]); out[1] = __builtin_fma(-w2, arg[0], -arg[4]); out[2] = -arg[5]; }
     early(out);
-    __builtin_amdgcn_sched_barrier(0);                          // the hand-over stays in front of the second triple
     DyadParts dp;
     dp.A = ay.x; dp.yy = ay.y; dp.z = ze1.x; dp.e1 = ze1.y; dp.e2 = e2v; dp.omc = qo.y;
     const double other[3] = {o01.x, o01.y, o2v};
