@@ -264,7 +264,7 @@ int lto_create(lto_ctx** out, int device_id) {
   if (!c) return LTO_EHIP;
   c->device = device_id;
   c->cu_count = 0;
-  { const double dflt[2][4] = {{66.0, 163.0, 249.0, 139.0}, {76.0, 190.0, 1e300, 1e300}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
+  { const double dflt[2][4] = {{63.0, 165.0, 246.0, 139.0}, {72.0, 191.0, 1e300, 1e300}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
   if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) { c->cu_count = 0; (void)hipGetLastError(); }
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -804,14 +804,21 @@ static int read_scalars(lto_ctx* c, hipStream_t st, const double* a, int na, con
     e = launch_iter_report(a, na, b, nb, c->rep_dev + 1, (long long*)c->rep_dev, seq, st);
     if (e != hipSuccess) return set_err(c, LTO_EHIP, "report", e);
     volatile long long* w = (volatile long long*)c->rep_host;
-    // busy poll for the first ~260 k reads (the usual case: microseconds behind the last kernel) with a look at the stream every 16 k,
-    // then a look and a short sleep per read, so that a sweep that takes seconds does not hold a core at 100 %
+    // busy poll (a look at the stream every 16 k reads) for the first 5 ms -- the usual case is microseconds behind the last kernel of
+    // an iteration the host enqueued in a fraction of its run time -- then a look and a short sleep per read, so that a sweep that
+    // takes seconds does not hold a core at 100 %.  (Counting reads instead of time sent a 0.45 ms iteration into the sleeps: a
+    // cached read takes a nanosecond.)
+    const auto t_start = std::chrono::steady_clock::now();
+    bool slow = false;
     for (unsigned long spin = 1;; ++spin) {
       if (*w == seq) break;
-      const bool slow = spin > 0x40000;
       if (slow || (spin & 0x3fff) == 0) {
         const hipError_t q = hipStreamQuery(st);
-        if (q == hipErrorNotReady) { if (slow) std::this_thread::sleep_for(std::chrono::microseconds(20)); continue; }
+        if (q == hipErrorNotReady) {
+          if (slow) std::this_thread::sleep_for(std::chrono::microseconds(20));
+          else slow = std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(5);
+          continue;
+        }
         if (q == hipSuccess && *w == seq) break;
         return set_err(c, LTO_EHIP, "report: the stream drained without the iteration's scalars", q);
       }
