@@ -64,10 +64,22 @@ template <int ND, int PM> struct Pipe8 {
   static constexpr bool LM_OFF = (ND == 14) && !Arg::LM;              // lambda_m integrated by the coefficient wave
   static constexpr int NB = LM_OFF ? ND - 1 : ND;                     // components the base wave integrates
   static constexpr int NA = LM_OFF ? ND - 1 : ND;                     // STM columns a row integrates (the rest: unit vectors)
-  static constexpr int INT_DOUBLES = 4 * 4 * NI * PIPE_SEG;           // ring [step & 3][stage][value][segment]
+  // Stage arguments travel as 16-byte pairs (round 4): ring [step & 3][stage][pair][segment][2], values in the order
+  //   (r0 r1) (r2 l0) (l1 l2) [(m lambda_m)]      l = lambda_v
+  // so that a stage's position and lambda_v are THREE 128-bit LDS stores on the base wave's stream instead of six 64-bit ones (an LDS
+  // store costs the issuing wave 22.5 ticks, a 128-bit one 31: tools/micro/lds_probe.hip) and the coefficient wave reads them
+  // back with three or four loads instead of six to eight.  Consecutive segments are 16 bytes apart: conflict-free both ways.
+  static constexpr int NPAIR = (ND == 14) ? 4 : 3;
+  static constexpr int SLABD = NPAIR * PIPE_SEG * 2;                  // doubles of one (step, stage) slab
+  static constexpr int INT_DOUBLES = 4 * 4 * SLABD;
+  // position in the slab's linear order of published value e (PipeArg::idx order: r0 r1 r2 [m] l0 l1 l2 [lambda_m])
+  __host__ __device__ static constexpr int lin(int e) { return (ND == 12) ? e : (e < 3 ? e : e == 3 ? 6 : e < 7 ? e - 1 : 7); }
+  __host__ __device__ static constexpr int at(int e, int seg) { return ((lin(e) >> 1) * PIPE_SEG + seg) * 2 + (lin(e) & 1); }
   static constexpr int COEF_DOUBLES = 4 * 4 * SD;                     // ring [step & 3][stage][record]
   static constexpr int HAND_DOUBLES = ND * 64;                        // [component][lane] of the alternating column job
 };
+
+typedef double p8_d2 __attribute__((ext_vector_type(2)));
 
 struct Pipe8Flags {
   int base_steps;    // steps whose stage arguments the base wave has published
@@ -146,9 +158,9 @@ __device__ __forceinline__ void pipe8_role_base(const IndirectArgs& a, const Pip
         rhs(yt, k);
 #pragma unroll
         for (int c = 0; c < NB; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
-        double* dst = s_int + (((step & 3) * 4 + slot) * NI) * PIPE_SEG + seg;
+        double* dst = s_int + ((step & 3) * 4 + slot) * P::SLABD;
 #pragma unroll
-        for (int e = 0; e < NI; ++e) dst[e * PIPE_SEG] = keep[e];
+        for (int e = 0; e < NI; ++e) dst[P::at(e, seg)] = keep[e];
         if (j == 0) p8_signal(&fl->base_steps, step + 1);   // the phase's first step: the coefficient wave is waiting for it
       }
     }
@@ -204,11 +216,10 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
                                                        double* s_int, Pipe8Flags* fl) {
   using P = Pipe8<ND, PM>;
   static_assert(ND == 12 || P::LM_OFF, "lambda_m on the chain: the stages do not pair");
-  constexpr int NI = P::NI, NB = P::NB;
+  constexpr int NB = P::NB;
   constexpr bool M14 = (ND == 14);
   constexpr int V = 3, MI = 6, LR = M14 ? 7 : 6, LV = LR + 3;      // first row of v, mass row, first rows of lambda_r, lambda_v
-  constexpr int EL = M14 ? 4 : 3;                                   // published value index of lambda_v,x (PipeArg::idx)
-  constexpr int SLAB = NI * PIPE_SEG;
+  constexpr int SLAB = P::SLABD;
   const int steps = a.steps;
   const double h = L.h, h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0), w2 = L.w2;
   const bool is_b = (q & 1) != 0;
@@ -231,10 +242,11 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
   for (int step = 0; step < steps; ++step) {
     if (PIPE_ROLE_ON(a, 1)) {
       {
-        double* slab = s_int + ((step & 3) * 4) * SLAB + seg;     // stage s of this step: slab + s * SLAB
+        double* slab = s_int + ((step & 3) * 4) * SLAB + 2 * seg;     // stage s of this step: slab + s * SLAB; pair q of it at + q * 2 PIPE_SEG
         auto publish = [&](double* d, const double (&pr)[3], const double (&pl)[3]) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) { d[i * PIPE_SEG] = pr[i]; d[(EL + i) * PIPE_SEG] = pl[i]; }
+          *reinterpret_cast<p8_d2*>(d) = p8_d2{pr[0], pr[1]};
+          *reinterpret_cast<p8_d2*>(d + 2 * PIPE_SEG) = p8_d2{pr[2], pl[0]};
+          *reinterpret_cast<p8_d2*>(d + 4 * PIPE_SEG) = p8_d2{pl[1], pl[2]};
         };
         StageOwn o;
         double pr[3], pl[3];
@@ -268,7 +280,7 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
           y2v[i] = __builtin_fma(h2, kv1[i], y[V + i]); y2g[i] = __builtin_fma(h2, g1[i], y[LR + i]); y2l[i] = __builtin_fma(h2, kl1[i], y[LV + i]);
         }
         if constexpr (M14) {
-          slab[3 * PIPE_SEG] = y[MI]; slab[SLAB + 3 * PIPE_SEG] = y2m;
+          slab[6 * PIPE_SEG] = y[MI]; slab[SLAB + 6 * PIPE_SEG] = y2m;       // pair 3, first half
           const double u2 = gf2 * im2;
           kv2[0] = __builtin_fma(w2, y2v[1], __builtin_fma(-u2, y2l[0], a2[0]));
           kv2[1] = __builtin_fma(-w2, y2v[0], __builtin_fma(-u2, y2l[1], a2[1]));
@@ -321,7 +333,7 @@ __device__ __forceinline__ void pipe8_role_base_paired(const IndirectArgs& a, co
           y4v[i] = __builtin_fma(h, kv3[i], y[V + i]); y4g[i] = __builtin_fma(h, g3[i], y[LR + i]); y4l[i] = __builtin_fma(h, kl3[i], y[LV + i]);
         }
         if constexpr (M14) {
-          slab[2 * SLAB + 3 * PIPE_SEG] = y3m; slab[3 * SLAB + 3 * PIPE_SEG] = y4m;
+          slab[2 * SLAB + 6 * PIPE_SEG] = y3m; slab[3 * SLAB + 6 * PIPE_SEG] = y4m;
           const double u4 = gf4 * im4;
           kv4[0] = __builtin_fma(w2, y4v[1], __builtin_fma(-u4, y4l[0], a4[0]));
           kv4[1] = __builtin_fma(-w2, y4v[0], __builtin_fma(-u4, y4l[1], a4[1]));
@@ -377,9 +389,12 @@ __device__ __forceinline__ void pipe8_role_coef(const IndirectArgs& a, const Pip
     double arg[ND], dead[ND];
 #pragma unroll
     for (int c = 0; c < ND; ++c) arg[c] = 0.0;
-    const double* src = s_int + (slab * NI) * PIPE_SEG + seg;
+    const p8_d2* src = reinterpret_cast<const p8_d2*>(s_int + slab * P::SLABD) + seg;
+    double lv[2 * P::NPAIR];
 #pragma unroll
-    for (int e = 0; e < NI; ++e) arg[P::Arg::idx[e]] = src[e * PIPE_SEG];
+    for (int q = 0; q < P::NPAIR; ++q) { const p8_d2 v = src[q * PIPE_SEG]; lv[2 * q] = v.x; lv[2 * q + 1] = v.y; }
+#pragma unroll
+    for (int e = 0; e < NI; ++e) arg[P::Arg::idx[e]] = lv[P::lin(e)];
     Coef vc;
     if constexpr (ND == 12) rhs12<PM, true>(arg, L.tp, dead, vc);
     else rhs14<PM, true>(arg, L.tp, dead, vc);
@@ -479,7 +494,6 @@ __device__ __forceinline__ void pipe8_role_columns_alt(const IndirectArgs& a, co
   // the state travels as 16-byte pairs (rows 2q, 2q + 1 of a lane side by side): seven 128-bit LDS instructions each way instead
   // of fourteen 64-bit ones (round 4, tools/micro/lds_probe.hip: a 128-bit store costs 31 ticks of issue against 2 x 22.5, a load 18
   // against 2 x 17.5) -- the hand-over is 10 % of a step on the two SIMDs that share this job
-  typedef double p8_d2 __attribute__((ext_vector_type(2)));
   static_assert(ND % 2 == 0, "pairs of rows");
   p8_d2* hand2 = reinterpret_cast<p8_d2*>(s_hand);
   auto load = [&]() {
@@ -525,7 +539,7 @@ __device__ __forceinline__ void pipe8_role_columns_alt(const IndirectArgs& a, co
 template <int ND, int PM>
 __global__ __launch_bounds__(512) void k_indirect_pipe8(const IndirectArgs a) {
   using P = Pipe8<ND, PM>;
-  __shared__ double s_int[P::INT_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double s_int[P::INT_DOUBLES];
   __shared__ double s_coef[P::COEF_DOUBLES];
   __shared__ __attribute__((aligned(16))) double s_hand[P::HAND_DOUBLES];
   __shared__ double s_lm[4 * PIPE_SEG];
