@@ -785,7 +785,7 @@ int lto_trial_points_dev(lto_ctx* c, void* stream, const double* X, const double
 // the word arriving is an error.  Without the block: two copies and a stream synchronisation (about 30 us).
 static bool report_reserve(lto_ctx* c, size_t doubles) {
   if (c->rep_host && c->rep_doubles >= doubles) return true;
-  if (c->rep_host) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->rep_host); c->rep_host = nullptr; c->rep_doubles = 0; }
+  if (c->rep_host) { (void)hipDeviceSynchronize(); (void)hipHostFree(c->rep_host); c->rep_host = nullptr; c->rep_doubles = 0; }   // (any stream may have carried the last report)
   void* hp = nullptr; void* dp = nullptr;
   const size_t want = doubles + 64;
   if (hipHostMalloc(&hp, sizeof(double) * (want + 1), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
