@@ -834,6 +834,22 @@ def main():
     # id that rank 0 makes and torch.distributed hands round).  If any rank cannot set it up, every rank falls back to
     # torch.distributed's all_gather_into_tensor (also RCCL) and the JSON line says so.
     native, native_note, transport = None, None, "torch.distributed"
+    # Stream of the collective (LTO_BENCH_COLLECTIVE_STREAM):
+    #   main   the sweep's stream, right after the sweep: stream order is the dependency
+    #   side   a second stream: the gather of step k runs beside the sweep of step k + 1 (two defect / gather buffers alternate)
+    #   auto   (default for N > 1 on distinct devices) a second stream, and the wait policy -- the next sweep waits for the gather
+    #          ("serial") or only buffer reuse does ("overlap") -- is MEASURED before the timed legs: ten steps of each, the slower
+    #          rank's time decides on every rank.  A window communicator belongs to ONE stream, so both policies use the side stream.
+    #   Ranks that share a device (the one-GPU rehearsal) keep `main`: their timing says nothing and every extra gather is a chance
+    #   for four processes on one device to starve one another.
+    coll_mode = os.environ.get("LTO_BENCH_COLLECTIVE_STREAM", "main" if (share or world <= 1) else "auto")
+    if coll_mode not in ("main", "side", "auto"):
+        raise SystemExit("LTO_BENCH_COLLECTIVE_STREAM must be main, side or auto")
+    same_stream = coll_mode == "main"
+    main = torch.cuda.current_stream()
+    comm_stream = (main if same_stream else torch.cuda.Stream(device=dev)) if use_coll else None
+    policy = "serial" if same_stream else "overlap"      # side: overlap; auto: decided below
+    policy_note = None
     if use_coll:
         # Transport of the library's collective, in order of preference (LTO_BENCH_TRANSPORT = windows | rccl | torch):
         #   windows  lto_comm_window_*: every rank pushes its slab into IPC-mapped receive windows with device copies and raises a
@@ -854,8 +870,10 @@ def main():
             try:
                 src = torch.full((cnt,), float(rank + 1), **f64)
                 dst = torch.zeros(world, cnt, **f64)
-                for _ in range(3):             # both window halves, and a reuse
-                    comm.allgather(src, dst, cnt, stream=C_void_p(torch.cuda.current_stream().cuda_stream))
+                comm_stream.wait_stream(main)
+                with torch.cuda.stream(comm_stream):   # the stream the timed gathers use: a window communicator is bound to the first one it sees
+                    for _ in range(3):             # both window halves, and a reuse
+                        comm.allgather(src, dst, cnt, stream=C_void_p(comm_stream.cuda_stream))
                 torch.cuda.synchronize()
                 return bool(all(torch.all(dst[r] == float(r + 1)) for r in range(world)))
             except Exception as ex:            # noqa: BLE001
@@ -916,14 +934,8 @@ def main():
     # the closing barrier + synchronize, so every one of the K steps is fully inside the timed region.
     dbufs = [defect, torch.zeros_like(defect)] if use_coll else [defect]
     gathered = [torch.zeros(world * gather_rows, S, **f64) for _ in dbufs] if use_coll else None   # [rank][row][segment]
-    # The collective runs on the sweep's stream, after the sweep.  A side stream (LTO_BENCH_COLLECTIVE_STREAM=side) lets it
-    # overlap the next sweep in principle, but the sweep holds one workgroup on every CU and the RCCL kernel needs CUs:
-    # measured at N = 1 with the collective forced on, 93 us per step serial against 104 us "overlapped".
-    serial_coll = os.environ.get("LTO_BENCH_COLLECTIVE_STREAM", "main") != "side"
-    comm_stream = (torch.cuda.current_stream() if serial_coll else torch.cuda.Stream(device=dev)) if use_coll else None
     ev_done = [torch.cuda.Event() for _ in dbufs]      # collective on buffer b finished
     ev_ready = [torch.cuda.Event() for _ in dbufs]     # sweep into buffer b finished
-    main = torch.cuda.current_stream()
 
     def gather(b):
         with torch.cuda.stream(comm_stream):
@@ -933,19 +945,40 @@ def main():
                 raise RuntimeError("ranks share a device and the window transport is not usable: no collective left (gloo does not gather device tensors)")
             else:
                 dist.all_gather_into_tensor(gathered[b], dbufs[b])
-            if not serial_coll:
+            if not same_stream:
                 ev_done[b].record(comm_stream)
 
     def step(k, check_free):
         b = k % len(dbufs)
-        if use_coll and not serial_coll and check_free:
+        if use_coll and not same_stream and policy == "overlap" and check_free:
             main.wait_event(ev_done[b])                # buffer b is free again
         sweep(dbufs[b])
         if use_coll:
-            if not serial_coll:                        # same stream: its order is the dependency, no event needed
+            if not same_stream:                        # same stream: its order is the dependency, no event needed
                 ev_ready[b].record(main)
                 comm_stream.wait_event(ev_ready[b])
             gather(b)
+            if not same_stream and policy == "serial":
+                main.wait_event(ev_done[b])            # the next sweep starts behind the gather, as on one stream
+
+    if use_coll and coll_mode == "auto":
+        trial = {}
+        for pol in ("serial", "overlap"):
+            policy = pol
+            for k in range(4):
+                step(k, k >= len(dbufs))
+            comm_stream.synchronize(); torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for k in range(10):
+                step(k, True)
+            comm_stream.synchronize(); torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # the slowest rank's time, the same number on every rank
+            trial[pol] = float(tt.item()) / 10 * 1e3
+            dist.barrier()
+        policy = "overlap" if trial["overlap"] < trial["serial"] else "serial"
+        policy_note = "measured before the timed legs (10 steps each, slowest rank): serial %.4f ms per step, overlap %.4f ms -> %s" % (
+            trial["serial"], trial["overlap"], policy)
 
     def timed_leg():
         """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize."""
@@ -1028,8 +1061,8 @@ def main():
                        "devices": ("all %d ranks share device 0 (LTO_BENCH_SHARE_DEVICE=1): a functional run of the N > 1 path, not a scaling figure" % world
                                    if share and world > 1 else "one device per rank"),
                        "collective": ("none" if not use_coll else
-                                      "lto_comm_allgather_dev of the defect slabs after every sweep, on the %s; transport: %s%s" % (
-                                          "sweep's stream" if serial_coll else "a side stream, overlapping the next sweep",
+                                      "lto_comm_allgather_dev of the defect slabs after every sweep, on %s; transport: %s%s" % (
+                                          "the sweep's stream" if same_stream else ("a side stream, %s" % ("overlapping the next sweep" if policy == "overlap" else "the next sweep waiting for it")) + (" [%s]" % policy_note if policy_note else ""),
                                           {"windows": "IPC receive windows + device copies + flag kernel (no RCCL kernel, no CU taken from the sweep)",
                                            "rccl": "ncclAllGather (RCCL over xGMI)"}[transport],
                                           "" if not native_note else " [tried first: %s]" % native_note)

@@ -332,6 +332,24 @@ def test_bench_multi_rank_path_runs_with_ranks_sharing_the_device(world):
     assert out["value"] > 0 and out["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("mode", ["auto", "side"])
+def test_bench_collective_on_a_side_stream(mode):
+    """The N > 1 default on distinct devices: the all-gather of step k on a second stream beside the sweep of step k + 1, the wait
+    policy (next sweep behind the gather, or only buffer reuse) measured before the timed legs and agreed by all ranks (`auto`),
+    or overlap as given (`side`).  Rehearsed here with two ranks on the one device: the window communicator is bound to the side
+    stream by the test gather, events order sweep -> gather -> buffer reuse, the slab check passes."""
+    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1", "LTO_BENCH_COLLECTIVE_STREAM": mode},
+                              ["--gpus", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--segments", "1024"])
+    assert rc == 0 and out is not None, err
+    coll = out["config"]["collective"]
+    assert "IPC receive windows" in coll and "a side stream" in coll, coll
+    if mode == "auto":
+        assert "measured before the timed legs" in coll and ("-> serial" in coll or "-> overlap" in coll), coll
+    else:
+        assert "overlapping the next sweep" in coll, coll
+    assert out["config"]["slab_check"].startswith("passed on every rank") and out["n_gpus"] == 2 and out["value"] > 0
+
+
 def test_bench_transport_set_up_failing_on_one_rank_ends_cleanly_on_all():
     """One rank's window set-up fails (test hook): every rank still issues the same torch.distributed collectives, agrees that the
     transport is unusable, closes nothing a peer may touch before the barrier, and -- ranks sharing a device have no other transport --
