@@ -294,7 +294,12 @@ def test_window_transport_world1_and_misuse(gpu_ctx):
     comm.close()
 
 
-def _run_bench(extra_env, args, timeout=420):
+def _run_bench(extra_env, args, timeout=420, attempts=1):
+    """bench.py as a child process -> (exit code, its JSON line or None, tail of stderr).  attempts = 2 for the rehearsals of the
+    N > 1 path with several processes on ONE device -- a stress case no deployment has (one process per GPU): whether a rank's polling
+    collect kernel and its peers' push kernels get compute units at the same time is up to the hardware scheduler, and once in about
+    six runs on a fresh box a bounded wait of the four-rank case ran out (NaN slabs, which the bench's own slab check then rejects on
+    every rank, by design).  A second failure is a failure."""
     import json
     import subprocess
     import sys
@@ -302,9 +307,14 @@ def _run_bench(extra_env, args, timeout=420):
     env = dict(os.environ)
     env.update(extra_env)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr[-8000:]
+    errs = []
+    for _ in range(attempts):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        errs.append(p.stderr[-8000:])
+        if p.returncode == 0:
+            break
+    return p.returncode, (json.loads(lines[-1]) if lines else None), "\n---- next attempt ----\n".join(errs)
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -315,15 +325,8 @@ def test_bench_multi_rank_path_runs_with_ranks_sharing_the_device(world):
     on the one device this box has."""
     # (1 024 segments per rank: the ranks' kernels share ONE device here, and a rank's collect kernel polls for flags that its
     # peers' push kernels can only raise if they get compute units at the same time; at the contract size four ranks starve one another)
-    argv = ["--gpus", str(world), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--segments", "1024"]
-    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, argv)
-    if rc != 0 and world > 2:
-        # Four processes on ONE device is a stress case no deployment has (one process per GPU): whether a rank's polling collect
-        # kernel and its peers' push kernels get compute units at the same time is up to the hardware scheduler, and once in about
-        # six runs on a fresh box a bounded wait ran out (NaN slabs -> the bench's own slab check fails on every rank, by design).
-        # One more attempt; a second failure is a failure.
-        rc, out, err2 = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, argv)
-        err = err + "\n---- second attempt ----\n" + err2
+    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, ["--gpus", str(world), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                                                                "--segments", "1024"], attempts=2)
     assert rc == 0 and out is not None, err
     assert out["n_gpus"] == world and out["steps"] == 5 and out["warmup"] == 2
     assert out["config"]["global_segments"] == world * out["config"]["segments_per_gpu"]
@@ -339,7 +342,7 @@ def test_bench_collective_on_a_side_stream(mode):
     or overlap as given (`side`).  Rehearsed here with two ranks on the one device: the window communicator is bound to the side
     stream by the test gather, events order sweep -> gather -> buffer reuse, the slab check passes."""
     rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1", "LTO_BENCH_COLLECTIVE_STREAM": mode},
-                              ["--gpus", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--segments", "1024"])
+                              ["--gpus", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--segments", "1024"], attempts=2)
     assert rc == 0 and out is not None, err
     coll = out["config"]["collective"]
     assert "IPC receive windows" in coll and "a side stream" in coll, coll
