@@ -280,6 +280,10 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
 /* RK4 plans only: the pipeline for large batches -- 48 segments and 16 wavefronts per workgroup, the base wave's lanes are 48
  * different segments, twelve column waves with one segment per DPP row. */
 #define LTO_KERNEL_PIPE48 7
+/* 32 segments and twelve wavefronts per workgroup: the eight-wave form's roles (paired-stage base role, four lanes per segment) with one
+ * barrier per step.  For batches between one round of LTO_KERNEL_PIPE8 and a few (4 097 ... 8 192 segments on MI355X: one round
+ * instead of two).  RK4; 12-dim, and 14-dim with p = 0 or p = 1; anything else: LTO_EINVAL at the sweep. */
+#define LTO_KERNEL_PIPE32 8
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* Lanes per segment of the DEFECT-ONLY sweep of an ndim = 12 DOP853_ADAPTIVE plan (the reference's setting, indirect.jl:63-90):
  * 0 = choose (default: four lanes -- a DPP quad per segment: r, v, lambda_v, lambda_r -- up to eight wavefronts of 16 segments per

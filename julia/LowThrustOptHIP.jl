@@ -300,9 +300,9 @@ last_call_ms(ctx::LtoContext) = ccall((:lto_last_call_ms, liblto), Cdouble, (Ptr
 "Measure the cost table LTO_KERNEL_AUTO chooses the RK4 STM kernel family by (microseconds per round) on this context's device."
 calibrate_kernels!(ctx::LtoContext) = check(ctx, ccall((:lto_calibrate_kernels, liblto), Cint, (Ptr{Cvoid},), ctx.handle))
 
-"(`[pipeline8, pipeline48 with 48 segments per workgroup, per-lane, pipeline48 with 44]` microseconds per round at 64 steps, calibrated?) for `ndim` = 12 or 14."
+"(`[pipeline8, pipeline48 with 48 segments per workgroup, per-lane, pipeline48 with 44, pipeline32]` microseconds per round at 64 steps, calibrated?) for `ndim` = 12 or 14."
 function kernel_round_costs(ctx::LtoContext, ndim::Integer)
-    us = zeros(Float64, 4)
+    us = zeros(Float64, 5)
     cal = Ref{Cint}(0)
     check(ctx, ccall((:lto_kernel_round_costs, liblto), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cint}), ctx.handle, ndim, us, cal))
     return us, cal[] != 0

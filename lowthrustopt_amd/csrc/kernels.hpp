@@ -95,6 +95,8 @@ hipError_t launch_indirect_defect4(int pm, const IndirectArgs& a, hipStream_t st
 hipError_t launch_indirect_stm_pipe8(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 // large batches (kernels_indirect_pipe48.hip): 48 segments and 16 waves per workgroup, base lane = segment, DPP column rows
 hipError_t launch_indirect_stm_pipe48(int ndim, int pm, const IndirectArgs& a, bool seg44, hipStream_t st);
+hipError_t launch_indirect_stm_pipe32(int ndim, int pm, const IndirectArgs& a, hipStream_t st);   // kernels_indirect_pipe32.hip
+bool indirect_stm_pipe32_available(int ndim, int pm);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);
 // base wave + one wave per sensitivity column for 32 segments, skewed by one RKF7(8) step (one barrier per step)

@@ -73,9 +73,9 @@ struct lto_ctx {
   // k_iter_report; word 0 is the sequence number the host polls, the values follow.  Grow-only; absent = copy + synchronise.
   // AUTO's cost table: microseconds per ROUND of each RK4 STM family at 64 steps, [ndim == 14][family] with family 0 = eight-wave
   // pipeline (rounds of 16 x CUs segments), 1 = 48-segment pipeline (48 x CUs), 2 = per-lane with three columns (64 x CUs; 12-dim
-  // only), 3 = 44-segment form of the large-batch pipeline (44 x CUs; 12-dim only).
+  // only), 3 = 44-segment form of the large-batch pipeline (44 x CUs; 12-dim only), 4 = 32-segment / twelve-wave pipeline (32 x CUs).
   // Defaults: MI355X, profiles/r04z; lto_calibrate_kernels replaces them with this device's own.
-  double round_cost[2][4];
+  double round_cost[2][5];
   bool calibrated;
   double* rep_host;
   double* rep_dev;
@@ -264,7 +264,7 @@ int lto_create(lto_ctx** out, int device_id) {
   if (!c) return LTO_EHIP;
   c->device = device_id;
   c->cu_count = 0;
-  { const double dflt[2][4] = {{63.0, 165.0, 246.0, 139.0}, {72.0, 191.0, 1e300, 1e300}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
+  { const double dflt[2][5] = {{63.0, 165.0, 246.0, 139.0, 111.0}, {72.0, 191.0, 1e300, 1e300, 128.0}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
   if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) { c->cu_count = 0; (void)hipGetLastError(); }
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -510,12 +510,14 @@ int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (kernel == LTO_KERNEL_PIPE)
     return set_err(p->ctx, LTO_EINVAL, "the four-wave pipeline kernel (selector 3 on an indirect plan) was removed in round 3: LTO_KERNEL_PIPE8 is faster at every size");
   if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP &&
-      kernel != LTO_KERNEL_PIPE8 && kernel != LTO_KERNEL_COOP2 && kernel != LTO_KERNEL_PIPE48)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE8, _COOP2 or _PIPE48");
+      kernel != LTO_KERNEL_PIPE8 && kernel != LTO_KERNEL_COOP2 && kernel != LTO_KERNEL_PIPE48 && kernel != LTO_KERNEL_PIPE32)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE8, _COOP2, _PIPE48 or _PIPE32");
   if (kernel == LTO_KERNEL_COOP2 && (p->integ.method != LTO_DOP853_ADAPTIVE || p->ndim != 12))
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_COOP2 is built for 12-dim DOP853_ADAPTIVE plans");
-  if ((kernel == LTO_KERNEL_PIPE8 || kernel == LTO_KERNEL_PIPE48) && p->integ.method != LTO_RK4)
+  if ((kernel == LTO_KERNEL_PIPE8 || kernel == LTO_KERNEL_PIPE48 || kernel == LTO_KERNEL_PIPE32) && p->integ.method != LTO_RK4)
     return set_err(p->ctx, LTO_EINVAL, "the pipeline kernels are built for fixed-step RK4 plans");
+  if (kernel == LTO_KERNEL_PIPE32 && !indirect_stm_pipe32_available(p->ndim, p->pm))
+    return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_PIPE32 is built for 12-dim plans and for 14-dim plans with p = 0 or p = 1");
   p->kernel = kernel;
   return LTO_OK;
 }
@@ -695,7 +697,10 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
       const double t8 = rounds(16 * cus) * cost[0];
       const double t48 = std::min(rounds(48 * cus) * cost[1], p->ndim == 12 ? rounds(44 * cus) * cost[3] : 1e300);
       const double tl = (p->ndim == 12) ? rounds(64 * cus) * cost[2] : 1e300;
-      kern = (t48 <= t8 && t48 <= tl) ? LTO_KERNEL_PIPE48 : (t8 <= tl ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PER_LANE);
+      const double t32 = indirect_stm_pipe32_available(p->ndim, p->pm) ? rounds(32 * cus) * cost[4] : 1e300;
+      kern = (t32 < t8 && t32 < t48 && t32 < tl) ? LTO_KERNEL_PIPE32
+             : (t48 <= t8 && t48 <= tl)          ? LTO_KERNEL_PIPE48
+                                                 : (t8 <= tl ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PER_LANE);
     }
   }
   // the large-batch pipeline has two forms for 12-dim (48 or 44 segments per workgroup, kernels_indirect_pipe48.hip): the cheaper
@@ -722,6 +727,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   else if (kern == LTO_KERNEL_COOP2) e = launch_indirect_stm_coop2(p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, seg44, st);
+  else if (kern == LTO_KERNEL_PIPE32) e = launch_indirect_stm_pipe32(p->ndim, p->pm, a, st);
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   if (e == hipSuccess && staged) e = launch_pack_soa(p->d_pa, 144, p->S, a.Phi, a.ldp, st);
@@ -870,8 +876,8 @@ int lto_calibrate_kernels(lto_ctx* c) {
   int rc = bind_device(c);
   if (rc) return rc;
   const long cus = c->cu_count > 0 ? c->cu_count : 256;
-  const long per_round[4] = {16 * cus, 48 * cus, 64 * cus, 44 * cus};
-  const int family_kernel[4] = {LTO_KERNEL_PIPE8, LTO_KERNEL_PIPE48, LTO_KERNEL_PER_LANE, LTO_KERNEL_PIPE48};
+  const long per_round[5] = {16 * cus, 48 * cus, 64 * cus, 44 * cus, 32 * cus};
+  const int family_kernel[5] = {LTO_KERNEL_PIPE8, LTO_KERNEL_PIPE48, LTO_KERNEL_PER_LANE, LTO_KERNEL_PIPE48, LTO_KERNEL_PIPE32};
   const long Smax = per_round[2], nmax = Smax + 1;
   hipStream_t st = c->stream;
   LTO_HIP(c, hipStreamSynchronize(st));
@@ -893,7 +899,7 @@ int lto_calibrate_kernels(lto_ctx* c) {
   lto_params prm = {0.012150585609624, 384400.0, 375190.25852, 0.05, 1000.0, 1.0, 1.0, 1.0};
   lto_integrator integ; std::memset(&integ, 0, sizeof integ);
   integ.method = LTO_RK4; integ.steps = 64;
-  double measured[2][4] = {{0, 0, 0, 0}, {0, 0, 1e300, 1e300}};
+  double measured[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 1e300, 1e300, 0}};
   for (int di = 0; di < 2 && rc == LTO_OK; ++di) {
     const int nd = di ? 14 : 12;
     for (long k = 0; k < nmax; ++k)
@@ -908,8 +914,8 @@ int lto_calibrate_kernels(lto_ctx* c) {
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, ht.data(), sizeof(double) * nmax, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "calibration upload", e); break; }
-    for (int f = 0; f < 4 && rc == LTO_OK; ++f) {
-      if (nd == 14 && f >= 2) continue;
+    for (int f = 0; f < 5 && rc == LTO_OK; ++f) {
+      if (nd == 14 && (f == 2 || f == 3)) continue;
       const long S = per_round[f];      // one full round: with 44 x CUs segments the 44-form is the cheaper one, with 48 x CUs the 48-form
       lto_indirect_plan* p = nullptr;
       rc = plan_build(c, nd, (int)(S + 1), 1, &prm, 1, &integ, &p);
@@ -945,7 +951,7 @@ int lto_calibrate_kernels(lto_ctx* c) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (rc != LTO_OK) return rc;
   for (int di = 0; di < 2; ++di)
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < 5; ++f)
       if (!(measured[di][f] > 0.0)) return set_err(c, LTO_EHIP, "calibration returned a non-positive time");
   std::memcpy(c->round_cost, measured, sizeof measured);
   c->calibrated = true;
@@ -955,7 +961,7 @@ int lto_calibrate_kernels(lto_ctx* c) {
 int lto_kernel_round_costs(const lto_ctx* c, int ndim, double* us_per_round, int* calibrated) {
   if (!c || !us_per_round) return LTO_ENULL;
   if (ndim != 12 && ndim != 14) return LTO_EINVAL;
-  for (int f = 0; f < 4; ++f) us_per_round[f] = c->round_cost[ndim == 14 ? 1 : 0][f];
+  for (int f = 0; f < 5; ++f) us_per_round[f] = c->round_cost[ndim == 14 ? 1 : 0][f];
   if (ndim == 14) us_per_round[2] = us_per_round[3] = -1.0;           // not candidates
   if (calibrated) *calibrated = c->calibrated ? 1 : 0;
   return LTO_OK;

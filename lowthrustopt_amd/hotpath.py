@@ -117,9 +117,9 @@ class Context:
         return {nd: self.kernel_round_costs(nd)[0] for nd in (12, 14)}
 
     def kernel_round_costs(self, ndim):
-        """([pipeline8, pipeline48 (48 segments per workgroup), per-lane, pipeline48 (44 segments)] us per round at 64 steps,
-        calibrated?) -- what LTO_KERNEL_AUTO chooses by."""
-        out = (C.c_double * 4)()
+        """([pipeline8, pipeline48 (48 segments per workgroup), per-lane, pipeline48 (44 segments), pipeline32] us per round at 64
+        steps, calibrated?) -- what LTO_KERNEL_AUTO chooses by."""
+        out = (C.c_double * 5)()
         cal = C.c_int(0)
         self.check(self.lib.lto_kernel_round_costs(self.handle, int(ndim), out, C.byref(cal)))
         return [float(v) for v in out], bool(cal.value)
@@ -657,7 +657,7 @@ class IndirectPlan:
         self.handle = h
         ctx._plans.add(self)
 
-    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE8, KERNEL_COOP2, KERNEL_PIPE48 = 0, 1, 2, 5, 6, 7   # 3, 4: removed in round 3 (four- / six-wave forms)
+    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE8, KERNEL_COOP2, KERNEL_PIPE48, KERNEL_PIPE32 = 0, 1, 2, 5, 6, 7, 8   # 3, 4: removed in round 3 (four- / six-wave forms)
 
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
@@ -674,7 +674,7 @@ class IndirectPlan:
 
     def last_kernel(self):
         """Name of the kernel family the last STM sweep ran (what AUTO resolved to)."""
-        return {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
+        return {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48", 8: "pipeline32"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
 
     def set_cols_per_lane(self, cols):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_cols_per_lane(self.handle, int(cols)))

@@ -43,7 +43,7 @@ KERNEL_METHODS = [(k, m) for k in ("per_lane", "coop") for m in METHODS] + [("pi
 
 def pick_kernel(plan, kernel):
     plan.set_kernel({"per_lane": plan.KERNEL_PER_LANE, "coop": plan.KERNEL_COOP,
-                     "pipe8": plan.KERNEL_PIPE8, "coop2": plan.KERNEL_COOP2, "pipe48": plan.KERNEL_PIPE48}[kernel])
+                     "pipe8": plan.KERNEL_PIPE8, "coop2": plan.KERNEL_COOP2, "pipe48": plan.KERNEL_PIPE48, "pipe32": plan.KERNEL_PIPE32}[kernel])
 
 
 def rel_l2(d_gpu, d_ref, x1):
@@ -1410,6 +1410,56 @@ def test_indirect_pipeline_kernel_equals_per_lane_at_full_size(gpu_ctx, ndim, st
             assert np.abs(P1 - P2).max() < 1e-11 * np.abs(P1).max(), kernel
 
 
+@pytest.mark.parametrize("ndim,p", [(12, 1.0), (12, 0.0), (12, 2.0), (12, 1.5), (14, 1.0), (14, 0.0)])
+@pytest.mark.parametrize("steps", [1, 2, 3, 64])
+def test_pipeline32_equals_the_eight_wave_form_bitwise(gpu_ctx, ndim, p, steps):
+    """LTO_KERNEL_PIPE32 (32 segments, twelve wavefronts, one barrier per step) runs the eight-wave kernel's roles -- the same
+    arithmetic in the same order per segment -- under the large-batch kernel's synchronisation: defect and STM equal
+    LTO_KERNEL_PIPE8's bit for bit, for every control-law class it is built for, step counts around the pipeline depth, a ragged
+    last workgroup and a batch of trajectories with their own grids; the per-lane kernel agrees within rounding."""
+    import torch
+    for n, nb in ((8197, 1), (41, 5)):
+        XC, T = synth.indirect_problem(n, n_batch=nb, seed=11)
+        if ndim == 14:
+            X = np.zeros((14, n, nb), order="F")
+            X[:6] = XC[:6]; X[6] = 1000.0; X[7:13] = XC[6:]; X[13] = 0.2
+            slot = 2000.0
+        else:
+            X, slot = XC, 1000.0
+        prm = lto.make_params(MU, DU, TU, 10.0 if p > 1.0 else 0.05, slot, 1.0, p, 1.0)
+        S = (n - 1) * nb
+        Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+        td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+        out = {}
+        for kernel in ("pipe8", "pipe32", "per_lane"):
+            plan = lto.IndirectPlan(gpu_ctx, n, nb, prm, lto.integrator(lto.RK4, steps=steps), ndim=ndim)
+            pick_kernel(plan, kernel)
+            Phi = torch.full((ndim * ndim, S), 7.0, dtype=torch.float64, device="cuda")
+            d = torch.full((ndim, S), 7.0, dtype=torch.float64, device="cuda")
+            plan.jacobian(Xd, n * nb, td, nb, Phi, S, d, S)
+            torch.cuda.synchronize()
+            assert plan.last_kernel() == {"pipe8": "pipeline8", "pipe32": "pipeline32", "per_lane": "per-lane"}[kernel]
+            out[kernel] = (Phi, d)
+            plan.close()
+        assert torch.equal(out["pipe32"][0], out["pipe8"][0]) and torch.equal(out["pipe32"][1], out["pipe8"][1])
+        P1, d1 = out["per_lane"]
+        assert float((out["pipe32"][1] - d1).abs().max()) < 1e-12 * max(1.0, float(d1.abs().max()))
+        assert float((out["pipe32"][0] - P1).abs().max()) < 1e-11 * float(P1.abs().max())
+
+
+def test_pipeline32_is_refused_where_the_stages_do_not_pair(gpu_ctx):
+    XC, T = synth.indirect_problem(9, seed=1)
+    prm = lto.make_params(MU, DU, TU, 10.0, 2000.0, 1.0, 2.0, 1.0)                       # 14-dim, unclamped p = 2: lambda_m is on the chain
+    plan = lto.IndirectPlan(gpu_ctx, 9, 1, prm, lto.integrator(lto.RK4, steps=8), ndim=14)
+    with pytest.raises(lto.LtoError):
+        plan.set_kernel(plan.KERNEL_PIPE32)
+    plan.close()
+    plan = lto.IndirectPlan(gpu_ctx, 9, 1, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), lto.integrator(), ndim=12)
+    with pytest.raises(lto.LtoError):
+        plan.set_kernel(plan.KERNEL_PIPE32)                                               # adaptive plan
+    plan.close()
+
+
 def test_large_batch_pipeline_forms_agree_bitwise(gpu_ctx):
     """12-dim, LTO_KERNEL_PIPE48: 12 288 segments run in the form with 48 segments per workgroup (one round), their first 11 261 as
     a problem of their own in the form with 44 (wave 12 leaves, the last workgroup is ragged): the same bits segment by segment,
@@ -1508,9 +1558,10 @@ def test_indirect_auto_kernel_choice(gpu_ctx):
     import torch
     assert torch.cuda.get_device_properties(0).multi_processor_count == 256
     cases = [(12, 30, lto.RK4, 64, "pipeline8"), (12, 4097, lto.RK4, 64, "pipeline8"), (14, 4097, lto.RK4, 64, "pipeline8"),
-             (14, 4098, lto.RK4, 64, "pipeline8"), (14, 8193, lto.RK4, 64, "pipeline8"),
-             (12, 8193, lto.RK4, 64, "pipeline8"), (12, 12289, lto.RK4, 8, "pipeline48"), (12, 16385, lto.RK4, 8, "per-lane"),
-             (14, 30, lto.RK4, 2, "per-lane"), (14, 12289, lto.RK4, 6, "pipeline48"), (14, 16385, lto.RK4, 6, "pipeline8"),
+             (14, 4098, lto.RK4, 64, "pipeline32"), (14, 8193, lto.RK4, 64, "pipeline32"),
+             (12, 8193, lto.RK4, 64, "pipeline32"), (12, 12289, lto.RK4, 8, "pipeline48"), (12, 16385, lto.RK4, 8, "pipeline32"),
+             (14, 30, lto.RK4, 2, "per-lane"), (14, 12289, lto.RK4, 6, "pipeline48"), (14, 16385, lto.RK4, 6, "pipeline32"),
+             (14, 20481, lto.RK4, 6, "pipeline8"), (12, 11265, lto.RK4, 6, "pipeline48"),
              (12, 32769, lto.RK4, 8, "pipeline48"), (14, 24577, lto.RK4, 6, "pipeline48"), (12, 24577, lto.RK4, 6, "pipeline48"),
              (12, 30, lto.DOP853_ADAPTIVE, 0, "cooperative2"), (14, 30, lto.DOP853_ADAPTIVE, 0, "cooperative"),
              (12, 30, lto.RKF78_ADAPTIVE, 0, "cooperative"), (14, 30, lto.RKF78_FIXED, 4, "cooperative")]
@@ -1544,19 +1595,19 @@ def test_kernel_cost_table_calibration():
     try:
         d12, cal = ctx.kernel_round_costs(12)
         d14, _ = ctx.kernel_round_costs(14)
-        assert not cal and d12 == [63.0, 165.0, 246.0, 139.0] and d14 == [72.0, 191.0, -1.0, -1.0]
+        assert not cal and d12 == [63.0, 165.0, 246.0, 139.0, 111.0] and d14 == [72.0, 191.0, -1.0, -1.0, 128.0]
         got = ctx.calibrate_kernels()
         m12, cal = ctx.kernel_round_costs(12)
         m14, _ = ctx.kernel_round_costs(14)
         assert cal and got[12] == m12 and got[14] == m14
-        for meas, dflt in ((m12, d12), (m14[:2], d14[:2])):
+        for meas, dflt in ((m12, d12), (m14[:2] + m14[4:], d14[:2] + d14[4:])):
             for a, b in zip(meas, dflt):
                 assert 0.6 * b < a < 1.6 * b, (meas, dflt)               # same device class: same size (clocks differ run to run)
-            assert all(x < y for x, y in zip(meas[:3], meas[1:3]))      # a round of 16 / 48 / 64 x CUs segments: dearer as it grows
-        assert m12[0] < m12[3] < m12[1]                                 # 44 x CUs segments in the 44-segment form: between the two
+        assert m12[0] < m12[1] < m12[2] and m14[0] < m14[1]            # a round of 16 / 48 / 64 x CUs segments: dearer as it grows
+        assert m12[0] < m12[4] < m12[3] < m12[1] and m14[0] < m14[4] < m14[1]   # 32 and 44 x CUs segments per round: in between
         if torch.cuda.get_device_properties(0).multi_processor_count == 256:
-            for ndim, n, want in ((14, 8193, "pipeline8"), (12, 8193, "pipeline8"), (14, 12289, "pipeline48"), (12, 12289, "pipeline48"),
-                                  (12, 11265, "pipeline48"), (12, 22529, "pipeline48")):
+            for ndim, n, want in ((14, 8193, "pipeline32"), (12, 8193, "pipeline32"), (14, 12289, "pipeline48"), (12, 12289, "pipeline48"),
+                                  (12, 11265, "pipeline48"), (12, 22529, "pipeline48"), (14, 4097, "pipeline8")):
                 XC, T = synth.indirect_problem(n, seed=2)
                 X = XC
                 if ndim == 14:
