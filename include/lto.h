@@ -109,12 +109,13 @@ double lto_last_call_ms(const lto_ctx* ctx);
 /* Kernel choice of the RK4 STM sweeps above one round of workgroups (lto_indirect_plan_set_kernel, LTO_KERNEL_AUTO): the family
  * whose rounds are cheapest for the segment count, from a table of microseconds per round at 64 steps -- us_per_round[0]:
  * eight-wave pipeline, rounds of 16 x CUs segments; [1]: large-batch pipeline with 48 segments per workgroup, 48 x CUs; [2]:
- * per-lane kernel with three columns, 64 x CUs; [3]: large-batch pipeline with 44 segments per workgroup, 44 x CUs ([2], [3]:
- * 12-dim only, reported as -1 for 14; LTO_KERNEL_PIPE48 stands for both forms and the cheaper one runs).  A new context holds
- * the figures measured on MI355X (profiles/r04z).  lto_calibrate_kernels measures them on the context's own device (about 50 ms:
- * 30 ms of warm-up sweeps, then the median of five launches of one full round per family and dimension) and AUTO uses those
- * from then on; lto_kernel_round_costs reads the table (us_per_round[4]; *calibrated = 1 after a calibration).  Results never
- * depend on the choice. */
+ * per-lane kernel with three columns, 64 x CUs; [3]: large-batch pipeline with 44 segments per workgroup, 44 x CUs; [4]:
+ * 32-segment / twelve-wave pipeline (LTO_KERNEL_PIPE32), 32 x CUs ([2], [3]: 12-dim only, reported as -1 for 14;
+ * LTO_KERNEL_PIPE48 stands for both of its forms and the cheaper one runs).  A new context holds the figures measured on MI355X
+ * (profiles/r04z).  lto_calibrate_kernels measures them on the context's own device (about 50 ms: 30 ms of warm-up sweeps, then
+ * the median of five launches of one full round per family and dimension) and AUTO uses those from then on;
+ * lto_kernel_round_costs reads the table (us_per_round[5]; *calibrated = 1 after a calibration).  Results never depend on the
+ * choice. */
 int lto_calibrate_kernels(lto_ctx* ctx);
 int lto_kernel_round_costs(const lto_ctx* ctx, int ndim, double* us_per_round, int* calibrated);
 
