@@ -279,11 +279,13 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  * select the first two, lto_indirect_plan_set_defect_lanes any of them. */
 #define LTO_KERNEL_COOP2 6
 /* RK4 plans only: the pipeline for large batches -- 48 segments and 16 wavefronts per workgroup, the base wave's lanes are 48
- * different segments, twelve column waves with one segment per DPP row. */
+ * different segments, twelve column waves with one segment per DPP row; 12-dim also with 44 segments and eleven column waves (the
+ * cheaper of the two forms for the segment count runs). */
 #define LTO_KERNEL_PIPE48 7
 /* 32 segments and twelve wavefronts per workgroup: the eight-wave form's roles (paired-stage base role, four lanes per segment) with one
  * barrier per step.  For batches between one round of LTO_KERNEL_PIPE8 and a few (4 097 ... 8 192 segments on MI355X: one round
- * instead of two).  RK4; 12-dim, and 14-dim with p = 0 or p = 1; anything else: LTO_EINVAL at the sweep. */
+ * instead of two).  RK4; 12-dim, and 14-dim with p = 0 or p = 1; anything else: LTO_EINVAL from lto_indirect_plan_set_kernel
+ * (AUTO does not consider it there).  Results equal LTO_KERNEL_PIPE8's bit for bit. */
 #define LTO_KERNEL_PIPE32 8
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* Lanes per segment of the DEFECT-ONLY sweep of an ndim = 12 DOP853_ADAPTIVE plan (the reference's setting, indirect.jl:63-90):
