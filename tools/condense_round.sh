@@ -13,6 +13,7 @@ S="python tools/summarize_profile.py $RUN $TAG"
 q() { "$@" > /dev/null; }
 q $S c2 "k_indirect_pipe8<14"
 q $S c2_ndim12 "k_indirect_pipe8<12" c2
+q $S c2_8192 "k_indirect_pipe32<14"
 q $S c3 "k_direct_jacobian_pipe<6"
 q $S c4 "k_indirect_pipe48<12"
 q $S c5 "k_indirect_defect4" - "k_node_records+k_pack"

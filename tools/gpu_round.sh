@@ -15,6 +15,7 @@ tail -3 "$OUT/pytest_gpu.log"
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null > "$OUT/bench_c2_driver.json"; last "$OUT/bench_c2_driver.json"
 python bench.py --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_200.json"; last "$OUT/bench_c2_200.json"
 python bench.py --workload hbm --ndim 12 --segments 1048576 --no-cpu-baseline --live-traffic on --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_hbm.json"; last "$OUT/bench_hbm.json"
+python bench.py --segments 8192 --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_8192.json"; last "$OUT/bench_c2_8192.json"    # 32-segment pipeline (AUTO above one round)
 python bench.py --workload c3 --cpu-seconds 5 2>/dev/null > "$OUT/bench_c3.json"; last "$OUT/bench_c3.json"
 python bench.py --ndim 12 --method dop853 --no-cpu-baseline --steps 50 2>/dev/null > "$OUT/bench_c2_dop853.json"; last "$OUT/bench_c2_dop853.json"
 python bench.py --ndim 12 --method rkf78 --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_rkf78x4.json"; last "$OUT/bench_c2_rkf78x4.json"
@@ -28,6 +29,7 @@ if [ "$PART" = all ] || [ "$PART" = prof ]; then
 # kernel traces + stats.  The device ramps its clocks over the first ~300 contract launches (91 -> 79 us per launch): the c2
 # and c3 traces time enough steps (4 000 / 2 000) for the average over ALL launches of the trace to be the ramped duration.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2" -- python bench.py --steps 4000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_8192" -- python bench.py --segments 8192 --steps 2000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2_8192.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c3" -- python bench.py --workload c3 --steps 2000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c3.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c4" -- python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/prof_c4.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_dop853" -- python bench.py --ndim 12 --method dop853 --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2_dop853.log" 2>&1
@@ -47,6 +49,7 @@ pmc_passes() {   # pmc_passes <key> <bench.py arguments...>
   echo "pmc $KEY done"
 }
 pmc_passes c2                                   # also holds the 12-dim leg (pmc_c2_ndim12) and the reference-integrator leg
+pmc_passes c2_8192 --segments 8192
 pmc_passes c3 --workload c3
 pmc_passes c4 --workload c4
 pmc_passes c5 --workload c5
