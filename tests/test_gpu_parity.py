@@ -1447,6 +1447,30 @@ def test_pipeline32_equals_the_eight_wave_form_bitwise(gpu_ctx, ndim, p, steps):
         assert float((out["pipe32"][0] - P1).abs().max()) < 1e-11 * float(P1.abs().max())
 
 
+def test_pipeline32_mixed_control_law_classes_in_one_batch(gpu_ctx):
+    """A batch whose trajectories belong to different control-law classes (p = 0, 1, 2 and a general p) takes one launch per class,
+    every launch storing its own segments only: LTO_KERNEL_PIPE32 equals LTO_KERNEL_PIPE8 bit for bit on such a batch too."""
+    import torch
+    n, nb = 2300, 4                                                  # 9 196 segments: two ragged rounds of 16-segment workgroups
+    XC, T = synth.indirect_problem(n, n_batch=nb, seed=17)
+    prms = [lto.make_params(MU, DU, TU, thr, 1000.0, 1.0, p, rho) for p, thr, rho in ((0.0, 0.05, 1.0), (1.0, 0.05, 0.3), (2.0, 10.0, 1.0), (1.5, 0.05, 1.0))]
+    S = (n - 1) * nb
+    Xd = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    out = {}
+    for kernel in ("pipe8", "pipe32"):
+        plan = lto.IndirectPlan(gpu_ctx, n, nb, prms, lto.integrator(lto.RK4, steps=7), ndim=12)
+        pick_kernel(plan, kernel)
+        Phi = torch.full((144, S), 7.0, dtype=torch.float64, device="cuda")
+        d = torch.full((12, S), 7.0, dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n * nb, td, nb, Phi, S, d, S)
+        torch.cuda.synchronize()
+        out[kernel] = (Phi, d)
+        plan.close()
+    assert bool(torch.isfinite(out["pipe32"][0]).all()) and not bool((out["pipe32"][0] == 7.0).all(dim=0).any())
+    assert torch.equal(out["pipe32"][0], out["pipe8"][0]) and torch.equal(out["pipe32"][1], out["pipe8"][1])
+
+
 def test_pipeline32_is_refused_where_the_stages_do_not_pair(gpu_ctx):
     XC, T = synth.indirect_problem(9, seed=1)
     prm = lto.make_params(MU, DU, TU, 10.0, 2000.0, 1.0, 2.0, 1.0)                       # 14-dim, unclamped p = 2: lambda_m is on the chain
