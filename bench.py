@@ -71,6 +71,125 @@ def to14(XC):
     return X
 
 
+HBM_SEGMENTS = 1048576    # the HBM evidence point's batch: enough segments for every CU to stream
+
+
+def default_ndim(wl):
+    """14 = BASELINE configs[1]'s system (c2, c2_defect); 12 = the reference's own system (everything else, incl. the HBM point)."""
+    return 14 if wl in ("c2", "c2_defect") else 12
+
+
+def default_segments(wl, world=1):
+    """Segments per GPU of a workload at its BASELINE size.  c4 / c5 shard a FIXED global size over the ranks (strong scaling);
+    the others give every rank the same batch (weak scaling)."""
+    if wl in ("c5", "c5_stm"):
+        return 65536 // max(world, 1)
+    if wl == "c4":
+        return (256 // max(world, 1)) * 1024
+    return {"c3": 16384, "hbm": HBM_SEGMENTS}.get(wl, 4096)
+
+
+def make_workload(wl, lto, synth, torch, ctx, st, dev, ndim=0, segments=0, method="", rank=0, world=1, cols=0, kernel=0):
+    """Synthetic inputs of one workload resident in HBM (struct-of-arrays), its plan, its outputs and `sweep(defect_buffer)` = one
+    step of the hot path on stream `st`.  Used by the contract leg of main() and by the compact `configs` legs."""
+    import types
+    nd = ndim or default_ndim(wl)
+    f64 = dict(dtype=torch.float64, device=dev)
+    w = types.SimpleNamespace(wl=wl, ndim=nd, method=method, Phi=None, XC=None, T=None, levels=0, extra={})
+    prm1 = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    c5 = wl in ("c5", "c5_stm")
+    if wl in ("c2", "c2_defect", "hbm") or c5:
+        S = segments or default_segments(wl, world)
+        n = S + 1
+        if c5:
+            XC, T = synth.indirect_problem(n, seed=1 + rank, dt_range=(0.05, 0.5))
+            prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1e-3)
+            integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13)
+            desc = "C5: indirect 12-dim defect%s, adaptive DOP853 rtol=atol=1e-13, dt_seg~U[0.05,0.5], rho=1e-3" % (
+                " + 12x12 STM" if wl == "c5_stm" else "")
+        else:
+            XC, T = synth.indirect_problem(n, seed=rank)
+            prm = prm1
+            steps = 1 if wl == "hbm" else 64
+            integ = lto.integrator(lto.RK4, steps=steps)
+            if method == "rkf78":
+                integ = lto.integrator(lto.RKF78_FIXED, steps=4)
+            elif method == "dop853":
+                integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13)
+            dd = (nd, nd, nd)
+            desc = {"c2": "C2: indirect %d-dim state+costate + %dx%d STM, RK4 x 64 steps, fp64, p=1 rho=1 thrust 0.05 N" % dd,
+                    "c2_defect": "C2 (defect only): indirect %d-dim state+costate, RK4 x 64 steps" % nd,
+                    "hbm": "HBM evidence point: indirect %d-dim + %dx%d STM, ONE RK4 step per segment" % dd}[wl]
+        if nd == 14:   # mass + mass costate: (r, v, m, lambda_r, lambda_v, lambda_m); params' mass slot = Isp
+            XC = to14(XC)
+            prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 2000.0, 1.0, 1.0, prm.rho)
+        X = torch.from_numpy(synth.to_soa_nodes(XC)).to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).to(dev)
+        plan = lto.IndirectPlan(ctx, n, 1, prm, integ, ndim=nd)
+        if cols:
+            plan.set_cols_per_lane(cols)
+        if kernel:
+            plan.set_kernel(kernel)
+        defect = torch.zeros(nd, S, **f64)
+        Phi = torch.zeros(nd * nd, S, **f64)
+        if wl in ("c2", "hbm", "c5_stm"):
+            def sweep(dbuf):
+                plan.jacobian(X, n, t, 1, Phi, S, dbuf, S, stream=st)
+        else:
+            def sweep(dbuf):
+                plan.defect(X, n, t, 1, dbuf, S, stream=st)
+        gather_rows = nd
+        if method:
+            desc += " [integrator %s]" % method
+    elif wl == "c4":
+        spt = 1024
+        levels = max(1, (segments or default_segments(wl, world)) // spt)
+        n = spt + 1
+        S = levels * spt
+        XC, T = synth.indirect_problem(n, n_batch=levels, seed=10 + rank)
+        rhos = synth.homotopy_rhos(256)[rank * levels:(rank + 1) * levels] if world * levels == 256 else synth.homotopy_rhos(levels)
+        prm = [lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, r) for r in rhos]
+        integ = lto.integrator(lto.RK4, steps=64)
+        X = torch.from_numpy(synth.to_soa_nodes(XC)).to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(T.T)).to(dev)   # [levels][n]
+        plan = lto.IndirectPlan(ctx, n, levels, prm, integ)
+        if cols:
+            plan.set_cols_per_lane(cols)
+        defect = torch.zeros(12, S, **f64)
+        Phi = torch.zeros(144, S, **f64)
+
+        def sweep(dbuf):
+            plan.jacobian(X, n * levels, t, levels, Phi, S, dbuf, S, stream=st)
+        desc = "C4: homotopy sweep, %d rho levels x 1024 segments per GPU, 12-dim + STM, RK4 x 64" % levels
+        gather_rows = 12
+        w.levels, w.extra["rhos"] = levels, rhos
+    else:  # c3
+        S = segments or default_segments(wl, world)
+        n = S + 1
+        Xd, Ud, Td = synth.direct_problem(n, seed=rank)
+        X = torch.from_numpy(synth.to_soa_nodes(Xd)).to(dev)
+        U = torch.from_numpy(synth.to_soa_nodes(Ud)).to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(Td[:, 0])).to(dev)
+        plan = lto.DirectPlan(ctx, 6, n, 1, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        if kernel:
+            plan.set_kernel(kernel)
+        defect = torch.zeros(6, S, **f64)
+        errs = torch.zeros(S, **f64)
+        Jac = torch.zeros(108, S, **f64)
+        dtf = torch.zeros(6, S, **f64)
+
+        def sweep(dbuf):
+            plan.jacobian(X, n, U, n, t, 1, Jac, S, dtf, dbuf, S, errs, stream=st)
+        desc = "C3: direct 6-dim, RKF7(8) nsteps=10 per half, on-device Jacobian blocks 6x18 + tf column + defect + errors"
+        gather_rows = 6
+        XC, T, prm, integ, Phi = Xd, Td, None, None, None
+        w.extra.update(U=Ud, Jac=Jac, dtf=dtf, errs=errs)
+    w.S, w.n, w.XC, w.T, w.prm, w.integ, w.plan, w.defect, w.Phi = S, n, XC, T, prm, integ, plan, defect, Phi
+    w.sweep, w.desc, w.gather_rows = sweep, desc, gather_rows
+    return w
+
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +206,7 @@ def parse():
                          "reference's own constant-mass system (parity path; default of the other workloads)")
     ap.add_argument("--method", default="", choices=["", "rk4", "rkf78", "dop853"], help="override the workload's integrator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="default line without the compact legs of the other BASELINE configs (`configs`)")
     ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
                     help="roofline.traffic from counter passes of THIS run: rank 0 at N = 1 starts `rocprofv3 --pmc FETCH_SIZE` and "
                          "`--pmc WRITE_SIZE` (separate passes) on a child that runs the workload's sweep only; auto = when rocprofv3 is on "
@@ -188,11 +308,15 @@ def dop853_flops(trial_steps, f_rhs, dim):
     return trial_steps * (12 * f_rhs + 148 * dim)
 
 
-def pmc_key(wl, ndim, method=None):
-    """Name of the stored counter profile of a workload: profiles/pmc_<key>.json (tools/gpu_round.sh, tools/summarize_profile.py)."""
+def pmc_key(wl, ndim, method=None, segments=0):
+    """Name of the stored counter profile of a workload: profiles/pmc_<key>.json (tools/gpu_round.sh, tools/summarize_profile.py).
+    A batch other than the workload's single-GPU BASELINE size is part of the key (`c2_8192`): a launch over 8 192 segments does not
+    move the bytes of one over 4 096."""
     key = wl
     if wl in ("c2", "c2_defect", "hbm") and ndim == 12:
         key += "_ndim12"
+    if segments and segments != default_segments(wl):
+        key += "_%d" % segments
     if method:
         key += "_" + method
     return key
@@ -255,7 +379,7 @@ def roofline(wl, ndim, S, kern_ms, work=None, samples=None, burst_n=N_BURST, met
     ach_tf = flops * S / dur / 1e12
     ach_gb = nbytes * S / dur / 1e9
     traffic, traffic_from = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % pmc_key(wl, ndim, method))
+    pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % pmc_key(wl, ndim, method, S))
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
@@ -269,7 +393,10 @@ def roofline(wl, ndim, S, kern_ms, work=None, samples=None, burst_n=N_BURST, met
                         "in separate --pmc passes)" % os.path.basename(pmc))
     model = ("builder-counted on lowthrustopt_amd/csrc/dynamics.hpp with SURVEY 8d's convention (+ - x / sqrt tanh = 1, FMA = 2): "
              "flops = steps x (stages x F_rhs + C_tab x dim); F_rhs 14-dim + 14x14 variational = 1 490 (116 base + 86 coefficient build + "
-             "14 x 92), 12-dim + 12x12 = 1 070 (SURVEY's figure; the same count gives 1 096)")
+             "14 x 92), 12-dim + 12x12 = 1 070 (SURVEY's figure; the same count gives 1 096).  Not all of the model's flops are executed: "
+             "for the always-thrust-limited control laws (p = 0, 1) the lambda_m column of the 14x14 STM is the unit vector and nothing feeds "
+             "lambda_m back, so the 14-dim kernel integrates 13 columns and 13 base components (kernels_indirect_pipe8.hip) -- about 4 % of "
+             "the model's flops are skipped algorithmically; frac counts the model's flops, the executed-work fraction is ~0.96 x frac")
     if wl == "hbm":
         # the one workload of this path whose arithmetic intensity (4.4 flop/B) is below the machine balance (9.8): HBM is its roof
         return {
@@ -661,6 +788,152 @@ def leg_newton(lto, synth, ctx, st, torch, sizes, cpu_seconds):
             "sizes": out}
 
 
+# ---- the other BASELINE configs as compact legs of the default line -------------------------------------------
+# key: (workload, timed steps, warm-up steps).  Each leg: W warm-up + K timed steps of the workload at its BASELINE size on this one
+# GPU, the dominant kernel's launch period from a burst inside one HIP event pair, the roofline object, a 64-segment oracle sample of
+# the leg's own last sweep, and the oracle timed on one host core on a bounded sample of the same workload.
+CONFIG_LEGS = (("c3", "c3", 20, 3), ("c4", "c4", 8, 2), ("c5", "c5", 20, 3), ("c5_stm", "c5_stm", 8, 2), ("hbm", "hbm", 20, 3))
+PARITY_SAMPLE = 64
+
+
+def _time_oracle(run, per_call, seconds, what):
+    """One host core on a bounded sample: `run` repeated until `seconds` have passed (at least once after one untimed call)."""
+    from oracle import oracle as O
+    O.lib(); O.set_threads(1)
+    run()
+    t0 = time.perf_counter()
+    calls = 0
+    while True:
+        run(); calls += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": per_call * calls / el, "unit": "segment-integrations/s", "cores": 1, "kind": "port",
+            "sample": "%d segments x %d sweeps in %.1f s; %s; host has %d cores" % (per_call, calls, el, what, os.cpu_count() or 0)}
+
+
+def config_parity_and_cpu(w, lto, seconds):
+    """(parity, cpu_baseline) of a compact leg: PARITY_SAMPLE segments of the leg's own last sweep against the oracle (checker), and
+    the oracle timed on the same sample (one core; the reference's algorithm for the adaptive configs, the same discrete map for the
+    fixed-step ones)."""
+    from oracle import oracle as O
+    wl, S, ns = w.wl, w.S, PARITY_SAMPLE
+    if wl == "c3":
+        Xh, Uh, th = w.XC[:, :ns + 1, 0], w.extra["U"][:, :ns + 1, 0], w.T[:ns + 1, 0]
+        d_o, e_o = O.direct_defect(Xh, Uh, th, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        Jd, dh, _ = O.direct_jacobian_dual(Xh, Uh, th, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        d_g = w.defect[:, :ns].cpu().numpy()
+        J_g = w.extra["Jac"][:, :ns].cpu().numpy().reshape(18, 6, ns).transpose(1, 0, 2)
+        span = w.T[-1, 0] - w.T[0, 0]
+        dtf_o = dh * (np.diff(th) / span)[None, :]
+        parity = {"defect_max_abs": float(np.abs(d_g - d_o).max()), "jacobian_rel_max": float(np.abs(J_g - Jd).max() / np.abs(Jd).max()),
+                  "tf_column_max_abs": float(np.abs(w.extra["dtf"][:, :ns].cpu().numpy() - dtf_o).max()),
+                  "errors_rel_max": float(np.abs(w.extra["errs"][:ns].cpu().numpy() - e_o).max() / e_o.max()),
+                  "sample_segments": ns, "tolerance": {"defect_max_abs": 1e-12, "jacobian_rel_max": 1e-11},
+                  "against": "CPU oracle: two-sided RKF7(8) shooting (direct.jl:66-109), dual-number derivative of the same discrete map, d/dh for the tf column"}
+
+        def run():
+            d, e = O.direct_defect(Xh, Uh, th, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+            O.direct_jacobian_fd(Xh, Uh, th, d, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+            O.direct_dtf_fd(Xh, Uh, th, 10, lto.MU, lto.DU, lto.TU, 2000.0)
+        return parity, _time_oracle(run, ns, seconds, "direct defect + 18-column forward-difference Jacobian + tf partial (the reference's method, "
+                                                       "direct.jl:111-166,503-516), RKF7(8) nsteps=10")
+    adaptive = wl in ("c5", "c5_stm")
+    method, steps = (O.DOP853_ADAPTIVE, 0) if adaptive else (O.RK4, 1 if wl == "hbm" else 64)
+    if wl == "c4":
+        # half the sample from the first level of this GPU's block (rho = 1), half from its last (rho = 1e-4 at 256 levels)
+        spt, half = 1024, ns // 2
+        picks = [(0, 0), (w.levels - 1, spt - half)]
+        rhos = w.extra["rhos"]
+        blocks = [(b, i0, [lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, float(rhos[b])]) for b, i0 in picks]
+        offs = [b * spt + i0 for b, i0, _ in blocks]
+        cnt = half
+    else:
+        rho = 1e-3 if adaptive else 1.0
+        blocks = [(0, 0, [lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, rho])]
+        offs, cnt = [0], min(ns, S)
+    num = den = 0.0
+    stm_err = stm_max = 0.0
+    want_stm = wl != "c5"
+    for (b, i0, prm_o), off in zip(blocks, offs):
+        Xh, th = w.XC[:, i0:i0 + cnt + 1, b], w.T[i0:i0 + cnt + 1, b]
+        if want_stm:
+            P_o, d_o, rc = O.indirect_jacobian(Xh, th, prm_o, method, steps)
+            P_g = w.Phi[:, off:off + cnt].cpu().numpy().reshape(12, 12, cnt).transpose(1, 0, 2)
+            stm_err = max(stm_err, float(np.abs(P_g - P_o).max())); stm_max = max(stm_max, float(np.abs(P_o).max()))
+        else:
+            d_o = O.indirect_defect(Xh, th, prm_o, method, steps)[0]
+        d_g = w.defect[:, off:off + cnt].cpu().numpy()
+        num += float(np.sum((d_g - d_o) ** 2)); den += float(np.sum((d_o + Xh[:, 1:]) ** 2))
+    parity = {"defect_rel_l2": float(np.sqrt(num / den)), "stm_rel_max": (stm_err / stm_max) if want_stm else None,
+              "sample_segments": cnt * len(blocks), "tolerance": 1e-10,
+              "against": ("CPU oracle, adaptive order 8 @ 1e-13%s (the converged flow; step sequences may differ)" % (" on dual numbers" if want_stm else "")
+                          if adaptive else "CPU oracle, same RK4 x %d discrete map, dual-number STM" % steps)}
+    b, i0, prm_o = blocks[-1]
+    Xh, th = w.XC[:, i0:i0 + cnt + 1, b], w.T[i0:i0 + cnt + 1, b]
+    if want_stm:
+        def run():
+            O.indirect_jacobian(Xh, th, prm_o, method, steps)
+    else:
+        def run():
+            O.indirect_defect(Xh, th, prm_o, method, steps)
+    what = {"c4": "indirect 12-dim + 12x12 STM by dual numbers through RK4 x 64 at the block's last rho level (same discrete map as the GPU run)",
+            "c5": "defectCalc as the reference computes it (indirect.jl:63-90): adaptive order-8 pair (DOP853 for Vern8) at rtol = atol = 1e-13, C5's segment lengths and rho",
+            "c5_stm": "jacobianCalc as the reference computes it (indirect.jl:93-146): the same adaptive solve on 12-partial dual numbers, C5's segment lengths and rho",
+            "hbm": "indirect 12-dim + 12x12 STM by dual numbers through ONE RK4 step (same discrete map as the GPU run)"}[wl]
+    return parity, _time_oracle(run, cnt, seconds, what)
+
+
+def leg_config(key, wl, steps, warmup, lto, synth, torch, ctx, st, dev, device_warmup_ms, cpu_seconds):
+    """One BASELINE config as a compact leg (see CONFIG_LEGS)."""
+    w = make_workload(wl, lto, synth, torch, ctx, st, dev)
+    try:
+        S, plan, sweep = w.S, w.plan, w.sweep
+        c5 = wl in ("c5", "c5_stm")
+        tw = time.perf_counter()
+        while (time.perf_counter() - tw) * 1e3 < device_warmup_ms:          # ramped clocks, as for the contract leg
+            for _ in range(2 if (c5 or wl == "c4") else 10):
+                sweep(w.defect)
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            sweep(w.defect)
+        rebalanced = False
+        if c5:
+            plan.rebalance(stream=st)             # lanes ordered by the warm-up sweep's step counts (on device), as `--workload c5`
+            rebalanced = True
+            sweep(w.defect)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sweep(w.defect)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kern_ms, burst_n, samples = sample_launches(torch, lambda: sweep(w.defect), n=3)
+        out = {"workload": w.desc, "segments": S, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3, "value": S * steps / el,
+               "unit": "segment-integrations/s", "dtype": "f64"}
+        if hasattr(plan, "last_kernel"):
+            out["kernel"] = plan.last_kernel()
+        if c5:
+            acc, rej = plan.step_counts(stream=st)
+            tot = (acc + rej).astype(np.float64)
+            f_rhs, dim = (1070, 156) if wl == "c5_stm" else (95, 12)
+            work = (dop853_flops(float(tot.sum()), f_rhs, dim) / S, 1456 if wl == "c5_stm" else 304)
+            out["roofline"] = roofline(wl, 12, S, kern_ms, work=work, samples=samples, burst_n=burst_n)
+            out["roofline"]["flops_from"] = "measured step counts of this sweep: %.2f trial steps per segment (max %d) x (12 x %d + 148 x %d)" % (
+                tot.mean(), int(tot.max()), f_rhs, dim)
+            out["adaptive"] = {"trial_steps_mean": float(tot.mean()), "trial_steps_max": int(tot.max()), "rebalanced": rebalanced}
+        else:
+            out["roofline"] = roofline(wl, 12, S, kern_ms, samples=samples, burst_n=burst_n)
+        for k in ("flops_model", "note", "kernel_ms_from"):          # said once, in the main line's roofline object
+            out["roofline"].pop(k, None)
+        assert bool(torch.isfinite(w.defect).all()), "non-finite defect in the %s leg" % key
+        if cpu_seconds > 0:
+            out["parity"], out["cpu_baseline"] = config_parity_and_cpu(w, lto, cpu_seconds)
+        return out
+    finally:
+        w.plan.close()
+
+
 def self_launch(a):
     """`bench.py --gpus N` without a launcher: start the contract's launcher as a CHILD process -- before anything in this process
     has touched the GPU (replacing a process that has initialised HIP takes the node down) -- and leave with its exit code.  Its
@@ -734,94 +1007,13 @@ def main():
         ctx.close()
         return
     if a.ndim == 0:
-        a.ndim = 14 if wl in ("c2", "c2_defect", "hbm") else 12
-    prm1 = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+        a.ndim = default_ndim(wl)
     f64 = dict(dtype=torch.float64, device=dev)
     c5 = wl in ("c5", "c5_stm")
-    if wl in ("c2", "c2_defect", "hbm") or c5:
-        S = a.segments or (65536 // max(world, 1) if c5 else 4096)
-        n = S + 1
-        if c5:
-            XC, T = synth.indirect_problem(n, seed=1 + rank, dt_range=(0.05, 0.5))
-            prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1e-3)
-            integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13)
-            desc = "C5: indirect 12-dim defect%s, adaptive DOP853 rtol=atol=1e-13, dt_seg~U[0.05,0.5], rho=1e-3" % (
-                " + 12x12 STM" if wl == "c5_stm" else "")
-        else:
-            XC, T = synth.indirect_problem(n, seed=rank)
-            prm = prm1
-            steps = 1 if wl == "hbm" else 64
-            integ = lto.integrator(lto.RK4, steps=steps)
-            if a.method == "rkf78":
-                integ = lto.integrator(lto.RKF78_FIXED, steps=4)
-            elif a.method == "dop853":
-                integ = lto.integrator(lto.DOP853_ADAPTIVE, rtol=1e-13, atol=1e-13)
-            dd = (a.ndim, a.ndim, a.ndim)
-            desc = {"c2": "C2: indirect %d-dim state+costate + %dx%d STM, RK4 x 64 steps, fp64, p=1 rho=1 thrust 0.05 N" % dd,
-                    "c2_defect": "C2 (defect only): indirect %d-dim state+costate, RK4 x 64 steps" % a.ndim,
-                    "hbm": "HBM evidence point: indirect %d-dim + %dx%d STM, ONE RK4 step per segment" % dd}[wl]
-        nd = a.ndim
-        if nd == 14:   # mass + mass costate: (r, v, m, lambda_r, lambda_v, lambda_m); params' mass slot = Isp
-            XC = to14(XC)
-            prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 2000.0, 1.0, 1.0, prm.rho)
-        X = torch.from_numpy(synth.to_soa_nodes(XC)).to(dev)
-        t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).to(dev)
-        plan = lto.IndirectPlan(ctx, n, 1, prm, integ, ndim=nd)
-        if a.cols:
-            plan.set_cols_per_lane(a.cols)
-        if a.kernel:
-            plan.set_kernel(a.kernel)
-        defect = torch.zeros(nd, S, **f64)
-        Phi = torch.zeros(nd * nd, S, **f64)
-        if wl in ("c2", "hbm", "c5_stm"):
-            def sweep(dbuf):
-                plan.jacobian(X, n, t, 1, Phi, S, dbuf, S, stream=st)
-        else:
-            def sweep(dbuf):
-                plan.defect(X, n, t, 1, dbuf, S, stream=st)
-        gather_rows = nd
-        if a.method:
-            desc += " [integrator %s]" % a.method
-    elif wl == "c4":
-        levels = 256 // max(world, 1) if not a.segments else max(1, a.segments // 1024)
-        spt = 1024
-        n = spt + 1
-        S = levels * spt
-        XC, T = synth.indirect_problem(n, n_batch=levels, seed=10 + rank)
-        rhos = synth.homotopy_rhos(256)[rank * levels:(rank + 1) * levels] if world * levels == 256 else synth.homotopy_rhos(levels)
-        prm = [lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, r) for r in rhos]
-        integ = lto.integrator(lto.RK4, steps=64)
-        X = torch.from_numpy(synth.to_soa_nodes(XC)).to(dev)
-        t = torch.from_numpy(np.ascontiguousarray(T.T)).to(dev)   # [levels][n]
-        plan = lto.IndirectPlan(ctx, n, levels, prm, integ)
-        if a.cols:
-            plan.set_cols_per_lane(a.cols)
-        defect = torch.zeros(12, S, **f64)
-        Phi = torch.zeros(144, S, **f64)
-
-        def sweep(dbuf):
-            plan.jacobian(X, n * levels, t, levels, Phi, S, dbuf, S, stream=st)
-        desc = "C4: homotopy sweep, %d rho levels x 1024 segments per GPU, 12-dim + STM, RK4 x 64" % levels
-        gather_rows = 12
-    else:  # c3
-        S = a.segments or 16384
-        n = S + 1
-        Xd, Ud, Td = synth.direct_problem(n, seed=rank)
-        X = torch.from_numpy(synth.to_soa_nodes(Xd)).to(dev)
-        U = torch.from_numpy(synth.to_soa_nodes(Ud)).to(dev)
-        t = torch.from_numpy(np.ascontiguousarray(Td[:, 0])).to(dev)
-        plan = lto.DirectPlan(ctx, 6, n, 1, 10, lto.MU, lto.DU, lto.TU, 2000.0)
-        if a.kernel:
-            plan.set_kernel(a.kernel)
-        defect = torch.zeros(6, S, **f64)
-        errs = torch.zeros(S, **f64)
-        Jac = torch.zeros(108, S, **f64)
-        dtf = torch.zeros(6, S, **f64)
-
-        def sweep(dbuf):
-            plan.jacobian(X, n, U, n, t, 1, Jac, S, dtf, dbuf, S, errs, stream=st)
-        desc = "C3: direct 6-dim, RKF7(8) nsteps=10 per half, on-device Jacobian blocks 6x18 + tf column + defect + errors"
-        gather_rows = 6
+    w = make_workload(wl, lto, synth, torch, ctx, st, dev, ndim=a.ndim, segments=a.segments, method=a.method, rank=rank, world=world,
+                      cols=a.cols, kernel=a.kernel)
+    S, n, XC, T, prm, integ, plan, defect, Phi, sweep, desc, gather_rows = (w.S, w.n, w.XC, w.T, w.prm, w.integ, w.plan, w.defect, w.Phi,
+                                                                            w.sweep, w.desc, w.gather_rows)
 
     if a.pmc_child:          # under rocprofv3 --pmc (live_traffic below): the workload's sweeps and nothing else
         for _ in range(a.warmup + a.steps):
@@ -1053,7 +1245,9 @@ def main():
         out = {
             "metric": "segment-integrations/sec (state+costate+STM)" if wl in ("c2", "c4", "hbm") else "segment-integrations/sec",
             "value": value, "unit": "segment-integrations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            # c4 / c5 shard a FIXED global size (256 levels, 65 536 segments) over the ranks; the others give every rank its own batch
+            "scaling": "strong" if (wl in ("c4", "c5", "c5_stm") and not a.segments) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
                        "slab_check": ("passed on every rank: own slab of the gathered defect vector bit-equal to the sweep's output, every slab finite"
@@ -1143,6 +1337,18 @@ def main():
         if world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
             # what a user of the reference's driver waits for per iteration
             out["newton_iteration"] = leg_newton(lto, synth, ctx, st, torch, [29, 4096], 0.0 if a.no_cpu_baseline else max(2.0, a.cpu_seconds / 4))
+        if world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments and not a.no_configs:
+            # BASELINE configs[2..4] and the HBM evidence point, each at its full single-GPU size, in this same line
+            plan.close(); plan = None
+            cfgs = {}
+            for key, cwl, ksteps, kwarm in CONFIG_LEGS:
+                try:
+                    cfgs[key] = leg_config(key, cwl, ksteps, kwarm, lto, synth, torch, ctx, st, dev, a.device_warmup_ms,
+                                           0.0 if a.no_cpu_baseline else max(1.0, a.cpu_seconds / 6))
+                except Exception as ex:      # noqa: BLE001 -- one leg's failure is reported in its place, the line is kept
+                    cfgs[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                torch.cuda.empty_cache()
+            out["configs"] = cfgs
         if ref12 is not None:
             out["reference_system_12dim"] = ref12[0]
             out["reference_integrator"] = refint[0]
@@ -1156,7 +1362,8 @@ def main():
         native.close()
     if use_coll:
         dist.destroy_process_group()
-    plan.close()       # plans before their context (lto_destroy frees what lto_*_plan_destroy touches)
+    if plan is not None:
+        plan.close()   # plans before their context (lto_destroy frees what lto_*_plan_destroy touches)
     ctx.close()
 
 

@@ -293,9 +293,17 @@ int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
  * SIMD, i.e. 512 x CUs segments (131 072 on MI355X); two lanes up to 262 144 segments; one beyond), or 1, 2, 4.  Two and four
  * lanes on other plans: LTO_EINVAL. */
 int lto_indirect_plan_set_defect_lanes(lto_indirect_plan* plan, int lanes);
+/* Record staging of a plan's ordered (rebalanced) sweeps, a bit mask: 1 = node and defect records are in place, 2 = Phi records
+ * too (only plans that run STM sweeps get them), 4 = an allocation for them failed and staging is off for this plan -- the sweeps
+ * then read and write the caller's arrays directly (same results, 3-8 x the HBM traffic); lto_last_error() holds the note. */
+int lto_indirect_plan_staging(const lto_indirect_plan* plan);
 /* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* plan);
-/* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3); 0 = choose from S. */
+/* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3; every lane re-integrates the base state with its columns);
+ * 0 = choose from S.  12 = the whole 12x12 STM in the segment's own lane (kernels_indirect_stream.hip): built for ndim = 12 RK4
+ * plans with ONE step per segment (LTO_EINVAL otherwise) -- the HBM-bound corner of the sweep, where the lane of a segment runs
+ * the four stage evaluations once and sends the twelve columns through the four stage matrices; 0 chooses it for such plans from
+ * 65 536 segments. */
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);
 
 /* Newton step of the indirect method solved on the device: delta = -Jac_full \ defect for the block-bidiagonal

@@ -97,6 +97,7 @@ SIGNATURES = {
     "lto_indirect_plan_copy_steps": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lto_indirect_plan_set_cols_per_lane": (C.c_int, [_vp, C.c_int]),
     "lto_indirect_plan_last_kernel": (C.c_int, [_vp]),
+    "lto_indirect_plan_staging": (C.c_int, [_vp]),
     "lto_indirect_plan_rebalance": (C.c_int, [_vp, _vp]),
     "lto_indirect_plan_reset_order": (C.c_int, [_vp]),
     "lto_indirect_plan_set_warm_start": (C.c_int, [_vp, C.c_int]),

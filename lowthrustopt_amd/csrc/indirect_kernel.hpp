@@ -159,25 +159,26 @@ __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, co
     double last = 0.0;
     if (t + h >= span) { h = span - t; last = 1.0; }
     double yn[D];
-    double err;
-    if constexpr (D > 14) err = dop853_try_mem<Sys, NERR>(sys, kTabDP8, h, rtol, atol, y, K, yn);
-    else err = dop853_try<Sys, NERR>(sys, h, rtol, atol, y, K, yn);
-    if (err < 1.0) {
-      double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow_m8th(err));
-      if (rejected != 0.0) factor = fmin(1.0, factor);
-      h_abs = h * factor;
+    double E5, E3;
+    if constexpr (D > 14) (void)dop853_try_mem<Sys, NERR>(sys, kTabDP8, h, rtol, atol, y, K, yn, E5, E3);
+    else (void)dop853_try<Sys, NERR>(sys, h, rtol, atol, y, K, yn, E5, E3);
+    // the step decision every DOP853 kernel of this library takes (rk.hpp dp8_decide): the one- / two- / four-lane defect sweeps
+    // AUTO switches between share one controller (advisor finding, round 4)
+    double h_next, accept, bad;
+    dp8_decide(E5, E3, h, rejected, (double)NERR, h_next, accept, bad);
+    h_abs = h_next;
+    if (accept != 0.0) {
       t = (last != 0.0) ? span : t + h;
 #pragma unroll
       for (int i = 0; i < D; ++i) { y[i] = yn[i]; K[0][i] = K[12][i]; }
       ++nacc;
       rejected = 0.0;
     } else {
-      h_abs = h * fmax(0.2, 0.9 * pow_m8th(err));
       rejected = 1.0;
       ++nrej;
-      if (err != err) {                       // a NaN never recovers: poison and stop instead of max_steps retries
+      if (bad != 0.0) {                       // a NaN never recovers: poison and stop instead of max_steps retries
 #pragma unroll
-        for (int i = 0; i < D; ++i) y[i] = err;
+        for (int i = 0; i < D; ++i) y[i] = bad;
         t = span;
       }
     }

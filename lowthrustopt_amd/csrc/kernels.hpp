@@ -96,6 +96,9 @@ hipError_t launch_indirect_stm_pipe8(int ndim, int pm, const IndirectArgs& a, hi
 // large batches (kernels_indirect_pipe48.hip): 48 segments and 16 waves per workgroup, base lane = segment, DPP column rows
 hipError_t launch_indirect_stm_pipe48(int ndim, int pm, const IndirectArgs& a, bool seg44, hipStream_t st);
 hipError_t launch_indirect_stm_pipe32(int ndim, int pm, const IndirectArgs& a, hipStream_t st);   // kernels_indirect_pipe32.hip
+// one RK4 step, lane = whole segment with all twelve STM columns (kernels_indirect_stream.hip): the HBM-bound corner of the sweep
+hipError_t launch_indirect_stm_stream(int pm, const IndirectArgs& a, hipStream_t st);
+bool indirect_stm_stream_available(int ndim, int method, int steps, long S);
 bool indirect_stm_pipe32_available(int ndim, int pm);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);

@@ -301,18 +301,8 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
         __syncthreads();
         const double E5 = total(0), E3 = total(1);
         constexpr double NCOMP = (double)(ND * (ND + 1));
-        const double err = (E5 == 0.0 && E3 == 0.0) ? 0.0 : fabs(h) * E5 / sqrt((E5 + 0.01 * E3) * NCOMP);
-        // identical arithmetic in every lane of the segment => identical decision, no broadcast needed
-        if (err < 1.0) {
-          double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 / sqrt(sqrt(sqrt(err))));
-          if (rejected != 0.0) factor = fmin(1.0, factor);
-          h_abs = h * factor;
-          accept = 1.0;
-        } else {
-          h_abs = h * fmax(0.2, 0.9 / sqrt(sqrt(sqrt(err))));
-          accept = 0.0;
-          if (err != err) bad = err;           // a NaN never recovers: poison the segment and stop (below)
-        }
+        // identical arithmetic in every lane of the segment => identical decision, no broadcast needed (rk.hpp dp8_decide)
+        dp8_decide(E5, E3, h, rejected, NCOMP, h_abs, accept, bad);
         __syncthreads();                       // s_part is rewritten by the next trial
       } else {
         // ode78: error and |x|_inf over the BASE state only (ode.jl:492-497): the base lane decides, LDS broadcasts

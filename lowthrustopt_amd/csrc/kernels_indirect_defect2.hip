@@ -146,24 +146,23 @@ __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
         e3 = __builtin_fma(s3, s3, e3);
       }
       const double E5 = pair_sum(e5), E3 = pair_sum(e3);
-      const double err = (E5 == 0.0 && E3 == 0.0) ? 0.0 : fabs(h) * E5 / sqrt((E5 + 0.01 * E3) * 12.0);
-      if (err < 1.0) {
-        double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 / sqrt(sqrt(sqrt(err))));
-        if (rejected != 0.0) factor = fmin(1.0, factor);
+      double h_next, accept, bad;
+      dp8_decide(E5, E3, h, rejected, 12.0, h_next, accept, bad);       // the controller of the four-lane and cooperative forms (rk.hpp)
+      if (accept != 0.0) {
         if (nacc == 0) h_rec = h_abs;
-        h_abs = h * factor;
+        h_abs = h_next;
         t = (last != 0.0) ? span : t + h;
 #pragma unroll
         for (int j = 0; j < 6; ++j) { y[j] = yn[j]; K[0][j] = K[12][j]; }
         ++nacc;
         rejected = 0.0;
       } else {
-        h_abs = h * fmax(0.2, 0.9 / sqrt(sqrt(sqrt(err))));
+        h_abs = h_next;
         rejected = 1.0;
         ++nrej;
-        if (err != err) {                     // a NaN never recovers: poison and stop instead of max_steps retries
+        if (bad != 0.0) {                     // a NaN never recovers: poison and stop instead of max_steps retries
 #pragma unroll
-          for (int j = 0; j < 6; ++j) y[j] = err;
+          for (int j = 0; j < 6; ++j) y[j] = bad;
           t = span;
         }
       }

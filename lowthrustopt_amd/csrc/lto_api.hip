@@ -118,7 +118,9 @@ struct lto_indirect_plan {
   int stats_age;            // qualifying sweeps so far
   double* d_xa;             // [n_nodes n_batch][NODE_REC]
   double* d_da;             // [S][12]
-  double* d_pa;             // [S][144], on the first staged STM sweep
+  double* d_pa;             // [S][144]: only for plans that run STM sweeps (stage_alloc's need_phi)
+  int stm_swept;            // an STM sweep has run on this plan
+  int stage_failed;         // an allocation of record staging failed: the sweeps gather from the caller's arrays (lto_indirect_plan_staging)
 };
 
 struct lto_direct_plan {
@@ -468,16 +470,32 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* p, void* stream, int* accept
 
 // Record staging (12-dim plans with the reference's integrator setting): the buffers come with the lane order, outside any sweep.
 static bool stage_capable(const lto_indirect_plan* p) { return p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE; }
-static int stage_alloc(lto_indirect_plan* p) {
+// need_phi: the plan runs STM sweeps, so the [S][144] Phi records are wanted too.  A defect-only plan (the line search's S x 20
+// trial plan) never gets them: at 256 x 1 024 x 20 segments they would pin 6 GB nothing reads (advisor finding, round 4).  An
+// allocation that fails switches staging off for what it was for -- the sweeps then gather from the caller's arrays as before --
+// and is reported: lto_indirect_plan_staging() carries the bit, lto_last_error() the text (the call still returns LTO_OK).
+static int stage_alloc(lto_indirect_plan* p, bool need_phi) {
   if (!stage_capable(p)) return LTO_OK;
   lto_ctx* c = p->ctx;
-  struct { double** ptr; size_t n; } want[3] = {{&p->d_xa, (size_t)NODE_REC * p->n_nodes * p->n_batch}, {&p->d_da, (size_t)12 * p->S}, {&p->d_pa, (size_t)144 * p->S}};
+  struct { double** ptr; size_t n; bool want; } want[3] = {{&p->d_xa, (size_t)NODE_REC * p->n_nodes * p->n_batch, true},
+                                                           {&p->d_da, (size_t)12 * p->S, true}, {&p->d_pa, (size_t)144 * p->S, need_phi}};
   for (auto& w : want) {
-    if (*w.ptr) continue;
+    if (*w.ptr || !w.want) continue;
     hipError_t e = pool_alloc(c, (void**)w.ptr, sizeof(double) * w.n);
-    if (e != hipSuccess) { *w.ptr = nullptr; (void)hipGetLastError(); return LTO_OK; }     // no staging: the sweeps gather from the caller's arrays as before
+    if (e != hipSuccess) {
+      *w.ptr = nullptr; (void)hipGetLastError();
+      p->stage_failed = 1;
+      std::snprintf(c->err, sizeof c->err, "note: record staging of ordered sweeps is off for this plan (%zu bytes: %s); results are unaffected",
+                    sizeof(double) * w.n, hipGetErrorString(e));
+      return LTO_OK;
+    }
   }
   return LTO_OK;
+}
+
+int lto_indirect_plan_staging(const lto_indirect_plan* p) {
+  if (!p) return 0;
+  return ((p->d_xa && p->d_da) ? 1 : 0) | (p->d_pa ? 2 : 0) | (p->stage_failed ? 4 : 0);
 }
 
 int lto_indirect_plan_rebalance(lto_indirect_plan* p, void* stream) {
@@ -494,7 +512,7 @@ int lto_indirect_plan_rebalance(lto_indirect_plan* p, void* stream) {
   hipError_t e = launch_segment_order(p->d_nacc, p->d_nrej, p->S, p->d_order + p->S, p->d_order, (hipStream_t)stream);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_segment_order", e);
   p->use_order = 1;
-  return stage_alloc(p);
+  return stage_alloc(p, p->stm_swept != 0);
 }
 
 int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
@@ -571,7 +589,10 @@ static void warm_filled(lto_indirect_plan* p, int which, const IndirectArgs& a) 
 
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
   if (!p) return LTO_ENULL;
-  if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2 or 3");
+  if (cols == 12) {
+    if (!indirect_stm_stream_available(p->ndim, p->integ.method, p->integ.steps, p->S))
+      return set_err(p->ctx, LTO_EINVAL, "cols_per_lane = 12 (the whole STM in the segment's lane) is built for 12-dim RK4 plans with ONE step per segment");
+  } else if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2, 3 or 12");
   if (p->ndim == 14 && cols == 3) return set_err(p->ctx, LTO_EUNSUPPORTED, "14 STM columns do not split into groups of 3: use 0 (auto), 1 or 2");
   p->cols_per_lane = cols;
   return LTO_OK;
@@ -661,6 +682,11 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   return LTO_OK;
 }
 
+// One-step RK4 STM sweeps (SURVEY 8d's HBM-bound corner): from this many segments AUTO's per-lane family runs the form whose lane is
+// a whole segment (kernels_indirect_stream.hip): one wavefront of 64 segments per SIMD of an MI355X.  Below, the per-(segment,
+// column group) lanes fill the chip with four to twelve times the wavefronts and the sweep is latency-bound either way.
+static const long kStreamMinSegments = 65536;
+
 int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* X, long ldx, const double* t,
                               int n_tgrids, double* Phi, long ldp, double* defect, long ldd) {
   if (!p) return LTO_ENULL;
@@ -715,6 +741,14 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   p->last_kernel = kern;
   rc = warm_args(p, 0, kern == LTO_KERNEL_COOP2, &a);
   if (rc) return rc;
+  p->stm_swept = 1;
+  if (a.order && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && !p->d_pa && !p->stage_failed) {
+    // the lane order was made before this plan's first STM sweep: the Phi records come now -- unless the stream is being captured
+    // (an allocation may not happen there; this sweep then runs unstaged and a later one outside a capture allocates)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) (void)stage_alloc(p, true);
+    else (void)hipGetLastError();
+  }
   const bool staged = a.order && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && p->d_pa;
   if (staged) {
     hipError_t q = launch_node_records(X, ldx, t, a.t_stride, p->n_nodes, (long)p->n_nodes * p->n_batch, p->d_xa, st);
@@ -728,6 +762,9 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, seg44, st);
   else if (kern == LTO_KERNEL_PIPE32) e = launch_indirect_stm_pipe32(p->ndim, p->pm, a, st);
+  else if (p->ndim == 12 && !a.order && (p->cols_per_lane == 12 || (p->cols_per_lane == 0 && p->S >= kStreamMinSegments &&
+                                                          indirect_stm_stream_available(12, p->integ.method, p->integ.steps, p->S))))
+    e = launch_indirect_stm_stream(p->pm, a, st);      // one RK4 step on a full chip: lane = segment, HBM-bound (kernels_indirect_stream.hip)
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   if (e == hipSuccess && staged) e = launch_pack_soa(p->d_pa, 144, p->S, a.Phi, a.ldp, st);
@@ -982,7 +1019,7 @@ static void host_order_adopt(lto_ctx* c, lto_indirect_plan* p, bool stm) {
   if (p->order_borrowed) { p->d_order = nullptr; p->use_order = 0; p->order_borrowed = 0; }   // cached plan: the context's order may have moved
   if (!host_order_wanted(p, stm) || !c->order_cache || c->order_S != p->S || c->order_ndim != p->ndim) return;
   p->d_order = c->order_cache; p->order_borrowed = 1; p->use_order = 1;
-  (void)stage_alloc(p);
+  (void)stage_alloc(p, stm);
 }
 
 static void host_order_refresh(lto_ctx* c, lto_indirect_plan* p, bool stm, hipStream_t st) {

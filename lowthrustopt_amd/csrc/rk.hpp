@@ -144,10 +144,11 @@ __device__ __forceinline__ double rkf78_step(const Sys& sys, const double h, con
 // Stages 1..11 from K[0] = f(y); ynew; K[12] = f(ynew) (FSAL); returns the scaled error norm
 // err = |h| e5^2 / sqrt((e5^2 + 0.01 e3^2) n) on scale_i = atol + rtol max(|y_i|, |ynew_i|),
 // over the first NERR components.
+// E5 / E3: the two error sums themselves (what dp8_decide takes).
 template <class Sys, int NERR>
 __device__ __forceinline__ double dop853_try(const Sys& sys, const double h, const double rtol, const double atol,
                                              const double (&y)[Sys::DIM], double (&K)[13][Sys::DIM],
-                                             double (&ynew)[Sys::DIM]) {
+                                             double (&ynew)[Sys::DIM], double& E5, double& E3) {
   constexpr int D = Sys::DIM;
   constexpr int NS = DP8_NSTAGES;
 #pragma unroll
@@ -195,6 +196,7 @@ __device__ __forceinline__ double dop853_try(const Sys& sys, const double h, con
     e5 = __builtin_fma(a5, a5, e5);
     e3 = __builtin_fma(a3, a3, e3);
   }
+  E5 = e5; E3 = e3;
   if (e5 == 0.0 && e3 == 0.0) return 0.0;
   return fabs(h) * e5 / sqrt((e5 + 0.01 * e3) * (double)NERR);
 }
@@ -214,10 +216,14 @@ __device__ __forceinline__ void dp8_decide(const double E5, const double E3, con
   const bool zero = (E5 == 0.0) & (E3 == 0.0);
   const double err_raw = (fabs(h) * E5) * rsqrt_nr(den);
   const double err = zero ? 0.0 : err_raw;
-  const double r8 = rsqrt_nr(rsqrt_nr(rsqrt_nr(err)));          // err^(-1/8); NaN for err = 0 or inf, which the selects below never pick
-  const double f = 0.9 * r8;
+  const double r8 = rsqrt_nr(rsqrt_nr(rsqrt_nr(err)));          // err^(-1/8); NaN for err = 0 and for err = inf
+  // The two non-finite r8 are selected away explicitly -- err = 0 (which also covers E5 = 0 with E3 != 0) grows by 10, err = inf
+  // shrinks by 0.2 -- so the result does not rest on fmin / fmax returning their non-NaN operand (it would not survive
+  // -ffinite-math-only on this unit; advisor finding, round 4).  A NaN err stays NaN in f and reaches `bad` below.
+  const double inf = __builtin_huge_val();
+  const double f = (err == 0.0) ? 10.0 : (err == inf ? 0.2 : 0.9 * r8);
   const bool acc = err < 1.0;
-  double fa = zero ? 10.0 : fmin(10.0, f);
+  double fa = fmin(10.0, f);
   fa = (rejected != 0.0) ? fmin(1.0, fa) : fa;
   const double fr = fmax(0.2, f);
   h_abs = h * (acc ? fa : fr);
@@ -425,7 +431,7 @@ __device__ __forceinline__ double rkf78_step_mem(const Sys& sys, const double h,
 template <class Sys, int NERR>
 __device__ __forceinline__ double dop853_try_mem(const Sys& sys, const TabMem& T, const double h, const double rtol,
                                                  const double atol, const double (&y)[Sys::DIM], double (*K)[Sys::DIM],
-                                                 double (&ynew)[Sys::DIM]) {
+                                                 double (&ynew)[Sys::DIM], double& E5, double& E3) {
   stages_mem<Sys>(sys, T, 12, h, y, K);
   combine_mem<Sys>(T, 12, h, y, K, ynew);
   sys.rhs(ynew, K[12]);
@@ -448,6 +454,7 @@ __device__ __forceinline__ double dop853_try_mem(const Sys& sys, const TabMem& T
     e5 = __builtin_fma(v5, v5, e5);
     e3 = __builtin_fma(v3, v3, e3);
   }
+  E5 = e5; E3 = e3;
   if (e5 == 0.0 && e3 == 0.0) return 0.0;
   return fabs(h) * e5 / sqrt((e5 + 0.01 * e3) * (double)NERR);
 }

@@ -676,6 +676,11 @@ class IndirectPlan:
         """Name of the kernel family the last STM sweep ran (what AUTO resolved to)."""
         return {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48", 8: "pipeline32"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
 
+    def staging(self):
+        """Record staging of the plan's ordered sweeps (lto_indirect_plan_staging): bit 1 node / defect records in place, bit 2 Phi records
+        too (plans that run STM sweeps), bit 4 an allocation failed and staging is off."""
+        return int(self.ctx.lib.lto_indirect_plan_staging(self.handle))
+
     def set_cols_per_lane(self, cols):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_cols_per_lane(self.handle, int(cols)))
 

@@ -307,13 +307,18 @@ def _run_bench(extra_env, args, timeout=420, attempts=1):
     env = dict(os.environ)
     env.update(extra_env)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    import warnings
     errs = []
-    for _ in range(attempts):
+    for k in range(attempts):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         errs.append(p.stderr[-8000:])
         if p.returncode == 0:
             break
+        if k + 1 < attempts:
+            # keep the flake rate visible (advisor finding, round 4): a first attempt that failed shows up in pytest's warnings summary
+            warnings.warn("shared-device rehearsal `bench.py %s` failed on attempt %d (exit %d), retried: %s" % (
+                " ".join(args), k + 1, p.returncode, p.stderr[-300:].replace("\n", " | ")))
     return p.returncode, (json.loads(lines[-1]) if lines else None), "\n---- next attempt ----\n".join(errs)
 
 
@@ -333,6 +338,25 @@ def test_bench_multi_rank_path_runs_with_ranks_sharing_the_device(world):
     assert "IPC receive windows" in out["config"]["collective"]
     assert out["config"]["slab_check"].startswith("passed on every rank")
     assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("wl,world,per_rank", [("c4", 2, 128 * 1024), ("c4", 4, 64 * 1024), ("c5", 2, 32768)])
+def test_bench_sharded_configs_with_ranks_sharing_the_device(wl, world, per_rank):
+    """BASELINE configs[3] / [4] through the N > 1 path: `--workload c4` gives every rank 256 / N homotopy levels of 1 024 segments,
+    `--workload c5` 65 536 / N segments (ordered lanes after the warm-up sweep) -- a FIXED global size, so the line says "strong" --
+    followed by the all-gather of the defect slabs (12 x segments-per-rank doubles per rank) and the slab check.  Ranks share device
+    0 here; on the driver's node every rank has its own."""
+    rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1"}, ["--workload", wl, "--gpus", str(world), "--steps", "3", "--warmup", "2",
+                                                                "--no-cpu-baseline"], attempts=2)
+    assert rc == 0 and out is not None, err
+    assert out["n_gpus"] == world and out["scaling"] == "strong"
+    assert out["config"]["segments_per_gpu"] == per_rank and out["config"]["global_segments"] == world * per_rank
+    assert {"c4": 262144, "c5": 65536}[wl] == out["config"]["global_segments"]
+    assert "IPC receive windows" in out["config"]["collective"]
+    assert out["config"]["slab_check"].startswith("passed on every rank")
+    assert out["value"] > 0
+    if wl == "c5":
+        assert out["adaptive"]["rebalanced"] is True
 
 
 @pytest.mark.parametrize("mode", ["auto", "side"])

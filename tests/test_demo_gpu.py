@@ -18,3 +18,46 @@ def test_halo_transfer_demo_converges():
     assert res["p2"][0] == 0 and res["p2"][1] <= 1e-10          # indirect.jl:280 convergence threshold
     assert res["p1"][0] == 0 and res["p1"][1] <= 1e-10
     assert res["rho"][0] == 0 and res["rho"][1] <= 1e-10
+
+
+@pytest.mark.gpu
+def test_halo_transfer_demo_continuation_to_the_reference_target():
+    """The demo's continuation run to the reference's own target, rho = 1e-4 (CRTBP_Multishoot_indirect_demo.jl:277-281:
+    `reduceFuel_indirect(..., rho_current = 1, rho_target = 1e-4)`), by both routes the library offers:
+      * sequentially -- drivers.reduceFuel_indirect, the mirror of HelperFunctions.jl:105-193 (halving with back-off), every
+        multiShoot_CRTBP_indirect call one lto_indirect_solve on the device;
+      * concurrently -- drivers.homotopy_solve: a ladder of 28 levels from 0.5 down to 1e-4 as one batch (lto_indirect_solve_batch).
+    Both end with status 0 and max |defect| <= 1e-10 (the reference's convergence threshold, indirect.jl:280), and their rho = 1e-4
+    trajectories agree to 1e-6."""
+    import time
+    import numpy as np
+    import lowthrustopt_amd as lto
+    from lowthrustopt_amd import drivers
+    from lowthrustopt_amd.constants import MU, DU, TU
+    spec = importlib.util.spec_from_file_location("halo_demo", os.path.join(ROOT, "examples", "halo_transfer_demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    t0 = time.perf_counter()
+    n = 30
+    X, t = demo.stacked_guess(n)
+    rng = np.random.default_rng(0)
+    XC = np.vstack([X, 0.1 * rng.standard_normal((6, n))])
+    XC[:, 1:-1] += 1e-10 * rng.standard_normal((12, n - 2))
+    XC, _, f = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, n, 1e3, 10.0, False, True, 10, 2.0, 1.0, verbose=False)
+    XC, _, f = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, n, 1e3, 10.0, False, False, 50, 2.0, 1.0, verbose=False)
+    assert f == 0
+    XC1, d1, f1 = drivers.multiShoot_CRTBP_indirect(XC, t, MU, DU, TU, n, 1e3, 0.05, False, False, 30, 1.0, 1.0, verbose=False)
+    assert f1 == 0 and np.abs(d1).max() <= 1e-10
+    rho_target = 1e-4
+    Xseq, dseq, fseq = drivers.reduceFuel_indirect(XC1, t, MU, DU, TU, n, 1e3, 0.05, 1.0, rho_target, verbose=False)
+    assert fseq == 0 and np.abs(dseq).max() <= 1e-10
+    rhos = np.geomspace(0.5, rho_target, 28)
+    Xl, Dl, st, waves = drivers.homotopy_solve(XC1, t, MU, DU, TU, 1e3, 0.05, rhos, ctx=lto.default_context(0), verbose=False)
+    assert np.all(st == 0) and np.abs(Dl).max() <= 1e-10
+    assert np.abs(Xl[:, :, -1] - Xseq).max() <= 1e-6 * max(1.0, np.abs(Xseq).max())
+    # the result is a bang-bang-like profile: at rho = 1e-4 the throttle 1/2 (1 + tanh((|lambda_v| - 1) / (2 rho))) is within 1e-6 of
+    # 0 or 1 at all but a few of the nodes
+    lam = np.linalg.norm(Xseq[9:12], axis=0)
+    thr = 0.5 * (1.0 + np.tanh((lam - 1.0) / (2.0 * rho_target)))
+    assert np.mean((thr < 1e-6) | (thr > 1.0 - 1e-6)) >= 0.8
+    assert time.perf_counter() - t0 < 30.0

@@ -1687,7 +1687,97 @@ def test_rebalanced_auto_sweeps_with_record_staging_are_bit_identical(gpu_ctx):
                 assert np.array_equal(a, b)
             for a, b in zip(out[3] + out[4], ref[3] + ref[4]):
                 assert np.array_equal(a, b)
+        assert plan.staging() == 3                                  # this plan runs STM sweeps: node, defect AND Phi records
         plan.reset_order()
         out = sweep()
         assert all(np.array_equal(a, b) for a, b in zip(out[:3], ref[:3]))
         plan.close()
+    # a plan that only ever runs defect sweeps (the line search's trial plan) gets no Phi records with its lane order (advisor
+    # finding, round 4: [S][144] doubles it would never read); they come with its first STM sweep if there ever is one
+    plan = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator())
+    d0 = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    assert plan.staging() == 0
+    plan.defect(Xd, n * B, td, B, d0, S)
+    plan.rebalance()
+    assert plan.staging() == 1
+    plan.defect(Xd, n * B, td, B, d0, S)
+    assert plan.staging() == 1
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(Xd, n * B, td, B, Phi, S, d0, S)
+    assert plan.staging() == 3
+    torch.cuda.synchronize()
+    assert np.array_equal(Phi.cpu().numpy(), ref[0])
+    plan.close()
+
+
+@pytest.mark.parametrize("pcase", ["p1_rho1", "p1_rho1e-3", "p2_clamped", "p1.5", "p0"])
+def test_one_step_whole_segment_lanes_vs_oracle_and_column_groups(gpu_ctx, oracle, pcase):
+    """RK4 with ONE step per segment and the whole 12x12 STM in the segment's own lane (kernels_indirect_stream.hip,
+    cols_per_lane = 12; AUTO from 65 536 segments: SURVEY 8d's HBM-bound corner): defect and Phi equal the oracle's dual-number
+    derivative of the same one-step map, and equal the per-(segment, column group) kernel's -- on a ragged batch (3 trajectories
+    x 333 segments: wavefronts that straddle trajectories, a partly filled last wavefront), with short segments so that one RK4
+    step is a meaningful integration."""
+    import torch
+    pp, rho, thr, lam = P_CASES[pcase]
+    n, B = 334, 3
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=31, dt_seg=0.01, lam_sigma=lam)
+    S1, S = n - 1, (n - 1) * B
+    prm = lto.make_params(MU, DU, TU, thr, 1000.0, 1.0, pp, rho)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()
+    plan = lto.IndirectPlan(gpu_ctx, n, B, prm, lto.integrator(lto.RK4, steps=1))
+    out = {}
+    for cols in (12, 3):
+        plan.set_cols_per_lane(cols)
+        Phi = torch.full((144, S), float("nan"), dtype=torch.float64, device="cuda")
+        d = torch.full((12, S), float("nan"), dtype=torch.float64, device="cuda")
+        plan.jacobian(X, n * B, t, B, Phi, S, d, S)
+        torch.cuda.synchronize()
+        assert plan.last_kernel() == "per-lane"
+        out[cols] = (Phi.cpu().numpy(), d.cpu().numpy())
+    plan.close()
+    P12, d12 = out[12]
+    assert np.all(np.isfinite(P12)) and np.all(np.isfinite(d12))
+    # same functions on the same operands in the same order as the column-group kernel: round-off only
+    assert np.abs(P12 - out[3][0]).max() <= 1e-14 * np.abs(out[3][0]).max()
+    assert np.abs(d12 - out[3][1]).max() <= 1e-15
+    prm_o = [MU, DU, TU, thr, 1000.0, 1.0, pp, rho]
+    for b in range(B):
+        P_o, d_o, rc = oracle.indirect_jacobian(XC[:, :, b], T[:, b], prm_o, oracle.RK4, 1)
+        assert rc == 0
+        sl = slice(b * S1, (b + 1) * S1)
+        Pg = P12[:, sl].reshape(12, 12, S1).transpose(1, 0, 2)
+        assert rel_l2(d12[:, sl], d_o, XC[:, 1:, b]) < 1e-13
+        assert np.abs(Pg - P_o).max() < 1e-12 * np.abs(P_o).max()
+
+
+def test_one_step_whole_segment_lanes_choice_and_misuse(gpu_ctx):
+    """AUTO takes the whole-segment lanes for one-step RK4 plans from 65 536 segments (checked through the results: they are the
+    forced form's bit for bit); cols_per_lane = 12 is refused for plans it is not built for (more than one step, 14-dim, 13-stage
+    integrators); a mixed-class batch is swept by one launch per class."""
+    import torch
+    n, B = 1025, 64                                    # 65 536 segments
+    XC, T = synth.indirect_problem(n, n_batch=4, seed=5, dt_seg=0.02)
+    XC = np.asfortranarray(np.tile(XC, (1, 1, B // 4))); T = np.asfortranarray(np.tile(T, (1, B // 4)))
+    S = (n - 1) * B
+    prm = [lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, (1.0, 2.0, 0.0, 1.5)[b % 4], 1.0) for b in range(B)]
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()
+    plan = lto.IndirectPlan(gpu_ctx, n, B, prm, lto.integrator(lto.RK4, steps=1))
+    res = []
+    for cols in (0, 12, 3):
+        plan.set_cols_per_lane(cols)
+        Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda"); d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(X, n * B, t, B, Phi, S, d, S)
+        torch.cuda.synchronize()
+        res.append((Phi, d))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])          # AUTO == forced whole-segment lanes
+    assert float((res[1][0] - res[2][0]).abs().max()) <= 1e-14 * float(res[2][0].abs().max())
+    S1 = n - 1                                                                                # copies of a trajectory: same bits wherever they sit
+    assert torch.equal(res[1][0][:, :S1], res[1][0][:, 4 * S1:5 * S1])
+    plan.close()
+    for kw, ndim in ((dict(method=lto.RK4, steps=2), 12), (dict(method=lto.RK4, steps=1), 14), (dict(method=lto.DOP853_ADAPTIVE), 12)):
+        pl = lto.IndirectPlan(gpu_ctx, 30, 1, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), lto.integrator(**kw), ndim=ndim)
+        with pytest.raises(lto._lib.LtoError):
+            pl.set_cols_per_lane(12)
+        pl.close()
