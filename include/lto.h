@@ -17,8 +17,10 @@
  *   - Return value: 0 = ok; < 0 = API misuse; > 0 = runtime failure (see LTO_E*).  Non-finite
  *     results are not errors: NaN/Inf propagate into the outputs so the caller's driver reproduces the
  *     reference's status_flag = 2 path (src/multiShoot_CRTBP_indirect.jl:339-341).
- *   - The library never throws across the ABI (it is built without exception support: running out of host
- *     memory or of threads inside a call ends the process instead), installs no signal handlers and keeps
+ *   - The library never throws across the ABI: it is built without exception support, and what it allocates on the host
+ *     inside a call (work arrays, its bookkeeping lists, the threads of a lto_group call) is checked -- running out of
+ *     host memory or of threads there returns LTO_ENOMEM, it does not end the caller's process (a Julia session).  It
+ *     installs no signal handlers and keeps
  *     no host pointer after a call returns.  One thread per context at a time; distinct contexts are
  *     independent.
  */
@@ -41,6 +43,7 @@ extern "C" {
 #define LTO_EHIP 1            /* HIP runtime error (message in lto_last_error)                   */
 #define LTO_EBADP 2           /* reference: error("Invalid value of p!") stateCostate_deriv.jl:52 */
 #define LTO_ENODEVICE 3       /* no usable gfx950 device                                         */
+#define LTO_ENOMEM 4          /* host memory (or a host thread) could not be had inside a call   */
 
 /* Integrators.  RK4 = GeneralCode/ode.jl:21-73; RKF78_FIXED = ode7_8, ode.jl:773-953 (the direct
  * path's integrator); RKF78_ADAPTIVE = ode78, ode.jl:364-544; DOP853_ADAPTIVE = order-8 adaptive pair
@@ -250,13 +253,20 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* plan);
  * (1e-13), which is why it is off by default: with it off, equal inputs give equal bits.  Turning it off forgets the stored sizes. */
 int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
 
-/* Tuning knobs for the STM sweep.  Kernel: AUTO picks, for fixed-step RK4 with >= 6 steps per segment, the three-role
- * pipeline kernels -- the eight-wave form while the batch is one round (16 segments per CU: 4 096 on MI355X), above that
- * whichever of eight-wave form (rounds of 16 x CUs segments), 48-segment form (rounds of 48 x CUs) and, for ndim = 12, per-lane
- * kernel with 3 columns per lane (rounds of 64 x CUs) needs the cheapest rounds for the segment count -- and otherwise the
- * per-lane kernel (each lane re-integrates the base state with 1-3 columns); for the 13-stage integrators the wave-specialised
- * kernel (base wave + column waves per 16 segments, coefficients handed over through LDS at every RK stage) -- for ndim = 12
- * with DOP853_ADAPTIVE, the reference's setting, its form with two lanes per state (LTO_KERNEL_COOP2). */
+/* Tuning knobs for the STM sweep.  Kernel: LTO_KERNEL_AUTO picks
+ *   - fixed-step RK4 with >= 6 steps per segment: the three-role pipeline kernels -- the eight-wave form (LTO_KERNEL_PIPE8) while
+ *     the batch is one round of it (16 segments per CU: 4 096 on MI355X); above that the family whose rounds are cheapest for the
+ *     segment count, by the context's cost table (lto_kernel_round_costs / lto_calibrate_kernels above): eight-wave form in
+ *     rounds of 16 x CUs segments, 32-segment form (LTO_KERNEL_PIPE32, where it is built) in rounds of 32 x CUs, large-batch form
+ *     (LTO_KERNEL_PIPE48) in rounds of 48 x CUs -- 12-dim also 44 x CUs --, and for ndim = 12 the per-lane kernel with 3 columns
+ *     per lane in rounds of 64 x CUs.  On MI355X (256 CUs, default table): 4 097 ... 8 192 segments -> PIPE32, 8 193 ... 12 288 ->
+ *     PIPE48, 262 144 -> PIPE48 in its 44-segment form (12-dim) / PIPE32 (14-dim);
+ *   - RK4 with fewer steps: the per-lane kernel (each lane re-integrates the base state with 1-3 columns); for ndim = 12 with ONE
+ *     step per segment and >= 65 536 segments its whole-segment form (lto_indirect_plan_set_cols_per_lane, 12);
+ *   - the 13-stage integrators: the wave-specialised kernel (LTO_KERNEL_COOP: base wave + column waves per 16 segments,
+ *     coefficients handed over through LDS at every RK stage) -- for ndim = 12 with DOP853_ADAPTIVE, the reference's setting, its
+ *     form with two lanes per state (LTO_KERNEL_COOP2).
+ * Results never depend on the choice beyond round-off; lto_indirect_plan_last_kernel reports what ran. */
 #define LTO_KERNEL_AUTO 0
 #define LTO_KERNEL_PER_LANE 1
 #define LTO_KERNEL_COOP 2
@@ -275,8 +285,8 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  * bottom halves of a column in different waves, the two halves of the base state in neighbouring DPP banks): six components
  * per lane keep all slopes of the 13-stage method in addressable registers (round 3: the base state takes a DPP quad, three
  * components per lane).  Other plans: LTO_EINVAL.  The defect-only sweep of such a plan comes with one, two or four lanes per
- * segment (AUTO: four up to 131 072 segments on MI355X, two up to 262 144, one beyond): LTO_KERNEL_PER_LANE and LTO_KERNEL_COOP2
- * select the first two, lto_indirect_plan_set_defect_lanes any of them. */
+ * segment (see lto_indirect_plan_set_defect_lanes for what AUTO takes): LTO_KERNEL_PER_LANE and LTO_KERNEL_COOP2 select the
+ * first two, lto_indirect_plan_set_defect_lanes any of them. */
 #define LTO_KERNEL_COOP2 6
 /* RK4 plans only: the pipeline for large batches -- 48 segments and 16 wavefronts per workgroup, the base wave's lanes are 48
  * different segments, twelve column waves with one segment per DPP row; 12-dim also with 44 segments and eleven column waves (the
@@ -289,9 +299,16 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
 #define LTO_KERNEL_PIPE32 8
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* Lanes per segment of the DEFECT-ONLY sweep of an ndim = 12 DOP853_ADAPTIVE plan (the reference's setting, indirect.jl:63-90):
- * 0 = choose (default: four lanes -- a DPP quad per segment: r, v, lambda_v, lambda_r -- up to eight wavefronts of 16 segments per
- * SIMD, i.e. 512 x CUs segments (131 072 on MI355X); two lanes up to 262 144 segments; one beyond), or 1, 2, 4.  Two and four
- * lanes on other plans: LTO_EINVAL. */
+ * 1, 2 or 4 (a DPP quad per segment: r, v, lambda_v, lambda_r), or 0 = choose (default).  The choice: by size -- four lanes up to
+ * eight wavefronts of 16 segments per SIMD, i.e. 512 x CUs segments (131 072 on MI355X), two lanes up to 262 144 segments, one
+ * beyond -- and, from 64 x CUs segments, by the trial-step statistics of an EARLIER defect sweep of the same plan once they are
+ * in (taken after the plan's first two sweeps, then every sixteenth): if no segment took more than three times the mean number
+ * of trial steps (a line search's trial trajectories) there is no tail worth shortening and fewer lanes issue fewer
+ * instructions -- two lanes up to 160 x CUs segments, one above.  The statistics are consumed behind an event, so the choice is
+ * a function of the plan's call sequence, not of timing (inside a graph capture the last verdict stands).  All forms take the
+ * same step controller (rk.hpp dp8_decide) but sum the error norm in different orders: results agree to round-off of the
+ * converged flow (~1e-15), and bit for bit only between sweeps with the same number of lanes.  Two and four lanes on other
+ * plans: LTO_EINVAL. */
 int lto_indirect_plan_set_defect_lanes(lto_indirect_plan* plan, int lanes);
 /* Record staging of a plan's ordered (rebalanced) sweeps, a bit mask: 1 = node and defect records are in place, 2 = Phi records
  * too (only plans that run STM sweeps get them), 4 = an allocation for them failed and staging is off for this plan -- the sweeps

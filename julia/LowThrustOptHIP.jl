@@ -372,9 +372,12 @@ trial_points_dev!(ctx::LtoContext, stream, X, delta, ld::Integer, ndim::Integer,
                      ctx.handle, devptr(stream), devptr(X), devptr(delta), ld, ndim, n_nodes, n_batch, n_alpha, devptr(alphas), devptr(Xt), ldt))
 
 "A few device scalars to a host `Vector{Float64}` (`out[1:na] <- a`, `out[na+1:na+nb] <- b`), back when they have arrived: the per-iteration read-back of a Newton loop."
-read_scalars_dev!(ctx::LtoContext, stream, a, na::Integer, b, nb::Integer, out::Vector{Float64}) =
+function read_scalars_dev!(ctx::LtoContext, stream, a, na::Integer, b, nb::Integer, out::Vector{Float64})
+    # the library copies na + nb doubles to `out`: a short vector would be a heap overwrite
+    (na >= 0 && nb >= 0 && length(out) >= na + nb) || throw(ArgumentError("read_scalars_dev!: out needs at least na + nb = $(na + nb) elements"))
     check(ctx, ccall((:lto_read_scalars_dev, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Cint, DevPtr, Cint, Ptr{Cdouble}),
                      ctx.handle, devptr(stream), devptr(a), na, devptr(b), nb, out))
+end
 
 "lineSearch's first minimiser per trajectory on the device (indirect.jl:244-245): step <- alpha, maxabs_out <- the chosen trial's max |defect|, defect <- its defect block (the check of :328-331 without another sweep)."
 line_search_pick_dev!(ctx::LtoContext, stream, sumsq, maxabs, alphas, n_alpha::Integer, trial_defect, ldt::Integer, ndim::Integer, seg_per_traj::Integer, n_batch::Integer, step, maxabs_out, defect, ldd::Integer) =

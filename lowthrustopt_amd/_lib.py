@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LTO_HIP_LIB") or os.path.join(_HERE, "liblto_hip.so")
 
 LTO_OK, LTO_EINVAL, LTO_ENULL, LTO_EUNSUPPORTED = 0, -1, -2, -3
-LTO_EHIP, LTO_EBADP, LTO_ENODEVICE = 1, 2, 3
+LTO_EHIP, LTO_EBADP, LTO_ENODEVICE, LTO_ENOMEM = 1, 2, 3, 4
 
 
 class LtoError(RuntimeError):

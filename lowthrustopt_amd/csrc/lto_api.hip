@@ -15,12 +15,11 @@
 #include <mutex>
 #include <new>
 #include <thread>
-#include <unordered_map>
 
-#include <vector>
 
 #include "../../include/lto.h"
 #include "kernels.hpp"
+#include "hostbuf.hpp"
 
 using namespace lto;
 
@@ -66,7 +65,7 @@ struct lto_ctx {
   // block the device cannot address directly (still page-locked: the copy engine moves it).  The list has its own lock:
   // a garbage collector may free a block from another thread while a sweep looks one up.
   struct Pinned { char* host; char* dev; size_t bytes; };
-  std::vector<Pinned> pinned;
+  lto::HostList<Pinned> pinned;
   std::mutex pinned_mu;
   double last_call_ms;     // wall time of the last host-pointer call, entry to return (lto_last_call_ms)
   // landing block of the Newton loop's per-iteration scalars (lto_indirect_solve_batch): page-locked, mapped, written by
@@ -116,6 +115,9 @@ struct lto_indirect_plan {
   long long* h_stats_dev;   // device view of the same block
   unsigned long long* d_stats_acc;   // [3] device scratch
   int stats_age;            // qualifying sweeps so far
+  hipEvent_t stats_ev;      // recorded behind every k_step_stats launch
+  int stats_pending;        // a k_step_stats launch has not been consumed yet
+  int stats_lanes;          // the statistics' verdict, latched when they are consumed: 0 none (size thresholds), 1 or 2 lanes per segment
   double* d_xa;             // [n_nodes n_batch][NODE_REC]
   double* d_da;             // [S][12]
   double* d_pa;             // [S][144]: only for plans that run STM sweeps (stage_alloc's need_phi)
@@ -283,8 +285,14 @@ int lto_create(lto_ctx** out, int device_id) {
 
 // page-locked blocks -> owning context (lto_host_free may come without the handle, from any thread)
 static std::mutex g_blocks_mu;
-static std::unordered_map<void*, lto_ctx*> g_blocks;
-static void host_block_forget(void* ptr) { std::lock_guard<std::mutex> lk(g_blocks_mu); g_blocks.erase(ptr); }
+struct HostBlock { void* ptr; lto_ctx* owner; };
+static lto::HostList<HostBlock> g_blocks;          // a handful of entries: linear search
+static lto_ctx* host_block_take(void* ptr) {       // under g_blocks_mu: the owner of `ptr`, the entry removed; nullptr if unknown
+  for (size_t k = 0; k < g_blocks.size(); ++k)
+    if (g_blocks[k].ptr == ptr) { lto_ctx* o = g_blocks[k].owner; g_blocks.erase_at(k); return o; }
+  return nullptr;
+}
+static void host_block_forget(void* ptr) { std::lock_guard<std::mutex> lk(g_blocks_mu); (void)host_block_take(ptr); }
 static bool ctx_has_blocks(lto_ctx* c) { std::lock_guard<std::mutex> lk(c->pinned_mu); return !c->pinned.empty(); }
 
 // A context has three kinds of owners: its handle (until lto_destroy), its plans, its page-locked blocks; garbage collectors
@@ -403,6 +411,10 @@ static int plan_build(lto_ctx* c, int ndim, int n_nodes, int n_batch, const lto_
         hipMemset(p->d_stats_acc, 0, sizeof(unsigned long long) * 4) == hipSuccess) {
       std::memset(hp, 0, 64);
       p->h_stats = (long long*)hp; p->h_stats_dev = (long long*)dp;
+      if (hipEventCreateWithFlags(&p->stats_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipHostFree(hp);
+        p->h_stats = nullptr; p->stats_ev = nullptr;
+      }
     } else {                       // no statistics: AUTO keeps its size thresholds
       (void)hipGetLastError();
       if (hp) (void)hipHostFree(hp);
@@ -443,6 +455,7 @@ static void plan_free(lto_indirect_plan* p) {
   pool_free(p->ctx, p->d_bvp, p->bvp_bytes);
   for (int k = 0; k < 2; ++k) pool_free(p->ctx, p->d_hfirst[k], sizeof(double) * (size_t)p->S);
   if (p->h_stats) (void)hipHostFree(p->h_stats);
+  if (p->stats_ev) (void)hipEventDestroy(p->stats_ev);
   pool_free(p->ctx, p->d_stats_acc, sizeof(unsigned long long) * 4);
   pool_free(p->ctx, p->d_xa, sizeof(double) * NODE_REC * (size_t)p->n_nodes * p->n_batch);
   pool_free(p->ctx, p->d_da, sizeof(double) * 12 * (size_t)p->S);
@@ -648,10 +661,24 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
       // of steps (the 20 trial trajectories of a line search) is throughput-bound once the chip is full, and fewer lanes per
       // segment issue fewer instructions per segment (tools/probe_linesearch_lanes.py, 20 x 4 096 segments: 166 / 147 / 124 us
       // with 4 / 2 / 1 lanes; 20 x 1 024: 73 / 61 / 94).  The previous sweep's statistics say which case this is.
+      // The verdict is the same in every run of the same call sequence (advisor finding, round 4: it used to be "whatever has
+      // arrived by then", read while the kernel might still be writing): statistics are consumed only behind the event recorded
+      // after k_step_stats -- the host waits for it here, i.e. for the EARLIER sweep that launched it, which a Newton loop has
+      // long read back -- then latched in the plan until the next statistics launch is consumed.  Inside a graph capture nothing
+      // may be waited for: the latched verdict stands.
       if (p->h_stats && p->S >= 64L * c->cu_count) {
-        const long long sum = ((volatile long long*)p->h_stats)[0], mx = ((volatile long long*)p->h_stats)[1], cnt = ((volatile long long*)p->h_stats)[2];
-        if (cnt == p->S && sum > 0 && mx * (long long)p->S <= 3 * sum)        // max <= 3 x mean: no tail worth shortening
-          lanes = (p->S <= 160L * c->cu_count) ? 2 : 1;
+        if (p->stats_pending) {
+          hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+          if (cap == hipStreamCaptureStatusNone && hipEventSynchronize(p->stats_ev) == hipSuccess) {
+            p->stats_pending = 0;
+            const long long sum = p->h_stats[0], mx = p->h_stats[1], cnt = p->h_stats[2];
+            p->stats_lanes = 0;
+            if (cnt == p->S && sum > 0 && mx * (long long)p->S <= 3 * sum)      // max <= 3 x mean: no tail worth shortening
+              p->stats_lanes = (p->S <= 160L * c->cu_count) ? 2 : 1;
+          }
+        }
+        if (p->stats_lanes) lanes = p->stats_lanes;
       }
     }
   }
@@ -676,7 +703,11 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
     // statistics for the next sweep's choice (a few us, stream-ordered, written by the kernel itself into page-locked memory)
     // not after every sweep (the extra launch and its host write cost ~10 us): after the first two, then every sixteenth
     const int age = p->stats_age++;
-    if (p->h_stats && (age < 2 || (age & 15) == 0)) (void)launch_step_stats(p->d_nacc, p->d_nrej, p->S, p->d_stats_acc, p->h_stats_dev, st);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;        // (an event recorded inside a capture cannot be waited for later)
+    if (p->h_stats && (age < 2 || (age & 15) == 0) && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
+        launch_step_stats(p->d_nacc, p->d_nrej, p->S, p->d_stats_acc, p->h_stats_dev, st) == hipSuccess &&
+        hipEventRecord(p->stats_ev, st) == hipSuccess)
+      p->stats_pending = 1;
   }
   p->swept = 1;
   return LTO_OK;
@@ -928,7 +959,8 @@ int lto_calibrate_kernels(lto_ctx* c) {
   // a state near the Earth-Moon L2 halo family (0.17 DU from the Moon), small costates; 1 000 kg / lambda_m = 0.1 for the 14-row layout
   const double x12[12] = {1.1599795702248494, 0.0097200000000000, -0.1240184140575570, 0.0087153964800000, -0.2085329310256100, 0.0105833000000000,
                           0.01, -0.02, 0.015, 0.02, 0.01, -0.01};
-  std::vector<double> hX((size_t)14 * nmax), ht((size_t)nmax);
+  lto::HostBuf<double> hX((size_t)14 * nmax), ht((size_t)nmax);
+  if (!hX.ok() || !ht.ok()) return set_err(c, LTO_ENOMEM, "lto_calibrate_kernels: out of host memory");
   for (long k = 0; k < nmax; ++k) ht[k] = 0.02 * (double)k;
   hipEvent_t e0, e1;
   LTO_HIP(c, hipEventCreate(&e0));
@@ -1139,11 +1171,14 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   const int B = n_batch;
   if ((long)B * NA * (n_nodes - 1) > 0x7fffffffL) return set_err(c, LTO_EINVAL, "too many line-search segments");
   // parameters / time grids of the B*NA line-search trial trajectories: trajectory b's, NA times
-  std::vector<lto_params> prm_l;
-  std::vector<double> t_l;
-  if (n_prm != 1) { prm_l.reserve((size_t)B * NA); for (int b = 0; b < B; ++b) for (int a = 0; a < NA; ++a) prm_l.push_back(prm[b]); }
+  lto::HostBuf<lto_params> prm_l;
+  lto::HostBuf<double> t_l;
+  if (n_prm != 1) {
+    if (!prm_l.alloc((size_t)B * NA)) return set_err(c, LTO_ENOMEM, "lto_indirect_solve_batch: out of host memory");
+    for (int b = 0; b < B; ++b) for (int a = 0; a < NA; ++a) prm_l[(size_t)b * NA + a] = prm[b];
+  }
   if (n_tgrids != 1) {
-    t_l.resize((size_t)B * NA * n_nodes);
+    if (!t_l.alloc((size_t)B * NA * n_nodes)) return set_err(c, LTO_ENOMEM, "lto_indirect_solve_batch: out of host memory");
     for (int b = 0; b < B; ++b) for (int a = 0; a < NA; ++a)
       std::memcpy(&t_l[((size_t)b * NA + a) * n_nodes], t + (size_t)b * n_nodes, sizeof(double) * n_nodes);
   }
@@ -1191,11 +1226,15 @@ int lto_indirect_solve_batch(lto_ctx* c, int ndim, int n_nodes, int n_batch, con
   double alphas[NA];
   for (int a = 0; a < NA; ++a) alphas[a] = 0.1 + (1.0 - 0.1) / (NA - 1) * a;
   alphas[NA - 1] = 1.0;
-  std::vector<double> h_mx(B), h_er(B, 1.0), h_step(B), h_back((size_t)3 * B), h_act(B, -1.0), h_search(B, -1.0);   // er = 1.0: :279
+  lto::HostBuf<double> h_mx(B), h_er(B, 1.0), h_step(B), h_back((size_t)3 * B), h_act(B, -1.0), h_search(B, -1.0);   // er = 1.0: :279
   bool soc_speculative = false;
   unsigned trial_sweeps = 0;
-  std::vector<int> it(B, 0), status(B, 0);
-  std::vector<char> active(B, 1);
+  lto::HostBuf<int> it(B, 0), status(B, 0);
+  lto::HostBuf<char> active(B, 1);
+  if (!h_mx.ok() || !h_er.ok() || !h_step.ok() || !h_back.ok() || !h_act.ok() || !h_search.ok() || !it.ok() || !status.ok() || !active.ok()) {
+    plan_free(pl); plan_free(p);
+    return set_err(c, LTO_ENOMEM, "lto_indirect_solve_batch: out of host memory");
+  }
 
   hipError_t e = hipMemcpyAsync(d_aos, XC_in, sizeof(double) * 12 * J, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * n * n_tgrids, hipMemcpyHostToDevice, st);
@@ -1628,8 +1667,19 @@ int lto_host_alloc(lto_ctx* c, size_t bytes, void** out) {
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "hipHostMalloc", e);
   void* dev = nullptr;
   if (hipHostGetDevicePointer(&dev, *out, 0) != hipSuccess) { dev = nullptr; (void)hipGetLastError(); }   // still page-locked: the copy engine moves it
-  { std::lock_guard<std::mutex> lk(c->pinned_mu); c->pinned.push_back({(char*)*out, (char*)dev, bytes ? bytes : 1}); }
-  { std::lock_guard<std::mutex> lk(g_blocks_mu); g_blocks[*out] = c; }
+  bool listed;
+  { std::lock_guard<std::mutex> lk(c->pinned_mu); listed = c->pinned.push({(char*)*out, (char*)dev, bytes ? bytes : 1}); }
+  if (listed) {
+    std::lock_guard<std::mutex> lk(g_blocks_mu);
+    listed = g_blocks.push({*out, c});
+  }
+  if (!listed) {                                   // out of host memory for the bookkeeping: no block
+    { std::lock_guard<std::mutex> lk(c->pinned_mu);
+      for (size_t k = 0; k < c->pinned.size(); ++k) if (c->pinned[k].host == (char*)*out) { c->pinned.erase_at(k); break; } }
+    (void)hipHostFree(*out);
+    *out = nullptr;
+    return set_err(c, LTO_ENOMEM, "lto_host_alloc: out of host memory");
+  }
   return LTO_OK;
 }
 
@@ -1640,11 +1690,19 @@ int lto_host_free(lto_ctx* c, void* ptr) {
   lto_ctx* owner = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_blocks_mu);
-    auto it = g_blocks.find(ptr);
-    if (it != g_blocks.end()) { owner = it->second; g_blocks.erase(it); }
+    owner = host_block_take(ptr);
   }
   if (!owner) return c ? set_err(c, LTO_EINVAL, "lto_host_free: not a block from lto_host_alloc (or freed twice)") : LTO_EINVAL;
-  // device work first, while the block still keeps its context alive; then the block leaves the list and the lifetime decision is taken
+  // The entry is neutralised FIRST (no device alias, no size: pinned_view skips it), so that no host-pointer call on another thread
+  // can be handed the device view of memory about to be freed; it stays in the list -- and keeps its context alive -- as a "dying"
+  // entry while the device work drains and the block is freed, and only that dying entry is erased afterwards: a concurrent
+  // lto_host_alloc that is given the same address again adds a LIVE entry with the same .host, which must survive (advisor
+  // finding, round 4).
+  {
+    std::lock_guard<std::mutex> lk(owner->pinned_mu);
+    for (auto& b : owner->pinned)
+      if (b.host == (char*)ptr && b.dev) { b.dev = nullptr; b.bytes = 0; break; }
+  }
   (void)hipSetDevice(owner->device);
   if (!ctx_is_closing(owner)) (void)hipStreamSynchronize(owner->stream);   // a sweep may still be writing the block in place
   else (void)hipDeviceSynchronize();
@@ -1652,7 +1710,7 @@ int lto_host_free(lto_ctx* c, void* ptr) {
   {
     std::lock_guard<std::mutex> lk(owner->pinned_mu);
     for (size_t k = 0; k < owner->pinned.size(); ++k)
-      if (owner->pinned[k].host == (char*)ptr) { owner->pinned[k] = owner->pinned.back(); owner->pinned.pop_back(); break; }
+      if (owner->pinned[k].host == (char*)ptr && !owner->pinned[k].dev) { owner->pinned.erase_at(k); break; }
   }
   if (ctx_release(owner, OWNER_BLOCK)) { ctx_free(owner); return e == hipSuccess ? LTO_OK : LTO_EHIP; }
   if (e != hipSuccess) return set_err(owner, LTO_EHIP, "hipHostFree", e);

@@ -28,12 +28,12 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
-#include <vector>
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include "../../include/lto.h"
+#include "hostbuf.hpp"
 
 namespace {
 
@@ -242,7 +242,7 @@ struct lto_comm {
   bool windows = false, opened = false;
   long max_count = 0;
   char* own = nullptr;                 // this rank's window: [flags: world x u32 | fail | push counters: 1024 B in all][2 halves][world][max_count] doubles
-  std::vector<char*> peer;             // every rank's window as mapped here (peer[rank] = own)
+  lto::HostBuf<char*> peer;            // every rank's window as mapped here (peer[rank] = own)
   unsigned int seq = 0;
   long wait_limit = 4000000L;          // polls before a wait gives up (lto_comm_set_wait_limit): ~ a few seconds
   hipStream_t bound = nullptr;         // the stream of this communicator's collectives (windows: all on ONE stream)
@@ -259,11 +259,11 @@ inline double* window_slab(char* base, int world, long max_count, int half, int 
 }
 
 struct lto_group_comm {
-  std::vector<lto_ctx*> ctx;         // borrowed from the group
-  std::vector<int> device;
-  std::vector<ncclComm_t> comm;      // empty when the group repeats a device
-  std::vector<hipEvent_t> ev;        // one per context: producer stream -> consumer streams (copy path)
-  std::vector<hipEvent_t> ev_done;   // one per context: its copies out of the others' slabs are complete
+  lto::HostBuf<lto_ctx*> ctx;        // borrowed from the group
+  lto::HostBuf<int> device;
+  lto::HostBuf<ncclComm_t> comm;     // empty when the group repeats a device
+  lto::HostBuf<hipEvent_t> ev;       // one per context: producer stream -> consumer streams (copy path)
+  lto::HostBuf<hipEvent_t> ev_done;  // one per context: its copies out of the others' slabs are complete
   double** d_ptrs = nullptr;         // device array of buffer pointers for k_reduce_buffers (copy path)
   bool clique = false;
   char err[512] = {0};
@@ -353,7 +353,7 @@ int lto_comm_window_export(lto_ctx* ctx, int world, int rank, long max_count, vo
   h.max_count = max_count; h.world = world; h.rank = rank; h.pid = (int)getpid(); h.magic = 0x4c544f57u;   // "LTOW"
   std::memset(handle_out, 0, LTO_COMM_WINDOW_BYTES);
   std::memcpy(handle_out, &h, sizeof h);
-  c->peer.assign(world, nullptr);
+  if (!c->peer.alloc((size_t)world)) { lto_comm_destroy(c); return LTO_ENOMEM; }
   c->peer[rank] = c->own;
   if (world == 1) c->opened = true;
   *out = c;
@@ -546,16 +546,19 @@ int lto_group_comm_create(lto_group* g, lto_group_comm** out) {
   const int n = lto_group_size(g);
   if (n < 1) return LTO_EINVAL;
   lto_group_comm* q = new (std::nothrow) lto_group_comm();
-  if (!q) return LTO_EHIP;
+  if (!q) return LTO_ENOMEM;
+  if (!q->ctx.alloc((size_t)n) || !q->device.alloc((size_t)n) || !q->ev.alloc((size_t)n) || !q->ev_done.alloc((size_t)n)) {
+    q->ev.n = q->ev_done.n = 0;          // (zero-filled or absent: nothing to destroy)
+    lto_group_comm_destroy(q);
+    return LTO_ENOMEM;
+  }
   bool distinct = true;
   for (int k = 0; k < n; ++k) {
     lto_ctx* c = lto_group_ctx(g, k);
-    q->ctx.push_back(c);
-    q->device.push_back(lto_ctx_device(c));
+    q->ctx[k] = c;
+    q->device[k] = lto_ctx_device(c);
     for (int m = 0; m < k; ++m) distinct &= q->device[m] != q->device[k];
   }
-  q->ev.resize(n, nullptr);
-  q->ev_done.resize(n, nullptr);
   for (int k = 0; k < n; ++k) {
     if (hipSetDevice(q->device[k]) != hipSuccess || hipEventCreateWithFlags(&q->ev[k], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&q->ev_done[k], hipEventDisableTiming) != hipSuccess) {
@@ -564,8 +567,8 @@ int lto_group_comm_create(lto_group* g, lto_group_comm** out) {
     }
   }
   if (distinct && n > 1 && rccl().ok) {
-    q->comm.resize(n, nullptr);
-    if (rccl().CommInitAll(q->comm.data(), n, q->device.data()) != ncclSuccess) { q->comm.clear(); lto_group_comm_destroy(q); return LTO_EHIP; }
+    if (!q->comm.alloc((size_t)n)) { lto_group_comm_destroy(q); return LTO_ENOMEM; }
+    if (rccl().CommInitAll(q->comm.data(), n, q->device.data()) != ncclSuccess) { q->comm.n = 0; lto_group_comm_destroy(q); return LTO_EHIP; }
     q->clique = true;
     for (int k = 0; k < n; ++k) {                      // direct peer copies where the topology allows; staged otherwise
       if (hipSetDevice(q->device[k]) != hipSuccess) continue;

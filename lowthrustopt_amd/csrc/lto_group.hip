@@ -11,13 +11,13 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
-#include <thread>
-#include <vector>
+#include <pthread.h>
 
 #include "../../include/lto.h"
+#include "hostbuf.hpp"
 
 struct lto_group {
-  std::vector<lto_ctx*> ctx;
+  lto::HostList<lto_ctx*> ctx;
   char err[512];
 };
 
@@ -25,17 +25,24 @@ namespace {
 
 struct Shard { long first; long count; };   // units: trajectories or segments
 
-// contiguous near-equal partition of `total` units over at most `parts` shards (no empty shard)
-std::vector<Shard> partition(long total, int parts) {
-  std::vector<Shard> out;
+// contiguous near-equal partition of `total` units over at most `parts` shards (no empty shard); sh.ok() is false when out of memory
+struct Shards {
+  lto::HostBuf<Shard> sh;
+  size_t count = 0;
+  bool ok() const { return sh.ok(); }
+  size_t size() const { return count; }
+  const Shard& operator[](size_t k) const { return sh[k]; }
+};
+void partition(long total, int parts, Shards& out) {
   const long g = parts < total ? parts : total;
+  if (!out.sh.alloc((size_t)g)) return;
   long first = 0;
   for (long r = 0; r < g; ++r) {
     const long cnt = total / g + (r < total % g ? 1 : 0);
-    out.push_back({first, cnt});
+    out.sh[r] = {first, cnt};
     first += cnt;
   }
-  return out;
+  out.count = (size_t)g;
 }
 
 int fail(lto_group* g, int code, const char* msg) {
@@ -43,19 +50,42 @@ int fail(lto_group* g, int code, const char* msg) {
   return code;
 }
 
-// run fn(shard index) on one thread per shard; first non-zero return code wins, its context's message is kept
+// run fn(shard index) on one thread per shard; first non-zero return code wins, its context's message is kept.  Threads are
+// pthreads, not std::thread: a thread that cannot be created is a return value here (LTO_ENOMEM after the started ones have been
+// joined), where std::thread's constructor would throw -- in a library built without exception support that ends the process.
 template <class F>
-int run_shards(lto_group* g, size_t n, F fn) {
-  std::vector<int> rc(n, 0);
-  std::vector<std::thread> th;
-  th.reserve(n);
-  for (size_t k = 1; k < n; ++k) th.emplace_back([&, k] { rc[k] = fn(k); });
-  rc[0] = fn(0);
-  for (auto& t : th) t.join();
+struct ShardJob { F* fn; size_t k; int rc; };
+template <class F>
+void* shard_main(void* arg) {
+  ShardJob<F>* j = (ShardJob<F>*)arg;
+  j->rc = (*j->fn)(j->k);
+  return nullptr;
+}
+template <class F>
+int run_shards(lto_group* g, const Shards& sh, F fn) {
+  if (!sh.ok()) return fail(g, LTO_ENOMEM, "out of host memory");
+  const size_t n = sh.size();
+  lto::HostBuf<ShardJob<F>> job(n);
+  lto::HostBuf<pthread_t> th(n);
+  if (!job.ok() || !th.ok()) return fail(g, LTO_ENOMEM, "out of host memory");
+  size_t started = 1;
+  int spawn_err = 0;
+  for (size_t k = 1; k < n; ++k) {
+    job[k].fn = &fn; job[k].k = k; job[k].rc = 0;
+    spawn_err = pthread_create(&th[k], nullptr, shard_main<F>, &job[k]);
+    if (spawn_err) break;
+    started = k + 1;
+  }
+  job[0].rc = spawn_err ? 0 : fn(0);               // nothing is computed for a call that cannot run all of its shards
+  for (size_t k = 1; k < started; ++k) (void)pthread_join(th[k], nullptr);
+  if (spawn_err) {
+    std::snprintf(g->err, sizeof g->err, "could not start the host thread of shard %zu (pthread_create: error %d)", started, spawn_err);
+    return LTO_ENOMEM;
+  }
   for (size_t k = 0; k < n; ++k)
-    if (rc[k]) {
+    if (job[k].rc) {
       std::snprintf(g->err, sizeof g->err, "shard %zu (device context %zu): %s", k, k, lto_last_error(g->ctx[k]));
-      return rc[k];
+      return job[k].rc;
     }
   g->err[0] = 0;
   return LTO_OK;
@@ -72,7 +102,7 @@ int lto_group_create(int n_devices, const int* device_ids, lto_group** out) {
   *out = nullptr;
   if (n_devices < 1 || !device_ids) return LTO_EINVAL;
   lto_group* g = new (std::nothrow) lto_group();
-  if (!g) return LTO_EHIP;
+  if (!g) return LTO_ENOMEM;
   g->err[0] = 0;
   for (int k = 0; k < n_devices; ++k) {
     lto_ctx* c = nullptr;
@@ -82,7 +112,12 @@ int lto_group_create(int n_devices, const int* device_ids, lto_group** out) {
       delete g;
       return rc;
     }
-    g->ctx.push_back(c);
+    if (!g->ctx.push(c)) {
+      lto_destroy(c);
+      for (lto_ctx* q : g->ctx) lto_destroy(q);
+      delete g;
+      return LTO_ENOMEM;
+    }
   }
   *out = g;
   return LTO_OK;
@@ -108,16 +143,18 @@ int lto_group_indirect_defect(lto_group* g, int ndim, int n_nodes, int n_batch, 
   if ((n_tgrids != 1 && n_tgrids != n_batch) || (n_prm != 1 && n_prm != n_batch)) return fail(g, LTO_EINVAL, "n_tgrids / n_prm must be 1 or n_batch");
   const long S = n_nodes - 1;
   if (by_batch(g, n_batch)) {
-    const auto sh = partition(n_batch, (int)g->ctx.size());
-    return run_shards(g, sh.size(), [&](size_t k) {
+    Shards sh;
+    partition(n_batch, (int)g->ctx.size(), sh);
+    return run_shards(g, sh, [&](size_t k) {
       const long b = sh[k].first, nb = sh[k].count;
       return lto_indirect_defect(g->ctx[k], ndim, n_nodes, (int)nb, XC + (long)ndim * n_nodes * b, t + (n_tgrids == 1 ? 0 : n_nodes * b),
                                  n_tgrids == 1 ? 1 : (int)nb, prm + (n_prm == 1 ? 0 : b), n_prm == 1 ? 1 : (int)nb, integ,
                                  defect + (long)ndim * S * b, errors ? errors + S * b : nullptr);
     });
   }
-  const auto sh = partition(S, (int)g->ctx.size());
-  return run_shards(g, sh.size(), [&](size_t k) {
+  Shards sh;
+  partition(S, (int)g->ctx.size(), sh);
+  return run_shards(g, sh, [&](size_t k) {
     const long s0 = sh[k].first, cnt = sh[k].count;
     return lto_indirect_defect(g->ctx[k], ndim, (int)cnt + 1, 1, XC + (long)ndim * s0, t + s0, 1, prm, 1, integ, defect + (long)ndim * s0,
                                errors ? errors + s0 : nullptr);
@@ -132,16 +169,18 @@ int lto_group_indirect_jacobian(lto_group* g, int ndim, int n_nodes, int n_batch
   if ((n_tgrids != 1 && n_tgrids != n_batch) || (n_prm != 1 && n_prm != n_batch)) return fail(g, LTO_EINVAL, "n_tgrids / n_prm must be 1 or n_batch");
   const long S = n_nodes - 1, nn = (long)ndim * ndim;
   if (by_batch(g, n_batch)) {
-    const auto sh = partition(n_batch, (int)g->ctx.size());
-    return run_shards(g, sh.size(), [&](size_t k) {
+    Shards sh;
+    partition(n_batch, (int)g->ctx.size(), sh);
+    return run_shards(g, sh, [&](size_t k) {
       const long b = sh[k].first, nb = sh[k].count;
       return lto_indirect_jacobian(g->ctx[k], ndim, n_nodes, (int)nb, XC + (long)ndim * n_nodes * b, t + (n_tgrids == 1 ? 0 : n_nodes * b),
                                    n_tgrids == 1 ? 1 : (int)nb, prm + (n_prm == 1 ? 0 : b), n_prm == 1 ? 1 : (int)nb, integ,
                                    Phi + nn * S * b, defect ? defect + (long)ndim * S * b : nullptr);
     });
   }
-  const auto sh = partition(S, (int)g->ctx.size());
-  return run_shards(g, sh.size(), [&](size_t k) {
+  Shards sh;
+  partition(S, (int)g->ctx.size(), sh);
+  return run_shards(g, sh, [&](size_t k) {
     const long s0 = sh[k].first, cnt = sh[k].count;
     return lto_indirect_jacobian(g->ctx[k], ndim, (int)cnt + 1, 1, XC + (long)ndim * s0, t + s0, 1, prm, 1, integ, Phi + nn * s0,
                                  defect ? defect + (long)ndim * s0 : nullptr);
@@ -156,16 +195,18 @@ int lto_group_direct_defect(lto_group* g, int nstate, int n_nodes, int n_batch, 
   if (n_tgrids != 1 && n_tgrids != n_batch) return fail(g, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
   const long S = n_nodes - 1;
   if (by_batch(g, n_batch)) {
-    const auto sh = partition(n_batch, (int)g->ctx.size());
-    return run_shards(g, sh.size(), [&](size_t k) {
+    Shards sh;
+    partition(n_batch, (int)g->ctx.size(), sh);
+    return run_shards(g, sh, [&](size_t k) {
       const long b = sh[k].first, nb = sh[k].count;
       return lto_direct_defect(g->ctx[k], nstate, n_nodes, (int)nb, X + (long)nstate * n_nodes * b, U + 3L * n_nodes * b,
                                t + (n_tgrids == 1 ? 0 : n_nodes * b), n_tgrids == 1 ? 1 : (int)nb, nsteps, prm,
                                defect + (long)nstate * S * b, errors ? errors + S * b : nullptr);
     });
   }
-  const auto sh = partition(S, (int)g->ctx.size());
-  return run_shards(g, sh.size(), [&](size_t k) {
+  Shards sh;
+  partition(S, (int)g->ctx.size(), sh);
+  return run_shards(g, sh, [&](size_t k) {
     const long s0 = sh[k].first, cnt = sh[k].count;
     return lto_direct_defect(g->ctx[k], nstate, (int)cnt + 1, 1, X + (long)nstate * s0, U + 3 * s0, t + s0, 1, nsteps, prm,
                              defect + (long)nstate * s0, errors ? errors + s0 : nullptr);
@@ -181,8 +222,9 @@ int lto_group_direct_jacobian(lto_group* g, int nstate, int n_nodes, int n_batch
   if (n_tgrids != 1 && n_tgrids != n_batch) return fail(g, LTO_EINVAL, "n_tgrids must be 1 or n_batch");
   const long S = n_nodes - 1, nj = (long)nstate * 2 * (nstate + 3);
   if (by_batch(g, n_batch)) {
-    const auto sh = partition(n_batch, (int)g->ctx.size());
-    return run_shards(g, sh.size(), [&](size_t k) {
+    Shards sh;
+    partition(n_batch, (int)g->ctx.size(), sh);
+    return run_shards(g, sh, [&](size_t k) {
       const long b = sh[k].first, nb = sh[k].count;
       return lto_direct_jacobian(g->ctx[k], nstate, n_nodes, (int)nb, X + (long)nstate * n_nodes * b, U + 3L * n_nodes * b,
                                  t + (n_tgrids == 1 ? 0 : n_nodes * b), n_tgrids == 1 ? 1 : (int)nb, nsteps, prm, Jac_temp + nj * S * b,
@@ -190,9 +232,10 @@ int lto_group_direct_jacobian(lto_group* g, int nstate, int n_nodes, int n_batch
                                  defect ? defect + (long)nstate * S * b : nullptr, errors ? errors + S * b : nullptr);
     });
   }
-  const auto sh = partition(S, (int)g->ctx.size());
+  Shards sh;
+  partition(S, (int)g->ctx.size(), sh);
   const double span_total = t[n_nodes - 1] - t[0];
-  return run_shards(g, sh.size(), [&](size_t k) {
+  return run_shards(g, sh, [&](size_t k) {
     const long s0 = sh[k].first, cnt = sh[k].count;
     double* dtf = ddefect_dtf ? ddefect_dtf + (long)nstate * s0 : nullptr;
     const int rc = lto_direct_jacobian(g->ctx[k], nstate, (int)cnt + 1, 1, X + (long)nstate * s0, U + 3 * s0, t + s0, 1, nsteps, prm,

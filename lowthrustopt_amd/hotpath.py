@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 from .constants import RK4, RKF78_FIXED, RKF78_ADAPTIVE, DOP853_ADAPTIVE  # noqa: F401
-from ._lib import LtoError, LtoIntegrator, LtoParams, LtoDirectParams
+from ._lib import LtoError, LtoIntegrator, LtoParams, LtoDirectParams, LTO_EINVAL
 
 
 def integrator(method=DOP853_ADAPTIVE, steps=0, rtol=1e-13, atol=1e-13, max_steps=0):
@@ -801,6 +801,11 @@ def line_search_pick(ctx, sumsq, maxabs, alphas, trial_defect, ldt, ndim, seg_pe
 
 def read_scalars(ctx, a, na, b, nb, out, stream=None):
     """out[:na] <- device a, out[na:na+nb] <- device b (or None), back when they have arrived (lto_read_scalars_dev): the per-iteration
-    read-back of a Newton loop.  `out`: a C-contiguous float64 numpy array."""
+    read-back of a Newton loop.  `out`: a C-contiguous float64 numpy array of at least na + nb elements -- checked here, because the
+    library copies na + nb doubles to the address it is given (a short or wrong-typed array would be a heap overwrite)."""
+    na, nb = int(na), int(nb if b is not None else 0)
+    if (not isinstance(out, np.ndarray) or out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]
+            or na < 0 or nb < 0 or out.size < na + nb):
+        raise LtoError(LTO_EINVAL, "read_scalars: `out` must be a writeable C-contiguous float64 array of at least na + nb = %d elements" % (na + nb))
     ctx.check(ctx.lib.lto_read_scalars_dev(ctx.handle, stream, _dptr(a), int(na), _dptr(b), int(nb), out.ctypes.data_as(C.c_void_p)))
     return out

@@ -1095,6 +1095,11 @@ def test_line_search_pick_and_scalar_read_back(gpu_ctx):
     assert np.array_equal(outb, np.arange(5000.0))
     with pytest.raises(lto.LtoError):
         lto.read_scalars(gpu_ctx, big, 0, None, 0, outb)
+    # the binding refuses a landing array the library's copy would overrun or misread (advisor finding, round 4): too short, wrong
+    # element type, not contiguous
+    for bad in (np.zeros(4999), np.zeros(5000, dtype=np.float32), np.zeros((5000, 2))[:, 0]):
+        with pytest.raises(lto.LtoError):
+            lto.read_scalars(gpu_ctx, big, 5000, None, 0, bad)
 
 
 @pytest.mark.parametrize("pcase", ["p1_rho1", "p2_clamped", "p1.5", "p0"])
