@@ -23,6 +23,7 @@ restatements that are INDEPENDENT of both the C++ oracle (oracle/lto_oracle.cpp)
 Usage: python tests/golden/gen_golden.py
 """
 import json
+from fractions import Fraction as F
 import os
 import sys
 
@@ -273,41 +274,74 @@ def np_prop_ep(t, state, MUq, DUq, TUq, Isp, control, td):
     return np.array(out)
 
 
+class FixedGridFehlberg78:
+    """Fehlberg's 13-stage 7(8) pair marched over a GIVEN grid, no step-size control: an independent statement of what the reference's
+    `ode7_8` computes (GeneralCode/ode.jl:773-953), used only to mint direct_numpy.json.
+
+    The tableau is Fehlberg's published one (NASA TR R-287, 1968, table of the RK7(8) formula), kept here stage by stage as
+    {earlier stage: coefficient}; the dense 13 x 13 array `self.lower` has stage s's row as its COLUMN s, so that a stage argument is
+    ONE matrix-vector product over all 13 slope columns (zeros included), x + (h K) @ lower[:, s] -- the association the reference
+    uses (`x + h*(F*beta[:, j])` with F scaled first), which is what makes the vectors reproducible to the bit.
+    The 8th-order solution uses stages 5 ... 9 and 11, 12; the error indicator is 41/840 h (k0 + k10 - k11 - k12), largest component.
+    """
+    NODES = (0, F(2, 27), F(1, 9), F(1, 6), F(5, 12), F(1, 2), F(5, 6), F(1, 6), F(2, 3), F(1, 3), 1, 0, 1)
+    STAGES = {
+        1: {0: F(2, 27)},
+        2: {0: F(1, 36), 1: F(1, 12)},
+        3: {0: F(1, 24), 2: F(1, 8)},
+        4: {0: F(5, 12), 2: F(-25, 16), 3: F(25, 16)},
+        5: {0: F(1, 20), 3: F(1, 4), 4: F(1, 5)},
+        6: {0: F(-25, 108), 3: F(125, 108), 4: F(-65, 27), 5: F(125, 54)},
+        7: {0: F(31, 300), 4: F(61, 225), 5: F(-2, 9), 6: F(13, 900)},
+        8: {0: 2, 3: F(-53, 6), 4: F(704, 45), 5: F(-107, 9), 6: F(67, 90), 7: 3},
+        9: {0: F(-91, 108), 3: F(23, 108), 4: F(-976, 135), 5: F(311, 54), 6: F(-19, 60), 7: F(17, 6), 8: F(-1, 12)},
+        10: {0: F(2383, 4100), 3: F(-341, 164), 4: F(4496, 1025), 5: F(-301, 82), 6: F(2133, 4100), 7: F(45, 82), 8: F(45, 164), 9: F(18, 41)},
+        11: {0: F(3, 205), 5: F(-6, 41), 6: F(-3, 205), 7: F(-3, 41), 8: F(3, 41), 9: F(6, 41)},
+        12: {0: F(-1777, 4100), 3: F(-341, 164), 4: F(4496, 1025), 5: F(-289, 82), 6: F(2193, 4100), 7: F(51, 82), 8: F(33, 164), 9: F(12, 41), 11: 1},
+    }
+    WEIGHTS8 = {5: F(34, 105), 6: F(9, 35), 7: F(9, 35), 8: F(9, 280), 9: F(9, 280), 11: F(41, 840), 12: F(41, 840)}
+    INDICATOR = {0: 1, 10: 1, 11: -1, 12: -1}
+
+    def __init__(self):
+        # numerator / denominator in binary64, as the reference's literals `2383/4100` are evaluated
+        q = lambda v: float(v.numerator) / float(v.denominator) if isinstance(v, F) else float(v)   # noqa: E731
+        self.nodes = [q(c) for c in self.NODES]
+        self.lower = np.zeros((13, 13))
+        for s, row in self.STAGES.items():
+            for k, v in row.items():
+                self.lower[k, s] = q(v)
+        self.weights = np.zeros(13)
+        for k, v in self.WEIGHTS8.items():
+            self.weights[k] = q(v)
+        self.indicator = np.zeros(13)
+        for k, v in self.INDICATOR.items():
+            self.indicator[k] = q(v)
+
+    def step(self, rhs, t, x, h, args):
+        """One step from (t, x): (x_next, largest component of the error indicator)."""
+        K = np.zeros((len(x), 13))
+        K[:, 0] = rhs(t, x, *args)
+        for s in range(1, 13):
+            K[:, s] = rhs(t + self.nodes[s] * h, x + (h * K) @ self.lower[:, s], *args)
+        x_next = x + (h * K) @ self.weights
+        return x_next, np.linalg.norm(((h * 41 / 840) * K) @ self.indicator, np.inf)
+
+    def march(self, rhs, grid, x0, *args):
+        """States at every grid point [n x len(grid)] and the largest indicator met on the way."""
+        out = np.zeros((len(x0), len(grid)))
+        out[:, 0] = x0
+        worst = 0.0
+        for k in range(1, len(grid)):
+            out[:, k], e = self.step(rhs, grid[k - 1], out[:, k - 1].copy(), grid[k] - grid[k - 1], args)
+            worst = max(worst, e)
+        return out, worst
+
+
+_RKF78 = FixedGridFehlberg78()
+
+
 def np_ode7_8(odefun, tspan, x0, *args):
-    """ode7_8, GeneralCode/ode.jl:773-953 (coefficients :875-892, loop :924-949)."""
-    alpha = np.array([2. / 27., 1 / 9, 1 / 6, 5 / 12, 0.5, 5 / 6, 1 / 6, 2 / 3, 1 / 3, 1, 0, 1])
-    beta = np.zeros((13, 12))
-    cols = [[2 / 27], [1 / 36, 1 / 12], [1 / 24, 0, 1 / 8], [5 / 12, 0, -25 / 16, 25 / 16], [0.05, 0, 0, 0.25, 0.2],
-            [-25 / 108, 0, 0, 125 / 108, -65 / 27, 125 / 54], [31 / 300, 0, 0, 0, 61 / 225, -2 / 9, 13 / 900],
-            [2, 0, 0, -53 / 6, 704 / 45, -107 / 9, 67 / 90, 3],
-            [-91 / 108, 0, 0, 23 / 108, -976 / 135, 311 / 54, -19 / 60, 17 / 6, -1 / 12],
-            [2383 / 4100, 0, 0, -341 / 164, 4496 / 1025, -301 / 82, 2133 / 4100, 45 / 82, 45 / 164, 18 / 41],
-            [3 / 205, 0, 0, 0, 0, -6 / 41, -3 / 205, -3 / 41, 3 / 41, 6 / 41],
-            [-1777 / 4100, 0, 0, -341 / 164, 4496 / 1025, -289 / 82, 2193 / 4100, 51 / 82, 33 / 164, 12 / 41, 0, 1]]
-    for j, c in enumerate(cols):
-        beta[:len(c), j] = c
-    chi = np.array([0, 0, 0, 0, 0, 34 / 105, 9 / 35, 9 / 35, 9 / 280, 9 / 280, 0, 41 / 840, 41 / 840])
-    psi = np.array([1., 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, -1, -1])
-    h = np.diff(tspan)
-    neq = len(x0)
-    N = len(tspan)
-    Xout = np.zeros((neq, N))
-    f = np.zeros((neq, 13))
-    Xout[:, 0] = x0
-    maxErr = 0.0
-    for ind in range(1, N):
-        ti = tspan[ind - 1]
-        hi = h[ind - 1]
-        xi = Xout[:, ind - 1].copy()
-        f[:, 0] = odefun(ti, xi, *args)
-        for j in range(12):
-            f[:, j + 1] = odefun(ti + alpha[j] * hi, xi + hi * f @ beta[:, j], *args)
-        Xout[:, ind] = xi + hi * f @ chi
-        gamma1 = hi * 41 / 840 * f @ psi
-        delta = np.linalg.norm(gamma1, np.inf)
-        if delta > maxErr:
-            maxErr = delta
-    return Xout, maxErr
+    return _RKF78.march(odefun, tspan, x0, *args)
 
 
 def np_direct_defect(X_all, u_all, t_TU, nstate, n_nodes, nsteps, Isp):
@@ -329,7 +363,7 @@ def np_direct_defect(X_all, u_all, t_TU, nstate, n_nodes, nsteps, Isp):
 
 
 def gen_direct():
-    out = {"doc": "numpy transliteration of ode7_8 + direct defectCalc, nsteps=10", "cases": []}
+    out = {"doc": "independent numpy statement of the fixed-grid Fehlberg 7(8) march (what ode7_8 computes) + the direct two-sided defect, nsteps=10", "cases": []}
     for nstate, seed in ((6, 0), (7, 1)):
         X, U, T = synth.direct_problem(9, seed=seed, nstate=nstate)
         X, U, t = X[:, :, 0], U[:, :, 0], T[:, 0]
