@@ -954,6 +954,11 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a))
+    if os.environ.get("LTO_BENCH_WATCHDOG_S"):
+        # diagnostic: every rank dumps its Python stacks to stderr and leaves after this many seconds (a hung collective otherwise
+        # sits until the launcher's own timeout and says nothing about where)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["LTO_BENCH_WATCHDOG_S"]), exit=True)
     import torch
     import lowthrustopt_amd as lto
     from lowthrustopt_amd import synth
@@ -1067,7 +1072,11 @@ def main():
                     for _ in range(3):             # both window halves, and a reuse
                         comm.allgather(src, dst, cnt, stream=C_void_p(comm_stream.cuda_stream))
                 torch.cuda.synchronize()
-                return bool(all(torch.all(dst[r] == float(r + 1)) for r in range(world)))
+                good = [bool(torch.all(dst[r] == float(r + 1))) for r in range(world)]
+                if not all(good):
+                    notes.append("test gather on rank %d: slabs of ranks %s wrong (first values %s), communicator failed = %s" % (
+                        rank, [r for r in range(world) if not good[r]], [float(dst[r][0]) for r in range(world)], comm.failed()))
+                return all(good)
             except Exception as ex:            # noqa: BLE001
                 notes.append("test gather: %s" % ex)
                 return False
@@ -1087,6 +1096,10 @@ def main():
                         exchange(b"")
                         raise RuntimeError("LTO_BENCH_FAIL_RANK")
                     cand = lto.Comm.windows(ctx, world, rank, gather_rows * S, exchange)
+                    if share:
+                        # ranks on ONE device: the collect kernel's polling blocks (thousands for a multi-megabyte slab) would keep the
+                        # peers' push kernels off the compute units; such payloads go by the copy engines here (lto.h)
+                        cand.set_kernel_payload(1 << 20)
                 else:
                     box = [None]
                     if rank == 0:
@@ -1115,6 +1128,7 @@ def main():
         native_note = "; ".join(notes) if notes else None
         if share and native is None and world > 1:
             # ranks that share a device have no other transport: every rank leaves the same way (no hang, no half-open windows)
+            sys.stderr.write("rank %d: %s\n" % (rank, native_note))
             if rank == 0:
                 print(json.dumps({"error": "no usable transport for ranks that share a device", "tried": native_note}), flush=True)
             dist.barrier()

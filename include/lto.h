@@ -465,6 +465,12 @@ int lto_comm_allreduce_dev(lto_comm* comm, void* stream, double* buf, long count
 #define LTO_COMM_WINDOW_BYTES 128
 int lto_comm_status(lto_comm* comm, void* stream, int* failed);
 int lto_comm_set_wait_limit(lto_comm* comm, long polls);
+/* Window transport: payloads of up to `bytes` per rank travel by the push / collect KERNELS (default 4 MiB: a kernel after a
+ * kernel costs ~2 us of queue hand-over, a copy-engine operation between kernels ~10 us), larger ones by the copy engines with a
+ * one-wavefront wait kernel; 0 = always the copy engines.  Every block of the collect kernel polls for its peers' flags, which is
+ * free when each rank owns its GPU (the deployment) and starves the peers' push kernels when several ranks SHARE one device
+ * and the payload needs thousands of blocks: rehearsals on a shared device lower this (bench.py, LTO_BENCH_SHARE_DEVICE). */
+int lto_comm_set_kernel_payload(lto_comm* comm, long bytes);
 int lto_comm_window_export(lto_ctx* ctx, int world, int rank, long max_count, void* handle_out, lto_comm** out);
 int lto_comm_window_open(lto_comm* comm, const void* all_handles);
 int lto_comm_uses_windows(const lto_comm* comm);

@@ -492,6 +492,7 @@ function comm_failed(c::LtoComm, stream)
     f[] != 0
 end
 "Polls (~1.5 us each) before a wait for a peer gives up and poisons the result."
+set_kernel_payload!(c::LtoComm, bytes::Integer) = comm_check(c, ccall((:lto_comm_set_kernel_payload, liblto), Cint, (Ptr{Cvoid}, Clong), c.handle, bytes))
 set_wait_limit!(c::LtoComm, polls::Integer) = comm_check(c, ccall((:lto_comm_set_wait_limit, liblto), Cint, (Ptr{Cvoid}, Clong), c.handle, polls))
 
 end # module

@@ -130,6 +130,7 @@ SIGNATURES = {
     "lto_comm_uses_windows": (C.c_int, [_vp]),
     "lto_comm_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
     "lto_comm_set_wait_limit": (C.c_int, [_vp, C.c_long]),
+    "lto_comm_set_kernel_payload": (C.c_int, [_vp, C.c_long]),
     "lto_group_ctx": (_vp, [_vp, C.c_int]),
     "lto_group_comm_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lto_group_comm_destroy": (None, [_vp]),

@@ -233,6 +233,7 @@ struct WindowHandle {
 };
 static_assert(sizeof(WindowHandle) <= LTO_COMM_WINDOW_BYTES, "window handle size");
 
+constexpr size_t WINDOW_KERNEL_BYTES = 4u << 20;   // payloads up to this size go by kernels, larger ones by the copy engines (default)
 struct lto_comm {
   int device = 0, world = 1, rank = 0;
   ncclComm_t comm = nullptr;
@@ -245,13 +246,13 @@ struct lto_comm {
   lto::HostBuf<char*> peer;            // every rank's window as mapped here (peer[rank] = own)
   unsigned int seq = 0;
   long wait_limit = 4000000L;          // polls before a wait gives up (lto_comm_set_wait_limit): ~ a few seconds
+  size_t kernel_bytes = WINDOW_KERNEL_BYTES;   // payloads up to this size go by kernels (lto_comm_set_kernel_payload)
   hipStream_t bound = nullptr;         // the stream of this communicator's collectives (windows: all on ONE stream)
   bool bound_set = false;
   char err[512] = {0};
 };
 namespace {
 constexpr size_t WINDOW_HEAD = 1024;   // flags at 0, fail word at 256, this rank's push counters at 512 (one per destination)
-constexpr size_t WINDOW_KERNEL_BYTES = 4u << 20;   // payloads up to this size go by kernels, larger ones by the copy engines
 inline size_t window_bytes(int world, long max_count) { return WINDOW_HEAD + sizeof(double) * 2 * (size_t)world * (size_t)max_count; }
 inline double* window_slab(char* base, int world, long max_count, int half, int rank) {
   return (double*)(base + WINDOW_HEAD) + ((size_t)half * world + rank) * (size_t)max_count;
@@ -400,7 +401,7 @@ int window_push(lto_comm* c, hipStream_t st, const double* send, long count, uns
                                     "use a second communicator for a second stream");
   const unsigned int seq = ++c->seq;
   const int half = (int)(seq & 1u);
-  const bool kernels = sizeof(double) * (size_t)count <= WINDOW_KERNEL_BYTES;
+  const bool kernels = sizeof(double) * (size_t)count <= c->kernel_bytes;
   if (kernels) {
     WindowPeers peers;
     for (int m = 0; m < c->world; ++m) {
@@ -532,6 +533,13 @@ int lto_comm_status(lto_comm* c, void* stream, int* failed) {
 }
 
 /* Polls (each ~ s_sleep 8 + one uncached load, ~1.5 us) before a wait for a peer's flag gives up and poisons the result. */
+int lto_comm_set_kernel_payload(lto_comm* c, long bytes) {
+  if (!c) return LTO_ENULL;
+  if (bytes < 0) return comm_fail(c, LTO_EINVAL, "bytes must be >= 0");
+  c->kernel_bytes = (size_t)bytes;
+  return LTO_OK;
+}
+
 int lto_comm_set_wait_limit(lto_comm* c, long polls) {
   if (!c) return LTO_ENULL;
   if (polls < 1) return comm_fail(c, LTO_EINVAL, "polls must be positive");

@@ -241,6 +241,10 @@ class Comm:
     def set_wait_limit(self, polls):
         self.check(self.lib.lto_comm_set_wait_limit(self.handle, int(polls)))
 
+    def set_kernel_payload(self, nbytes):
+        """Window transport: payloads up to `nbytes` per rank go by the push / collect kernels, larger ones by the copy engines."""
+        self.check(self.lib.lto_comm_set_kernel_payload(self.handle, int(nbytes)))
+
     def allgather(self, send, recv, count, stream=None):
         """recv [world][count] <- send [count] of every rank."""
         self.check(self.lib.lto_comm_allgather_dev(self.handle, stream, _dptr(send), _dptr(recv), int(count)))
