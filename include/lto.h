@@ -259,8 +259,9 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  *     segment count, by the context's cost table (lto_kernel_round_costs / lto_calibrate_kernels above): eight-wave form in
  *     rounds of 16 x CUs segments, 32-segment form (LTO_KERNEL_PIPE32, where it is built) in rounds of 32 x CUs, large-batch form
  *     (LTO_KERNEL_PIPE48) in rounds of 48 x CUs -- 12-dim also 44 x CUs --, and for ndim = 12 the per-lane kernel with 3 columns
- *     per lane in rounds of 64 x CUs.  On MI355X (256 CUs, default table): 4 097 ... 8 192 segments -> PIPE32, 8 193 ... 12 288 ->
- *     PIPE48, 262 144 -> PIPE48 in its 44-segment form (12-dim) / PIPE32 (14-dim);
+ *     per lane in rounds of 64 x CUs, and for ndim = 12 the whole-segment lanes (LTO_KERNEL_LANE) in rounds of 256 x CUs.  On
+ *     MI355X (256 CUs, default table): 4 097 ... 8 192 segments -> PIPE32, 8 193 ... 12 288 -> PIPE48, 65 536 and 262 144 -> LANE
+ *     (12-dim) / PIPE32 (14-dim);
  *   - RK4 with fewer steps: the per-lane kernel (each lane re-integrates the base state with 1-3 columns); for ndim = 12 with ONE
  *     step per segment and >= 65 536 segments its whole-segment form (lto_indirect_plan_set_cols_per_lane, 12);
  *   - the 13-stage integrators: the wave-specialised kernel (LTO_KERNEL_COOP: base wave + column waves per 16 segments,
@@ -297,6 +298,14 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  * instead of two).  RK4; 12-dim, and 14-dim with p = 0 or p = 1; anything else: LTO_EINVAL from lto_indirect_plan_set_kernel
  * (AUTO does not consider it there).  Results equal LTO_KERNEL_PIPE8's bit for bit. */
 #define LTO_KERNEL_PIPE32 8
+/* RK4, ndim = 12 plans only (others: LTO_EINVAL): a lane owns a whole segment -- its base trajectory, the four stage matrices of
+ * every step and all twelve STM columns, which it sends through those matrices one after the other (eight columns parked in
+ * accumulation registers, four in LDS).  No DPP row with idle lanes, no barrier, no hand-over: ~75 wave-instructions per segment
+ * and RK4 step against ~118 of LTO_KERNEL_PIPE48 -- but one wavefront of 64 segments per SIMD, so it only pays once the batch
+ * fills the chip: AUTO compares its rounds of 256 x CUs segments (620 us at 64 steps on MI355X) with the pipelines' rounds and
+ * takes it from about 48 000 segments on MI355X (not for the sizes just above a multiple of a pipeline's smaller round).  Phi
+ * and defect equal the pipeline kernels' bit for bit. */
+#define LTO_KERNEL_LANE 9
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* Lanes per segment of the DEFECT-ONLY sweep of an ndim = 12 DOP853_ADAPTIVE plan (the reference's setting, indirect.jl:63-90):
  * 1, 2 or 4 (a DPP quad per segment: r, v, lambda_v, lambda_r), or 0 = choose (default).  The choice: by size -- four lanes up to

@@ -99,6 +99,9 @@ hipError_t launch_indirect_stm_pipe32(int ndim, int pm, const IndirectArgs& a, h
 // one RK4 step, lane = whole segment with all twelve STM columns (kernels_indirect_stream.hip): the HBM-bound corner of the sweep
 hipError_t launch_indirect_stm_stream(int pm, const IndirectArgs& a, hipStream_t st);
 bool indirect_stm_stream_available(int ndim, int method, int steps, long S);
+// RK4, any number of steps, lane = whole segment with the full STM (kernels_indirect_lane.hip): batches that fill the chip many times over
+hipError_t launch_indirect_stm_lane(int pm, const IndirectArgs& a, hipStream_t st);
+bool indirect_stm_lane_available(int ndim, int method, long S);
 bool indirect_stm_pipe32_available(int ndim, int pm);
 hipError_t launch_direct_defect(int nstate, const DirectArgs& a, hipStream_t st);
 hipError_t launch_direct_jacobian(int nstate, const DirectArgs& a, hipStream_t st);

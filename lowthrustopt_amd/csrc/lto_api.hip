@@ -540,9 +540,11 @@ int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
     return set_err(p->ctx, LTO_EINVAL, "the six-wave pipeline kernel (selector 4) was removed in round 3: LTO_KERNEL_PIPE8 replaced it");
   if (kernel == LTO_KERNEL_PIPE)
     return set_err(p->ctx, LTO_EINVAL, "the four-wave pipeline kernel (selector 3 on an indirect plan) was removed in round 3: LTO_KERNEL_PIPE8 is faster at every size");
-  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP &&
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_LANE &&
       kernel != LTO_KERNEL_PIPE8 && kernel != LTO_KERNEL_COOP2 && kernel != LTO_KERNEL_PIPE48 && kernel != LTO_KERNEL_PIPE32)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE8, _COOP2, _PIPE48 or _PIPE32");
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE8, _COOP2, _PIPE48, _PIPE32 or _LANE");
+  if (kernel == LTO_KERNEL_LANE && !indirect_stm_lane_available(p->ndim, p->integ.method, p->S))
+    return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_LANE is built for 12-dim RK4 plans");
   if (kernel == LTO_KERNEL_COOP2 && (p->integ.method != LTO_DOP853_ADAPTIVE || p->ndim != 12))
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_COOP2 is built for 12-dim DOP853_ADAPTIVE plans");
   if ((kernel == LTO_KERNEL_PIPE8 || kernel == LTO_KERNEL_PIPE48 || kernel == LTO_KERNEL_PIPE32) && p->integ.method != LTO_RK4)
@@ -717,6 +719,9 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
 // a whole segment (kernels_indirect_stream.hip): one wavefront of 64 segments per SIMD of an MI355X.  Below, the per-(segment,
 // column group) lanes fill the chip with four to twelve times the wavefronts and the sweep is latency-bound either way.
 static const long kStreamMinSegments = 65536;
+// RK4 STM sweeps with >= 6 steps, 12-dim: microseconds per round of the form whose lane is a whole segment (kernels_indirect_lane.hip;
+// a round = 256 segments per CU) at 64 steps on MI355X, for AUTO's comparison with the pipelines' round costs.
+static const double kLaneRoundUs = 620.0;
 
 int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* X, long ldx, const double* t,
                               int n_tgrids, double* Phi, long ldp, double* defect, long ldd) {
@@ -758,6 +763,14 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
       kern = (t32 < t8 && t32 < t48 && t32 < tl) ? LTO_KERNEL_PIPE32
              : (t48 <= t8 && t48 <= tl)          ? LTO_KERNEL_PIPE48
                                                  : (t8 <= tl ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PER_LANE);
+      // the whole-segment lanes (kernels_indirect_lane.hip, 12-dim): rounds of 256 x CUs segments -- four wavefronts of 64 per CU, one
+      // per SIMD -- at kLaneRoundUs on MI355X (a round of 65 536 segments, 64 steps: profiles/r05_probe_lane.txt), scaled with the
+      // device like the 44-segment pipeline's figure (the table's calibrated entry of the same regime).  A partly filled round costs
+      // a whole one, so the pipelines keep the sizes just above a multiple of their own, smaller rounds (e.g. 32 768 segments).
+      if (indirect_stm_lane_available(p->ndim, p->integ.method, p->S) && !p->use_order) {
+        const double t_lane = rounds(256 * cus) * kLaneRoundUs * (cost[3] / 139.0);
+        if (t_lane < std::min(std::min(t8, t48), std::min(tl, t32))) kern = LTO_KERNEL_LANE;
+      }
     }
   }
   // the large-batch pipeline has two forms for 12-dim (48 or 44 segments per workgroup, kernels_indirect_pipe48.hip): the cheaper
@@ -793,6 +806,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, seg44, st);
   else if (kern == LTO_KERNEL_PIPE32) e = launch_indirect_stm_pipe32(p->ndim, p->pm, a, st);
+  else if (kern == LTO_KERNEL_LANE) e = launch_indirect_stm_lane(p->pm, a, st);
   else if (p->ndim == 12 && !a.order && (p->cols_per_lane == 12 || (p->cols_per_lane == 0 && p->S >= kStreamMinSegments &&
                                                           indirect_stm_stream_available(12, p->integ.method, p->integ.steps, p->S))))
     e = launch_indirect_stm_stream(p->pm, a, st);      // one RK4 step on a full chip: lane = segment, HBM-bound (kernels_indirect_stream.hip)

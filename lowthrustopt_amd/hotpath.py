@@ -661,7 +661,7 @@ class IndirectPlan:
         self.handle = h
         ctx._plans.add(self)
 
-    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE8, KERNEL_COOP2, KERNEL_PIPE48, KERNEL_PIPE32 = 0, 1, 2, 5, 6, 7, 8   # 3, 4: removed in round 3 (four- / six-wave forms)
+    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE8, KERNEL_COOP2, KERNEL_PIPE48, KERNEL_PIPE32, KERNEL_LANE = 0, 1, 2, 5, 6, 7, 8, 9   # 3, 4: removed in round 3 (four- / six-wave forms)
 
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
@@ -678,7 +678,7 @@ class IndirectPlan:
 
     def last_kernel(self):
         """Name of the kernel family the last STM sweep ran (what AUTO resolved to)."""
-        return {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48", 8: "pipeline32"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
+        return {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48", 8: "pipeline32", 9: "segment-lane"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
 
     def staging(self):
         """Record staging of the plan's ordered sweeps (lto_indirect_plan_staging): bit 1 node / defect records in place, bit 2 Phi records

@@ -47,7 +47,7 @@ def test_configs3_homotopy_sweep_256_levels_x_1024_segments_with_stm(gpu_ctx, or
     S1 = n - 1
     for b in (0, 1, 100, 255):
         p1 = lto.IndirectPlan(gpu_ctx, n, 1, prms[b], integ)
-        p1.set_kernel({"per-lane": p1.KERNEL_PER_LANE, "pipeline8": p1.KERNEL_PIPE8, "cooperative": p1.KERNEL_COOP, "cooperative2": p1.KERNEL_COOP2, "pipeline48": p1.KERNEL_PIPE48}[kernel])    # the family the batch ran
+        p1.set_kernel({"per-lane": p1.KERNEL_PER_LANE, "pipeline8": p1.KERNEL_PIPE8, "cooperative": p1.KERNEL_COOP, "cooperative2": p1.KERNEL_COOP2, "pipeline48": p1.KERNEL_PIPE48, "segment-lane": p1.KERNEL_LANE}[kernel])    # the family the batch ran
         if kernel == "per-lane":
             p1.set_cols_per_lane(3)           # what AUTO picks for the 262 144-segment batch (kernels_indirect.hip)
         Phi1 = torch.zeros(144, S1, dtype=torch.float64, device="cuda")

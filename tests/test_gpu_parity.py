@@ -43,7 +43,7 @@ KERNEL_METHODS = [(k, m) for k in ("per_lane", "coop") for m in METHODS] + [("pi
 
 def pick_kernel(plan, kernel):
     plan.set_kernel({"per_lane": plan.KERNEL_PER_LANE, "coop": plan.KERNEL_COOP,
-                     "pipe8": plan.KERNEL_PIPE8, "coop2": plan.KERNEL_COOP2, "pipe48": plan.KERNEL_PIPE48, "pipe32": plan.KERNEL_PIPE32}[kernel])
+                     "pipe8": plan.KERNEL_PIPE8, "coop2": plan.KERNEL_COOP2, "pipe48": plan.KERNEL_PIPE48, "pipe32": plan.KERNEL_PIPE32, "lane": plan.KERNEL_LANE}[kernel])
 
 
 def rel_l2(d_gpu, d_ref, x1):
@@ -1785,4 +1785,80 @@ def test_one_step_whole_segment_lanes_choice_and_misuse(gpu_ctx):
         pl = lto.IndirectPlan(gpu_ctx, 30, 1, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), lto.integrator(**kw), ndim=ndim)
         with pytest.raises(lto._lib.LtoError):
             pl.set_cols_per_lane(12)
+        pl.close()
+
+
+@pytest.mark.parametrize("pp,steps", [(1.0, 9), (0.0, 3), (2.0, 64), (1.5, 7), (1.0, 258)])
+def test_segment_lane_kernel_equals_the_pipelines_bitwise(gpu_ctx, oracle, pp, steps):
+    """LTO_KERNEL_LANE (kernels_indirect_lane.hip: a lane owns a whole segment -- base trajectory, stage matrices, all twelve STM
+    columns): the same FMAs in the same order as the three-role pipelines, so Phi and defect equal LTO_KERNEL_PIPE48's bit for bit
+    -- every control-law class, a ragged batch (3 trajectories x 1 111 segments with their own grids), step counts on both sides
+    of the columns' rescaling period (256) -- and the oracle's dual-number STM of the same discrete map to round-off."""
+    import torch
+    n, B = 1112, 3
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=17, dt_seg=0.12)
+    S1, S = n - 1, (n - 1) * B
+    thr = 10.0 if pp > 1.0 else 0.05
+    prm = lto.make_params(MU, DU, TU, thr, 1000.0, 1.0, pp, 1.0)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()
+    plan = lto.IndirectPlan(gpu_ctx, n, B, prm, lto.integrator(lto.RK4, steps=steps))
+    out = {}
+    for kernel, name in (("lane", "segment-lane"), ("pipe48", "pipeline48")):
+        pick_kernel(plan, kernel)
+        Phi = torch.full((144, S), float("nan"), dtype=torch.float64, device="cuda")
+        d = torch.full((12, S), float("nan"), dtype=torch.float64, device="cuda")
+        plan.jacobian(X, n * B, t, B, Phi, S, d, S)
+        torch.cuda.synchronize()
+        assert plan.last_kernel() == name
+        out[kernel] = (Phi, d)
+    plan.close()
+    assert bool(torch.isfinite(out["lane"][0]).all())
+    assert torch.equal(out["lane"][1], out["pipe48"][1])
+    assert torch.equal(out["lane"][0], out["pipe48"][0])
+    b = B - 1
+    P_o, d_o, rc = oracle.indirect_jacobian(XC[:, :65, b], T[:65, b], [MU, DU, TU, thr, 1000.0, 1.0, pp, 1.0], oracle.RK4, steps)
+    assert rc == 0
+    Pg = out["lane"][0][:, b * S1:b * S1 + 64].cpu().numpy().reshape(12, 12, 64).transpose(1, 0, 2)
+    assert np.abs(Pg - P_o).max() < 1e-10 * np.abs(P_o).max()
+    assert rel_l2(out["lane"][1][:, b * S1:b * S1 + 64].cpu().numpy(), d_o, XC[:, 1:65, b]) < 1e-12
+
+
+def test_segment_lane_kernel_choice_mixed_classes_and_misuse(gpu_ctx):
+    """AUTO takes LTO_KERNEL_LANE for 12-dim RK4 plans from 256 segments per CU (65 536 on MI355X) and the large-batch pipeline
+    below; a batch that mixes control-law classes is swept by one launch per class; the selector is refused on 14-dim and on
+    13-stage plans."""
+    import torch
+    n, B = 1025, 64
+    XC, T = synth.indirect_problem(n, n_batch=4, seed=23)
+    XC = np.asfortranarray(np.tile(XC, (1, 1, B // 4))); T = np.asfortranarray(np.tile(T, (1, B // 4)))
+    S1, S = n - 1, (n - 1) * B
+    prm = [lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, (1.0, 2.0, 0.0, 1.5)[b % 4], 10.0 ** -(b % 3)) for b in range(B)]
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()
+    plan = lto.IndirectPlan(gpu_ctx, n, B, prm, lto.integrator(lto.RK4, steps=8))
+    res = {}
+    for kernel in ("auto", "pipe48"):
+        if kernel != "auto":
+            pick_kernel(plan, kernel)
+        Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda"); d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        plan.jacobian(X, n * B, t, B, Phi, S, d, S)
+        torch.cuda.synchronize()
+        res[kernel] = (Phi, d, plan.last_kernel())
+    plan.close()
+    assert res["auto"][2] == "segment-lane" and res["pipe48"][2] == "pipeline48"
+    assert torch.equal(res["auto"][0], res["pipe48"][0]) and torch.equal(res["auto"][1], res["pipe48"][1])
+    assert torch.equal(res["auto"][0][:, :S1], res["auto"][0][:, 12 * S1:13 * S1])       # trajectory 12 = a copy of trajectory 0 (same p, same rho)
+    small = lto.IndirectPlan(gpu_ctx, 32769, 1, prm[0], lto.integrator(lto.RK4, steps=8))   # 32 768 segments: below the boundary
+    Xs = torch.from_numpy(synth.to_soa_nodes(synth.indirect_problem(32769, seed=1)[0])).cuda()
+    ts = torch.arange(32769, dtype=torch.float64, device="cuda") * 0.1
+    Phi = torch.zeros(144, 32768, dtype=torch.float64, device="cuda")
+    small.jacobian(Xs, 32769, ts, 1, Phi, 32768, None, 0)
+    torch.cuda.synchronize()
+    assert small.last_kernel() == "pipeline48"
+    small.close()
+    for kw, ndim in ((dict(method=lto.RK4, steps=8), 14), (dict(method=lto.DOP853_ADAPTIVE), 12)):
+        pl = lto.IndirectPlan(gpu_ctx, 30, 1, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), lto.integrator(**kw), ndim=ndim)
+        with pytest.raises(lto._lib.LtoError):
+            pl.set_kernel(pl.KERNEL_LANE)
         pl.close()
