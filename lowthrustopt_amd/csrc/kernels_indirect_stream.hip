@@ -15,8 +15,10 @@
 //
 //   HBM: every load / store instruction of a wavefront moves 512 contiguous bytes (struct-of-arrays, segment index fastest): node
 //   i and node i + 1 come from the same cache lines, each line of Phi and of the defect is written exactly once, whole.  Stores
-//   are fire-and-forget (nothing waits for them), two wavefronts per SIMD (<= 256 VGPRs) overlap one segment block's loads with
-//   the other's arithmetic.
+//   are fire-and-forget (nothing waits for them) and NONTEMPORAL: 1.3 GB of Phi per million segments that nobody re-reads would
+//   otherwise be written into the L2 and evicted from it line by line (0.310 -> 0.254 ms per 1 048 576 segments, 4.9 -> 6.0 TB/s
+//   algorithmic; profiles/r05_probe_stream.txt).  Two wavefronts per SIMD (<= 256 VGPRs) overlap one segment block's loads with
+//   the other's arithmetic (one per SIMD with 512 registers: the same time).
 //
 // A column starts at the unit vector only because steps == 1; plans with 2 ... 5 RK4 steps keep the per-column-group kernel.
 // Arithmetic per entry = rhs12<PM, true> / var_col12 / the RK4 update of rk4_step, in the same order as k_indirect<12,PM,RK4,COLS>.
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     // base stages would not fit two wavefronts per SIMD
     char* drow = (char*)a.defect;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) *(double*)(drow + (long)c * a.ldd * 8 + off) = y[c] - a.X[c * a.ldx + node + 1];
+    for (int c = 0; c < 12; ++c) __builtin_nontemporal_store(y[c] - a.X[c * a.ldx + node + 1], (double*)(drow + (long)c * a.ldd * 8 + off));
   }
   if (a.errors) a.errors[s] = 0.0;
   if (a.nacc) a.nacc[s] = a.steps;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     var_col12(vc[3], w2, ct, dc);
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-      *(double*)(prow + off) = __builtin_fma(h6, dc[r], acc[r]);
+      __builtin_nontemporal_store(__builtin_fma(h6, dc[r], acc[r]), (double*)(prow + off));
       prow += row_bytes;
     }
   }
