@@ -299,8 +299,8 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  * (AUTO does not consider it there).  Results equal LTO_KERNEL_PIPE8's bit for bit. */
 #define LTO_KERNEL_PIPE32 8
 /* RK4, ndim = 12 plans only (others: LTO_EINVAL): a lane owns a whole segment -- its base trajectory, the four stage matrices of
- * every step and all twelve STM columns, which it sends through those matrices one after the other (eight columns parked in
- * accumulation registers, four in LDS).  No DPP row with idle lanes, no barrier, no hand-over: ~75 wave-instructions per segment
+ * every step and all twelve STM columns, which it sends through those matrices one after the other (six columns parked in
+ * accumulation registers, six in LDS).  No DPP row with idle lanes, no barrier, no hand-over: ~75 wave-instructions per segment
  * and RK4 step against ~118 of LTO_KERNEL_PIPE48 -- but one wavefront of 64 segments per SIMD, so it only pays once the batch
  * fills the chip: AUTO compares its rounds of 256 x CUs segments (620 us at 64 steps on MI355X) with the pipelines' rounds and
  * takes it from about 48 000 segments on MI355X (not for the sizes just above a multiple of a pipeline's smaller round).  Phi

@@ -14,10 +14,14 @@
 //                     order, so Phi equals the pipelines' bit for bit).
 //   No LDS, no barrier, no idle lane, nothing computed twice: ~60 wave-instructions per segment and step.
 //
-// The price is state: Phi is 144 doubles per lane.  The kernel runs ONE wavefront per SIMD (512 registers per lane: 256
-// addressable + 256 accumulation registers, which the compiler uses as the columns' parking space -- a column comes in and goes
-// back once per step, ~48 v_accvgpr moves against ~225 FMAs), so it needs 64 segments per SIMD to fill the chip: AUTO takes it from
-// 65 536 segments per 256 CUs (lto_api.hip), below that the pipelines' lane groups are the better use of the machine.
+// The price is state: Phi is 144 doubles per lane, next to 68 doubles of stage matrices and ~50 of a column in flight.  The kernel
+// runs ONE wavefront per SIMD (512 registers per lane: 256 addressable + 256 accumulation registers): six columns live in
+// registers -- the compiler parks them in the accumulation registers and moves one in and out per step, ~830 v_accvgpr moves per
+// step against ~3 800 FP64 instructions -- and six in LDS (36 KB per wavefront, four wavefronts per CU; 16-byte pieces, one per lane
+// and access).  More register columns spill to scratch, more LDS columns do not fit four wavefronts per CU (LANE_COLS_IN_REGISTERS).
+// So it needs 64 segments per SIMD to fill the chip: AUTO compares its rounds of 256 x CUs segments with the pipelines' (lto_api.hip).
+// The stage arguments pass through an empty asm before the matrices are built from them: otherwise the compiler merges that
+// evaluation into the base stage's and keeps ~20 by-products per stage alive across the step (+110 registers).
 // 12-dim; every control-law class; RK4 with any number of steps.
 #include "kernels.hpp"
 #include "pipe_common.hpp"
