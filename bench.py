@@ -911,7 +911,7 @@ def leg_config(key, wl, steps, warmup, lto, synth, torch, ctx, st, dev, device_w
         kern_ms, burst_n, samples = sample_launches(torch, lambda: sweep(w.defect), n=3)
         out = {"workload": w.desc, "segments": S, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3, "value": S * steps / el,
                "unit": "segment-integrations/s", "dtype": "f64"}
-        if hasattr(plan, "last_kernel"):
+        if hasattr(plan, "last_kernel") and wl in ("c4", "c5_stm", "hbm"):       # the family of the STM sweep (defect-only sweeps have no such report)
             out["kernel"] = plan.last_kernel()
         if c5:
             acc, rej = plan.step_counts(stream=st)

@@ -12,8 +12,8 @@ if [ "$PART" = all ] || [ "$PART" = bench ]; then
 # progress goes straight into the log (a pipe into tail would hold it back until the end: the GPU box kills a run that stays silent for 7 minutes)
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
 tail -3 "$OUT/pytest_gpu.log"
-python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null > "$OUT/bench_c2_driver.json"; last "$OUT/bench_c2_driver.json"
-python bench.py --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_200.json"; last "$OUT/bench_c2_200.json"
+T0=$SECONDS; python bench.py --gpus 1 --steps 20 --warmup 5 2>"$OUT/bench_c2_driver.err" > "$OUT/bench_c2_driver.json"; echo "driver line: $((SECONDS - T0)) s wall"; last "$OUT/bench_c2_driver.json"
+python bench.py --no-cpu-baseline --no-configs 2>/dev/null > "$OUT/bench_c2_200.json"; last "$OUT/bench_c2_200.json"
 python bench.py --workload hbm --ndim 12 --segments 1048576 --no-cpu-baseline --live-traffic on --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_hbm.json"; last "$OUT/bench_hbm.json"
 python bench.py --segments 8192 --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_8192.json"; last "$OUT/bench_c2_8192.json"    # 32-segment pipeline (AUTO above one round)
 python bench.py --workload c3 --cpu-seconds 5 2>/dev/null > "$OUT/bench_c3.json"; last "$OUT/bench_c3.json"
@@ -24,11 +24,12 @@ python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/nul
 python bench.py --workload c5_stm --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null > "$OUT/bench_c5_stm.json"; last "$OUT/bench_c5_stm.json"
 python bench.py --workload newton --cpu-seconds 6 2>/dev/null > "$OUT/bench_newton.json"; last "$OUT/bench_newton.json"
 python tools/probe_calibration.py 2>/dev/null > "$OUT/probe_calibration.txt"; cat "$OUT/probe_calibration.txt"
+python tools/kernel_resources.py > "$OUT/kernel_resources.txt"; head -1 "$OUT/kernel_resources.txt"
 fi
 if [ "$PART" = all ] || [ "$PART" = prof ]; then
 # kernel traces + stats.  The device ramps its clocks over the first ~300 contract launches (91 -> 79 us per launch): the c2
 # and c3 traces time enough steps (4 000 / 2 000) for the average over ALL launches of the trace to be the ramped duration.
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2" -- python bench.py --steps 4000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2" -- python bench.py --steps 4000 --warmup 5 --no-cpu-baseline --no-configs > "$OUT/prof_c2.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_8192" -- python bench.py --segments 8192 --steps 2000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2_8192.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c3" -- python bench.py --workload c3 --steps 2000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c3.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c4" -- python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/prof_c4.log" 2>&1
@@ -48,7 +49,7 @@ pmc_passes() {   # pmc_passes <key> <bench.py arguments...>
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/$KEY/pmc_sq" -- python bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_sq_$KEY.log" 2>&1
   echo "pmc $KEY done"
 }
-pmc_passes c2                                   # also holds the 12-dim leg (pmc_c2_ndim12) and the reference-integrator leg
+pmc_passes c2 --no-configs                                   # also holds the 12-dim leg (pmc_c2_ndim12) and the reference-integrator leg
 pmc_passes c2_8192 --segments 8192
 pmc_passes c3 --workload c3
 pmc_passes c4 --workload c4
@@ -63,9 +64,9 @@ find "$OUT" -name "*.csv" | wc -l
 #   python tools/summarize_profile.py $OUT <tag> c2 "k_indirect_pipe8<14"
 #   python tools/summarize_profile.py $OUT <tag> c2_ndim12 "k_indirect_pipe8<12" c2
 #   python tools/summarize_profile.py $OUT <tag> c3 "k_direct_jacobian_pipe<6"
-#   python tools/summarize_profile.py $OUT <tag> c4 "k_indirect_pipe48<12"
+#   python tools/summarize_profile.py $OUT <tag> c4 "k_indirect_lane"
 #   python tools/summarize_profile.py $OUT <tag> c5 "k_indirect_defect4"
 #   python tools/summarize_profile.py $OUT <tag> c5_stm "k_indirect_coop2"
 #   python tools/summarize_profile.py $OUT <tag> c2_ndim12_dop853 "k_indirect_coop2" c2_dop853
-#   python tools/summarize_profile.py $OUT <tag> hbm_ndim12 "k_indirect<12"
+#   python tools/summarize_profile.py $OUT <tag> hbm_ndim12 "k_indirect_stream"
 #   python tools/summarize_profile.py $OUT <tag> newton_bvp_chunk "k_bvp_chunk<12, true" newton      (likewise _tail, _backchunk, _chunk_rhs)
