@@ -57,8 +57,10 @@ __device__ __forceinline__ void col_reg_stage(const VarCoef12& v, const double a
   out[11] = __builtin_fma(-a, arg[8], init[11]);
 }
 
-// One RK4 step of one column, carrying u = 3^k y: col_dpp_step<12> of pipe_common.hpp with register coefficients.
-__device__ __forceinline__ void col_reg_step(const VarCoef12 (&vc)[4], const ColStepConst& k, const int step, double (&y)[12]) {
+// One RK4 step of one column, carrying u = 3^k y: col_dpp_step<12> of pipe_common.hpp with register coefficients; its rescaling by
+// 3^-256 every 256 steps is done by the caller for all columns at once (the same multiplication on the same value, one branch per
+// step instead of twelve).
+__device__ __forceinline__ void col_reg_step(const VarCoef12 (&vc)[4], const ColStepConst& k, double (&y)[12]) {
   double B[12], V1[12], V2[12], V3[12];
   col_reg_stage(vc[0], k.h2w, k.h2, y, y, V1);
 #pragma unroll
@@ -70,10 +72,6 @@ __device__ __forceinline__ void col_reg_step(const VarCoef12 (&vc)[4], const Col
 #pragma unroll
   for (int c = 0; c < 12; ++c) B[c] += V3[c];
   col_reg_stage(vc[3], k.h2w, k.h2, V3, B, y);
-  if (((step + 1) & (COL_RESCALE_EVERY - 1)) == 0) {
-#pragma unroll
-    for (int c = 0; c < 12; ++c) y[c] *= COL_RESCALE;
-  }
 }
 
 constexpr int LANE_COLS_IN_REGISTERS = 6;
@@ -162,14 +160,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int col = 0; col < 12; ++col) {
       __builtin_amdgcn_sched_barrier(0);           // one column at a time: interleaving two of them costs more registers than there are
-      if (col < NREG) col_reg_step(vc, kc, step, phi[col]);
+      if (col < NREG) col_reg_step(vc, kc, phi[col]);
       else {
         double u[12];
 #pragma unroll
         for (int q = 0; q < 6; ++q) { const double2 t = s_park[(col - NREG) * 6 + q][lane_opaque]; u[2 * q] = t.x; u[2 * q + 1] = t.y; }
-        col_reg_step(vc, kc, step, u);
+        col_reg_step(vc, kc, u);
 #pragma unroll
         for (int q = 0; q < 6; ++q) s_park[(col - NREG) * 6 + q][threadIdx.x] = make_double2(u[2 * q], u[2 * q + 1]);
+      }
+    }
+    if (((step + 1) & (COL_RESCALE_EVERY - 1)) == 0) {       // every 256 steps: u <- 3^-256 u, all columns (pipe_common.hpp COL_RESCALE)
+#pragma unroll
+      for (int col = 0; col < NREG; ++col)
+#pragma unroll
+        for (int c = 0; c < 12; ++c) phi[col][c] *= COL_RESCALE;
+#pragma unroll
+      for (int j = 0; j < NLDS * 6; ++j) {
+        double2 t = s_park[j][lane_opaque];
+        t.x *= COL_RESCALE; t.y *= COL_RESCALE;
+        s_park[j][threadIdx.x] = t;
       }
     }
   }
