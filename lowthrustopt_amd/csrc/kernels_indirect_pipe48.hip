@@ -85,7 +85,15 @@ __device__ __forceinline__ void pipe48_role_base(const IndirectArgs& a, const Pi
   // of x_i before the loop and parks them across it -- 20 spilled dwords in a kernel that runs at 128 registers per lane)
   int s_e = L.s;
   long node_e = L.node;
-  if constexpr (ND == 12) asm volatile("" : "+v"(s_e), "+v"(node_e));   // (14-dim: the same pin moves its spills INTO the step loop: 193 -> 233 us at 12 288 segments)
+  if constexpr (ND == 12) {
+    // (14-dim: the same pin moves its spills INTO the step loop: 193 -> 233 us at 12 288 segments)
+    // Round 5: the node index is not carried across the loop at all (it was the one value the 44-segment form still spilled: a
+    // store before the loop, a load behind it) but formed again from the segment index, which is pinned so that the division
+    // cannot be hoisted in front of the loop.
+    asm volatile("" : "+v"(s_e));
+    const int traj_e = s_e / a.seg_per_traj;
+    node_e = (long)traj_e * a.n_nodes + (s_e - traj_e * a.seg_per_traj);
+  }
   if (L.in_range && live) {
     if (a.defect) {
 #pragma unroll
