@@ -121,6 +121,11 @@ double lto_last_call_ms(const lto_ctx* ctx);
  * choice. */
 int lto_calibrate_kernels(lto_ctx* ctx);
 int lto_kernel_round_costs(const lto_ctx* ctx, int ndim, double* us_per_round, int* calibrated);
+/* The sixth family AUTO weighs for ndim = 12 (round 5; kept out of the five-entry table so that its callers' arrays stay valid):
+ * microseconds per round of 256 x CUs segments at 64 steps of the whole-segment lanes (LTO_KERNEL_LANE) -- 620 on MI355X by
+ * default, this device's figure after lto_calibrate_kernels (which then also sweeps one such round: ~5 ms more, and the context's
+ * work arena grows to ~110 MB). */
+double lto_kernel_lane_round_us(const lto_ctx* ctx);
 
 /* --------------------------------------------------------- host-pointer API (what Julia ccalls)
  * Each call: plan looked up in the context's cache by (shape, integrator, parameter values) -> H2D ->

@@ -89,6 +89,7 @@ SIGNATURES = {
     "lto_trial_points_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_long]),
     "lto_calibrate_kernels": (C.c_int, [_vp]),
     "lto_kernel_round_costs": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "lto_kernel_lane_round_us": (C.c_double, [_vp]),
     "lto_read_scalars_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "lto_line_search_pick_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_long, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_long]),
     "lto_indirect_dense_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.c_int, _vp, _vp, _vp, C.c_long, _vp]),

@@ -23,6 +23,11 @@
 
 using namespace lto;
 
+// RK4 STM sweeps with >= 6 steps, 12-dim: microseconds per round of the form whose lane is a whole segment (kernels_indirect_lane.hip;
+// a round = 256 segments per CU) at 64 steps on MI355X, for AUTO's comparison with the pipelines' round costs (default of
+// lto_ctx::lane_round_us; lto_calibrate_kernels measures it on the context's own device).
+static const double kLaneRoundUs = 620.0;
+
 struct lto_ctx {
   int device;
   int cu_count;    // compute units of the device: the kernel choice works in rounds of workgroups per CU
@@ -75,6 +80,7 @@ struct lto_ctx {
   // only), 3 = 44-segment form of the large-batch pipeline (44 x CUs; 12-dim only), 4 = 32-segment / twelve-wave pipeline (32 x CUs).
   // Defaults: MI355X, profiles/r04z; lto_calibrate_kernels replaces them with this device's own.
   double round_cost[2][5];
+  double lane_round_us;    // the whole-segment lanes (kernels_indirect_lane.hip, 12-dim): us per round of 256 x CUs segments at 64 steps
   bool calibrated;
   double* rep_host;
   double* rep_dev;
@@ -269,6 +275,7 @@ int lto_create(lto_ctx** out, int device_id) {
   c->device = device_id;
   c->cu_count = 0;
   { const double dflt[2][5] = {{63.0, 165.0, 246.0, 139.0, 111.0}, {72.0, 191.0, 1e300, 1e300, 128.0}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
+  c->lane_round_us = kLaneRoundUs;
   if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) { c->cu_count = 0; (void)hipGetLastError(); }
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -719,9 +726,6 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
 // a whole segment (kernels_indirect_stream.hip): one wavefront of 64 segments per SIMD of an MI355X.  Below, the per-(segment,
 // column group) lanes fill the chip with four to twelve times the wavefronts and the sweep is latency-bound either way.
 static const long kStreamMinSegments = 65536;
-// RK4 STM sweeps with >= 6 steps, 12-dim: microseconds per round of the form whose lane is a whole segment (kernels_indirect_lane.hip;
-// a round = 256 segments per CU) at 64 steps on MI355X, for AUTO's comparison with the pipelines' round costs.
-static const double kLaneRoundUs = 620.0;
 
 int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* X, long ldx, const double* t,
                               int n_tgrids, double* Phi, long ldp, double* defect, long ldd) {
@@ -764,11 +768,11 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
              : (t48 <= t8 && t48 <= tl)          ? LTO_KERNEL_PIPE48
                                                  : (t8 <= tl ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PER_LANE);
       // the whole-segment lanes (kernels_indirect_lane.hip, 12-dim): rounds of 256 x CUs segments -- four wavefronts of 64 per CU, one
-      // per SIMD -- at kLaneRoundUs on MI355X (a round of 65 536 segments, 64 steps: profiles/r05_probe_lane.txt), scaled with the
-      // device like the 44-segment pipeline's figure (the table's calibrated entry of the same regime).  A partly filled round costs
-      // a whole one, so the pipelines keep the sizes just above a multiple of their own, smaller rounds (e.g. 32 768 segments).
+      // per SIMD -- at lto_ctx::lane_round_us: kLaneRoundUs, the MI355X figure (a round of 65 536 segments, 64 steps:
+      // profiles/r05_probe_lane.txt), or this device's (lto_calibrate_kernels).  A partly filled round costs a whole one, so the
+      // pipelines keep the sizes just above a multiple of their own, smaller rounds (e.g. 32 768 segments).
       if (indirect_stm_lane_available(p->ndim, p->integ.method, p->S) && !p->use_order) {
-        const double t_lane = rounds(256 * cus) * kLaneRoundUs * (cost[3] / 139.0);
+        const double t_lane = rounds(256 * cus) * c->lane_round_us;
         if (t_lane < std::min(std::min(t8, t48), std::min(tl, t32))) kern = LTO_KERNEL_LANE;
       }
     }
@@ -960,7 +964,8 @@ int lto_calibrate_kernels(lto_ctx* c) {
   const long cus = c->cu_count > 0 ? c->cu_count : 256;
   const long per_round[5] = {16 * cus, 48 * cus, 64 * cus, 44 * cus, 32 * cus};
   const int family_kernel[5] = {LTO_KERNEL_PIPE8, LTO_KERNEL_PIPE48, LTO_KERNEL_PER_LANE, LTO_KERNEL_PIPE48, LTO_KERNEL_PIPE32};
-  const long Smax = per_round[2], nmax = Smax + 1;
+  const long lane_round = 256 * cus;                 // the whole-segment lanes' round (12-dim): the largest batch measured
+  const long Smax = lane_round, nmax = Smax + 1;
   hipStream_t st = c->stream;
   LTO_HIP(c, hipStreamSynchronize(st));
   rc = arena_reserve(c, al256(sizeof(double) * 14 * nmax) + al256(sizeof(double) * nmax) + al256(sizeof(double) * 196 * Smax) + al256(sizeof(double) * 14 * Smax) + 4096);
@@ -983,6 +988,7 @@ int lto_calibrate_kernels(lto_ctx* c) {
   lto_integrator integ; std::memset(&integ, 0, sizeof integ);
   integ.method = LTO_RK4; integ.steps = 64;
   double measured[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 1e300, 1e300, 0}};
+  double measured_lane = 0.0;
   for (int di = 0; di < 2 && rc == LTO_OK; ++di) {
     const int nd = di ? 14 : 12;
     for (long k = 0; k < nmax; ++k)
@@ -997,13 +1003,13 @@ int lto_calibrate_kernels(lto_ctx* c) {
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, ht.data(), sizeof(double) * nmax, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { rc = set_err(c, LTO_EHIP, "calibration upload", e); break; }
-    for (int f = 0; f < 5 && rc == LTO_OK; ++f) {
-      if (nd == 14 && (f == 2 || f == 3)) continue;
-      const long S = per_round[f];      // one full round: with 44 x CUs segments the 44-form is the cheaper one, with 48 x CUs the 48-form
+    for (int f = 0; f < 6 && rc == LTO_OK; ++f) {     // f = 5: the whole-segment lanes (12-dim only)
+      if (nd == 14 && (f == 2 || f == 3 || f == 5)) continue;
+      const long S = (f == 5) ? lane_round : per_round[f];      // one full round: with 44 x CUs segments the 44-form is the cheaper one, with 48 x CUs the 48-form
       lto_indirect_plan* p = nullptr;
       rc = plan_build(c, nd, (int)(S + 1), 1, &prm, 1, &integ, &p);
       if (rc) break;
-      p->kernel = family_kernel[f];
+      p->kernel = (f == 5) ? LTO_KERNEL_LANE : family_kernel[f];
       p->p48_form = (f == 3) ? 44 : 48;
       if (f == 2) p->cols_per_lane = 3;
       auto sweep = [&]() { return lto_indirect_jacobian_dev(p, st, d_X, nmax, d_t, 1, d_phi, S, d_def, S); };
@@ -1027,7 +1033,8 @@ int lto_calibrate_kernels(lto_ctx* c) {
       plan_free(p);
       if (rc == LTO_OK) {
         std::sort(ms, ms + 5);
-        measured[di][f] = ms[2] * 1e3 * (64.0 / integ.steps);
+        if (f == 5) measured_lane = ms[2] * 1e3 * (64.0 / integ.steps);
+        else measured[di][f] = ms[2] * 1e3 * (64.0 / integ.steps);
       }
     }
   }
@@ -1036,10 +1043,14 @@ int lto_calibrate_kernels(lto_ctx* c) {
   for (int di = 0; di < 2; ++di)
     for (int f = 0; f < 5; ++f)
       if (!(measured[di][f] > 0.0)) return set_err(c, LTO_EHIP, "calibration returned a non-positive time");
+  if (!(measured_lane > 0.0)) return set_err(c, LTO_EHIP, "calibration returned a non-positive time");
   std::memcpy(c->round_cost, measured, sizeof measured);
+  c->lane_round_us = measured_lane;
   c->calibrated = true;
   return LTO_OK;
 }
+
+double lto_kernel_lane_round_us(const lto_ctx* c) { return c ? c->lane_round_us : 0.0; }
 
 int lto_kernel_round_costs(const lto_ctx* c, int ndim, double* us_per_round, int* calibrated) {
   if (!c || !us_per_round) return LTO_ENULL;

@@ -116,6 +116,10 @@ class Context:
         self.check(self.lib.lto_calibrate_kernels(self.handle))
         return {nd: self.kernel_round_costs(nd)[0] for nd in (12, 14)}
 
+    def kernel_lane_round_us(self):
+        """us per round of 256 x CUs segments (64 steps) of the whole-segment RK4 kernel (LTO_KERNEL_LANE): default or calibrated."""
+        return float(self.lib.lto_kernel_lane_round_us(self.handle))
+
     def kernel_round_costs(self, ndim):
         """([pipeline8, pipeline48 (48 segments per workgroup), per-lane, pipeline48 (44 segments), pipeline32] us per round at 64
         steps, calibrated?) -- what LTO_KERNEL_AUTO chooses by."""

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lowthrustopt_amd as lto
 
 c = lto.Context(0)
-print("defaults  ", c.kernel_round_costs(12), c.kernel_round_costs(14))
-print("calibrated", c.calibrate_kernels())
-print("again     ", c.calibrate_kernels())
+print("defaults  ", c.kernel_round_costs(12), c.kernel_round_costs(14), "whole-segment lanes", c.kernel_lane_round_us())
+print("calibrated", c.calibrate_kernels(), "whole-segment lanes", c.kernel_lane_round_us())
+print("again     ", c.calibrate_kernels(), "whole-segment lanes", c.kernel_lane_round_us())
 c.close()
