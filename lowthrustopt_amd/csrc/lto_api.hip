@@ -26,7 +26,7 @@ using namespace lto;
 // RK4 STM sweeps with >= 6 steps, 12-dim: microseconds per round of the form whose lane is a whole segment (kernels_indirect_lane.hip;
 // a round = 256 segments per CU) at 64 steps on MI355X, for AUTO's comparison with the pipelines' round costs (default of
 // lto_ctx::lane_round_us; lto_calibrate_kernels measures it on the context's own device).
-static const double kLaneRoundUs = 620.0;
+static const double kLaneRoundUs = 590.0;
 
 struct lto_ctx {
   int device;

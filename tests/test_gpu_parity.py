@@ -1625,9 +1625,9 @@ def test_kernel_cost_table_calibration():
         d12, cal = ctx.kernel_round_costs(12)
         d14, _ = ctx.kernel_round_costs(14)
         assert not cal and d12 == [63.0, 165.0, 246.0, 139.0, 111.0] and d14 == [72.0, 191.0, -1.0, -1.0, 128.0]
-        assert ctx.kernel_lane_round_us() == 620.0                       # the sixth family (12-dim): whole-segment lanes, rounds of 256 x CUs
+        assert ctx.kernel_lane_round_us() == 590.0                       # the sixth family (12-dim): whole-segment lanes, rounds of 256 x CUs
         got = ctx.calibrate_kernels()
-        assert 0.6 * 620.0 < ctx.kernel_lane_round_us() < 1.6 * 620.0 and ctx.kernel_lane_round_us() != 620.0
+        assert 0.6 * 590.0 < ctx.kernel_lane_round_us() < 1.6 * 590.0 and ctx.kernel_lane_round_us() != 590.0
         m12, cal = ctx.kernel_round_costs(12)
         m14, _ = ctx.kernel_round_costs(14)
         assert cal and got[12] == m12 and got[14] == m14
