@@ -36,6 +36,14 @@ def make_case(seed):
     if method == lto.RK4:        # the pipeline kernels exist for fixed-step RK4 only (own generator: the other draws stay put)
         kernel = int(np.random.default_rng(7000 + seed).choice([kernel, 3, 4, 5, 7]))
         kernel = 5 if kernel in (3, 4) else kernel   # selectors 3 / 4 (four- / six-wave forms) were removed in round 3: those draws take their successor
+    if method == lto.RK4 and ndim == 12:
+        # round 5 (own generator: the other draws stay put): a third of the 12-dim RK4 cases run the whole-segment lanes
+        # (LTO_KERNEL_LANE), a further sixth the one-step sweep with the whole STM in the segment's lane (cols_per_lane = 12)
+        pick = int(np.random.default_rng(11000 + seed).integers(0, 6))
+        if pick < 2:
+            kernel = 9
+        elif pick == 2:
+            kernel, cols, steps = 1, 12, 1
     XC, T = synth.indirect_problem(n, n_batch=B, seed=seed, dt_range=(lo, hi), lam_sigma=lam)
     if ndim == 14:
         X = np.zeros((14, n, B), order="F")
@@ -204,3 +212,54 @@ def test_device_newton_solve_random_sizes_vs_dense(gpu_ctx, seed):
             got = den[:, :, b].reshape(-1, order="F")
             assert np.all(got[~keep] == 0.0), what
             assert np.abs(got - ref).max() < 1e-7 * max(1.0, np.abs(ref).max()), what
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LTO_FUZZ_SEEDS_LANE", "32"))))
+def test_whole_segment_kernels_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
+    """The two kernels of round 5 whose lane owns a whole segment -- LTO_KERNEL_LANE (RK4, any number of steps) and the one-step
+    sweep with cols_per_lane = 12 -- on random 12-dim configurations: node counts that leave wavefronts ragged or straddle
+    trajectories, batches with mixed control-law classes, sharp and smooth switches, both time directions, one RK4 step up to
+    more than the columns' rescaling period; defect and STM against the oracle's dual-number derivative of the same discrete map,
+    and the defect-only sweep of the same plan."""
+    import torch
+    rng = np.random.default_rng(13000 + seed)
+    one_step = bool(seed % 3 == 0)
+    steps = 1 if one_step else int(rng.choice([1, 2, 5, 24, 64, 257]))
+    B = int(rng.choice([1, 2, 5]))
+    n = int(rng.integers(2, 150))
+    lo = 10.0 ** rng.uniform(-3, -1.3)
+    hi = lo * 10.0 ** rng.uniform(0, 0.6)
+    ps = [float(rng.choice([0.0, 1.0, 2.0, 1.5, 3.0])) for _ in range(B)]
+    rhos = [10.0 ** rng.uniform(-4.0, 0.0) for _ in range(B)]
+    thr = [float(rng.choice([0.05, 10.0])) for _ in range(B)]
+    td = float(rng.choice([1.0, 1.0, -1.0]))
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=500 + seed, dt_range=(lo, hi), lam_sigma=float(rng.choice([0.1, 0.5, 1.0])))
+    prm_l = [[MU, DU, TU, thr[b], 1000.0, td, ps[b], rhos[b]] for b in range(B)]
+    S = n - 1
+    J = S * B
+    plan = lto.IndirectPlan(gpu_ctx, n, B, [lto.make_params(*q) for q in prm_l], lto.integrator(lto.RK4, steps=steps))
+    if one_step:
+        plan.set_cols_per_lane(12)
+    else:
+        plan.set_kernel(plan.KERNEL_LANE)
+    Xd = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    tdv = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    Phi = torch.full((144, J), 3.0, dtype=torch.float64, device="cuda")
+    d = torch.full((12, J), 3.0, dtype=torch.float64, device="cuda")
+    d0 = torch.full((12, J), 3.0, dtype=torch.float64, device="cuda")
+    plan.jacobian(Xd, n * B, tdv, B, Phi, J, d, J)
+    plan.defect(Xd, n * B, tdv, B, d0, J)
+    torch.cuda.synchronize()
+    assert plan.last_kernel() == ("per-lane" if one_step else "segment-lane")
+    plan.close()
+    Pn = Phi.cpu().numpy().reshape(12, 12, J).transpose(1, 0, 2)
+    dn, d0n = d.cpu().numpy(), d0.cpu().numpy()
+    for b in range(B):
+        Xb, tb, sl = XC[:, :, b], T[:, b], slice(b * S, (b + 1) * S)
+        P_o, d_o, rc = oracle.indirect_jacobian(Xb, tb, prm_l[b], oracle.RK4, steps)
+        assert rc == 0
+        scale = np.linalg.norm(d_o + Xb[:, 1:])
+        what = "seed %d: steps %d B %d n %d one_step %s p %g rho %g td %g" % (seed, steps, B, n, one_step, ps[b], rhos[b], td)
+        assert np.linalg.norm(dn[:, sl] - d_o) < 1e-10 * scale, what
+        assert np.linalg.norm(d0n[:, sl] - d_o) < 1e-10 * scale, what
+        assert np.abs(Pn[:, :, sl] - P_o).max() < 1e-10 * np.abs(P_o).max(), what
