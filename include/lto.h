@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LTO_VERSION 100 /* 0.1.0 */
+#define LTO_VERSION 101 /* 0.1.1: round 5 added LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us; nothing was removed or changed */
 
 /* error codes */
 #define LTO_OK 0
