@@ -1316,7 +1316,7 @@ def main():
                                "group": grp,
                                "note": "efficiency = segment-steps executed / (group x slowest segment per wavefront / workgroup); rebalanced = "
                                        "lto_indirect_plan_rebalance ordered the lanes by the warm-up sweep's step counts"}
-        if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect", "hbm") and not a.method:
+        if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect") and not a.method:
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds, ndim=a.ndim)
             if wl == "c2":
                 # the same sweep the way the reference executes it (adaptive order 8 @ 1e-13 + dual numbers, 12-dim)
@@ -1328,6 +1328,15 @@ def main():
             if ncpu > 1:   # same restatement with the segment loop spread over every host core (reported, not the target)
                 out["cpu_baseline_all_cores"] = cpu_baseline("c3" if wl == "c3" else "c2", max(3.0, a.cpu_seconds / 3), threads=ncpu,
                                                              ndim=a.ndim)
+        if world == 1 and not a.no_cpu_baseline and not a.method and (wl in ("c3", "c4", "c5", "c5_stm") or (wl == "hbm" and a.ndim == 12)):
+            # the single-workload lines carry what their `configs` legs carry: an oracle sample of this run's own last sweep and the
+            # oracle timed on one core on that sample
+            par, cpu = config_parity_and_cpu(w, lto, max(1.0, a.cpu_seconds / 4))
+            out["parity"] = par
+            if wl == "c3":
+                out.setdefault("cpu_baseline", cpu)         # (the leg above timed the same thing on a larger sample)
+            else:
+                out["cpu_baseline"] = cpu
         if world == 1 and wl == "c2" and not a.method and not a.segments:
             out["host_api"] = leg_host_api(lto, ctx, XC, T, prm, integ, a.ndim, S)
         want_live = a.live_traffic == "on" or (a.live_traffic == "auto" and not a.no_cpu_baseline)
