@@ -267,8 +267,9 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  *     per lane in rounds of 64 x CUs, and for ndim = 12 the whole-segment lanes (LTO_KERNEL_LANE) in rounds of 256 x CUs.  On
  *     MI355X (256 CUs, default table): 4 097 ... 8 192 segments -> PIPE32, 8 193 ... 12 288 -> PIPE48, 65 536 and 262 144 -> LANE
  *     (12-dim) / PIPE32 (14-dim);
- *   - RK4 with fewer steps: the per-lane kernel (each lane re-integrates the base state with 1-3 columns); for ndim = 12 with ONE
- *     step per segment and >= 65 536 segments its whole-segment form (lto_indirect_plan_set_cols_per_lane, 12);
+ *   - RK4 with fewer steps: the per-lane kernel (each lane re-integrates the base state with 1-3 columns); for ndim = 12 on a
+ *     full chip the whole-segment forms instead: ONE step per segment and >= 65 536 segments the one-step sweep
+ *     (lto_indirect_plan_set_cols_per_lane, 12), 2 ... 5 steps LTO_KERNEL_LANE when its rounds are the cheaper ones;
  *   - the 13-stage integrators: the wave-specialised kernel (LTO_KERNEL_COOP: base wave + column waves per 16 segments,
  *     coefficients handed over through LDS at every RK stage) -- for ndim = 12 with DOP853_ADAPTIVE, the reference's setting, its
  *     form with two lanes per state (LTO_KERNEL_COOP2).

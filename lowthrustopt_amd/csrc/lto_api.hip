@@ -755,7 +755,15 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
     const long cus = c->cu_count > 0 ? c->cu_count : 256;
     if (p->integ.method != LTO_RK4)   // 12-dim DOP853: the two-lanes-per-state form (0.221 against 0.260 ms at 4 096 segments)
       kern = (p->integ.method == LTO_DOP853_ADAPTIVE && p->ndim == 12) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
-    else if (p->integ.steps < 6) kern = LTO_KERNEL_PER_LANE;   // fill and drain phases outweigh the shorter phase
+    else if (p->integ.steps < 6) {
+      kern = LTO_KERNEL_PER_LANE;                              // fill and drain phases outweigh the pipelines' shorter phase
+      // 2 ... 5 steps on a full chip (12-dim): the whole-segment lanes have no fill or drain either and run no base stage twice --
+      // by the same round costs as below (per-lane kernel with three columns: rounds of 64 x CUs; one step: its own form, section 4.3b)
+      if (p->integ.steps >= 2 && indirect_stm_lane_available(p->ndim, p->integ.method, p->S) && !p->use_order && p->cols_per_lane == 0) {
+        const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };
+        if (rounds(256 * cus) * c->lane_round_us < rounds(64 * cus) * c->round_cost[0][2]) kern = LTO_KERNEL_LANE;
+      }
+    }
     else if (p->S <= 16 * cus) kern = LTO_KERNEL_PIPE8;
     else {
       const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };

@@ -1851,6 +1851,21 @@ def test_segment_lane_kernel_choice_mixed_classes_and_misuse(gpu_ctx):
     assert res["auto"][2] == "segment-lane" and res["pipe48"][2] == "pipeline48"
     assert torch.equal(res["auto"][0], res["pipe48"][0]) and torch.equal(res["auto"][1], res["pipe48"][1])
     assert torch.equal(res["auto"][0][:, :S1], res["auto"][0][:, 12 * S1:13 * S1])       # trajectory 12 = a copy of trajectory 0 (same p, same rho)
+    # RK4 with 2 ... 5 steps on a full chip: AUTO's per-lane family gives way to the whole-segment lanes too (no fill or drain,
+    # no base stage run twice); the per-lane kernel with three columns per lane agrees within rounding
+    plan3 = lto.IndirectPlan(gpu_ctx, n, B, prm, lto.integrator(lto.RK4, steps=3))
+    got = {}
+    for kernel in ("auto", "per_lane"):
+        if kernel != "auto":
+            pick_kernel(plan3, kernel)
+        Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda"); d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+        plan3.jacobian(X, n * B, t, B, Phi, S, d, S)
+        torch.cuda.synchronize()
+        got[kernel] = (Phi, d, plan3.last_kernel())
+    plan3.close()
+    assert got["auto"][2] == "segment-lane" and got["per_lane"][2] == "per-lane"
+    assert float((got["auto"][0] - got["per_lane"][0]).abs().max()) <= 1e-12 * float(got["per_lane"][0].abs().max())
+    assert float((got["auto"][1] - got["per_lane"][1]).abs().max()) <= 1e-13
     small = lto.IndirectPlan(gpu_ctx, 32769, 1, prm[0], lto.integrator(lto.RK4, steps=8))   # 32 768 segments: below the boundary
     Xs = torch.from_numpy(synth.to_soa_nodes(synth.indirect_problem(32769, seed=1)[0])).cuda()
     ts = torch.arange(32769, dtype=torch.float64, device="cuda") * 0.1
