@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void k_indirect_dense(const IndirectArgs a, con
 // column group is blockIdx.y and the g = 0 lanes also emit the defect.
 template <int ND, int PM, int METHOD, int COLS>
 __global__ __launch_bounds__(64) void k_indirect(const IndirectArgs a) {
-  const int sl = blockIdx.x * 64 + threadIdx.x;
+  const int sl = xcd_unit(a, blockIdx.x, gridDim.x) * 64 + threadIdx.x;   // an XCD's wavefronts own a contiguous range of segments (kernels.hpp)
   if (sl >= a.S) return;
   const int s = a.order ? a.order[sl] : sl;    // balanced order: neighbouring lanes take similar numbers of steps
   const int g = blockIdx.y;

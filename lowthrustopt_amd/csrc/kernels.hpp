@@ -22,6 +22,7 @@ struct IndirectArgs {
   double* Phi; long ldp;           // [144][ldp] (col*12+row) or null
   int* nacc; int* nrej;            // [S] adaptive step counters or null
   const int* order;                // [S] or null: lane -> segment map of adaptive sweeps (lto_indirect_plan_rebalance)
+  int xcd_ranges;                  // 1: `order` is the windowed kind (LTO_ORDER_WINDOW below): workgroup b works on unit xcd_unit(b, grid), not b
   int class_filter;                // set by the launchers: 1 = this launch handles only trajectories of the kernel's p-class
   double stm_scale;                // 3^-(steps mod 256): the DPP column lanes of the pipeline kernels carry 3^k Phi (pipe_common.hpp)
   double* h_first;                 // [S] or null: step size of the segment's first ACCEPTED trial step (written by the two-lane adaptive kernels)
@@ -122,6 +123,28 @@ hipError_t launch_pack_soa2(const double* aos_a, int ndim_a, long count_a, doubl
 hipError_t launch_unpack_soa2(const double* soa_a, long ld_a, int ndim_a, long count_a, double* aos_a, const double* soa_b, long ld_b,
                               int ndim_b, long count_b, double* aos_b, hipStream_t st);
 constexpr int LTO_ORDER_BINS = 1024;   // int workspace launch_segment_order needs
+// Windowed lane order (round 5): segments are ordered by step count INSIDE windows of LTO_ORDER_WINDOW consecutive segments, the
+// windows by their slowest segment, heaviest first, dealt to the eight XCDs in turn (each XCD's windows contiguous in the order).
+// With the sweep kernels' workgroups mapped to contiguous ranges per XCD (xcd_unit below), the wavefronts that share a window run
+// on ONE XCD at about the same time: its L2 sees every line of the window's nodes, defects and Phi whole, so the sweep reads and
+// writes the caller's struct-of-arrays operands directly -- no record passes (kernels.hpp IndirectArgs::Xa / Da / Pa).
+constexpr int LTO_ORDER_WINDOW = 1024;
+constexpr int LTO_XCDS = 8;
+// ints of workspace behind the S entries of an order array: window-local order [S], per window (key, destination, slot) [3 nwin], bins
+inline size_t order_workspace_ints(long S) { return (size_t)S + 3 * (size_t)((S + LTO_ORDER_WINDOW - 1) / LTO_ORDER_WINDOW) + LTO_ORDER_BINS + 64; }
+inline size_t order_bytes(long S) { return sizeof(int) * ((size_t)S + order_workspace_ints(S)); }
+hipError_t launch_segment_order_windowed(const int* nacc, const int* nrej, int S, int weave, int* work, int* order, hipStream_t st);
+// Workgroup b of a grid of nb -> the unit it works on, such that the workgroups an XCD receives (round-robin dispatch: b mod 8) own a
+// CONTIGUOUS range of units: the nodes two neighbouring units share, and the windows of an ordered sweep, then sit in one L2.
+// A bijection of [0, nb) for every nb.
+__device__ __forceinline__ int xcd_unit_of(const int b, const int nb) {
+  const int x = b % LTO_XCDS, j = b / LTO_XCDS;
+  const int chunk = nb / LTO_XCDS, rem = nb % LTO_XCDS;
+  return x * chunk + (x < rem ? x : rem) + j;
+}
+// Only the windowed order wants the ranges: in natural order (slow segments cluster along a trajectory) and in the global order
+// (heaviest first) a contiguous eighth per XCD would be an eighth of very different weight.
+#define xcd_unit(a, b, nb) ((a).xcd_ranges ? xcd_unit_of((b), (nb)) : (b))
 // node records for the staged sweeps: Xa[j][0..11] = X[c][j], Xa[j][12] = the node's time (t[b * t_stride + k], j = b n_nodes + k)
 hipError_t launch_node_records(const double* X, long ldx, const double* t, int t_stride, int n_nodes, long J, double* Xa, hipStream_t st);
 hipError_t launch_step_stats(const int* nacc, const int* nrej, int S, unsigned long long* acc, long long* host_out, hipStream_t st);

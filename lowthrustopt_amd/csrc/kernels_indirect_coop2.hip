@@ -89,7 +89,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     grow[j] = BASE ? ((q4 == 0) ? 0 : (q4 == 1) ? 3 : (q4 == 2) ? 9 : 6) + j : (ROLE == C2_TOP) ? j : (j < 3 ? 9 + j : 3 + j);
   const int widx = BASE ? 6 : (ROLE == C2_TOP ? cwave : 3 + cwave);     // this wavefront's entry in the partial-sum table
 
-  const int s_raw = blockIdx.x * C2_SEG + seg;
+  const int s_raw = xcd_unit(a, blockIdx.x, gridDim.x) * C2_SEG + seg;      // an XCD's workgroups own a contiguous range of segments (kernels.hpp)
   const int s_lin = s_raw < a.S ? s_raw : a.S - 1;             // shadow lanes repeat the last segment
   const int s = a.order ? a.order[s_lin] : s_lin;              // balanced order (lto_indirect_plan_rebalance)
   const bool in_range = (s_raw < a.S);

@@ -20,7 +20,7 @@ template <int PM>
 __global__ __launch_bounds__(64) void k_indirect_defect2(const IndirectArgs a) {
   const int lane = threadIdx.x;
   const bool is_a = ((lane >> 2) & 1) == 0;
-  const int sl = blockIdx.x * 32 + (lane >> 3) * 4 + (lane & 3);       // 32 segments per wavefront
+  const int sl = xcd_unit(a, blockIdx.x, gridDim.x) * 32 + (lane >> 3) * 4 + (lane & 3);       // 32 segments per wavefront; an XCD's wavefronts own a contiguous range (kernels.hpp)
   if (sl >= a.S) return;                                               // both lanes of a pair leave together
   const int s = a.order ? a.order[sl] : sl;
   const int traj = s / a.seg_per_traj;
@@ -201,7 +201,7 @@ template <int PM>
 __global__ __launch_bounds__(64) void k_indirect_defect4(const IndirectArgs a) {
   const int lane = threadIdx.x;
   const int q4 = lane & 3;
-  const int sl = blockIdx.x * 16 + (lane >> 2);                        // 16 segments per wavefront
+  const int sl = xcd_unit(a, blockIdx.x, gridDim.x) * 16 + (lane >> 2);   // 16 segments per wavefront; an XCD's wavefronts own a contiguous range (kernels.hpp)
   if (sl >= a.S) return;                                               // the four lanes of a quad leave together
   const int s = a.order ? a.order[sl] : sl;
   const int traj = s / a.seg_per_traj;

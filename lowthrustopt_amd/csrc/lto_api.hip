@@ -45,7 +45,8 @@ struct lto_ctx {
   // lane order of the last large adaptive sweep made through the host-pointer API (which builds a plan per call):
   // consecutive Newton iterations sweep the same problem, so the previous call's step counts balance this one.
   // A stale order is still a valid permutation -- it can only cost speed, never correctness.
-  int* order_cache;      // [order_S + LTO_ORDER_BINS]
+  int* order_cache;      // [order_S + workspace] (kernels.hpp order_bytes)
+  int order_kind;        // 1 global, 2 windowed
   long order_S;
   int order_ndim;
   // plans of the host-pointer API, kept between calls (a Newton iteration calls with the same shapes and parameters
@@ -100,6 +101,7 @@ struct lto_indirect_plan {
   int* d_nrej;
   int* d_order;     // [S] lane -> segment map of adaptive sweeps + LTO_ORDER_BINS ints of sort workspace (lazily allocated)
   int use_order;
+  int order_kind;      // what d_order holds: 1 = the global order (record staging), 2 = the windowed order (kernels.hpp LTO_ORDER_WINDOW)
   int order_borrowed;  // d_order belongs to the context's cache
   int swept;           // an adaptive sweep has filled the step counters
   int cols_per_lane;
@@ -458,7 +460,7 @@ static void plan_free(lto_indirect_plan* p) {
   pool_free(p->ctx, p->d_tp, sizeof(TrajParams) * (size_t)p->n_prm);
   pool_free(p->ctx, p->d_nacc, sizeof(int) * (size_t)p->S);
   pool_free(p->ctx, p->d_nrej, sizeof(int) * (size_t)p->S);
-  if (!p->order_borrowed) pool_free(p->ctx, p->d_order, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS));
+  if (!p->order_borrowed) pool_free(p->ctx, p->d_order, order_bytes(p->S));
   pool_free(p->ctx, p->d_bvp, p->bvp_bytes);
   for (int k = 0; k < 2; ++k) pool_free(p->ctx, p->d_hfirst[k], sizeof(double) * (size_t)p->S);
   if (p->h_stats) (void)hipHostFree(p->h_stats);
@@ -486,6 +488,30 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* p, void* stream, int* accept
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "copy step counters", e);
   return LTO_OK;
+}
+
+// Lane order of the adaptive sweeps.  Round 5: ordered inside windows of consecutive segments, the windows dealt to the XCDs
+// (kernels.hpp LTO_ORDER_WINDOW) -- the sweeps then gather from and scatter to the caller's arrays inside one L2 and need no record
+// staging.  LTO_ORDER_MODE=global in the environment (development switch) or more than 8 M segments: the global order of round 4 with
+// its record staging.
+// A plan that runs STM sweeps keeps the global order and its records: with sixteen workgroup-rounds per CU the sweep's time is the
+// sum of its rounds, longest-processing-time-first over ALL workgroups is what keeps that sum short, and the windowed order costs
+// 17 % of time there (1.75 against 1.50 ms at C5 + STM) for its 2.6 x less traffic.  A defect-only plan (C5 itself, the line
+// search's trial plan) takes the windowed order: same time, a third of the traffic, no record passes.
+static int order_kind_for(bool stm) {
+  static const int forced = [] {
+    const char* e = std::getenv("LTO_ORDER_MODE");
+    return !e ? 0 : std::strcmp(e, "global") == 0 ? 1 : std::strcmp(e, "windowed") == 0 ? 2 : 0;
+  }();
+  return forced ? forced : (stm ? 1 : 2);
+}
+static int order_weave() {
+  static const int w = [] { const char* e = std::getenv("LTO_ORDER_WEAVE"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= 255) ? v : 0; }();      // 0 = the kernel's choice
+  return w;
+}
+static hipError_t segment_order(int kind, const int* nacc, const int* nrej, long S, int* work, int* order, hipStream_t st) {
+  return kind == 2 ? launch_segment_order_windowed(nacc, nrej, (int)S, order_weave(), work, order, st)
+                   : launch_segment_order(nacc, nrej, (int)S, work, order, st);
 }
 
 // Record staging (12-dim plans with the reference's integrator setting): the buffers come with the lane order, outside any sweep.
@@ -526,13 +552,15 @@ int lto_indirect_plan_rebalance(lto_indirect_plan* p, void* stream) {
   int rc = bind_device(c);
   if (rc) return rc;
   if (!p->d_order) {
-    hipError_t e = pool_alloc(c, (void**)&p->d_order, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS));
+    hipError_t e = pool_alloc(c, (void**)&p->d_order, order_bytes(p->S));
     if (e != hipSuccess) return set_err(c, LTO_EHIP, "order allocation", e);
   }
-  hipError_t e = launch_segment_order(p->d_nacc, p->d_nrej, p->S, p->d_order + p->S, p->d_order, (hipStream_t)stream);
+  const int kind = order_kind_for(p->stm_swept != 0);
+  hipError_t e = segment_order(kind, p->d_nacc, p->d_nrej, p->S, p->d_order + p->S, p->d_order, (hipStream_t)stream);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_segment_order", e);
   p->use_order = 1;
-  return stage_alloc(p, p->stm_swept != 0);
+  p->order_kind = kind;
+  return kind == 2 ? LTO_OK : stage_alloc(p, p->stm_swept != 0);
 }
 
 int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
@@ -634,6 +662,7 @@ static int fill_indirect_args(lto_indirect_plan* p, const double* X, long ldx, c
   a->steps = p->integ.steps; a->rtol = p->integ.rtol; a->atol = p->integ.atol; a->max_steps = p->integ.max_steps;
   a->nacc = p->d_nacc; a->nrej = p->d_nrej;
   a->order = p->use_order ? p->d_order : nullptr;
+  a->xcd_ranges = (p->use_order && p->order_kind == 2) ? 1 : 0;
   a->stm_scale = std::pow(3.0, -(double)(p->integ.steps > 0 ? p->integ.steps % 256 : 0));   // pipe_common.hpp COL_RESCALE_EVERY
   p->swept = 1;                                    // every caller launches a sweep right after a successful fill
   return LTO_OK;
@@ -694,7 +723,7 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   rc = warm_args(p, 1, lanes > 1, &a);
   if (rc) return rc;
   // balanced lane order: nodes in, defects out as records (IndirectArgs::Xa / Da), coalesced transposes either side of the sweep
-  const bool staged = a.order && lanes > 1 && p->d_xa && p->d_da;
+  const bool staged = a.order && p->order_kind == 1 && lanes > 1 && p->d_xa && p->d_da;
   if (staged) {
     hipError_t q = launch_node_records(X, ldx, t, a.t_stride, p->n_nodes, (long)p->n_nodes * p->n_batch, p->d_xa, st);
     if (q != hipSuccess) return set_err(c, LTO_EHIP, "launch_node_records", q);
@@ -798,14 +827,14 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   rc = warm_args(p, 0, kern == LTO_KERNEL_COOP2, &a);
   if (rc) return rc;
   p->stm_swept = 1;
-  if (a.order && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && !p->d_pa && !p->stage_failed) {
+  if (a.order && p->order_kind == 1 && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && !p->d_pa && !p->stage_failed) {
     // the lane order was made before this plan's first STM sweep: the Phi records come now -- unless the stream is being captured
     // (an allocation may not happen there; this sweep then runs unstaged and a later one outside a capture allocates)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) (void)stage_alloc(p, true);
     else (void)hipGetLastError();
   }
-  const bool staged = a.order && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && p->d_pa;
+  const bool staged = a.order && p->order_kind == 1 && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && p->d_pa;
   if (staged) {
     hipError_t q = launch_node_records(X, ldx, t, a.t_stride, p->n_nodes, (long)p->n_nodes * p->n_batch, p->d_xa, st);
     if (q != hipSuccess) return set_err(c, LTO_EHIP, "launch_node_records", q);
@@ -1082,9 +1111,9 @@ static bool host_order_wanted(const lto_indirect_plan* p, bool stm) {
 
 static void host_order_adopt(lto_ctx* c, lto_indirect_plan* p, bool stm) {
   if (p->order_borrowed) { p->d_order = nullptr; p->use_order = 0; p->order_borrowed = 0; }   // cached plan: the context's order may have moved
-  if (!host_order_wanted(p, stm) || !c->order_cache || c->order_S != p->S || c->order_ndim != p->ndim) return;
-  p->d_order = c->order_cache; p->order_borrowed = 1; p->use_order = 1;
-  (void)stage_alloc(p, stm);
+  if (!host_order_wanted(p, stm) || !c->order_cache || c->order_S != p->S || c->order_ndim != p->ndim || c->order_kind != order_kind_for(stm)) return;
+  p->d_order = c->order_cache; p->order_borrowed = 1; p->use_order = 1; p->order_kind = c->order_kind;
+  if (p->order_kind == 1) (void)stage_alloc(p, stm);
 }
 
 static void host_order_refresh(lto_ctx* c, lto_indirect_plan* p, bool stm, hipStream_t st) {
@@ -1092,14 +1121,15 @@ static void host_order_refresh(lto_ctx* c, lto_indirect_plan* p, bool stm, hipSt
   if (!c->order_cache || c->order_S != p->S) {
     if (p->use_order) return;                      // (cannot happen: adoption requires a matching cache)
     if (c->order_cache) { (void)hipStreamSynchronize(st); (void)hipFree(c->order_cache); c->order_cache = nullptr; }
-    if (hipMalloc((void**)&c->order_cache, sizeof(int) * ((size_t)p->S + LTO_ORDER_BINS)) != hipSuccess) {
+    if (hipMalloc((void**)&c->order_cache, order_bytes(p->S)) != hipSuccess) {
       c->order_cache = nullptr; (void)hipGetLastError();
       return;                                      // balancing is an optimisation: carry on without it
     }
     c->order_S = p->S;
   }
   c->order_ndim = p->ndim;
-  if (launch_segment_order(p->d_nacc, p->d_nrej, p->S, c->order_cache + p->S, c->order_cache, st) != hipSuccess) {
+  c->order_kind = order_kind_for(stm);
+  if (segment_order(c->order_kind, p->d_nacc, p->d_nrej, p->S, c->order_cache + p->S, c->order_cache, st) != hipSuccess) {
     (void)hipGetLastError();
     c->order_S = 0;                                // never adopt a half-written order
   }

@@ -1699,19 +1699,28 @@ def test_rebalanced_auto_sweeps_with_record_staging_are_bit_identical(gpu_ctx):
         out = sweep()
         assert all(np.array_equal(a, b) for a, b in zip(out[:3], ref[:3]))
         plan.close()
-    # a plan that only ever runs defect sweeps (the line search's trial plan) gets no Phi records with its lane order (advisor
-    # finding, round 4: [S][144] doubles it would never read); they come with its first STM sweep if there ever is one
+    # a plan that only ever runs defect sweeps (the line search's trial plan) takes the windowed order and no records at all (round
+    # 5; the advisor's finding of round 4 was that it pinned [S][144] doubles of Phi records it never read).  Its first STM sweep
+    # runs with that order as it stands; the next rebalance knows the plan runs STM sweeps and gives it the global order and records.
     plan = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator())
     d0 = torch.zeros(12, S, dtype=torch.float64, device="cuda")
     assert plan.staging() == 0
     plan.defect(Xd, n * B, td, B, d0, S)
+    torch.cuda.synchronize()
+    d_nat = d0.cpu().numpy().copy()                                  # this plan's own lanes per segment, natural order
     plan.rebalance()
-    assert plan.staging() == 1
+    assert plan.staging() == 0
+    d0.fill_(-3.0)
     plan.defect(Xd, n * B, td, B, d0, S)
-    assert plan.staging() == 1
+    torch.cuda.synchronize()
+    assert np.array_equal(d0.cpu().numpy(), d_nat)
     Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
     plan.jacobian(Xd, n * B, td, B, Phi, S, d0, S)
+    torch.cuda.synchronize()
+    assert plan.staging() == 0 and np.array_equal(Phi.cpu().numpy(), ref[0])
+    plan.rebalance()
     assert plan.staging() == 3
+    plan.jacobian(Xd, n * B, td, B, Phi, S, d0, S)
     torch.cuda.synchronize()
     assert np.array_equal(Phi.cpu().numpy(), ref[0])
     plan.close()
@@ -1879,3 +1888,40 @@ def test_segment_lane_kernel_choice_mixed_classes_and_misuse(gpu_ctx):
         with pytest.raises(lto._lib.LtoError):
             pl.set_kernel(pl.KERNEL_LANE)
         pl.close()
+
+
+@pytest.mark.parametrize("n_nodes,B,lanes", [(1024, 1, 4), (1025, 1, 4), (1026, 1, 2), (2048, 1, 1), (667, 3, 4), (1025, 9, 4), (2050, 8, 2),
+                                             (1025, 17, 4)])
+def test_windowed_lane_order_is_a_permutation_and_changes_no_result(gpu_ctx, n_nodes, B, lanes):
+    """Defect-only plans (C5 itself, the line search's trial plan) take the WINDOWED lane order since round 5: segments ordered by
+    step count inside windows of 1 024 consecutive segments, the windows ranked by their slowest segment, dealt to the eight XCDs
+    and interleaved there 16 segments at a time (kernels_util.hip k_order_window / _place / _copy), with the sweep's workgroups
+    mapped to contiguous ranges per XCD -- no record staging.  For batch sizes on both sides of the window size and of a multiple
+    of eight windows, with a short last window, and for every lanes-per-segment form: the ordered sweep returns the natural-order
+    sweep's bits for EVERY segment (a position the order missed would keep its fill value, one it named twice would be a race),
+    step counters included, and the plan holds no staging records."""
+    import torch
+    XC, T = synth.indirect_problem(n_nodes, n_batch=B, seed=77, dt_range=(0.02, 0.4))
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1e-2)
+    Xd = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    S = (n_nodes - 1) * B
+    plan = lto.IndirectPlan(gpu_ctx, n_nodes, B, prm, lto.integrator())
+    plan.set_defect_lanes(lanes)
+
+    def sweep():
+        d = torch.full((12, S), -3.0, dtype=torch.float64, device="cuda")
+        plan.defect(Xd, n_nodes * B, td, B, d, S)
+        acc, rej = plan.step_counts()
+        torch.cuda.synchronize()
+        return d.cpu().numpy(), acc, rej
+
+    ref = sweep()
+    assert np.all(np.isfinite(ref[0])) and (ref[1] + ref[2]).max() > 2 * (ref[1] + ref[2]).min()
+    for _ in range(2):
+        plan.rebalance()
+        out = sweep()
+        assert plan.staging() == 0
+        for a, b in zip(out, ref):
+            assert np.array_equal(a, b)
+    plan.close()
