@@ -128,10 +128,20 @@ constexpr int LTO_ORDER_BINS = 1024;   // int workspace launch_segment_order nee
 // With the sweep kernels' workgroups mapped to contiguous ranges per XCD (xcd_unit below), the wavefronts that share a window run
 // on ONE XCD at about the same time: its L2 sees every line of the window's nodes, defects and Phi whole, so the sweep reads and
 // writes the caller's struct-of-arrays operands directly -- no record passes (kernels.hpp IndirectArgs::Xa / Da / Pa).
-constexpr int LTO_ORDER_WINDOW = 1024;
+constexpr int LTO_ORDER_WINDOW = 1024;       // largest window (one thread per segment in k_order_window)
 constexpr int LTO_XCDS = 8;
+// Window size for a batch of S segments: as close to 1 024 as gives every XCD the same number of windows -- 8 k windows for
+// k = ceil(S / 8 192), a multiple of 16 segments (the interleave unit) -- so that the XCDs' lists line up with the contiguous
+// eighths of the order the kernels' workgroups are mapped to (xcd_unit below).  S = 65 536, 262 144, 20 x 4 096: 1 024.
+inline int order_window_size(long S) {
+  const long k = (S + 8191) / 8192 > 0 ? (S + 8191) / 8192 : 1;
+  long w = (S + 8 * k - 1) / (8 * k);
+  w = (w + 15) / 16 * 16;
+  return (int)(w < 16 ? 16 : (w > LTO_ORDER_WINDOW ? LTO_ORDER_WINDOW : w));
+}
+inline long order_windows(long S) { const long w = order_window_size(S); return (S + w - 1) / w; }
 // ints of workspace behind the S entries of an order array: window-local order [S], per window (key, destination, slot) [3 nwin], bins
-inline size_t order_workspace_ints(long S) { return (size_t)S + 3 * (size_t)((S + LTO_ORDER_WINDOW - 1) / LTO_ORDER_WINDOW) + LTO_ORDER_BINS + 64; }
+inline size_t order_workspace_ints(long S) { return (size_t)S + 3 * (size_t)order_windows(S) + LTO_ORDER_BINS + 64; }
 inline size_t order_bytes(long S) { return sizeof(int) * ((size_t)S + order_workspace_ints(S)); }
 hipError_t launch_segment_order_windowed(const int* nacc, const int* nrej, int S, int weave, int* work, int* order, hipStream_t st);
 // Workgroup b of a grid of nb -> the unit it works on, such that the workgroups an XCD receives (round-robin dispatch: b mod 8) own a

@@ -214,18 +214,18 @@ hipError_t launch_segment_order(const int* nacc, const int* nrej, int S, int* bi
 // ---- windowed order (kernels.hpp LTO_ORDER_WINDOW): three small launches.
 // (1) one workgroup per window: counting sort of its <= 1 024 segments by step count, heaviest first, into `local` (window-major);
 //     the window's key = its largest step count.
-__global__ __launch_bounds__(LTO_ORDER_WINDOW) void k_order_window(const int* nacc, const int* nrej, int S, int* local, int* wkey) {
+__global__ __launch_bounds__(LTO_ORDER_WINDOW) void k_order_window(const int* nacc, const int* nrej, int S, int W, int* local, int* wkey) {
   static_assert(LTO_ORDER_WINDOW == ORDER_BINS, "one thread per bin in the scan");
   __shared__ int h[ORDER_BINS];
   __shared__ int a[ORDER_BINS];
   __shared__ int top;
-  const int i = threadIdx.x;
-  const int s = blockIdx.x * LTO_ORDER_WINDOW + i;
+  const int i = threadIdx.x;                    // 1 024 threads: one per bin; the first W of them also own a segment
+  const int s = blockIdx.x * W + i;
   h[i] = 0;
   if (i == 0) top = 0;
   __syncthreads();
   int key = -1, rank = 0;
-  if (s < S) { key = order_key(nacc, nrej, s); rank = atomicAdd(&h[key], 1); atomicMax(&top, key); }
+  if (i < W && s < S) { key = order_key(nacc, nrej, s); rank = atomicAdd(&h[key], 1); atomicMax(&top, key); }
   __syncthreads();
   const int mine = h[ORDER_BINS - 1 - i];       // position i holds key ORDER_BINS-1-i: descending
   a[i] = mine;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(LTO_ORDER_WINDOW) void k_order_window(const int* na
   }
   h[ORDER_BINS - 1 - i] = a[i] - mine;          // start of bin (ORDER_BINS-1-i) inside the window
   __syncthreads();
-  if (s < S) local[blockIdx.x * LTO_ORDER_WINDOW + h[key] + rank] = s;
+  if (key >= 0) local[blockIdx.x * W + h[key] + rank] = s;
   if (i == 0) wkey[blockIdx.x] = top;
 }
 // (2) one workgroup: rank the windows by key (counting sort, heaviest first; a short last window ranks last) and give each its
@@ -249,14 +249,14 @@ __global__ __launch_bounds__(LTO_ORDER_WINDOW) void k_order_window(const int* na
 //     processing time first: what keeps the sweep from ending on a heavy wavefront that started late), while the group's windows
 //     (weave x ~200 KB of nodes and defects) stay inside the XCD's 4 MB of L2.
 //     wdst[w] = first position of w's group (or of w itself: the short window, never interleaved); winfo[w] = group size << 8 | slot.
-__global__ __launch_bounds__(ORDER_BINS) void k_order_place(const int* wkey, int nwin, int S, int weave, int* wdst, int* winfo) {
+__global__ __launch_bounds__(ORDER_BINS) void k_order_place(const int* wkey, int nwin, int S, int W, int weave, int* wdst, int* winfo) {
   // weave = 0: every window of an XCD's list in ONE group up to 16 windows (a sweep of one or two rounds must not end on the heavy
   // wavefronts of a small last group: the line search's 80 windows took 85 instead of 67 us with groups of 8 + 2), groups of 16 beyond
   if (weave <= 0) { const int nx = (nwin + LTO_XCDS - 1) / LTO_XCDS; weave = nx < 16 ? (nx < 1 ? 1 : nx) : 16; }
   __shared__ int h[ORDER_BINS];
   __shared__ int a[ORDER_BINS];
   const int i = threadIdx.x;
-  const bool has_short = (S % LTO_ORDER_WINDOW) != 0;
+  const bool has_short = (S % W) != 0;
   const int nfull = has_short ? nwin - 1 : nwin;              // full windows are ranked 0 .. nfull-1, the short one is rank nwin-1
   h[i] = 0;
   __syncthreads();
@@ -274,11 +274,11 @@ __global__ __launch_bounds__(ORDER_BINS) void k_order_place(const int* wkey, int
   h[ORDER_BINS - 1 - i] = a[i] - mine;          // first rank of the windows with key (ORDER_BINS-1-i); bumped as ranks are handed out
   __syncthreads();
   const int xs = (nwin - 1) % LTO_XCDS;          // the XCD whose list ends with the short window (if there is one)
-  const int deficit = nwin * LTO_ORDER_WINDOW - S;
+  const int deficit = nwin * W - S;
   auto list_len = [&](const int x) { return (nwin - x + LTO_XCDS - 1) / LTO_XCDS; };        // windows with rank = x mod 8
   auto list_start = [&](const int x) {
     int before = 0;
-    for (int q = 0; q < x; ++q) before += list_len(q) * LTO_ORDER_WINDOW - ((has_short && q == xs) ? deficit : 0);
+    for (int q = 0; q < x; ++q) before += list_len(q) * W - ((has_short && q == xs) ? deficit : 0);
     return before;
   };
   for (int w = i; w < nwin; w += ORDER_BINS) {
@@ -286,36 +286,37 @@ __global__ __launch_bounds__(ORDER_BINS) void k_order_place(const int* wkey, int
     const int r = is_short ? nwin - 1 : atomicAdd(&h[wkey[w]], 1);
     const int x = r % LTO_XCDS, j = r / LTO_XCDS;
     const int nf = list_len(x) - ((has_short && x == xs) ? 1 : 0);                           // full windows of this list
-    if (is_short) { wdst[w] = list_start(x) + nf * LTO_ORDER_WINDOW; winfo[w] = 0; continue; }
+    if (is_short) { wdst[w] = list_start(x) + nf * W; winfo[w] = 0; continue; }
     const int g = j / weave, m = j % weave;
     const int mg = (nf - g * weave) < weave ? (nf - g * weave) : weave;
-    wdst[w] = list_start(x) + g * weave * LTO_ORDER_WINDOW;
+    wdst[w] = list_start(x) + g * weave * W;
     winfo[w] = (mg << 8) | m;
   }
 }
 // (3) one workgroup per window: its local order to its place
-__global__ __launch_bounds__(256) void k_order_copy(const int* local, const int* wdst, const int* winfo, int S, int* order) {
+__global__ __launch_bounds__(256) void k_order_copy(const int* local, const int* wdst, const int* winfo, int S, int W, int* order) {
   const int w = blockIdx.x;
-  const int n = (S - w * LTO_ORDER_WINDOW) < LTO_ORDER_WINDOW ? (S - w * LTO_ORDER_WINDOW) : LTO_ORDER_WINDOW;
+  const int n = (S - w * W) < W ? (S - w * W) : W;
   const int dst = wdst[w], info = winfo[w];
   const int mg = info >> 8, m = info & 255;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int pos = (mg == 0) ? dst + i : dst + ((i >> 4) * mg + m) * 16 + (i & 15);
-    if (pos >= 0 && pos < S) order[pos] = local[w * LTO_ORDER_WINDOW + i];
+    if (pos >= 0 && pos < S) order[pos] = local[w * W + i];
   }
 }
 
 hipError_t launch_segment_order_windowed(const int* nacc, const int* nrej, int S, int weave, int* work, int* order, hipStream_t st) {
   if (S <= 0) return hipSuccess;
-  const int nwin = (S + LTO_ORDER_WINDOW - 1) / LTO_ORDER_WINDOW;
+  const int W = order_window_size(S);
+  const int nwin = (S + W - 1) / W;
   if (weave < 0 || weave > 255) return hipErrorInvalidValue;      // 0 = choose (k_order_place)
   int* local = work;
   int* wkey = work + S;
   int* wdst = wkey + nwin;
   int* winfo = wdst + nwin;
-  hipLaunchKernelGGL(k_order_window, dim3(nwin), dim3(LTO_ORDER_WINDOW), 0, st, nacc, nrej, S, local, wkey);
-  hipLaunchKernelGGL(k_order_place, dim3(1), dim3(ORDER_BINS), 0, st, wkey, nwin, S, weave, wdst, winfo);
-  hipLaunchKernelGGL(k_order_copy, dim3(nwin), dim3(256), 0, st, local, wdst, winfo, S, order);
+  hipLaunchKernelGGL(k_order_window, dim3(nwin), dim3(LTO_ORDER_WINDOW), 0, st, nacc, nrej, S, W, local, wkey);
+  hipLaunchKernelGGL(k_order_place, dim3(1), dim3(ORDER_BINS), 0, st, wkey, nwin, S, W, weave, wdst, winfo);
+  hipLaunchKernelGGL(k_order_copy, dim3(nwin), dim3(256), 0, st, local, wdst, winfo, S, W, order);
   return hipGetLastError();
 }
 
