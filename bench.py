@@ -186,6 +186,11 @@ def make_workload(wl, lto, synth, torch, ctx, st, dev, ndim=0, segments=0, metho
         w.extra.update(U=Ud, Jac=Jac, dtf=dtf, errs=errs)
     w.S, w.n, w.XC, w.T, w.prm, w.integ, w.plan, w.defect, w.Phi = S, n, XC, T, prm, integ, plan, defect, Phi
     w.sweep, w.desc, w.gather_rows = sweep, desc, gather_rows
+    # the compact line's name of the workload: BASELINE config, system, batch, integrator
+    w.token = {"c2": "c2 indirect %d-dim+STM S=%d %s" % (nd, S, method or "rk4x64"), "c2_defect": "c2_defect indirect %d-dim S=%d %s" % (nd, S, method or "rk4x64"),
+               "hbm": "hbm indirect %d-dim+STM S=%d rk4x1" % (nd, S), "c3": "c3 direct 6-dim+Jac6x18+tf S=%d rkf78 nsteps=10" % S,
+               "c4": "c4 homotopy %dx1024 12-dim+STM rk4x64" % w.levels, "c5": "c5 indirect 12-dim defect S=%d dop853 1e-13" % S,
+               "c5_stm": "c5_stm indirect 12-dim+STM S=%d dop853 1e-13" % S}[wl]
     return w
 
 
@@ -207,6 +212,11 @@ def parse():
     ap.add_argument("--method", default="", choices=["", "rk4", "rkf78", "dop853"], help="override the workload's integrator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="default line without the compact legs of the other BASELINE configs (`configs`)")
+    ap.add_argument("--verbose", action="store_true",
+                    help="print the long form of the line (every leg's full roofline object, the prose notes on how each figure was obtained); "
+                         "default: the compact line of compact_line() -- numbers and short tokens only, under LINE_BUDGET bytes")
+    ap.add_argument("--detail", default="", help="also write the long form to this file (the compact line's `detail` then names it)")
+    ap.add_argument("--strict", action="store_true", help="exit 1 when a leg failed or a parity figure exceeds its tolerance (the line's `ok` says so either way)")
     ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
                     help="roofline.traffic from counter passes of THIS run: rank 0 at N = 1 starts `rocprofv3 --pmc FETCH_SIZE` and "
                          "`--pmc WRITE_SIZE` (separate passes) on a child that runs the workload's sweep only; auto = when rocprofv3 is on "
@@ -272,6 +282,8 @@ def cpu_baseline(workload, seconds, threads=1, ndim=12, reference_algorithm=Fals
             break
     O.set_threads(1)
     return {"value": per_call * calls / el, "unit": "segment-integrations/s", "cores": used, "kind": "port",
+            "sample_token": "%d seg x %d sweeps / %.1f s, oracle %s, %d host cores" % (
+                per_call, calls, el, "c3 FD-Jacobian" if workload == "c3" else ("dop853 duals 12-dim" if reference_algorithm else "rk4x64 duals %d-dim" % ndim), os.cpu_count() or 0),
             "sample": "%d segments x %d sweeps in %.1f s; %s; host has %d cores" % (per_call, calls, el, what, os.cpu_count() or 0)}
 
 
@@ -796,7 +808,7 @@ CONFIG_LEGS = (("c3", "c3", 20, 3), ("c4", "c4", 8, 2), ("c5", "c5", 20, 3), ("c
 PARITY_SAMPLE = 64
 
 
-def _time_oracle(run, per_call, seconds, what):
+def _time_oracle(run, per_call, seconds, what, token=""):
     """One host core on a bounded sample: `run` repeated until `seconds` have passed (at least once after one untimed call)."""
     from oracle import oracle as O
     O.lib(); O.set_threads(1)
@@ -809,6 +821,7 @@ def _time_oracle(run, per_call, seconds, what):
         if el >= seconds:
             break
     return {"value": per_call * calls / el, "unit": "segment-integrations/s", "cores": 1, "kind": "port",
+            "sample_token": "%d seg x %d sweeps / %.1f s, oracle %s, %d host cores" % (per_call, calls, el, token, os.cpu_count() or 0),
             "sample": "%d segments x %d sweeps in %.1f s; %s; host has %d cores" % (per_call, calls, el, what, os.cpu_count() or 0)}
 
 
@@ -837,7 +850,7 @@ def config_parity_and_cpu(w, lto, seconds):
             O.direct_jacobian_fd(Xh, Uh, th, d, 10, lto.MU, lto.DU, lto.TU, 2000.0)
             O.direct_dtf_fd(Xh, Uh, th, 10, lto.MU, lto.DU, lto.TU, 2000.0)
         return parity, _time_oracle(run, ns, seconds, "direct defect + 18-column forward-difference Jacobian + tf partial (the reference's method, "
-                                                       "direct.jl:111-166,503-516), RKF7(8) nsteps=10")
+                                                       "direct.jl:111-166,503-516), RKF7(8) nsteps=10", "c3 FD-Jacobian")
     adaptive = wl in ("c5", "c5_stm")
     method, steps = (O.DOP853_ADAPTIVE, 0) if adaptive else (O.RK4, 1 if wl == "hbm" else 64)
     if wl == "c4":
@@ -881,7 +894,7 @@ def config_parity_and_cpu(w, lto, seconds):
             "c5": "defectCalc as the reference computes it (indirect.jl:63-90): adaptive order-8 pair (DOP853 for Vern8) at rtol = atol = 1e-13, C5's segment lengths and rho",
             "c5_stm": "jacobianCalc as the reference computes it (indirect.jl:93-146): the same adaptive solve on 12-partial dual numbers, C5's segment lengths and rho",
             "hbm": "indirect 12-dim + 12x12 STM by dual numbers through ONE RK4 step (same discrete map as the GPU run)"}[wl]
-    return parity, _time_oracle(run, cnt, seconds, what)
+    return parity, _time_oracle(run, cnt, seconds, what, {"c4": "rk4x64 duals", "c5": "dop853", "c5_stm": "dop853 duals", "hbm": "rk4x1 duals"}[wl])
 
 
 def leg_config(key, wl, steps, warmup, lto, synth, torch, ctx, st, dev, device_warmup_ms, cpu_seconds):
@@ -913,6 +926,8 @@ def leg_config(key, wl, steps, warmup, lto, synth, torch, ctx, st, dev, device_w
                "unit": "segment-integrations/s", "dtype": "f64"}
         if hasattr(plan, "last_kernel") and wl in ("c4", "c5_stm", "hbm"):       # the family of the STM sweep (defect-only sweeps have no such report)
             out["kernel"] = plan.last_kernel()
+        else:
+            out["kernel"] = {"c3": "direct-jacobian", "c5": "defect-lanes"}.get(wl)
         if c5:
             acc, rej = plan.step_counts(stream=st)
             tot = (acc + rej).astype(np.float64)
@@ -932,6 +947,179 @@ def leg_config(key, wl, steps, warmup, lto, synth, torch, ctx, st, dev, device_w
         return out
     finally:
         w.plan.close()
+
+
+# ---- the line the driver parses ---------------------------------------------------------------------------------------------------------
+# Round 5's default line had grown to 21.9 KB (prose repeated per leg) and the driver, which keeps the last ~8 KB of stdout, could not
+# parse it.  The default line is now compact_line(long form): the contract keys, numbers and short tokens only, LINE_BUDGET bytes at most
+# (tests/test_bench_meta.py holds it there); how each figure is obtained is said ONCE, in DESIGN.md section 6, and `--verbose` /
+# `--detail FILE` still give the long form.
+LINE_BUDGET = 6000
+DETAIL_DEFAULT = "profiles/r06z_bench_c2_verbose.json"      # the long form of the builder's run of this same command
+TOL_REL = 1e-10                                              # north_star: relative defect error vs the reference path
+# errors (direct.jl:104): ~1e-17, a cancellation at the rounding level -- a one-ulp change of an input moves it by 3e-4 of its maximum
+# (tests/test_oracle_golden.py::test_direct_errors_output_is_conditioned_at_the_rounding_level), so 1e-3 is what can be asked
+TOL_C3 = {"defect_max_abs": 1e-12, "jacobian_rel_max": 1e-11, "tf_column_max_abs": 1e-9, "errors_rel_max": 1e-3}
+
+
+def parity_ok(par):
+    """A leg's parity figures against the tolerances written next to them (indirect legs: relative defect L2 and max |dPhi| / max |Phi|
+    <= 1e-10; direct leg: TOL_C3)."""
+    if not par:
+        return None
+    if "defect_max_abs" in par:
+        return all(par.get(k) is not None and par[k] <= tol for k, tol in TOL_C3.items())
+    vals = [par.get("defect_rel_l2"), par.get("stm_rel_max")]
+    return all(v <= TOL_REL for v in vals if v is not None) and vals[0] is not None and par.get("oracle_rc", 0) == 0
+
+
+def _num(x, sig=5):
+    """Numbers of the compact line: `sig` significant digits; non-finite -> None (JSON has no NaN)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (sig, x))
+
+
+def _roof_compact(r, S):
+    if not r:
+        return None
+    other = r.get("hbm") or r.get("fp64") or {}
+    o = {"bound": r["bound"], "pipe": r.get("bound_actual"), "achieved": _num(r["achieved"]), "peak": r["peak"], "unit": r["unit"], "frac": _num(r["frac"], 4),
+         "traffic": _num(r.get("traffic"), 4), "algorithmic": int(r["bytes_per_segment"] * S) if r.get("bytes_per_segment") else None,
+         "kernel_ms": _num(r.get("kernel_ms")), "flops_per_segment": _num(r.get("flops_per_segment"), 6), "bytes_per_segment": r.get("bytes_per_segment"),
+         "other_roof_frac": _num(other.get("frac"), 3)}
+    src = r.get("traffic_from") or ""
+    o["traffic_src"] = "live" if src.startswith("measured in this run") else ("stored" if r.get("traffic") is not None else None)
+    return o
+
+
+def _leg_compact(leg, S=None):
+    """A leg of the long form -> {ms_per_step, value, kernel, kernel_ms, frac, bound, traffic, algorithmic, parity_defect, parity_stm,
+    cpu_value, ok}."""
+    if leg is None:
+        return None
+    if "error" in leg:
+        return {"error": str(leg["error"])[:120], "ok": False}
+    r = leg.get("roofline") or {}
+    S = S or leg.get("segments")
+    par = leg.get("parity") or {}
+    o = {"ms_per_step": _num(leg.get("ms_per_step")), "value": _num(leg.get("value")), "kernel": leg.get("kernel") or leg.get("stm_kernel"),
+         "kernel_ms": _num(r.get("kernel_ms")), "frac": _num(r.get("frac"), 4), "bound": r.get("bound"), "traffic": _num(r.get("traffic"), 4),
+         "algorithmic": int(r["bytes_per_segment"] * S) if (r.get("bytes_per_segment") and S) else None,
+         "parity_defect": _num(par.get("defect_rel_l2", par.get("defect_max_abs")), 3),
+         "parity_stm": _num(par.get("stm_rel_max", par.get("jacobian_rel_max")), 3),
+         "cpu_value": _num((leg.get("cpu_baseline") or {}).get("value"))}
+    if "errors_rel_max" in par:
+        o["parity_errors"] = _num(par["errors_rel_max"], 3)
+    ad = leg.get("adaptive")
+    if ad:
+        o["trial_steps"] = [_num(ad.get("trial_steps_mean", ad.get("steps_accepted_mean", 0.0) + ad.get("steps_rejected_mean", 0.0)), 4),
+                            ad.get("trial_steps_max", None)]
+    if par:
+        o["ok"] = parity_ok(par)
+    return o
+
+
+def legs_failed(out):
+    """Names of the legs of the long form whose parity is out of tolerance or that raised."""
+    bad = []
+    if out.get("parity") is not None and not parity_ok(out["parity"]):
+        bad.append("main")
+    for name in ("reference_system_12dim", "reference_integrator"):
+        leg = out.get(name)
+        if leg is not None and leg.get("parity") is not None and not parity_ok(leg["parity"]):
+            bad.append(name)
+    for key, leg in (out.get("configs") or {}).items():
+        if "error" in leg or (leg.get("parity") is not None and not parity_ok(leg["parity"])):
+            bad.append(key)
+    for it in ((out.get("newton_iteration") or {}).get("sizes") or []):
+        if not it.get("finite", True):
+            bad.append("newton_%d" % it["segments"])
+    return bad
+
+
+def compact_line(out, detail=None):
+    """The default line: the long form `out` reduced to the contract keys, numbers and short tokens."""
+    if "error" in out and "metric" not in out:
+        return out
+    cfg = out.get("config", {})
+    S = cfg.get("segments_per_gpu")
+    line = {k: out.get(k) for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _num(out["value"], 6), _num(out["ms_per_step"], 6)
+    c = {"workload": cfg.get("workload_token") or str(cfg.get("workload", ""))[:100], "segments_per_gpu": S, "global_segments": cfg.get("global_segments"),
+         "kernel": cfg.get("stm_kernel"), "collective": cfg.get("collective_token", "none")}
+    for k in ("stream", "devices_token", "slab_ok", "transports", "rccl_ranks", "policy"):
+        if cfg.get(k) is not None:
+            c[k] = cfg[k]
+    line["config"] = c
+    line["roofline"] = _roof_compact(out.get("roofline"), S)
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _num(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb.get("sample_token") or str(cb.get("sample", ""))[:60]}
+        for k, short in (("cpu_baseline_reference_algorithm", "ref_alg"), ("cpu_baseline_all_cores", "all_cores")):
+            if out.get(k):
+                line["cpu_baseline"][short] = [_num(out[k]["value"]), out[k]["cores"]]
+    par = out.get("parity")
+    if par:
+        line["parity"] = {"defect_rel_l2": _num(par.get("defect_rel_l2", par.get("defect_max_abs")), 3),
+                          "stm_rel_max": _num(par.get("stm_rel_max", par.get("jacobian_rel_max")), 3), "tol": TOL_REL if "defect_rel_l2" in par else TOL_C3["defect_max_abs"],
+                          "n": par.get("sample_segments"), "ok": parity_ok(par)}
+    if out.get("cold_clocks"):
+        line["cold_ms_per_step"] = _num(out["cold_clocks"]["ms_per_step"])
+    if out.get("adaptive"):
+        ad = out["adaptive"]
+        line["adaptive"] = {k: _num(v, 4) for k, v in ad.items() if k != "note"}
+    if out.get("reference_system_12dim"):
+        line["ref12"] = _leg_compact(out["reference_system_12dim"], 4096)
+    ri = out.get("reference_integrator")
+    if ri:
+        o = _leg_compact(ri, 4096)
+        o["defect_only_ms"] = _num(ri["defect_only"]["ms_per_step"])
+        o["warm_ms"] = [_num(ri["warm_start"]["ms_per_step"]), _num(ri["warm_start"]["defect_only_ms_per_step"])]
+        line["refint"] = o
+    ha = out.get("host_api")
+    if ha:
+        line["host_api_ms"] = {"pageable": _num(ha["ms_per_call_pageable"], 4), "pinned": _num(ha["ms_per_call_page_locked"], 4),
+                               "in_lib": [_num(ha["ms_in_library_pageable"], 4), _num(ha["ms_in_library_page_locked"], 4)]}
+    nw = out.get("newton_iteration")
+    if nw:
+        line["newton_us"] = {str(it["segments"]): [_num(it["us_per_iteration"], 4), _num(it["us_per_iteration_without_host_reads"], 4), _num(it["split_sum_us"], 4),
+                                                     _num((it.get("cpu_baseline") or {}).get("value"), 4)] for it in nw["sizes"]}
+    if out.get("configs"):
+        line["configs"] = {k: _leg_compact(v) for k, v in out["configs"].items()}
+    bad = legs_failed(out)
+    line["ok"] = not bad
+    if bad:
+        line["failed"] = bad
+    line["detail"] = detail or DETAIL_DEFAULT
+    return line
+
+
+def emit(out, a):
+    """Print the line (compact unless --verbose) as the LAST thing on stdout; `--detail FILE` keeps the long form.  Returns the exit code
+    (`--strict`: 1 when a leg failed)."""
+    bad = legs_failed(out) if "metric" in out else []
+    out["ok"] = not bad
+    if bad:
+        out["failed"] = bad
+        sys.stderr.write("bench.py: legs out of tolerance or failed: %s\n" % ", ".join(bad))
+    detail = None
+    if a.detail:
+        try:
+            with open(a.detail, "w") as fh:
+                json.dump(out, fh)
+                fh.write("\n")
+            detail = os.path.relpath(a.detail, ROOT) if os.path.isabs(a.detail) else a.detail
+        except OSError as ex:
+            sys.stderr.write("bench.py: --detail %s: %s\n" % (a.detail, ex))
+    text = json.dumps(out if a.verbose else compact_line(out, detail))
+    sys.stdout.flush()
+    print(text, flush=True)
+    return 1 if (bad and a.strict) else 0
 
 
 def self_launch(a):
@@ -1004,12 +1192,16 @@ def main():
             return
         res = leg_newton(lto, synth, ctx, st, torch, sizes, 0.0 if a.no_cpu_baseline else a.cpu_seconds / 3)
         big = res["sizes"][-1]
-        print(json.dumps({"metric": "time per iteration of multiShoot_CRTBP_indirect's Newton loop (device-resident)", "value": big["us_per_iteration"],
-                          "unit": "us", "n_gpus": 1, "steps": 40, "warmup": 5, "ms_per_step": big["us_per_iteration"] * 1e-3,
-                          "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": "newton: %d segments, 12-dim, adaptive order 8 @ 1e-13" % big["segments"]},
-                          "newton_iteration": res}), flush=True)
+        code = emit({"metric": "time per iteration of multiShoot_CRTBP_indirect's Newton loop (device-resident)", "value": big["us_per_iteration"],
+                     "unit": "us", "n_gpus": 1, "steps": 40, "warmup": 5, "ms_per_step": big["us_per_iteration"] * 1e-3,
+                     "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                     "config": {"workload": "newton: %d segments, 12-dim, adaptive order 8 @ 1e-13" % big["segments"],
+                                "workload_token": "newton S=%d 12-dim dop853 1e-13" % big["segments"], "segments_per_gpu": big["segments"],
+                                "global_segments": big["segments"]},
+                     "newton_iteration": res}, a)
         ctx.close()
+        if code:
+            raise SystemExit(code)
         return
     if a.ndim == 0:
         a.ndim = default_ndim(wl)
@@ -1030,7 +1222,8 @@ def main():
     # The collective of the product: the library's own RCCL all-gather (lto_comm_allgather_dev; communicator created from an
     # id that rank 0 makes and torch.distributed hands round).  If any rank cannot set it up, every rank falls back to
     # torch.distributed's all_gather_into_tensor (also RCCL) and the JSON line says so.
-    native, native_note, transport = None, None, "torch.distributed"
+    native, native_note, transport = None, None, "torch"
+    comms = {}               # transport name -> communicator that every rank set up and whose test gather came back right everywhere
     # Stream of the collective (LTO_BENCH_COLLECTIVE_STREAM):
     #   main   the sweep's stream, right after the sweep: stream order is the dependency
     #   side   a second stream: the gather of step k runs beside the sweep of step k + 1 (two defect / gather buffers alternate)
@@ -1046,15 +1239,22 @@ def main():
     main = torch.cuda.current_stream()
     comm_stream = (main if same_stream else torch.cuda.Stream(device=dev)) if use_coll else None
     policy = "serial" if same_stream else "overlap"      # side: overlap; auto: decided below
-    policy_note = None
+    policy_trial = None
+    transport_trial = None
+    rccl_ranks = None
     if use_coll:
-        # Transport of the library's collective, in order of preference (LTO_BENCH_TRANSPORT = windows | rccl | torch):
+        # Transports of the library's collective (LTO_BENCH_TRANSPORT = auto | windows | rccl | torch; default auto):
+        #   rccl     lto_comm_create + ncclAllGather: the collective north_star names (RCCL over xGMI)
         #   windows  lto_comm_window_*: every rank pushes its slab into IPC-mapped receive windows with device copies and raises a
         #            flag; no RCCL kernel, so no compute unit is taken from the sweep that holds a workgroup on every CU
-        #   rccl     lto_comm_create + ncclAllGather
-        #   torch    torch.distributed.all_gather_into_tensor (also RCCL)
-        # A transport is used only if EVERY rank set it up AND a test gather of rank-stamped slabs came back right everywhere.
-        want = "windows" if share else os.environ.get("LTO_BENCH_TRANSPORT", "windows")
+        #   torch    torch.distributed.all_gather_into_tensor (also RCCL): only when neither of the library's own could be set up
+        # auto: BOTH are set up, checked (a test gather of rank-stamped slabs must come back right on every rank) and TIMED before the
+        # timed legs (ten steps each, the slowest rank's time); the faster one carries the timed legs, and the line reports both times
+        # and the number of ranks the RCCL communicator saw (`rccl_ranks` = ncclCommCount), whichever was chosen.  Ranks that share a
+        # device (the one-GPU rehearsal) have the windows only: RCCL refuses two ranks on one device.
+        want = "windows" if share else os.environ.get("LTO_BENCH_TRANSPORT", "auto")
+        if want not in ("auto", "windows", "rccl", "torch"):
+            raise SystemExit("LTO_BENCH_TRANSPORT must be auto, windows, rccl or torch")
         notes = []
 
         def agreed(ok):
@@ -1083,7 +1283,7 @@ def main():
 
         # Every torch.distributed collective below is issued by EVERY rank whatever failed locally (advisor finding, round 3: a rank
         # that skipped one left its peers hanging in it): a failed step travels as None / an empty blob, the verdict is all-reduced.
-        kinds = ["windows"] if share else (["windows", "rccl"] if want == "windows" else ["rccl"] if want == "rccl" else [])
+        kinds = ["windows"] if share else {"auto": ["windows", "rccl"], "windows": ["windows", "rccl"], "rccl": ["rccl"], "torch": []}[want]
         for kind in kinds:
             cand = half = None
             try:
@@ -1100,6 +1300,9 @@ def main():
                         # ranks on ONE device: the collect kernel's polling blocks (thousands for a multi-megabyte slab) would keep the
                         # peers' push kernels off the compute units; such payloads go by the copy engines here (lto.h)
                         cand.set_kernel_payload(1 << 20)
+                        # ... and a peer that is time-sliced out by three others may take long to raise its flag: the bounded wait gets
+                        # ten times the default polls before it poisons the result (the default, ~6 s, ran out once in six four-rank runs)
+                        cand.set_wait_limit(40000000)
                 else:
                     box = [None]
                     if rank == 0:
@@ -1111,21 +1314,26 @@ def main():
                     if box[0] is None:
                         raise RuntimeError("rank 0 could not create an RCCL id")
                     cand = lto.Comm(ctx, world, rank, box[0])
-            except Exception as ex:      # noqa: BLE001 -- any failure means "try the next transport"
+            except Exception as ex:      # noqa: BLE001 -- any failure means "this transport is out"
                 half = getattr(ex, "comm", None)
                 notes.append("%s: %s: %s" % (kind, type(ex).__name__, ex))
             ok = agreed(cand is not None)
             if ok:
                 ok = agreed(gather_works(cand))
             if ok:
-                native, transport = cand, kind
-                break
+                comms[kind] = cand
+                continue
             dist.barrier()               # nobody closes (unmaps) anything a peer may still be touching
             for c in (cand, half):
                 if c is not None:
                     c.close()
             notes.append("%s not usable on every rank" % kind)
         native_note = "; ".join(notes) if notes else None
+        if "rccl" in comms:
+            rccl_ranks = comms["rccl"].rccl_ranks()
+        if comms:
+            transport = next(k for k in kinds if k in comms)       # overwritten below when both are there and were timed
+            native = comms[transport]
         if share and native is None and world > 1:
             # ranks that share a device have no other transport: every rank leaves the same way (no hang, no half-open windows)
             sys.stderr.write("rank %d: %s\n" % (rank, native_note))
@@ -1167,24 +1375,41 @@ def main():
             if not same_stream and policy == "serial":
                 main.wait_event(ev_done[b])            # the next sweep starts behind the gather, as on one stream
 
+    def trial_ms(steps=10):
+        """`steps` steps of the N > 1 path as configured right now, after four untimed ones: ms per step, the slowest rank's time (the
+        same number on every rank)."""
+        for k in range(4):
+            step(k, k >= len(dbufs))
+        comm_stream.synchronize(); torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k, True)
+        comm_stream.synchronize(); torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        return float(tt.item()) / steps * 1e3
+
+    if use_coll and len(comms) > 1:
+        # both transports of the library carried the test gather: time each in the step loop the timed legs run (the wait policy at
+        # its safe setting), the faster one carries the timed legs unless LTO_BENCH_TRANSPORT names one
+        keep = policy
+        policy = "serial"
+        transport_trial = {}
+        for kind in kinds:
+            native = comms[kind]
+            transport_trial[kind + "_ms"] = trial_ms()
+        policy = keep
+        transport = want if want in comms else min(comms, key=lambda k: transport_trial[k + "_ms"])
+        transport_trial["chosen"] = transport
+        native = comms[transport]
     if use_coll and coll_mode == "auto":
-        trial = {}
+        policy_trial = {}
         for pol in ("serial", "overlap"):
             policy = pol
-            for k in range(4):
-                step(k, k >= len(dbufs))
-            comm_stream.synchronize(); torch.cuda.synchronize(); dist.barrier()
-            t0 = time.perf_counter()
-            for k in range(10):
-                step(k, True)
-            comm_stream.synchronize(); torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # the slowest rank's time, the same number on every rank
-            trial[pol] = float(tt.item()) / 10 * 1e3
-            dist.barrier()
-        policy = "overlap" if trial["overlap"] < trial["serial"] else "serial"
-        policy_note = "measured before the timed legs (10 steps each, slowest rank): serial %.4f ms per step, overlap %.4f ms -> %s" % (
-            trial["serial"], trial["overlap"], policy)
+            policy_trial[pol + "_ms"] = trial_ms()
+        policy = "overlap" if policy_trial["overlap_ms"] < policy_trial["serial_ms"] else "serial"
+        policy_trial["chosen"] = policy
 
     def timed_leg():
         """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize."""
@@ -1254,6 +1479,7 @@ def main():
     # sanity: the sweep produced finite numbers (a failed launch would leave zeros / raise earlier)
     assert bool(torch.isfinite(defect).all()), "non-finite defect in benchmark sweep"
 
+    exit_code = 0
     if rank == 0:
         value = world * S * a.steps / elapsed
         out = {
@@ -1263,17 +1489,22 @@ def main():
             # c4 / c5 shard a FIXED global size (256 levels, 65 536 segments) over the ranks; the others give every rank its own batch
             "scaling": "strong" if (wl in ("c4", "c5", "c5_stm") and not a.segments) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "segments_per_gpu": S, "global_segments": world * S,
+            "config": {"workload": desc, "workload_token": w.token, "segments_per_gpu": S, "global_segments": world * S,
+                       # collective_token: none | windows | rccl | torch;  stream: main | side;  the long forms follow
+                       "collective_token": (transport if use_coll else "none"), "stream": (("main" if same_stream else "side") if use_coll else None),
+                       "devices_token": (("shared" if share and world > 1 else "distinct") if use_coll else None),
+                       "slab_ok": (True if use_coll else None),          # asserted above on every rank: own slab bit-equal, every slab finite
+                       "transports": transport_trial, "rccl_ranks": rccl_ranks, "policy": policy_trial if policy_trial else (policy if use_coll else None),
                        "slab_check": ("passed on every rank: own slab of the gathered defect vector bit-equal to the sweep's output, every slab finite"
                                       if use_coll else "no collective"),
                        "devices": ("all %d ranks share device 0 (LTO_BENCH_SHARE_DEVICE=1): a functional run of the N > 1 path, not a scaling figure" % world
                                    if share and world > 1 else "one device per rank"),
                        "collective": ("none" if not use_coll else
                                       "lto_comm_allgather_dev of the defect slabs after every sweep, on %s; transport: %s%s" % (
-                                          "the sweep's stream" if same_stream else ("a side stream, %s" % ("overlapping the next sweep" if policy == "overlap" else "the next sweep waiting for it")) + (" [%s]" % policy_note if policy_note else ""),
+                                          "the sweep's stream" if same_stream else ("a side stream, %s" % ("overlapping the next sweep" if policy == "overlap" else "the next sweep waiting for it")),
                                           {"windows": "IPC receive windows + device copies + flag kernel (no RCCL kernel, no CU taken from the sweep)",
                                            "rccl": "ncclAllGather (RCCL over xGMI)"}[transport],
-                                          "" if not native_note else " [tried first: %s]" % native_note)
+                                          "" if not native_note else " [set-up notes: %s]" % native_note)
                                       if native is not None else
                                       "torch.distributed all_gather_into_tensor (RCCL) after every sweep; the library's "
                                       "communicator was not used: %s" % native_note), "integrator": "see workload"},
@@ -1378,16 +1609,18 @@ def main():
             if not a.no_cpu_baseline:
                 ref12[1]()
                 refint[1]()
-        print(json.dumps(out), flush=True)
+        exit_code = emit(out, a)
     if use_coll:
         dist.barrier()              # nobody unmaps a window a peer may still be pushing into
-    if native is not None:
-        native.close()
+    for c in comms.values():
+        c.close()
     if use_coll:
         dist.destroy_process_group()
     if plan is not None:
         plan.close()   # plans before their context (lto_destroy frees what lto_*_plan_destroy touches)
     ctx.close()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

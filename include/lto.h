@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LTO_VERSION 101 /* 0.1.1: round 5 added LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us; nothing was removed or changed */
+#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
 
 /* error codes */
 #define LTO_OK 0
@@ -465,6 +465,9 @@ void lto_comm_destroy(lto_comm* comm);
 const char* lto_comm_last_error(const lto_comm* comm);
 int lto_comm_size(const lto_comm* comm);
 int lto_comm_rank(const lto_comm* comm);
+/* Number of ranks RCCL itself reports for this communicator (ncclCommCount): world for an lto_comm_create communicator, 0 for a
+ * window communicator (no RCCL behind it), LTO_ENULL / LTO_EUNSUPPORTED (< 0) when it cannot be asked.  What a scaling run quotes as "RCCL saw N ranks". */
+int lto_comm_rccl_ranks(const lto_comm* comm);
 /* recv [world][count] <- send [count] of every rank (equal counts); asynchronous on `stream` (hipStream_t). */
 int lto_comm_allgather_dev(lto_comm* comm, void* stream, const double* send, double* recv, long count);
 /* buf [count] <- LTO_COMM_SUM / LTO_COMM_MAX over ranks, in place; asynchronous on `stream`.  Both propagate NaN (the max

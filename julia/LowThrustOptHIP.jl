@@ -492,7 +492,14 @@ function comm_failed(c::LtoComm, stream)
     f[] != 0
 end
 "Polls (~1.5 us each) before a wait for a peer gives up and poisons the result."
-set_kernel_payload!(c::LtoComm, bytes::Integer) = comm_check(c, ccall((:lto_comm_set_kernel_payload, liblto), Cint, (Ptr{Cvoid}, Clong), c.handle, bytes))
 set_wait_limit!(c::LtoComm, polls::Integer) = comm_check(c, ccall((:lto_comm_set_wait_limit, liblto), Cint, (Ptr{Cvoid}, Clong), c.handle, polls))
+"Window transport: payloads of up to `bytes` per rank travel by the push / collect kernels, larger ones by the copy engines (lto.h)."
+set_kernel_payload!(c::LtoComm, bytes::Integer) = comm_check(c, ccall((:lto_comm_set_kernel_payload, liblto), Cint, (Ptr{Cvoid}, Clong), c.handle, bytes))
+"Ranks RCCL itself reports for this communicator (ncclCommCount); 0 for a window communicator."
+function rccl_ranks(c::LtoComm)
+    n = ccall((:lto_comm_rccl_ranks, liblto), Cint, (Ptr{Cvoid},), c.handle)
+    n >= 0 || error("lto_comm_rccl_ranks failed with code $n")
+    Int(n)
+end
 
 end # module

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
         }
 #pragma unroll
       for (int c = 0; c < NS; ++c) {
-        if (is_base) maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
+        if (is_base) maxErr = fmax(maxErr, fabs(rkf78_err_term(h, K[0][c], K[10][c], K[11][c], K[12][c])));
         y[c] = __builtin_fma(h, acc[c], y[c]);
       }
     } else {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
 #pragma unroll
         for (int k = 0; k < 13; ++k)
           if (TabRKF78::B[k] != 0.0) acc = __builtin_fma(TabRKF78::B[k], K[k][c], acc);
-        if (is_base) maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
+        if (is_base) maxErr = fmax(maxErr, fabs(rkf78_err_term(h, K[0][c], K[10][c], K[11][c], K[12][c])));
         y[c] = __builtin_fma(h, acc, y[c]);
       }
     }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
       if constexpr (METHOD == M_RKF78_FIXED) if (is_base) {
 #pragma unroll
         for (int c = 0; c < ND; ++c)
-          maxErr = fmax(maxErr, fabs((K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0))));
+          maxErr = fmax(maxErr, fabs(rkf78_err_term(h, K[0][c], K[10][c], K[11][c], K[12][c])));
       }
     }
     nacc = a.steps;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_indirect_coop(const IndirectArgs a) {
           double delta = 0.0, nx = 0.0, gsum = 0.0;
 #pragma unroll
           for (int c = 0; c < ND; ++c) {
-            const double g = (K[0][c] + K[10][c] - K[11][c] - K[12][c]) * (h * (41.0 / 840.0));
+            const double g = rkf78_err_term(h, K[0][c], K[10][c], K[11][c], K[12][c]);
             delta = fmax(delta, fabs(g));
             nx = fmax(nx, fabs(y[c]));
             gsum += g + y[c];

@@ -43,6 +43,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -64,6 +65,7 @@ Rccl& rccl() {
     q.CommInitRank = (decltype(q.CommInitRank))sym("ncclCommInitRank");
     q.CommInitAll = (decltype(q.CommInitAll))sym("ncclCommInitAll");
     q.CommDestroy = (decltype(q.CommDestroy))sym("ncclCommDestroy");
+    q.CommCount = (decltype(q.CommCount))sym("ncclCommCount");
     q.AllGather = (decltype(q.AllGather))sym("ncclAllGather");
     q.AllReduce = (decltype(q.AllReduce))sym("ncclAllReduce");
     q.GroupStart = (decltype(q.GroupStart))sym("ncclGroupStart");
@@ -331,6 +333,13 @@ void lto_comm_destroy(lto_comm* c) {
 const char* lto_comm_last_error(const lto_comm* c) { return c ? c->err : "null communicator"; }
 int lto_comm_size(const lto_comm* c) { return c ? c->world : 0; }
 int lto_comm_rank(const lto_comm* c) { return c ? c->rank : -1; }
+int lto_comm_rccl_ranks(const lto_comm* c) {
+  if (!c) return LTO_ENULL;
+  if (c->windows || !c->comm) return 0;
+  int n = 0;
+  if (!rccl().CommCount || rccl().CommCount(c->comm, &n) != ncclSuccess) return LTO_EUNSUPPORTED;
+  return n;
+}
 
 /* ---- window transport: export (every rank) -> the launcher gathers the world handles -> open (every rank) ---- */
 int lto_comm_window_export(lto_ctx* ctx, int world, int rank, long max_count, void* handle_out, lto_comm** out) {

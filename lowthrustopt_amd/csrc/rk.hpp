@@ -68,6 +68,19 @@ struct TabRKF78 {
   static constexpr double E[13] = {41. / 840, 0, 0, 0, 0, 0, 0, 0, 0, 0, 41. / 840, -41. / 840, -41. / 840};
 };
 
+// Error term of one component in the reference's operation order (ode.jl:940, `gamma1 = hi*41/840*f*psi_`): the slopes are scaled
+// by (hi*41)/840 first, then summed over k in order against psi_ = (1, 0 ... 0, 1, -1, -1) -- every product rounded before it is added
+// (no contraction).  The term is a difference of O(1) slopes at the 1e-16 level (errors ~ 1e-17 at the demo's step size), so the
+// order of these seven operations is what its low bits are made of.
+__device__ __forceinline__ double rkf78_err_term(const double h, const double k0, const double k10, const double k11, const double k12) {
+  const double c = __ddiv_rn(__dmul_rn(h, 41.0), 840.0);
+  double g = __dmul_rn(c, k0);
+  g = __dadd_rn(g, __dmul_rn(c, k10));
+  g = __dadd_rn(g, -__dmul_rn(c, k11));
+  g = __dadd_rn(g, -__dmul_rn(c, k12));
+  return g;
+}
+
 // One RKF7(8) step.  ynew = y + h sum_k chi_k f_k (local extrapolation, ode.jl:937);
 // returns delta = || h 41/840 sum_k psi_k f_k ||_inf over the first NERR components (ode.jl:940-943).
 // NANPROP (adaptive callers): a NaN component makes delta NaN, as the reference's maximum() does; fmax alone drops it.
@@ -132,7 +145,7 @@ __device__ __forceinline__ double rkf78_step(const Sys& sys, const double h, con
   for (int i = 0; i < D; ++i) {
     ynew[i] = __builtin_fma(h, a[i], y[i]);
     if (i < NERR) {
-      const double g = (K[0][i] + K[10][i] - K[11][i] - K[12][i]) * (h * (41.0 / 840.0));
+      const double g = rkf78_err_term(h, K[0][i], K[10][i], K[11][i], K[12][i]);
       delta = fmax(delta, fabs(g));
       if (NANPROP) gsum += g;
     }
@@ -420,7 +433,7 @@ __device__ __forceinline__ double rkf78_step_mem(const Sys& sys, const double h,
   double delta = 0.0, gsum = 0.0;
 #pragma unroll
   for (int i = 0; i < NERR; ++i) {
-    const double g = (K[0][i] + K[10][i] - K[11][i] - K[12][i]) * (h * (41.0 / 840.0));
+    const double g = rkf78_err_term(h, K[0][i], K[10][i], K[11][i], K[12][i]);
     delta = fmax(delta, fabs(g));
     gsum += g;
   }

@@ -231,6 +231,13 @@ class Comm:
     def uses_windows(self):
         return bool(self.lib.lto_comm_uses_windows(self.handle))
 
+    def rccl_ranks(self):
+        """Ranks RCCL reports for this communicator (ncclCommCount); 0 for a window communicator."""
+        n = self.lib.lto_comm_rccl_ranks(self.handle)
+        if n < 0:
+            raise LtoError(n, "lto_comm_rccl_ranks failed")
+        return int(n)
+
     def check(self, rc):
         if rc != 0:
             msg = self.lib.lto_comm_last_error(self.handle)

@@ -61,3 +61,84 @@ def test_roofline_object_quotes_the_profile_of_its_own_batch_size():
     assert r["traffic"] is None and "no counter profile" in r["traffic_from"]
     h = bench.roofline("hbm", 12, bench.HBM_SEGMENTS, 0.254)
     assert h["bound"] == "hbm" and abs(h["frac"] - 1456 * bench.HBM_SEGMENTS / 0.254e-3 / 8e12) < 1e-6
+
+
+def _canned_long_form():
+    """A long form with every leg the default run produces: the builder's round-5 driver line (profiles/, 21.9 KB -- the one the driver
+    could not parse), which has all of them."""
+    with open(os.path.join(ROOT, "profiles", "r05z_bench_c2_driver.json")) as fh:
+        return json.loads(fh.read().strip().splitlines()[-1])
+
+
+def test_default_line_budget():
+    """the default line is compact_line(long form) -- under LINE_BUDGET (6 000) bytes, a JSON object that
+    round-trips, with the contract keys and roofline / cpu_baseline / parity at the top level, numbers and short tokens only."""
+    long_form = _canned_long_form()
+    assert len(json.dumps(long_form)) > 20000
+    line = bench.compact_line(long_form)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_BUDGET == 6000, len(text)
+    back = json.loads(text)
+    assert back == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity", "configs", "ok", "detail"):
+        assert k in back, k
+    assert back["metric"] == long_form["metric"] and back["steps"] == 20 and back["warmup"] == 5 and back["n_gpus"] == 1
+    assert abs(back["value"] / long_form["value"] - 1) < 1e-5 and abs(back["ms_per_step"] / long_form["ms_per_step"] - 1) < 1e-5
+    r = back["roofline"]
+    assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and r["bound"] in ("hbm", "mfma")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and abs(r["frac"] / long_form["roofline"]["frac"] - 1) < 1e-3
+    assert r["algorithmic"] == 1920 * 4096 and r["traffic"] > 0
+    cb = back["cpu_baseline"]
+    assert set(cb) >= {"value", "unit", "cores", "kind", "sample"} and cb["kind"] == "port" and cb["cores"] == 1
+    assert list(back["configs"]) == ["c3", "c4", "c5", "c5_stm", "hbm"]
+    for key, leg in back["configs"].items():
+        assert set(leg) >= {"ms_per_step", "value", "kernel", "kernel_ms", "frac", "bound", "traffic", "algorithmic", "parity_defect",
+                            "parity_stm", "cpu_value", "ok"}, key
+        assert leg["ok"] is True and leg["frac"] > 0
+    assert back["ok"] is True and "failed" not in back
+
+    def strings(o):
+        if isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, list):
+            for v in o:
+                yield from strings(v)
+        elif isinstance(o, str):
+            yield o
+    assert max(len(s) for s in strings(back)) <= 100            # tokens, not prose
+
+
+def test_line_reports_a_failed_leg_and_a_parity_figure_out_of_tolerance():
+    """Advisor finding, round 5: a crashed leg or a parity regression must not look like success."""
+    long_form = _canned_long_form()
+    long_form["configs"]["c4"] = {"error": "RuntimeError: planted"}
+    long_form["configs"]["c5"]["parity"]["defect_rel_l2"] = 3e-9
+    long_form["reference_integrator"]["parity"]["stm_rel_max"] = 1e-6
+    assert bench.legs_failed(long_form) == ["reference_integrator", "c4", "c5"]
+    line = bench.compact_line(long_form)
+    assert line["ok"] is False and line["failed"] == ["reference_integrator", "c4", "c5"]
+    assert line["configs"]["c4"]["ok"] is False and line["configs"]["c5"]["ok"] is False and line["refint"]["ok"] is False
+    assert len(json.dumps(line)) < bench.LINE_BUDGET
+    long_form = _canned_long_form()
+    long_form["parity"]["defect_rel_l2"] = float("nan")
+    assert bench.legs_failed(long_form) == ["main"] and bench.compact_line(long_form)["parity"]["ok"] is False
+
+
+def test_multi_rank_line_stays_compact_and_names_both_transports():
+    """N > 1: no config legs, no per-rank prose; the line shows the time of both transports, which one carried the timed legs, and how
+    many ranks RCCL saw."""
+    long_form = _canned_long_form()
+    for k in ("configs", "reference_system_12dim", "reference_integrator", "newton_iteration", "host_api", "cpu_baseline", "parity",
+              "cpu_baseline_all_cores", "cpu_baseline_reference_algorithm"):
+        long_form.pop(k, None)
+    long_form["n_gpus"] = 8
+    long_form["config"].update(collective_token="windows", stream="side", devices_token="distinct", slab_ok=True, rccl_ranks=8,
+                               transports={"windows_ms": 0.081, "rccl_ms": 0.094, "chosen": "windows"},
+                               policy={"serial_ms": 0.09, "overlap_ms": 0.081, "chosen": "overlap"}, global_segments=8 * 4096)
+    line = bench.compact_line(long_form)
+    assert len(json.dumps(line)) < 2000
+    c = line["config"]
+    assert c["collective"] == "windows" and c["rccl_ranks"] == 8 and c["transports"]["chosen"] == "windows" and c["policy"]["chosen"] == "overlap"
+    assert c["stream"] == "side" and c["devices_token"] == "distinct" and c["slab_ok"] is True

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_codes():
     lib = lto.load_library()
-    assert lib.lto_version() == 101
+    assert lib.lto_version() == 102
     assert (_lib.LTO_EINVAL, _lib.LTO_ENULL, _lib.LTO_EUNSUPPORTED) == (-1, -2, -3)
     assert lib.lto_create(None, 0) == _lib.LTO_ENULL
 

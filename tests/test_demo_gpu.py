@@ -61,3 +61,32 @@ def test_halo_transfer_demo_continuation_to_the_reference_target():
     thr = 0.5 * (1.0 + np.tanh((lam - 1.0) / (2.0 * rho_target)))
     assert np.mean((thr < 1e-6) | (thr > 1.0 - 1e-6)) >= 0.8
     assert time.perf_counter() - t0 < 30.0
+
+
+@pytest.mark.gpu
+def test_default_bench_line_is_compact_complete_and_every_leg_within_tolerance():
+    """The line the driver parses (advisor finding on bench.py:1371): `bench.py` with the driver's flags prints
+    ONE line last on stdout, under 6 000 bytes, with roofline / cpu_baseline / parity at the top level and the five BASELINE config
+    legs; every leg's oracle sample is COMPARED with its tolerance (`ok`), and `--strict` turns a failed leg into a non-zero exit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2",
+                        "--live-traffic", "off", "--strict"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 6000, (len(lines), len(lines[-1]))
+    out = json.loads(lines[0])
+    assert out["ok"] is True and "failed" not in out
+    assert out["steps"] == 20 and out["warmup"] == 5 and out["n_gpus"] == 1 and out["dtype"] == "f64"
+    assert out["parity"]["ok"] is True and out["parity"]["defect_rel_l2"] < 1e-10
+    assert out["roofline"]["bound"] == "mfma" and 0.2 < out["roofline"]["frac"] < 1.0 and out["roofline"]["traffic"] > 0
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert list(out["configs"]) == ["c3", "c4", "c5", "c5_stm", "hbm"]
+    for key, leg in out["configs"].items():
+        assert leg["ok"] is True and leg["frac"] > 0 and leg["kernel_ms"] > 0 and leg["cpu_value"] > 0, (key, leg)
+    assert out["configs"]["hbm"]["bound"] == "hbm"
+    assert out["ref12"]["ok"] is True and out["refint"]["ok"] is True
