@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
+#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks, lto_last_call_order (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
 
 /* error codes */
 #define LTO_OK 0
@@ -108,6 +108,10 @@ double lto_last_kernel_ms(lto_ctx* ctx);
 /* Wall time [ms] of the last host-pointer call on this context (lto_indirect_defect, lto_indirect_jacobian, lto_direct_*),
  * from entry to return as measured inside the library: what a C or Julia caller waits for, without a binding's overhead. */
 double lto_last_call_ms(const lto_ctx* ctx);
+/* Lane order the last host-pointer indirect call of this context swept with: 0 = natural, 1 = the global order, 2 = the windowed
+ * order (both made from an earlier call's step counts and kept in the context, one slot per kind: defect sweeps take the windowed
+ * order, STM sweeps and Newton steps the global one, so a loop that alternates defectCalc and jacobianCalc keeps both). */
+int lto_last_call_order(const lto_ctx* ctx);
 
 /* Kernel choice of the RK4 STM sweeps above one round of workgroups (lto_indirect_plan_set_kernel, LTO_KERNEL_AUTO): the family
  * whose rounds are cheapest for the segment count, from a table of microseconds per round at 64 steps -- us_per_round[0]:

@@ -296,6 +296,8 @@ devptr(::Nothing) = C_NULL
 ctx_stream(ctx::LtoContext) = ccall((:lto_ctx_stream, liblto), Ptr{Cvoid}, (Ptr{Cvoid},), ctx.handle)
 "Wall time [ms] of the last host-pointer call on `ctx`, entry to return, as measured inside the library."
 last_call_ms(ctx::LtoContext) = ccall((:lto_last_call_ms, liblto), Cdouble, (Ptr{Cvoid},), ctx.handle)
+"Lane order of the last host-pointer indirect call: 0 natural, 1 global, 2 windowed."
+last_call_order(ctx::LtoContext) = Int(ccall((:lto_last_call_order, liblto), Cint, (Ptr{Cvoid},), ctx.handle))
 
 "Measure the cost table LTO_KERNEL_AUTO chooses the RK4 STM kernel family by (microseconds per round) on this context's device."
 calibrate_kernels!(ctx::LtoContext) = check(ctx, ccall((:lto_calibrate_kernels, liblto), Cint, (Ptr{Cvoid},), ctx.handle))

@@ -45,10 +45,11 @@ struct lto_ctx {
   // lane order of the last large adaptive sweep made through the host-pointer API (which builds a plan per call):
   // consecutive Newton iterations sweep the same problem, so the previous call's step counts balance this one.
   // A stale order is still a valid permutation -- it can only cost speed, never correctness.
-  int* order_cache;      // [order_S + workspace] (kernels.hpp order_bytes)
-  int order_kind;        // 1 global, 2 windowed
-  long order_S;
-  int order_ndim;
+  // One slot per kind of order (round 6; advisor finding: defect sweeps want the windowed order, STM sweeps / Newton steps the global
+  // one, and a loop that alternates defectCalc and jacobianCalc at the same size evicted the other call's order every time).
+  int* order_cache[3];   // [kind]: [order_S + workspace] (kernels.hpp order_bytes); kind 1 global, 2 windowed (slot 0 unused)
+  long order_S[3];
+  int order_ndim[3];
   // plans of the host-pointer API, kept between calls (a Newton iteration calls with the same shapes and parameters
   // every time: no parameter upload, no device allocation per call); owned by the context
   struct HostPlan {
@@ -74,6 +75,7 @@ struct lto_ctx {
   lto::HostList<Pinned> pinned;
   std::mutex pinned_mu;
   double last_call_ms;     // wall time of the last host-pointer call, entry to return (lto_last_call_ms)
+  int last_call_order;     // lane order the last host-pointer indirect call swept with: 0 natural, 1 global, 2 windowed (lto_last_call_order)
   // landing block of the Newton loop's per-iteration scalars (lto_indirect_solve_batch): page-locked, mapped, written by
   // k_iter_report; word 0 is the sequence number the host polls, the values follow.  Grow-only; absent = copy + synchronise.
   // AUTO's cost table: microseconds per ROUND of each RK4 STM family at 64 steps, [ndim == 14][family] with family 0 = eight-wave
@@ -333,7 +335,7 @@ static void ctx_free(lto_ctx* c) {
   for (const lto_ctx::Pinned& b : c->pinned) { host_block_forget(b.host); (void)hipHostFree(b.host); }   // none left on the deferred path
   c->pinned.clear();
   if (c->arena) (void)hipFree(c->arena);
-  if (c->order_cache) (void)hipFree(c->order_cache);
+  for (int k = 0; k < 3; ++k) if (c->order_cache[k]) (void)hipFree(c->order_cache[k]);
   if (c->rep_host) (void)hipHostFree(c->rep_host);
   for (int i = 0; i < 8; ++i) if (c->pool[i].ptr) (void)hipFree(c->pool[i].ptr);
   (void)hipEventDestroy(c->ev0);
@@ -363,6 +365,7 @@ double lto_last_kernel_ms(lto_ctx* c) {
 }
 
 double lto_last_call_ms(const lto_ctx* c) { return c ? c->last_call_ms : -1.0; }
+int lto_last_call_order(const lto_ctx* c) { return c ? c->last_call_order : LTO_ENULL; }
 
 // entry-to-return wall time of a host-pointer call, kept in the context
 struct CallTimer {
@@ -492,7 +495,7 @@ int lto_indirect_plan_copy_steps(lto_indirect_plan* p, void* stream, int* accept
 
 // Lane order of the adaptive sweeps.  Round 5: ordered inside windows of consecutive segments, the windows dealt to the XCDs
 // (kernels.hpp LTO_ORDER_WINDOW) -- the sweeps then gather from and scatter to the caller's arrays inside one L2 and need no record
-// staging.  LTO_ORDER_MODE=global in the environment (development switch) or more than 8 M segments: the global order of round 4 with
+// staging.  LTO_ORDER_MODE=global in the environment (development switch, read once per process): the global order of round 4 with
 // its record staging.
 // A plan that runs STM sweeps keeps the global order and its records: with sixteen workgroup-rounds per CU the sweep's time is the
 // sum of its rounds, longest-processing-time-first over ALL workgroups is what keeps that sum short, and the windowed order costs
@@ -1110,28 +1113,31 @@ static bool host_order_wanted(const lto_indirect_plan* p, bool stm) {
 }
 
 static void host_order_adopt(lto_ctx* c, lto_indirect_plan* p, bool stm) {
+  c->last_call_order = 0;
   if (p->order_borrowed) { p->d_order = nullptr; p->use_order = 0; p->order_borrowed = 0; }   // cached plan: the context's order may have moved
-  if (!host_order_wanted(p, stm) || !c->order_cache || c->order_S != p->S || c->order_ndim != p->ndim || c->order_kind != order_kind_for(stm)) return;
-  p->d_order = c->order_cache; p->order_borrowed = 1; p->use_order = 1; p->order_kind = c->order_kind;
-  if (p->order_kind == 1) (void)stage_alloc(p, stm);
+  const int kind = order_kind_for(stm);
+  if (!host_order_wanted(p, stm) || !c->order_cache[kind] || c->order_S[kind] != p->S || c->order_ndim[kind] != p->ndim) return;
+  p->d_order = c->order_cache[kind]; p->order_borrowed = 1; p->use_order = 1; p->order_kind = kind;
+  c->last_call_order = kind;
+  if (kind == 1) (void)stage_alloc(p, stm);
 }
 
 static void host_order_refresh(lto_ctx* c, lto_indirect_plan* p, bool stm, hipStream_t st) {
   if (!host_order_wanted(p, stm)) return;
-  if (!c->order_cache || c->order_S != p->S) {
+  const int kind = order_kind_for(stm);
+  if (!c->order_cache[kind] || c->order_S[kind] != p->S) {
     if (p->use_order) return;                      // (cannot happen: adoption requires a matching cache)
-    if (c->order_cache) { (void)hipStreamSynchronize(st); (void)hipFree(c->order_cache); c->order_cache = nullptr; }
-    if (hipMalloc((void**)&c->order_cache, order_bytes(p->S)) != hipSuccess) {
-      c->order_cache = nullptr; (void)hipGetLastError();
+    if (c->order_cache[kind]) { (void)hipStreamSynchronize(st); (void)hipFree(c->order_cache[kind]); c->order_cache[kind] = nullptr; }
+    if (hipMalloc((void**)&c->order_cache[kind], order_bytes(p->S)) != hipSuccess) {
+      c->order_cache[kind] = nullptr; (void)hipGetLastError();
       return;                                      // balancing is an optimisation: carry on without it
     }
-    c->order_S = p->S;
+    c->order_S[kind] = p->S;
   }
-  c->order_ndim = p->ndim;
-  c->order_kind = order_kind_for(stm);
-  if (segment_order(c->order_kind, p->d_nacc, p->d_nrej, p->S, c->order_cache + p->S, c->order_cache, st) != hipSuccess) {
+  c->order_ndim[kind] = p->ndim;
+  if (segment_order(kind, p->d_nacc, p->d_nrej, p->S, c->order_cache[kind] + p->S, c->order_cache[kind], st) != hipSuccess) {
     (void)hipGetLastError();
-    c->order_S = 0;                                // never adopt a half-written order
+    c->order_S[kind] = 0;                          // never adopt a half-written order
   }
 }
 

@@ -111,6 +111,10 @@ class Context:
         """Wall time of the last host-pointer call as measured inside the library (entry to return)."""
         return float(self.lib.lto_last_call_ms(self.handle))
 
+    def last_call_order(self):
+        """Lane order of the last host-pointer indirect call: 0 natural, 1 global, 2 windowed (lto_last_call_order)."""
+        return int(self.lib.lto_last_call_order(self.handle))
+
     def calibrate_kernels(self):
         """Measure AUTO's cost table (us per round of every RK4 STM family) on this context's device (lto_calibrate_kernels)."""
         self.check(self.lib.lto_calibrate_kernels(self.handle))

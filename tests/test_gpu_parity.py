@@ -917,6 +917,31 @@ def test_host_api_reuses_step_order_between_calls(gpu_ctx):
     assert np.array_equal(u1, u2)
 
 
+def test_host_api_keeps_one_lane_order_per_kind_when_defect_and_jacobian_calls_alternate():
+    """Advisor finding, round 5: defectCalc wants the windowed order (kind 2), jacobianCalc / the Newton step the global one (kind 1);
+    with ONE cache slot a Julia-style loop that alternates the two at the same size evicted the other call's order every time and
+    every sweep ran in natural order.  One slot per kind: the first round of each call runs in natural order (0) and leaves its
+    order behind, from the second round on each call adopts its own kind.  Results do not depend on the order."""
+    ctx = lto.Context(0)                       # a fresh context: nothing cached
+    n = 16500                                  # >= 16 384 segments: both kinds of call want an order
+    XC, T = synth.indirect_problem(n, seed=52, dt_range=(0.02, 0.4))
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1e-2)
+    integ = lto.integrator()
+    seen, res = [], []
+    for rnd in range(3):
+        d, _ = lto.indirect_defectCalc(XC, t, prm, integ, ctx=ctx)
+        seen.append(ctx.last_call_order())
+        Phi, dj = lto.indirect_stm(XC, t, prm, integ, ctx=ctx)
+        seen.append(ctx.last_call_order())
+        res.append((d, Phi, dj))
+    assert seen == [0, 0, 2, 1, 2, 1], seen
+    for d, Phi, dj in res[1:]:
+        assert np.array_equal(Phi, res[0][1]) and np.array_equal(dj, res[0][2])
+        assert np.abs(d - res[0][0]).max() < 1e-12          # (the defect-only sweep may change its lanes per segment with the statistics)
+    ctx.close()
+
+
 # ------------------------------------------------------------------------------------------------ direct
 @pytest.mark.parametrize("nstate", [6, 7])
 def test_direct_defect_vs_oracle_and_golden(gpu_ctx, oracle, nstate):
