@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks, lto_last_call_order (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
+#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks, lto_last_call_order, lto_indirect_auto_kernel; LTO_KERNEL_PIPE is now LTO_KERNEL_DIRECT_PIPE (same value), LTO_KERNEL_PIPE6_REMOVED is gone (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
 
 /* error codes */
 #define LTO_OK 0
@@ -276,8 +276,8 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  *     the batch is one round of it (16 segments per CU: 4 096 on MI355X); above that the family whose rounds are cheapest for the
  *     segment count, by the context's cost table (lto_kernel_round_costs / lto_calibrate_kernels above): eight-wave form in
  *     rounds of 16 x CUs segments, 32-segment form (LTO_KERNEL_PIPE32, where it is built) in rounds of 32 x CUs, large-batch form
- *     (LTO_KERNEL_PIPE48) in rounds of 48 x CUs -- 12-dim also 44 x CUs --, and for ndim = 12 the per-lane kernel with 3 columns
- *     per lane in rounds of 64 x CUs, and for ndim = 12 the whole-segment lanes (LTO_KERNEL_LANE) in rounds of 256 x CUs.  On
+ *     (LTO_KERNEL_PIPE48) in rounds of 48 x CUs -- 12-dim also 44 x CUs --, and for ndim = 12 the whole-segment lanes
+ *     (LTO_KERNEL_LANE) in rounds of 256 x CUs (lto_indirect_auto_kernel below is this rule as a pure function).  On
  *     MI355X (256 CUs, default table): 4 097 ... 8 192 segments -> PIPE32, 8 193 ... 12 288 -> PIPE48, 65 536 and 262 144 -> LANE
  *     (12-dim) / PIPE32 (14-dim);
  *   - RK4 with fewer steps: the per-lane kernel (each lane re-integrates the base state with 1-3 columns); for ndim = 12 on a
@@ -286,20 +286,22 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  *   - the 13-stage integrators: the wave-specialised kernel (LTO_KERNEL_COOP: base wave + column waves per 16 segments,
  *     coefficients handed over through LDS at every RK stage) -- for ndim = 12 with DOP853_ADAPTIVE, the reference's setting, its
  *     form with two lanes per state (LTO_KERNEL_COOP2).
- * Results never depend on the choice beyond round-off; lto_indirect_plan_last_kernel reports what ran. */
+ * Results never depend on the choice beyond round-off; lto_indirect_plan_last_kernel reports what ran.
+ * Round 6 removed three dominated forms; their selectors stay valid and resolve to the family that took over: LTO_KERNEL_PER_LANE on
+ * a 13-stage plan selects the one-lane DEFECT sweep only (its STM sweep runs the cooperative kernels -- the one-column-per-lane form
+ * with memory-resident slopes is gone), LTO_KERNEL_COOP on an RK4 plan runs the pipeline AUTO would take, LTO_KERNEL_COOP on a
+ * 12-dim DOP853 plan runs LTO_KERNEL_COOP2. */
 #define LTO_KERNEL_AUTO 0
 #define LTO_KERNEL_PER_LANE 1
 #define LTO_KERNEL_COOP 2
+/* Direct plans only (lto_direct_plan_set_kernel): the pipelined Jacobian kernel (base wave + one wave per sensitivity column per 32
+ * segments, skewed by one RKF7(8) step); AUTO takes it from 3 072 segments.  On an indirect plan: LTO_EINVAL. */
+#define LTO_KERNEL_DIRECT_PIPE 3
 /* RK4 plans only (other integrators: LTO_EINVAL): base wave, coefficient wave and column waves per 16 segments run as a software
- * pipeline skewed by one RK4 step.  _PIPE8: four column waves, one STM column per lane, a DPP row = one segment and the
+ * pipeline skewed by one RK4 step.  Four column waves, one STM column per lane, a DPP row = one segment and the
  * coefficients broadcast inside the FMA (v_fmac_f64_dpp row_newbcast), TWO RK4 steps per phase and eight waves -- a fourth of
  * the column work alternates between two SIMDs so that all four SIMDs of a CU carry the same load -- and a base wave that
- * evaluates RK4 stages 1|2 and then 3|4 side by side in neighbouring lanes (one workgroup per CU: 91 KB of LDS).
- * On an INDIRECT plan selector 3 (the four-wave form of rounds 1-2, two columns per lane) and selector 4 (the six-wave form)
- * are gone since round 3 -- _PIPE8 is faster at every size -- and return LTO_EINVAL; LTO_KERNEL_PIPE remains the selector of
- * the direct plans' pipelined Jacobian kernel. */
-#define LTO_KERNEL_PIPE 3
-#define LTO_KERNEL_PIPE6_REMOVED 4
+ * evaluates RK4 stages 1|2 and then 3|4 side by side in neighbouring lanes (one workgroup per CU: 91 KB of LDS). */
 #define LTO_KERNEL_PIPE8 5
 /* ndim = 12, DOP853_ADAPTIVE plans only: the cooperative kernel with every 12-component state split over two lanes (top /
  * bottom halves of a column in different waves, the two halves of the base state in neighbouring DPP banks): six components
@@ -326,6 +328,12 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  * and defect equal the pipeline kernels' bit for bit. */
 #define LTO_KERNEL_LANE 9
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
+/* What LTO_KERNEL_AUTO resolves to for the STM sweep of a plan of this shape on a device with `n_cus` compute units, by the MI355X
+ * cost table (a context's own table after lto_calibrate_kernels may differ): ndim 12 | 14, method LTO_RK4 ..., steps per segment,
+ * p the control-law exponent (0, 1, 2 or > 1), n_segments = (n_nodes - 1) x n_batch, ordered = the plan sweeps with a lane order.
+ * A pure function: no context, no device -- callable on a host without a GPU (sizing an N-GPU run, tests).  Returns LTO_KERNEL_* or
+ * LTO_EINVAL. */
+int lto_indirect_auto_kernel(int ndim, int method, int steps, double p, long n_segments, int n_cus, int ordered);
 /* Lanes per segment of the DEFECT-ONLY sweep of an ndim = 12 DOP853_ADAPTIVE plan (the reference's setting, indirect.jl:63-90):
  * 1, 2 or 4 (a DPP quad per segment: r, v, lambda_v, lambda_r), or 0 = choose (default).  The choice: by size -- four lanes up to
  * eight wavefronts of 16 segments per SIMD, i.e. 512 x CUs segments (131 072 on MI355X), two lanes up to 262 144 segments, one

@@ -388,8 +388,14 @@ line_search_pick_dev!(ctx::LtoContext, stream, sumsq, maxabs, alphas, n_alpha::I
 
 "Order the lanes of the following adaptive sweeps by the last sweep's step counts (results unchanged)."
 rebalance!(pl::LtoIndirectPlan, stream) = check(pl.ctx, ccall((:lto_indirect_plan_rebalance, liblto), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), pl.handle, devptr(stream)))
-"LTO_KERNEL_*: 0 auto, 1 per-lane, 2 cooperative, 3 / 4 / 5 pipeline forms (RK4 plans), 6 cooperative with two lanes per state (12-dim DOP853 plans), 7 pipeline for large batches (RK4 plans)."
+"LTO_KERNEL_*: 0 auto, 1 per-lane, 2 cooperative, 5 eight-wave pipeline (RK4 plans), 6 cooperative with two lanes per state (12-dim DOP853 plans), 7 pipeline for large batches, 8 32-segment pipeline, 9 whole-segment lanes (RK4 plans); 3 = the direct plans' pipelined Jacobian kernel."
 set_kernel!(pl::LtoIndirectPlan, kernel::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_kernel, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, kernel))
+"Family LTO_KERNEL_AUTO resolves to for an STM sweep of this shape on a device with `n_cus` compute units (MI355X cost table): LTO_KERNEL_* (no GPU needed)."
+function auto_kernel(ndim::Integer, method::Integer, steps::Integer, p::Real, n_segments::Integer; n_cus::Integer = 256, ordered::Bool = false)
+    k = ccall((:lto_indirect_auto_kernel, liblto), Cint, (Cint, Cint, Cint, Cdouble, Clong, Cint, Cint), ndim, method, steps, p, n_segments, n_cus, ordered ? 1 : 0)
+    k >= 0 || error("lto_indirect_auto_kernel: invalid shape (code $k)")
+    Int(k)
+end
 "Adaptive sweeps start every segment from its first accepted step size of the plan's previous sweep of the same kind (12-dim DOP853 plans; lto.h)."
 set_warm_start!(pl::LtoIndirectPlan, on::Bool = true) = check(pl.ctx, ccall((:lto_indirect_plan_set_warm_start, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, on ? 1 : 0))
 "Lanes per segment of the defect-only sweep of a 12-dim DOP853 plan: 0 = choose (four up to 131 072 segments, then two, then one), 1, 2 or 4."

@@ -77,8 +77,7 @@ __device__ __forceinline__ void run_rkf78_adaptive(const Sys& sys, const double 
     if (t + h > span) h = span - t;
     double yn[D];
     double delta;
-    if constexpr (D > 14) { double K[13][D]; delta = rkf78_step_mem<Sys, NERR>(sys, h, y, K, yn); }
-    else delta = rkf78_step<Sys, NERR, true>(sys, h, y, yn);
+    delta = rkf78_step<Sys, NERR, true>(sys, h, y, yn);
     double nx = 0.0;
 #pragma unroll
     for (int i = 0; i < NERR; ++i) nx = fmax(nx, fabs(y[i]));
@@ -160,8 +159,7 @@ __device__ __forceinline__ void run_dop853(const Sys& sys, const double span, co
     if (t + h >= span) { h = span - t; last = 1.0; }
     double yn[D];
     double E5, E3;
-    if constexpr (D > 14) (void)dop853_try_mem<Sys, NERR>(sys, kTabDP8, h, rtol, atol, y, K, yn, E5, E3);
-    else (void)dop853_try<Sys, NERR>(sys, h, rtol, atol, y, K, yn, E5, E3);
+    (void)dop853_try<Sys, NERR>(sys, h, rtol, atol, y, K, yn, E5, E3);
     // the step decision every DOP853 kernel of this library takes (rk.hpp dp8_decide): the one- / two- / four-lane defect sweeps
     // AUTO switches between share one controller (advisor finding, round 4)
     double h_next, accept, bad;
@@ -203,8 +201,7 @@ __device__ __forceinline__ void advance(const Sys& sys, const double span, const
     for (int k = 0; k < a.steps; ++k) {
       double yn[D];
       double delta;
-      if constexpr (D > 14) { double K[13][D]; delta = rkf78_step_mem<Sys, ND>(sys, h, y, K, yn); }
-      else delta = rkf78_step<Sys, ND>(sys, h, y, yn);
+      delta = rkf78_step<Sys, ND>(sys, h, y, yn);
       maxErr = fmax(maxErr, delta);
 #pragma unroll
       for (int c = 0; c < D; ++c) y[c] = yn[c];

@@ -30,12 +30,8 @@ hipError_t launch_indirect_stm(int pm, int method, int cols, const IndirectArgs&
     }
     return hipErrorInvalidValue;
   }
-  // 13-stage methods keep ~11 slope vectors live: one column per lane.
-  switch (method) {
-    case M_RKF78_FIXED: return launch_pm<12, M_RKF78_FIXED, 1>(pm, a, st);
-    case M_RKF78_ADAPTIVE: return launch_pm<12, M_RKF78_ADAPTIVE, 1>(pm, a, st);
-    case M_DOP853_ADAPTIVE: return launch_pm<12, M_DOP853_ADAPTIVE, 1>(pm, a, st);
-  }
+  // 13-stage methods: no per-lane STM form (round 6: the memory-resident one-column-per-lane kernels, never AUTO's choice, are gone --
+  // lto_api.hip sends such sweeps to the cooperative kernels)
   return hipErrorInvalidValue;
 }
 

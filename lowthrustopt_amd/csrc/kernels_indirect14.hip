@@ -25,12 +25,7 @@ hipError_t launch_indirect14_stm(int pm, int method, int cols, const IndirectArg
     }
     return hipErrorInvalidValue;
   }
-  switch (method) {
-    case M_RKF78_FIXED: return launch_pm<14, M_RKF78_FIXED, 1>(pm, a, st);
-    case M_RKF78_ADAPTIVE: return launch_pm<14, M_RKF78_ADAPTIVE, 1>(pm, a, st);
-    case M_DOP853_ADAPTIVE: return launch_pm<14, M_DOP853_ADAPTIVE, 1>(pm, a, st);
-  }
-  return hipErrorInvalidValue;
+  return hipErrorInvalidValue;      // 13-stage methods: cooperative kernels only (see kernels_indirect.hip)
 }
 
 hipError_t launch_indirect14_dense(int pm, int method, const IndirectArgs& a, const DenseArgs& d, hipStream_t st) {

@@ -403,14 +403,12 @@ hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const Indirect
   if (a.S <= 0) return hipSuccess;
   if (ndim == 12) {
     switch (method) {
-      case M_RK4: return launch_coop_pm<12, M_RK4>(pm, a, st);
+      // (round 6: RK4 runs the pipelines at every size, 12-dim DOP853 the two-lanes-per-state form -- lto_api.hip never asks for them here)
       case M_RKF78_FIXED: return launch_coop_pm<12, M_RKF78_FIXED>(pm, a, st);
       case M_RKF78_ADAPTIVE: return launch_coop_pm<12, M_RKF78_ADAPTIVE>(pm, a, st);
-      case M_DOP853_ADAPTIVE: return launch_coop_pm<12, M_DOP853_ADAPTIVE>(pm, a, st);
     }
   } else if (ndim == 14) {
     switch (method) {
-      case M_RK4: return launch_coop_pm<14, M_RK4>(pm, a, st);
       case M_RKF78_FIXED: return launch_coop_pm<14, M_RKF78_FIXED>(pm, a, st);
       case M_RKF78_ADAPTIVE: return launch_coop_pm<14, M_RKF78_ADAPTIVE>(pm, a, st);
       case M_DOP853_ADAPTIVE: return launch_coop_pm<14, M_DOP853_ADAPTIVE>(pm, a, st);

@@ -27,6 +27,9 @@ using namespace lto;
 // a round = 256 segments per CU) at 64 steps on MI355X, for AUTO's comparison with the pipelines' round costs (default of
 // lto_ctx::lane_round_us; lto_calibrate_kernels measures it on the context's own device).
 static const double kLaneRoundUs = 590.0;
+// us per round at 64 steps, MI355X: [12-dim | 14-dim][eight-wave (16 x CUs) | 48-segment (48 x CUs) | per-lane with 3 columns (64 x CUs) |
+// 44-segment (44 x CUs) | 32-segment (32 x CUs)]; lto_calibrate_kernels replaces them with the context's own device's
+static const double kRoundCostDefault[2][5] = {{63.0, 165.0, 246.0, 139.0, 111.0}, {72.0, 191.0, 1e300, 1e300, 128.0}};
 
 struct lto_ctx {
   int device;
@@ -278,7 +281,7 @@ int lto_create(lto_ctx** out, int device_id) {
   if (!c) return LTO_EHIP;
   c->device = device_id;
   c->cu_count = 0;
-  { const double dflt[2][5] = {{63.0, 165.0, 246.0, 139.0, 111.0}, {72.0, 191.0, 1e300, 1e300, 128.0}}; std::memcpy(c->round_cost, dflt, sizeof dflt); }
+  std::memcpy(c->round_cost, kRoundCostDefault, sizeof kRoundCostDefault);
   c->lane_round_us = kLaneRoundUs;
   if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) { c->cu_count = 0; (void)hipGetLastError(); }
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -574,10 +577,7 @@ int lto_indirect_plan_reset_order(lto_indirect_plan* p) {
 
 int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
-  if (kernel == LTO_KERNEL_PIPE6_REMOVED)
-    return set_err(p->ctx, LTO_EINVAL, "the six-wave pipeline kernel (selector 4) was removed in round 3: LTO_KERNEL_PIPE8 replaced it");
-  if (kernel == LTO_KERNEL_PIPE)
-    return set_err(p->ctx, LTO_EINVAL, "the four-wave pipeline kernel (selector 3 on an indirect plan) was removed in round 3: LTO_KERNEL_PIPE8 is faster at every size");
+  // (selectors 3 and 4 are not indirect families: 3 = LTO_KERNEL_DIRECT_PIPE, the direct plans' pipelined Jacobian kernel; 4 is unassigned)
   if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_COOP && kernel != LTO_KERNEL_LANE &&
       kernel != LTO_KERNEL_PIPE8 && kernel != LTO_KERNEL_COOP2 && kernel != LTO_KERNEL_PIPE48 && kernel != LTO_KERNEL_PIPE32)
     return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE8, _COOP2, _PIPE48, _PIPE32 or _LANE");
@@ -754,6 +754,44 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   return LTO_OK;
 }
 
+/* What LTO_KERNEL_AUTO resolves to for an STM sweep: a pure function of the plan's shape and the cost table (no device, no context
+ * state), so that the choice at sizes this build never ran on -- the per-rank batches of an 8-GPU run -- can be pinned by a CPU test
+ * (tests/test_auto_kernel.py).  cost: us per round at 64 steps of the eight-wave / 48-segment / (unused) / 44-segment / 32-segment
+ * pipelines for this dimension; per_lane3_us: the 12-dim per-lane kernel with three columns, rounds of 64 x CUs (only for RK4 with
+ * 2 ... 5 steps); lane_us: the whole-segment lanes, rounds of 256 x CUs.
+ * RK4 with >= 6 steps: the pipelines -- the eight-wave form while the batch is one round of it (16 segments per CU), above that the
+ * family whose rounds are cheapest for THIS segment count, a partly filled round costing a whole one.  (Round 6: the per-lane kernel
+ * left this table -- its rounds, 246 us per 64 x CUs, never beat the 32-segment pipeline's, 2 x 111 us.)  RK4 with fewer steps: the
+ * per-lane kernel (fill and drain phases outweigh the pipelines' shorter phase), on a full chip its whole-segment forms.  13-stage
+ * methods: the cooperative kernels; 12-dim DOP853 (the reference's setting) the two-lanes-per-state form. */
+static int auto_stm_kernel(int ndim, int method, int steps, int pm, long S, long cus, bool ordered, int cols_per_lane, const double* cost,
+                           double per_lane3_us, double lane_us) {
+  const auto rounds = [&](long per_round) { return (double)((S + per_round - 1) / per_round); };
+  if (method != LTO_RK4) return (method == LTO_DOP853_ADAPTIVE && ndim == 12) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
+  if (steps < 6) {
+    if (steps >= 2 && indirect_stm_lane_available(ndim, method, S) && !ordered && cols_per_lane == 0 &&
+        rounds(256 * cus) * lane_us < rounds(64 * cus) * per_lane3_us)
+      return LTO_KERNEL_LANE;
+    return LTO_KERNEL_PER_LANE;
+  }
+  if (S <= 16 * cus) return LTO_KERNEL_PIPE8;
+  const double t8 = rounds(16 * cus) * cost[0];
+  const double t48 = std::min(rounds(48 * cus) * cost[1], ndim == 12 ? rounds(44 * cus) * cost[3] : 1e300);
+  const double t32 = indirect_stm_pipe32_available(ndim, pm) ? rounds(32 * cus) * cost[4] : 1e300;
+  int kern = (t32 < t8 && t32 < t48) ? LTO_KERNEL_PIPE32 : (t48 <= t8 ? LTO_KERNEL_PIPE48 : LTO_KERNEL_PIPE8);
+  // the whole-segment lanes (kernels_indirect_lane.hip, 12-dim): rounds of 256 x CUs segments -- four wavefronts of 64 per CU, one per
+  // SIMD.  A partly filled round costs a whole one, so the pipelines keep the sizes just above a multiple of their own, smaller rounds.
+  if (indirect_stm_lane_available(ndim, method, S) && !ordered && rounds(256 * cus) * lane_us < std::min(std::min(t8, t48), t32)) kern = LTO_KERNEL_LANE;
+  return kern;
+}
+
+int lto_indirect_auto_kernel(int ndim, int method, int steps, double p, long n_segments, int n_cus, int ordered) {
+  if ((ndim != 12 && ndim != 14) || method < LTO_RK4 || method > LTO_DOP853_ADAPTIVE || n_segments < 1 || n_cus < 1) return LTO_EINVAL;
+  if (!(p == 0.0 || p >= 1.0)) return LTO_EINVAL;           // the reference's error("Invalid value of p!") is a run-time code; here: not a plan
+  const int pm = 1 << p_class(p);
+  return auto_stm_kernel(ndim, method, steps, pm, n_segments, n_cus, ordered != 0, 0, kRoundCostDefault[ndim == 14 ? 1 : 0], kRoundCostDefault[0][2], kLaneRoundUs);
+}
+
 // One-step RK4 STM sweeps (SURVEY 8d's HBM-bound corner): from this many segments AUTO's per-lane family runs the form whose lane is
 // a whole segment (kernels_indirect_stream.hip): one wavefront of 64 segments per SIMD of an MI355X.  Below, the per-(segment,
 // column group) lanes fill the chip with four to twelve times the wavefronts and the sweep is latency-bound either way.
@@ -783,40 +821,17 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   // kernel with 3 columns per lane in rounds of 64 x CUs.  13-stage methods: the wave-specialised kernel (DOP853 @1e-13,
   // 4 096 segments: 0.32 ms vs 1.9 ms per-lane), for the reference's setting (12-dim, DOP853) its two-lanes-per-state form.
   int kern = p->kernel;
-  if (kern == LTO_KERNEL_AUTO) {
-    const long cus = c->cu_count > 0 ? c->cu_count : 256;
-    if (p->integ.method != LTO_RK4)   // 12-dim DOP853: the two-lanes-per-state form (0.221 against 0.260 ms at 4 096 segments)
-      kern = (p->integ.method == LTO_DOP853_ADAPTIVE && p->ndim == 12) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
-    else if (p->integ.steps < 6) {
-      kern = LTO_KERNEL_PER_LANE;                              // fill and drain phases outweigh the pipelines' shorter phase
-      // 2 ... 5 steps on a full chip (12-dim): the whole-segment lanes have no fill or drain either and run no base stage twice --
-      // by the same round costs as below (per-lane kernel with three columns: rounds of 64 x CUs; one step: its own form, section 4.3b)
-      if (p->integ.steps >= 2 && indirect_stm_lane_available(p->ndim, p->integ.method, p->S) && !p->use_order && p->cols_per_lane == 0) {
-        const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };
-        if (rounds(256 * cus) * c->lane_round_us < rounds(64 * cus) * c->round_cost[0][2]) kern = LTO_KERNEL_LANE;
-      }
-    }
-    else if (p->S <= 16 * cus) kern = LTO_KERNEL_PIPE8;
-    else {
-      const auto rounds = [&](long per_round) { return (double)((p->S + per_round - 1) / per_round); };
-      const double* cost = c->round_cost[p->ndim == 14 ? 1 : 0];     // us per round: defaults or this device's (lto_calibrate_kernels)
-      const double t8 = rounds(16 * cus) * cost[0];
-      const double t48 = std::min(rounds(48 * cus) * cost[1], p->ndim == 12 ? rounds(44 * cus) * cost[3] : 1e300);
-      const double tl = (p->ndim == 12) ? rounds(64 * cus) * cost[2] : 1e300;
-      const double t32 = indirect_stm_pipe32_available(p->ndim, p->pm) ? rounds(32 * cus) * cost[4] : 1e300;
-      kern = (t32 < t8 && t32 < t48 && t32 < tl) ? LTO_KERNEL_PIPE32
-             : (t48 <= t8 && t48 <= tl)          ? LTO_KERNEL_PIPE48
-                                                 : (t8 <= tl ? LTO_KERNEL_PIPE8 : LTO_KERNEL_PER_LANE);
-      // the whole-segment lanes (kernels_indirect_lane.hip, 12-dim): rounds of 256 x CUs segments -- four wavefronts of 64 per CU, one
-      // per SIMD -- at lto_ctx::lane_round_us: kLaneRoundUs, the MI355X figure (a round of 65 536 segments, 64 steps:
-      // profiles/r05_probe_lane.txt), or this device's (lto_calibrate_kernels).  A partly filled round costs a whole one, so the
-      // pipelines keep the sizes just above a multiple of their own, smaller rounds (e.g. 32 768 segments).
-      if (indirect_stm_lane_available(p->ndim, p->integ.method, p->S) && !p->use_order) {
-        const double t_lane = rounds(256 * cus) * c->lane_round_us;
-        if (t_lane < std::min(std::min(t8, t48), std::min(tl, t32))) kern = LTO_KERNEL_LANE;
-      }
-    }
-  }
+  if (kern == LTO_KERNEL_AUTO)
+    kern = auto_stm_kernel(p->ndim, p->integ.method, p->integ.steps, p->pm, p->S, c->cu_count > 0 ? c->cu_count : 256, p->use_order != 0, p->cols_per_lane,
+                           c->round_cost[p->ndim == 14 ? 1 : 0], c->round_cost[0][2], c->lane_round_us);
+  // Families that are gone since round 6 resolve to the one that took over (results agree to round-off, lto_indirect_plan_last_kernel
+  // says what ran): the 13-stage methods have no per-lane STM form any more, RK4 no cooperative form, and 12-dim DOP853 only the
+  // two-lanes-per-state cooperative form.
+  if (p->integ.method != LTO_RK4 && kern == LTO_KERNEL_PER_LANE) kern = LTO_KERNEL_COOP;
+  if (p->integ.method == LTO_RK4 && kern == LTO_KERNEL_COOP)
+    kern = auto_stm_kernel(p->ndim, LTO_RK4, p->integ.steps < 6 ? 6 : p->integ.steps, p->pm, p->S, c->cu_count > 0 ? c->cu_count : 256, p->use_order != 0, 0,
+                           c->round_cost[p->ndim == 14 ? 1 : 0], c->round_cost[0][2], c->lane_round_us);
+  if (p->integ.method == LTO_DOP853_ADAPTIVE && p->ndim == 12 && kern == LTO_KERNEL_COOP) kern = LTO_KERNEL_COOP2;
   // the large-batch pipeline has two forms for 12-dim (48 or 44 segments per workgroup, kernels_indirect_pipe48.hip): the cheaper
   // rounds for this segment count, whether AUTO or the caller chose the family
   bool seg44 = false;
@@ -1506,8 +1521,8 @@ int lto_direct_plan_set_kernel(lto_direct_plan* p, int kernel) {
   if (!p) return LTO_ENULL;
   if (kernel == LTO_KERNEL_COOP)
     return set_err(p->ctx, LTO_EINVAL, "the wave-specialised direct Jacobian kernel was removed in round 3 (never faster than _PER_LANE or _PIPE)");
-  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_PIPE)
-    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE or _PIPE");
+  if (kernel != LTO_KERNEL_AUTO && kernel != LTO_KERNEL_PER_LANE && kernel != LTO_KERNEL_DIRECT_PIPE)
+    return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE or _DIRECT_PIPE");
   p->kernel = kernel;
   return LTO_OK;
 }
@@ -1591,8 +1606,8 @@ int lto_direct_jacobian_dev(lto_direct_plan* p, void* stream, const double* X, l
   // sensitivity column) but needs 10 waves of one workgroup resident per 32 segments: it wins once the per-lane kernel no
   // longer fits the chip in one round.
   int kern = p->kernel;
-  if (kern == LTO_KERNEL_AUTO) kern = (p->S >= 3072) ? LTO_KERNEL_PIPE : LTO_KERNEL_PER_LANE;
-  hipError_t e = (kern == LTO_KERNEL_PIPE) ? launch_direct_jacobian_pipe(p->nstate, a, st) : launch_direct_jacobian(p->nstate, a, st);
+  if (kern == LTO_KERNEL_AUTO) kern = (p->S >= 3072) ? LTO_KERNEL_DIRECT_PIPE : LTO_KERNEL_PER_LANE;
+  hipError_t e = (kern == LTO_KERNEL_DIRECT_PIPE) ? launch_direct_jacobian_pipe(p->nstate, a, st) : launch_direct_jacobian(p->nstate, a, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_direct_jacobian", e);
   return LTO_OK;

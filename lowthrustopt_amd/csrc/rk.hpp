@@ -244,41 +244,6 @@ __device__ __forceinline__ void dp8_decide(const double E5, const double E3, con
   bad = (err != err) ? err : 0.0;                                // a NaN never recovers: the caller poisons the segment
 }
 
-// ------------------------------------------------------------------------------------ memory-resident slopes
-// 13-stage methods on base + STM column (D = 24 or 28) need 13 D slopes = 312-364 doubles per lane, more than
-// the 256-double register file: fully unrolled code then spills >1000 registers to scratch (and hipcc 7.2 was
-// observed to MIScompile such kernels, DESIGN.md "Compiler hazards").  These variants keep the slopes in an
-// explicitly memory-resident array K[stage][D] (scratch, L1/L2-cached, 256-B coalesced per wave access) indexed
-// by a RUNTIME stage loop, keep y / accumulators in registers, and read the tableau from constant memory with
-// wave-uniform (scalar) loads.  Same arithmetic (a = sum_k A[s][k] K_k in k order, then y + h a) as the unrolled
-// forms, so results agree to the last bit or two.
-struct TabMem {
-  double A[13][13];
-  double B[13];
-  double E5[13];   // RKF7(8): psi * 41/840      DOP853: E5
-  double E3[13];   // RKF7(8): unused            DOP853: E3
-};
-
-static __device__ __constant__ TabMem kTabRKF78 = {
-    {{0},
-     {2. / 27},
-     {1. / 36, 1. / 12},
-     {1. / 24, 0, 1. / 8},
-     {5. / 12, 0, -25. / 16, 25. / 16},
-     {0.05, 0, 0, 0.25, 0.2},
-     {-25. / 108, 0, 0, 125. / 108, -65. / 27, 125. / 54},
-     {31. / 300, 0, 0, 0, 61. / 225, -2. / 9, 13. / 900},
-     {2, 0, 0, -53. / 6, 704. / 45, -107. / 9, 67. / 90, 3},
-     {-91. / 108, 0, 0, 23. / 108, -976. / 135, 311. / 54, -19. / 60, 17. / 6, -1. / 12},
-     {2383. / 4100, 0, 0, -341. / 164, 4496. / 1025, -301. / 82, 2133. / 4100, 45. / 82, 45. / 164, 18. / 41},
-     {3. / 205, 0, 0, 0, 0, -6. / 41, -3. / 205, -3. / 41, 3. / 41, 6. / 41},
-     {-1777. / 4100, 0, 0, -341. / 164, 4496. / 1025, -289. / 82, 2193. / 4100, 51. / 82, 33. / 164, 12. / 41, 0, 1}},
-    {0, 0, 0, 0, 0, 34. / 105, 9. / 35, 9. / 35, 9. / 280, 9. / 280, 0, 41. / 840, 41. / 840},
-    {41. / 840, 0, 0, 0, 0, 0, 0, 0, 0, 0, 41. / 840, -41. / 840, -41. / 840},
-    {0}};
-
-static __device__ __constant__ TabMem kTabDP8 = DP8_TABMEM_INIT;
-
 // The DOP853 tableau for code that reads its coefficients with scalar loads where they are needed (the lone-wavefront kernels of the
 // reference's integrator setting: as literals every coefficient costs two s_mov_b32 in an instruction stream that IS the sweep's
 // duration -- 152 of ~2 000 instructions per trial step).  Packed: the non-zero weights of argument 1, 2, .. 11 (rows of A), of
@@ -376,100 +341,6 @@ __device__ __forceinline__ void dp8_load_err(const unsigned long base, double (&
     if constexpr (DP8_E5[k] != 0.0) e5[k] = T->w[at5];
     if constexpr (DP8_E3[k] != 0.0) e3[k] = T->w[at3];
   });
-}
-
-// Slopes 1 .. ns-1 from K[0] = f(y), runtime stage loop.
-template <class Sys>
-__device__ __forceinline__ void stages_mem(const Sys& sys, const TabMem& T, const int ns, const double h,
-                                           const double (&y)[Sys::DIM], double (*K)[Sys::DIM]) {
-  constexpr int D = Sys::DIM;
-#pragma unroll 1
-  for (int s = 1; s < ns; ++s) {
-    double acc[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) acc[i] = 0.0;
-#pragma unroll 1
-    for (int k = 0; k < s; ++k) {
-      const double a = T.A[s][k];
-      if (a != 0.0) {   // wave-uniform
-#pragma unroll
-        for (int i = 0; i < D; ++i) acc[i] = __builtin_fma(a, K[k][i], acc[i]);
-      }
-    }
-    double yt[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) yt[i] = __builtin_fma(h, acc[i], y[i]);
-    sys.rhs(yt, K[s]);
-  }
-}
-
-// ynew = y + h sum_k B_k K_k over the first ns slopes
-template <class Sys>
-__device__ __forceinline__ void combine_mem(const TabMem& T, const int ns, const double h, const double (&y)[Sys::DIM],
-                                            double (*K)[Sys::DIM], double (&ynew)[Sys::DIM]) {
-  constexpr int D = Sys::DIM;
-  double acc[D];
-#pragma unroll
-  for (int i = 0; i < D; ++i) acc[i] = 0.0;
-#pragma unroll 1
-  for (int k = 0; k < ns; ++k) {
-    const double b = T.B[k];
-    if (b != 0.0) {
-#pragma unroll
-      for (int i = 0; i < D; ++i) acc[i] = __builtin_fma(b, K[k][i], acc[i]);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < D; ++i) ynew[i] = __builtin_fma(h, acc[i], y[i]);
-}
-
-// RKF7(8) step, memory-resident slopes; same contract as rkf78_step.
-template <class Sys, int NERR>
-__device__ __forceinline__ double rkf78_step_mem(const Sys& sys, const double h, const double (&y)[Sys::DIM],
-                                                 double (*K)[Sys::DIM], double (&ynew)[Sys::DIM]) {
-  sys.rhs(y, K[0]);
-  stages_mem<Sys>(sys, kTabRKF78, 13, h, y, K);
-  combine_mem<Sys>(kTabRKF78, 13, h, y, K, ynew);
-  double delta = 0.0, gsum = 0.0;
-#pragma unroll
-  for (int i = 0; i < NERR; ++i) {
-    const double g = rkf78_err_term(h, K[0][i], K[10][i], K[11][i], K[12][i]);
-    delta = fmax(delta, fabs(g));
-    gsum += g;
-  }
-  return (gsum != gsum) ? gsum : delta;
-}
-
-// DOP853 trial step, memory-resident slopes; same contract as dop853_try (K[0] = f(y) on entry, K[12] = f(ynew) on exit).
-template <class Sys, int NERR>
-__device__ __forceinline__ double dop853_try_mem(const Sys& sys, const TabMem& T, const double h, const double rtol,
-                                                 const double atol, const double (&y)[Sys::DIM], double (*K)[Sys::DIM],
-                                                 double (&ynew)[Sys::DIM], double& E5, double& E3) {
-  stages_mem<Sys>(sys, T, 12, h, y, K);
-  combine_mem<Sys>(T, 12, h, y, K, ynew);
-  sys.rhs(ynew, K[12]);
-  double a5[NERR], a3[NERR];
-#pragma unroll
-  for (int i = 0; i < NERR; ++i) { a5[i] = 0.0; a3[i] = 0.0; }
-#pragma unroll 1
-  for (int k = 0; k <= 12; ++k) {
-    const double c5 = T.E5[k], c3 = T.E3[k];
-    if (c5 != 0.0 || c3 != 0.0) {
-#pragma unroll
-      for (int i = 0; i < NERR; ++i) { a5[i] = __builtin_fma(c5, K[k][i], a5[i]); a3[i] = __builtin_fma(c3, K[k][i], a3[i]); }
-    }
-  }
-  double e5 = 0.0, e3 = 0.0;
-#pragma unroll
-  for (int i = 0; i < NERR; ++i) {
-    const double inv_sc = rcp_nr(__builtin_fma(rtol, fmax(fabs(y[i]), fabs(ynew[i])), atol));
-    const double v5 = a5[i] * inv_sc, v3 = a3[i] * inv_sc;
-    e5 = __builtin_fma(v5, v5, e5);
-    e3 = __builtin_fma(v3, v3, e3);
-  }
-  E5 = e5; E3 = e3;
-  if (e5 == 0.0 && e3 == 0.0) return 0.0;
-  return fabs(h) * e5 / sqrt((e5 + 0.01 * e3) * (double)NERR);
 }
 
 }  // namespace lto

@@ -175,6 +175,15 @@ class Group:
             pass
 
 
+def auto_kernel(ndim, method, steps, p, n_segments, n_cus=256, ordered=False):
+    """lto_indirect_auto_kernel: the family LTO_KERNEL_AUTO resolves to for an STM sweep of this shape (MI355X cost table), by name.
+    A pure function of the library: needs no GPU."""
+    k = _lib.load_library().lto_indirect_auto_kernel(int(ndim), int(method), int(steps), float(p), int(n_segments), int(n_cus), 1 if ordered else 0)
+    if k < 0:
+        raise LtoError(k, "lto_indirect_auto_kernel: invalid shape")
+    return IndirectPlan.KERNEL_NAMES[k]
+
+
 class Comm:
     """lto_comm: RCCL communicator of one rank (one process per GPU).  `uid` = 128 bytes from Comm.unique_id() on one rank,
     handed to every rank by the launcher (torch.distributed broadcast, MPI, a file).  Operands are device pointers
@@ -676,7 +685,8 @@ class IndirectPlan:
         self.handle = h
         ctx._plans.add(self)
 
-    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE8, KERNEL_COOP2, KERNEL_PIPE48, KERNEL_PIPE32, KERNEL_LANE = 0, 1, 2, 5, 6, 7, 8, 9   # 3, 4: removed in round 3 (four- / six-wave forms)
+    KERNEL_AUTO, KERNEL_PER_LANE, KERNEL_COOP, KERNEL_PIPE8, KERNEL_COOP2, KERNEL_PIPE48, KERNEL_PIPE32, KERNEL_LANE = 0, 1, 2, 5, 6, 7, 8, 9   # 3: LTO_KERNEL_DIRECT_PIPE (direct plans)
+    KERNEL_NAMES = {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48", 8: "pipeline32", 9: "segment-lane"}
 
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
@@ -693,7 +703,7 @@ class IndirectPlan:
 
     def last_kernel(self):
         """Name of the kernel family the last STM sweep ran (what AUTO resolved to)."""
-        return {0: "none yet", 1: "per-lane", 2: "cooperative", 5: "pipeline8", 6: "cooperative2", 7: "pipeline48", 8: "pipeline32", 9: "segment-lane"}[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
+        return self.KERNEL_NAMES[self.ctx.lib.lto_indirect_plan_last_kernel(self.handle)]
 
     def staging(self):
         """Record staging of the plan's ordered sweeps (lto_indirect_plan_staging): bit 1 node / defect records in place, bit 2 Phi records

@@ -221,3 +221,78 @@ def test_configs3_size_14dim_large_batch_pipelines_oracle_sample(gpu_ctx, oracle
         assert np.abs(Pn - P_o).max() < 1e-10 * np.abs(P_o).max()
     # copies of a trajectory inside the batch give the same bits wherever they sit
     assert torch.equal(Phi[:, :S1], Phi[:, 4 * S1:5 * S1]) and torch.equal(d[:, 3 * S1:4 * S1], d[:, 255 * S1:256 * S1])
+
+
+# ---- the per-rank batches of an N-GPU run of the sharded configs (tests/per_rank_sizes.py) ---------------------
+from per_rank_sizes import C4 as PER_RANK_C4, C5_STM as PER_RANK_C5     # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_configs3_homotopy_sweep_per_rank_batches(gpu_ctx, oracle, world):
+    """configs[3] as `bench.py --workload c4 --gpus N` shards it: the LAST rank's block of 256 / N rho levels (ending at rho = 1e-4) x
+    1 024 segments.  AUTO runs the family tests/per_rank_sizes.py lists for that batch (the whole-segment lanes down to 65 536
+    segments, the 44-segment pipeline at 32 768) and an oracle sample on the block's first and last level agrees to 1e-10.  (N = 1 is
+    test_configs3_homotopy_sweep_256_levels_x_1024_segments_with_stm.)"""
+    import torch
+    S, family = PER_RANK_C4[world]
+    n, B = 1025, S // 1024
+    assert B * world == 256
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=10 + world - 1)
+    rhos = synth.homotopy_rhos(256)[(world - 1) * B:]
+    prm_l = [[MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, float(r)] for r in rhos]
+    plan = lto.IndirectPlan(gpu_ctx, n, B, [lto.make_params(*q) for q in prm_l], lto.integrator(lto.RK4, steps=64))
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T.T)).cuda()
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+    d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+    plan.jacobian(X, n * B, t, B, Phi, S, d, S)
+    torch.cuda.synchronize()
+    assert plan.last_kernel() == family == lto.auto_kernel(12, lto.RK4, 64, 1.0, S)
+    plan.close()
+    assert bool(torch.isfinite(Phi).all()) and bool(torch.isfinite(d).all())
+    for b in (0, B - 1):
+        for i in (0, 500, 1023):
+            s = b * 1024 + i
+            y, P_o, rc, _, _ = oracle.flow_stm_state_costate(XC[:, i, b], prm_l[b], T[i + 1, b] - T[i, b], oracle.RK4, 64)
+            assert rc == 0
+            P_g = Phi[:, s].cpu().numpy().reshape(12, 12).T
+            assert np.abs(P_g - P_o).max() < 1e-10 * np.abs(P_o).max()
+            assert np.linalg.norm(d[:, s].cpu().numpy() - (y - XC[:, i + 1, b])) < 1e-10 * np.linalg.norm(y)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c5_per_rank_batches_with_stm(gpu_ctx, oracle, world):
+    """configs[4] as `bench.py --workload c5 | c5_stm --gpus N` shards it: 65 536 / N segments of the C5 inputs (dt ~ U[0.05, 0.5],
+    rho = 1e-3), adaptive order 8 @ 1e-13, lanes ordered after a first sweep as the bench does.  STM sweep (AUTO: the two-lanes-per-
+    state cooperative kernel at every one of these sizes) and defect-only sweep against the oracle's converged flow on a sample;
+    ordered and natural sweeps agree bit for bit.  (N = 1 is test_indirect_adaptive_full_size_properties[c5].)"""
+    import torch
+    S, family = PER_RANK_C5[world]
+    n = S + 1
+    XC, T = synth.indirect_problem(n, seed=1 + world - 1, dt_range=(0.05, 0.5))
+    prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1e-3]
+    plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator())
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda"); Phi2 = torch.zeros_like(Phi)
+    d = torch.zeros(12, S, dtype=torch.float64, device="cuda"); d2 = torch.zeros_like(d); d0 = torch.zeros_like(d)
+    plan.jacobian(X, n, t, 1, Phi, S, d, S)
+    assert plan.last_kernel() == family == lto.auto_kernel(12, lto.DOP853_ADAPTIVE, 0, 1.0, S)
+    plan.rebalance()
+    plan.jacobian(X, n, t, 1, Phi2, S, d2, S)
+    plan.defect(X, n, t, 1, d0, S)
+    torch.cuda.synchronize()
+    assert plan.last_kernel() == family
+    assert torch.equal(Phi, Phi2) and torch.equal(d, d2)
+    acc, rej = plan.step_counts()
+    assert acc.min() >= 1 and (acc + rej).max() <= 400
+    plan.close()
+    heavy = int(np.argmax(acc + rej))
+    for s in sorted({0, 1, S // 2, S - 1, heavy}):
+        y, P_o, rc, _, _ = oracle.flow_stm_state_costate(XC[:, s, 0], prm_l, T[s + 1, 0] - T[s, 0], oracle.DOP853_ADAPTIVE, 0)
+        assert rc == 0
+        P_g = Phi[:, s].cpu().numpy().reshape(12, 12).T
+        assert np.abs(P_g - P_o).max() < 1e-9 * np.abs(P_o).max()
+        ref = y - XC[:, s + 1, 0]
+        assert np.linalg.norm(d[:, s].cpu().numpy() - ref) < 1e-10 * np.linalg.norm(y)
+        assert np.linalg.norm(d0[:, s].cpu().numpy() - ref) < 1e-10 * np.linalg.norm(y)

@@ -37,8 +37,10 @@ METHODS = {
 }
 
 
-# STM kernel families x integrators: the three-role pipeline kernel is built for fixed-step RK4 only
-KERNEL_METHODS = [(k, m) for k in ("per_lane", "coop") for m in METHODS] + [("pipe8", "rk4x64"), ("pipe48", "rk4x64"), ("coop2", "dop853_adaptive")]
+# STM kernel families x integrators (round 6: the per-lane family is RK4's, the cooperative family the 13-stage methods' -- the
+# one-column-per-lane 13-stage form and the cooperative RK4 form were dominated everywhere and are gone; their selectors resolve to
+# the family that took over, test_removed_kernel_forms_resolve_to_their_successors); the pipelines are built for fixed-step RK4 only
+KERNEL_METHODS = [("per_lane", "rk4x64")] + [("coop", m) for m in METHODS if m != "rk4x64"] + [("pipe8", "rk4x64"), ("pipe48", "rk4x64"), ("coop2", "dop853_adaptive")]
 
 
 def pick_kernel(plan, kernel):
@@ -656,7 +658,8 @@ def test_indirect_adaptive_full_size_properties(gpu_ctx, oracle, inputs):
         acc, rej = plan.step_counts()
         assert acc.min() >= 1 and acc.max() <= 400 and rej.min() >= 0 and rej.max() <= 400
         out[kern] = (Phi, d)
-    assert ran[plan.KERNEL_AUTO] == "cooperative2" and ran[plan.KERNEL_COOP] == "cooperative" and ran[plan.KERNEL_PER_LANE] == "per-lane"
+    # (round 6: the one-piece cooperative and the per-lane STM forms of this setting are gone; their selectors run the two-lane form)
+    assert ran[plan.KERNEL_AUTO] == ran[plan.KERNEL_COOP] == ran[plan.KERNEL_PER_LANE] == "cooperative2"
     # the defect-only sweep as AUTO runs it (two lanes per segment) and with one lane per segment
     d_auto = torch.zeros(12, S, dtype=torch.float64, device="cuda")
     d_lane = torch.zeros(12, S, dtype=torch.float64, device="cuda")
@@ -1637,7 +1640,44 @@ def test_indirect_auto_kernel_choice(gpu_ctx):
         plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
         torch.cuda.synchronize()
         assert plan.last_kernel() == want, (ndim, n, method, steps, plan.last_kernel())
+        assert lto.auto_kernel(ndim, method, steps, 1.0, S) == want          # the pure function the CPU suite pins (tests/test_auto_kernel.py)
         assert bool(torch.isfinite(Phi).all())
+
+
+def test_removed_kernel_forms_resolve_to_their_successors(gpu_ctx, oracle):
+    """Round 6 pruned three dominated STM forms; their selectors stay valid (lto.h): LTO_KERNEL_PER_LANE on a 13-stage plan and
+    LTO_KERNEL_COOP on a 12-dim DOP853 plan run the cooperative kernels AUTO takes, LTO_KERNEL_COOP on an RK4 plan the pipeline AUTO
+    takes -- same bits as AUTO, oracle-correct -- while LTO_KERNEL_PER_LANE still selects the one-lane DEFECT sweep."""
+    import torch
+    n = 70
+    S = n - 1
+    XC, T = synth.indirect_problem(n, seed=8, dt_range=(0.05, 0.4))
+    Xd = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    prm_l = [MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1e-2]
+    for method, steps, sel, want in ((lto.DOP853_ADAPTIVE, 0, "KERNEL_PER_LANE", "cooperative2"), (lto.DOP853_ADAPTIVE, 0, "KERNEL_COOP", "cooperative2"),
+                                     (lto.RKF78_FIXED, 6, "KERNEL_PER_LANE", "cooperative"), (lto.RKF78_ADAPTIVE, 0, "KERNEL_PER_LANE", "cooperative"),
+                                     (lto.RK4, 32, "KERNEL_COOP", "pipeline8"), (lto.RK4, 3, "KERNEL_COOP", "pipeline8")):
+        plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(method, steps=steps))
+        out = []
+        for kern in (plan.KERNEL_AUTO, getattr(plan, sel)):
+            plan.set_kernel(kern)
+            Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda"); d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+            plan.jacobian(Xd, n, td, 1, Phi, S, d, S)
+            torch.cuda.synchronize()
+            out.append((Phi, d, plan.last_kernel()))
+        assert out[1][2] == want, (method, sel, out[1][2])
+        if out[0][2] == want:
+            assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        P_o, d_o, rc = oracle.indirect_jacobian(XC[:, :, 0], T[:, 0], prm_l, method, steps)
+        assert rc == 0
+        P_g = out[1][0].cpu().numpy().reshape(12, 12, S).transpose(1, 0, 2)
+        assert np.abs(P_g - P_o).max() < 1e-9 * np.abs(P_o).max() and np.abs(out[1][1].cpu().numpy() - d_o).max() < 1e-10
+        plan.close()
+    with pytest.raises(lto.LtoError):
+        lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(lto.RK4, steps=8)).set_kernel(3)     # LTO_KERNEL_DIRECT_PIPE is a direct plan's
+    with pytest.raises(lto.LtoError):
+        lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(*prm_l), lto.integrator(lto.RK4, steps=8)).set_kernel(4)     # never assigned again
 
 
 def test_kernel_cost_table_calibration():
