@@ -95,7 +95,7 @@ def make_workload(wl, lto, synth, torch, ctx, st, dev, ndim=0, segments=0, metho
     import types
     nd = ndim or default_ndim(wl)
     f64 = dict(dtype=torch.float64, device=dev)
-    w = types.SimpleNamespace(wl=wl, ndim=nd, method=method, Phi=None, XC=None, T=None, levels=0, extra={})
+    w = types.SimpleNamespace(wl=wl, ndim=nd, method=method, Phi=None, XC=None, T=None, levels=0, extra={}, blocks=False)
     prm1 = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
     c5 = wl in ("c5", "c5_stm")
     if wl in ("c2", "c2_defect", "hbm") or c5:
@@ -132,6 +132,11 @@ def make_workload(wl, lto, synth, torch, ctx, st, dev, ndim=0, segments=0, metho
             plan.set_kernel(kernel)
         defect = torch.zeros(nd, S, **f64)
         Phi = torch.zeros(nd * nd, S, **f64)
+        if wl == "c5_stm" and nd == 12 and os.environ.get("LTO_BENCH_C5_LAYOUT", "blocks") == "blocks":
+            # the reference's own layout (one 12x12 block per segment, indirect.jl:121-123; defect[12 x S] column-major): the ordered
+            # sweep then writes its records straight into the caller's arrays -- no record arrays, no transposes (lto.h LTO_LAYOUT_BLOCKS)
+            plan.set_output_layout(plan.LAYOUT_BLOCKS)
+            w.blocks = True
         if wl in ("c2", "hbm", "c5_stm"):
             def sweep(dbuf):
                 plan.jacobian(X, n, t, 1, Phi, S, dbuf, S, stream=st)
@@ -190,7 +195,7 @@ def make_workload(wl, lto, synth, torch, ctx, st, dev, ndim=0, segments=0, metho
     w.token = {"c2": "c2 indirect %d-dim+STM S=%d %s" % (nd, S, method or "rk4x64"), "c2_defect": "c2_defect indirect %d-dim S=%d %s" % (nd, S, method or "rk4x64"),
                "hbm": "hbm indirect %d-dim+STM S=%d rk4x1" % (nd, S), "c3": "c3 direct 6-dim+Jac6x18+tf S=%d rkf78 nsteps=10" % S,
                "c4": "c4 homotopy %dx1024 12-dim+STM rk4x64" % w.levels, "c5": "c5 indirect 12-dim defect S=%d dop853 1e-13" % S,
-               "c5_stm": "c5_stm indirect 12-dim+STM S=%d dop853 1e-13" % S}[wl]
+               "c5_stm": "c5_stm indirect 12-dim+STM S=%d dop853 1e-13%s" % (S, " blocks" if w.blocks else "")}[wl]
     return w
 
 
@@ -825,6 +830,19 @@ def _time_oracle(run, per_call, seconds, what, token=""):
             "sample": "%d segments x %d sweeps in %.1f s; %s; host has %d cores" % (per_call, calls, el, what, os.cpu_count() or 0)}
 
 
+def phi_sample(w, off, cnt, nd=12):
+    """Phi of segments off .. off + cnt of a workload's last sweep as [row][col][segment], whatever layout the plan writes."""
+    if w.blocks:             # [S][col * nd + row]
+        return w.Phi.reshape(-1)[off * nd * nd:(off + cnt) * nd * nd].cpu().numpy().reshape(cnt, nd, nd).transpose(2, 1, 0)
+    return w.Phi[:, off:off + cnt].cpu().numpy().reshape(nd, nd, cnt).transpose(1, 0, 2)
+
+
+def defect_sample(w, off, cnt, nd=12):
+    if w.blocks:             # [S][nd]
+        return w.defect.reshape(-1)[off * nd:(off + cnt) * nd].cpu().numpy().reshape(cnt, nd).T
+    return w.defect[:, off:off + cnt].cpu().numpy()
+
+
 def config_parity_and_cpu(w, lto, seconds):
     """(parity, cpu_baseline) of a compact leg: PARITY_SAMPLE segments of the leg's own last sweep against the oracle (checker), and
     the oracle timed on the same sample (one core; the reference's algorithm for the adaptive configs, the same discrete map for the
@@ -872,11 +890,11 @@ def config_parity_and_cpu(w, lto, seconds):
         Xh, th = w.XC[:, i0:i0 + cnt + 1, b], w.T[i0:i0 + cnt + 1, b]
         if want_stm:
             P_o, d_o, rc = O.indirect_jacobian(Xh, th, prm_o, method, steps)
-            P_g = w.Phi[:, off:off + cnt].cpu().numpy().reshape(12, 12, cnt).transpose(1, 0, 2)
+            P_g = phi_sample(w, off, cnt)
             stm_err = max(stm_err, float(np.abs(P_g - P_o).max())); stm_max = max(stm_max, float(np.abs(P_o).max()))
         else:
             d_o = O.indirect_defect(Xh, th, prm_o, method, steps)[0]
-        d_g = w.defect[:, off:off + cnt].cpu().numpy()
+        d_g = defect_sample(w, off, cnt)
         num += float(np.sum((d_g - d_o) ** 2)); den += float(np.sum((d_o + Xh[:, 1:]) ** 2))
     parity = {"defect_rel_l2": float(np.sqrt(num / den)), "stm_rel_max": (stm_err / stm_max) if want_stm else None,
               "sample_segments": cnt * len(blocks), "tolerance": 1e-10,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks, lto_last_call_order, lto_indirect_auto_kernel; LTO_KERNEL_PIPE is now LTO_KERNEL_DIRECT_PIPE (same value), LTO_KERNEL_PIPE6_REMOVED is gone (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
+#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks, lto_last_call_order, lto_indirect_auto_kernel, lto_indirect_plan_set_output_layout; LTO_KERNEL_PIPE is now LTO_KERNEL_DIRECT_PIPE (same value), LTO_KERNEL_PIPE6_REMOVED is gone (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
 
 /* error codes */
 #define LTO_OK 0
@@ -350,6 +350,18 @@ int lto_indirect_plan_set_defect_lanes(lto_indirect_plan* plan, int lanes);
  * too (only plans that run STM sweeps get them), 4 = an allocation for them failed and staging is off for this plan -- the sweeps
  * then read and write the caller's arrays directly (same results, 3-8 x the HBM traffic); lto_last_error() holds the note. */
 int lto_indirect_plan_staging(const lto_indirect_plan* plan);
+/* Output layout of a plan's sweeps (round 6).  LTO_LAYOUT_SOA (default): defect [ndim][ldd], Phi [(col*ndim+row)][ldp] -- struct of
+ * arrays, segment index fastest.  LTO_LAYOUT_BLOCKS: one block per segment, defect [S][ndim] and Phi [S][ndim*ndim] with the block
+ * column-major -- i.e. exactly the reference's (Julia's, column-major) defect[ndim x S] and the Phi_i blocks of jacobianCalc
+ * (indirect.jl:121-123), what the host-pointer entry points return; ldd / ldp are then ignored.  Built for ndim = 12
+ * DOP853_ADAPTIVE plans (the reference's integrator setting; others: LTO_EUNSUPPORTED): their kernels write a segment's results
+ * as one record, so with a lane order (lto_indirect_plan_rebalance) the sweep needs no record arrays of its own and no transposes
+ * behind it -- C5 + STM (65 536 segments): 104 instead of 280 MB of HBM traffic per sweep (algorithmic 95), same bits.  The
+ * defect-only sweep of such a plan runs with two or four lanes per segment (the one-lane kernel writes struct-of-arrays only);
+ * lto_indirect_newton_solve_dev reads struct-of-arrays and refuses such a plan. */
+#define LTO_LAYOUT_SOA 0
+#define LTO_LAYOUT_BLOCKS 1
+int lto_indirect_plan_set_output_layout(lto_indirect_plan* plan, int layout);
 /* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* plan);
 /* Per-lane kernel only: STM columns integrated per lane (1, 2 or 3; every lane re-integrates the base state with its columns);

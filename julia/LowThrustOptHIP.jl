@@ -398,6 +398,8 @@ function auto_kernel(ndim::Integer, method::Integer, steps::Integer, p::Real, n_
 end
 "Adaptive sweeps start every segment from its first accepted step size of the plan's previous sweep of the same kind (12-dim DOP853 plans; lto.h)."
 set_warm_start!(pl::LtoIndirectPlan, on::Bool = true) = check(pl.ctx, ccall((:lto_indirect_plan_set_warm_start, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, on ? 1 : 0))
+"Output layout of the plan's sweeps: 0 = struct of arrays, 1 = one block per segment (defect [S][ndim], Phi [S][ndim*ndim] column-major: Julia's own layout; 12-dim DOP853 plans)."
+set_output_layout!(pl::LtoIndirectPlan, layout::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_output_layout, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, layout))
 "Lanes per segment of the defect-only sweep of a 12-dim DOP853 plan: 0 = choose (four up to 131 072 segments, then two, then one), 1, 2 or 4."
 set_defect_lanes!(pl::LtoIndirectPlan, lanes::Integer = 0) = check(pl.ctx, ccall((:lto_indirect_plan_set_defect_lanes, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, lanes))
 

@@ -126,6 +126,7 @@ SIGNATURES = {
     "lto_comm_rank": (C.c_int, [_vp]),
     "lto_comm_rccl_ranks": (C.c_int, [_vp]),
     "lto_last_call_order": (C.c_int, [_vp]),
+    "lto_indirect_plan_set_output_layout": (C.c_int, [_vp, C.c_int]),
     "lto_indirect_auto_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_long, C.c_int, C.c_int]),
     "lto_comm_allgather_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_long]),
     "lto_comm_allreduce_dev": (C.c_int, [_vp, _vp, _vp, C.c_long, C.c_int]),

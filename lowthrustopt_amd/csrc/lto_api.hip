@@ -136,6 +136,7 @@ struct lto_indirect_plan {
   double* d_pa;             // [S][144]: only for plans that run STM sweeps (stage_alloc's need_phi)
   int stm_swept;            // an STM sweep has run on this plan
   int stage_failed;         // an allocation of record staging failed: the sweeps gather from the caller's arrays (lto_indirect_plan_staging)
+  int out_blocks;           // LTO_LAYOUT_BLOCKS: Phi [S][144] and defect [S][12] per-segment blocks instead of struct-of-arrays (lto_indirect_plan_set_output_layout)
 };
 
 struct lto_direct_plan {
@@ -529,8 +530,9 @@ static bool stage_capable(const lto_indirect_plan* p) { return p->ndim == 12 && 
 static int stage_alloc(lto_indirect_plan* p, bool need_phi) {
   if (!stage_capable(p)) return LTO_OK;
   lto_ctx* c = p->ctx;
+  const bool own = !p->out_blocks;       // LTO_LAYOUT_BLOCKS: the caller's Phi / defect arrays ARE the records
   struct { double** ptr; size_t n; bool want; } want[3] = {{&p->d_xa, (size_t)NODE_REC * p->n_nodes * p->n_batch, true},
-                                                           {&p->d_da, (size_t)12 * p->S, true}, {&p->d_pa, (size_t)144 * p->S, need_phi}};
+                                                           {&p->d_da, (size_t)12 * p->S, own}, {&p->d_pa, (size_t)144 * p->S, need_phi && own}};
   for (auto& w : want) {
     if (*w.ptr || !w.want) continue;
     hipError_t e = pool_alloc(c, (void**)w.ptr, sizeof(double) * w.n);
@@ -547,7 +549,17 @@ static int stage_alloc(lto_indirect_plan* p, bool need_phi) {
 
 int lto_indirect_plan_staging(const lto_indirect_plan* p) {
   if (!p) return 0;
+  if (p->out_blocks) return (p->d_xa ? 3 : 0) | (p->stage_failed ? 4 : 0);      // node records only: results go straight to the caller's blocks
   return ((p->d_xa && p->d_da) ? 1 : 0) | (p->d_pa ? 2 : 0) | (p->stage_failed ? 4 : 0);
+}
+
+int lto_indirect_plan_set_output_layout(lto_indirect_plan* p, int layout) {
+  if (!p) return LTO_ENULL;
+  if (layout != LTO_LAYOUT_SOA && layout != LTO_LAYOUT_BLOCKS) return set_err(p->ctx, LTO_EINVAL, "layout must be LTO_LAYOUT_SOA or LTO_LAYOUT_BLOCKS");
+  if (layout == LTO_LAYOUT_BLOCKS && !stage_capable(p))
+    return set_err(p->ctx, LTO_EUNSUPPORTED, "LTO_LAYOUT_BLOCKS is built for 12-dim DOP853_ADAPTIVE plans (the kernels that write per-segment records)");
+  p->out_blocks = layout == LTO_LAYOUT_BLOCKS;
+  return LTO_OK;
 }
 
 int lto_indirect_plan_rebalance(lto_indirect_plan* p, void* stream) {
@@ -679,7 +691,7 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   int rc = fill_indirect_args(p, X, ldx, t, n_tgrids, &a);
   if (rc) return rc;
   if (!defect) return set_err(c, LTO_ENULL, "defect is NULL");
-  if (ldd < p->S) return set_err(c, LTO_EINVAL, "ldd smaller than the segment count");
+  if (ldd < p->S && !p->out_blocks) return set_err(c, LTO_EINVAL, "ldd smaller than the segment count");
   a.defect = defect; a.ldd = ldd; a.errors = errors;
   rc = bind_device(c);
   if (rc) return rc;
@@ -723,20 +735,24 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
       }
     }
   }
+  if (p->out_blocks && lanes == 1) lanes = 2;          // the one-lane kernel writes struct-of-arrays only
   rc = warm_args(p, 1, lanes > 1, &a);
   if (rc) return rc;
   // balanced lane order: nodes in, defects out as records (IndirectArgs::Xa / Da), coalesced transposes either side of the sweep
-  const bool staged = a.order && p->order_kind == 1 && lanes > 1 && p->d_xa && p->d_da;
+  // (LTO_LAYOUT_BLOCKS: the caller's defect array is the record array -- no transpose behind the sweep, whatever the order)
+  const bool blocks = p->out_blocks != 0;
+  const bool staged = a.order && p->order_kind == 1 && lanes > 1 && p->d_xa && (blocks || p->d_da);
   if (staged) {
     hipError_t q = launch_node_records(X, ldx, t, a.t_stride, p->n_nodes, (long)p->n_nodes * p->n_batch, p->d_xa, st);
     if (q != hipSuccess) return set_err(c, LTO_EHIP, "launch_node_records", q);
     a.Xa = p->d_xa; a.Da = p->d_da;
   }
+  if (blocks) a.Da = defect;
   hipError_t e = lanes == 4        ? launch_indirect_defect4(p->pm, a, st)
                  : lanes == 2      ? launch_indirect_defect2(p->pm, a, st)
                  : (p->ndim == 12) ? launch_indirect_defect(p->pm, p->integ.method, a, st)
                                    : launch_indirect14_defect(p->pm, p->integ.method, a, st);
-  if (e == hipSuccess && staged) e = launch_pack_soa(p->d_da, 12, p->S, defect, ldd, st);
+  if (e == hipSuccess && staged && !blocks) e = launch_pack_soa(p->d_da, 12, p->S, defect, ldd, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_defect", e);
   warm_filled(p, 1, a);
@@ -805,7 +821,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   int rc = fill_indirect_args(p, X, ldx, t, n_tgrids, &a);
   if (rc) return rc;
   if (!Phi) return set_err(c, LTO_ENULL, "Phi is NULL");
-  if (ldp < p->S || (defect && ldd < p->S)) return set_err(c, LTO_EINVAL, "ldp/ldd smaller than the segment count");
+  if (!p->out_blocks && (ldp < p->S || (defect && ldd < p->S))) return set_err(c, LTO_EINVAL, "ldp/ldd smaller than the segment count");
   a.Phi = Phi; a.ldp = ldp; a.defect = defect; a.ldd = ldd;
   rc = bind_device(c);
   if (rc) return rc;
@@ -845,20 +861,25 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   rc = warm_args(p, 0, kern == LTO_KERNEL_COOP2, &a);
   if (rc) return rc;
   p->stm_swept = 1;
-  if (a.order && p->order_kind == 1 && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && !p->d_pa && !p->stage_failed) {
+  const bool blocks = p->out_blocks != 0;
+  if (blocks && kern != LTO_KERNEL_COOP2) return set_err(c, LTO_EUNSUPPORTED, "LTO_LAYOUT_BLOCKS needs the two-lanes-per-state cooperative kernel (LTO_KERNEL_AUTO or _COOP2)");
+  if (!blocks && a.order && p->order_kind == 1 && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && !p->d_pa && !p->stage_failed) {
     // the lane order was made before this plan's first STM sweep: the Phi records come now -- unless the stream is being captured
     // (an allocation may not happen there; this sweep then runs unstaged and a later one outside a capture allocates)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) (void)stage_alloc(p, true);
     else (void)hipGetLastError();
   }
-  const bool staged = a.order && p->order_kind == 1 && kern == LTO_KERNEL_COOP2 && p->d_xa && p->d_da && p->d_pa;
+  // LTO_LAYOUT_BLOCKS: the caller's Phi / defect arrays are the per-segment records the kernel writes (IndirectArgs::Pa / Da) -- no
+  // record arrays of the plan's own and no transposes behind the sweep, with or without a lane order
+  const bool staged = a.order && p->order_kind == 1 && kern == LTO_KERNEL_COOP2 && p->d_xa && (blocks || (p->d_da && p->d_pa));
   if (staged) {
     hipError_t q = launch_node_records(X, ldx, t, a.t_stride, p->n_nodes, (long)p->n_nodes * p->n_batch, p->d_xa, st);
     if (q != hipSuccess) return set_err(c, LTO_EHIP, "launch_node_records", q);
     a.Xa = p->d_xa; a.Pa = p->d_pa;
     if (a.defect) a.Da = p->d_da;
   }
+  if (blocks) { a.Pa = Phi; if (a.defect) a.Da = defect; }
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
   else if (kern == LTO_KERNEL_COOP2) e = launch_indirect_stm_coop2(p->pm, a, st);
@@ -871,8 +892,8 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
     e = launch_indirect_stm_stream(p->pm, a, st);      // one RK4 step on a full chip: lane = segment, HBM-bound (kernels_indirect_stream.hip)
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
-  if (e == hipSuccess && staged) e = launch_pack_soa(p->d_pa, 144, p->S, a.Phi, a.ldp, st);
-  if (e == hipSuccess && staged && a.Da) e = launch_pack_soa(p->d_da, 12, p->S, a.defect, a.ldd, st);
+  if (e == hipSuccess && staged && !blocks) e = launch_pack_soa(p->d_pa, 144, p->S, a.Phi, a.ldp, st);
+  if (e == hipSuccess && staged && !blocks && a.Da) e = launch_pack_soa(p->d_da, 12, p->S, a.defect, a.ldd, st);
   timing_end(c, st);
   if (e != hipSuccess) return set_err(c, LTO_EHIP, "launch_indirect_stm", e);
   warm_filled(p, 0, a);
@@ -886,6 +907,7 @@ int lto_indirect_newton_solve_dev(lto_indirect_plan* p, void* stream, const doub
   if (!p) return LTO_ENULL;
   lto_ctx* c = p->ctx;
   if (p->ndim != 12) return set_err(c, LTO_EUNSUPPORTED, "device Newton solve is built for ndim = 12");
+  if (p->out_blocks) return set_err(c, LTO_EUNSUPPORTED, "device Newton solve reads struct-of-arrays Phi / defect: use a plan with LTO_LAYOUT_SOA");
   if (!defect || !delta) return set_err(c, LTO_ENULL, "defect or delta is NULL");
   if (ldd < p->S || (Phi && ldp < p->S) || ldx < (long)p->n_nodes * p->n_batch) return set_err(c, LTO_EINVAL, "leading dimension too small");
   int rc = bind_device(c);

@@ -691,6 +691,13 @@ class IndirectPlan:
     def set_kernel(self, kernel):
         self.ctx.check(self.ctx.lib.lto_indirect_plan_set_kernel(self.handle, int(kernel)))
 
+    LAYOUT_SOA, LAYOUT_BLOCKS = 0, 1
+
+    def set_output_layout(self, layout):
+        """LAYOUT_BLOCKS: the sweeps write defect [S][ndim] and Phi [S][ndim*ndim] (one column-major block per segment: Julia's
+        layout) instead of struct-of-arrays; 12-dim DOP853 plans only (lto_indirect_plan_set_output_layout)."""
+        self.ctx.check(self.ctx.lib.lto_indirect_plan_set_output_layout(self.handle, int(layout)))
+
     def set_defect_lanes(self, lanes=0):
         """Lanes per segment of the defect-only sweep of a 12-dim DOP853 plan: 0 = choose, 1, 2 or 4
         (lto_indirect_plan_set_defect_lanes)."""

@@ -1791,6 +1791,56 @@ def test_rebalanced_auto_sweeps_with_record_staging_are_bit_identical(gpu_ctx):
     plan.close()
 
 
+@pytest.mark.parametrize("n_nodes,B", [(1500, 1), (333, 5)])
+def test_block_output_layout_equals_struct_of_arrays_bitwise(gpu_ctx, n_nodes, B):
+    """LTO_LAYOUT_BLOCKS (round 6): a 12-dim DOP853 plan writes defect [S][12] and Phi [S][144] -- one column-major block per segment,
+    the reference's own layout (indirect.jl:121-123) -- instead of struct-of-arrays.  Same kernels, same bits: natural order, after
+    lto_indirect_plan_rebalance (the ordered sweep then writes its records straight into the caller's arrays: no record arrays of the
+    plan's own, no transposes), STM sweep and defect-only sweep, mixed control-law classes in one batch.  Misuse is refused."""
+    import torch
+    n = n_nodes
+    S = (n - 1) * B
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=61, dt_range=(0.02, 0.45))
+    prms = [lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 2.0 if b == 1 else 1.0, 10.0 ** -(b % 3)) for b in range(B)]
+    Xd = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    f64 = dict(dtype=torch.float64, device="cuda")
+    soa = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator())
+    blk = lto.IndirectPlan(gpu_ctx, n, B, prms, lto.integrator())
+    blk.set_output_layout(blk.LAYOUT_BLOCKS)
+    for ordered in (False, True):
+        P1 = torch.zeros(144, S, **f64); d1 = torch.zeros(12, S, **f64); d1o = torch.zeros(12, S, **f64)
+        P2 = torch.full((S, 144), -7.0, **f64); d2 = torch.full((S, 12), -7.0, **f64); d2o = torch.full((S, 12), -7.0, **f64)
+        soa.jacobian(Xd, n * B, td, B, P1, S, d1, S)
+        blk.jacobian(Xd, n * B, td, B, P2, 0, d2, 0)                     # ldp / ldd are not looked at
+        soa.defect(Xd, n * B, td, B, d1o, S)
+        blk.defect(Xd, n * B, td, B, d2o, 0)
+        torch.cuda.synchronize()
+        assert soa.last_kernel() == blk.last_kernel() == "cooperative2"
+        assert torch.equal(P2.T.contiguous(), P1) and torch.equal(d2.T.contiguous(), d1), ordered
+        assert float((d2o.T - d1o).abs().max()) < 1e-12                  # (the defect-only sweeps may differ in lanes per segment)
+        assert bool(torch.isfinite(P2).all())
+        if not ordered:
+            soa.rebalance(); blk.rebalance()
+        else:
+            assert soa.staging() & 3 == 3 and blk.staging() & 3 == 3
+    soa.close(); blk.close()
+    rk4 = lto.IndirectPlan(gpu_ctx, 8, 1, prms[0], lto.integrator(lto.RK4, steps=8))
+    with pytest.raises(lto.LtoError) as ei:
+        rk4.set_output_layout(rk4.LAYOUT_BLOCKS)
+    assert ei.value.code == -3                                            # LTO_EUNSUPPORTED: the RK4 kernels write struct-of-arrays
+    with pytest.raises(lto.LtoError):
+        rk4.set_output_layout(2)
+    rk4.set_output_layout(rk4.LAYOUT_SOA)
+    rk4.close()
+    blk = lto.IndirectPlan(gpu_ctx, 8, 1, prms[0], lto.integrator())
+    blk.set_output_layout(blk.LAYOUT_BLOCKS)
+    with pytest.raises(lto.LtoError) as ei:
+        blk.newton_solve(torch.zeros(144, 7, **f64), 7, torch.zeros(12, 7, **f64), 7, torch.zeros(12, 8, **f64), 8)
+    assert ei.value.code == -3
+    blk.close()
+
+
 @pytest.mark.parametrize("pcase", ["p1_rho1", "p1_rho1e-3", "p2_clamped", "p1.5", "p0"])
 def test_one_step_whole_segment_lanes_vs_oracle_and_column_groups(gpu_ctx, oracle, pcase):
     """RK4 with ONE step per segment and the whole 12x12 STM in the segment's own lane (kernels_indirect_stream.hip,
