@@ -866,6 +866,41 @@ __device__ __forceinline__ void var_col12_bottom_dy(const DyadParts& p, const do
   dw[2] = -w[5];
   dw[3] = -hx; dw[4] = -hy; dw[5] = -hz;
 }
+// 14-dim forms of the two column halves (always-thrust-limited laws; kernels_indirect_coop2_14.hip): top w = (a, b, mu) =
+// (delta r, delta v, delta m) with the received d = delta lambda_v; bottom w = (d, g, nu) = (delta lambda_v, delta lambda_r,
+// delta lambda_m) with the received (a, mu).  The 12-dim part is var_col12_top_dy / _bottom_dy; the mass couplings of var_col14
+// with the unit vector lhat written as inv_n lambda_v and the factor folded into the coefficients the base wave publishes:
+//   b'  += umn lambda_v mu,       umn = (umag / mass) / n                (d u / d m = (umag / m) lhat)
+//   mu'  = mnn (lambda_v . d),    mnn = -kappa_td mass umag' / n         (d mdot / d lambda_v)
+//   nu'  = Lm mu + Lnn (lambda_v . d),   Lm = 2 umag n / mass^2,  Lnn = -(umag' n + umag) / (mass n)
+// (nothing depends on nu for these laws, so the lambda_m column of the STM stays the unit vector and is not integrated).
+__device__ __forceinline__ void var_col14_top_dy(const DyadParts& p, const double lx, const double ly, const double lz, const double ua,
+                                                 const double ubn, const double umn, const double mnn, const double w2, const double (&w)[7],
+                                                 const double (&d)[3], double (&dw)[7]) {
+  const double B = p.A - 1.0;
+  double g0, g1, g2;
+  dyad_G(p, B, w[0], w[1], w[2], g0, g1, g2);
+  const double dx = d[0], dyv = d[1], dz = d[2];
+  dw[0] = w[3]; dw[1] = w[4]; dw[2] = w[5];
+  const double ld = __builtin_fma(lx, dx, __builtin_fma(ly, dyv, lz * dz));
+  const double tl = __builtin_fma(umn, w[6], ubn * ld);       // the two multiples of lambda_v: U's dyad and d u / d m
+  dw[3] = __builtin_fma(w2, w[4], __builtin_fma(-ua, dx, __builtin_fma(tl, lx, g0)));
+  dw[4] = __builtin_fma(-w2, w[3], __builtin_fma(-ua, dyv, __builtin_fma(tl, ly, g1)));
+  dw[5] = __builtin_fma(-ua, dz, __builtin_fma(tl, lz, g2));
+  dw[6] = mnn * ld;
+}
+__device__ __forceinline__ void var_col14_bottom_dy(const DyadParts& p, const double lx, const double ly, const double lz, const double q1,
+                                                    const double q2, const double es, const double Lm, const double Lnn, const double w2,
+                                                    const double (&w)[7], const double (&av)[3], const double mu, double (&dw)[7]) {
+  const double w6[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+  double d6[6];
+  var_col12_bottom_dy(p, lx, ly, lz, q1, q2, es, w2, w6, av, d6);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) dw[j] = d6[j];
+  const double ld = __builtin_fma(lx, w[0], __builtin_fma(ly, w[1], lz * w[2]));
+  dw[6] = __builtin_fma(Lm, mu, Lnn * ld);
+}
+
 // G, H, U of the 12-dim system from the base argument's position r, lambda_v and the base lane's by-products: the
 // VAR block of rhs12 without its reciprocal square roots and control law.
 __device__ __forceinline__ void coef12_from_parts(const double x, const double yy, const double z, const double lx0, const double ly0,

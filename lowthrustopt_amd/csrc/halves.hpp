@@ -151,4 +151,79 @@ __device__ __forceinline__ void rhs12_base_quad(const double (&w)[3], const Quad
   if constexpr (WITH_PARTS) { bp.a0 = a0; bp.e = e; bp.q = 5.0 * t * is; bp.es = es; bp.omc = omc; }
 }
 
+// ---- 14-dim system (state + mass + costates + mass costate), always-thrust-limited laws (p = 0, p = 1): the quad of
+// rhs12_base_quad with a fourth component in two of its lanes -- lane 1 owns (v, m), lane 3 owns (lambda_r, lambda_m); lanes 0 and 2
+// carry a zero there.  The mass enters through accelLimit = cT / m alone (dynamics.hpp rhs14): one reciprocal, off the
+// reciprocal-square-root chains, and
+//   m' = -kappa_td umag m,   lambda_m' = -umag n / m          (GeneralCode/twoBody_stateCostate_mass_deriv.jl:57,76 in CRTBP units).
+// By-products beyond QuadParts, for the variational terms of the mass (dynamics.hpp var_col14):
+//   inv_m, un = d umag / d n, m = umag.
+struct QuadParts14 { QuadParts q; double inv_m, mass, un, umag, n; };
+template <int PM>
+__device__ __forceinline__ void rhs14_base_quad(const double (&w)[4], const QuadLane& Q, const TrajParams& tp, double (&k)[4], QuadParts14& bp,
+                                                double (&P)[3]) {
+  static_assert(PM == PM_P0 || PM == PM_P1, "the 14-dim quad is built for the laws whose thrust is cT sigma(n) / mass");
+  auto t0022 = [](const double v) { return quad_take<quad_perm(0, 0, 2, 2)>(v); };
+  auto t1133 = [](const double v) { return quad_take<quad_perm(1, 1, 3, 3)>(v); };
+  auto t2222 = [](const double v) { return quad_take<quad_perm(2, 2, 2, 2)>(v); };
+  auto t1032 = [](const double v) { return quad_take<quad_perm(1, 0, 3, 2)>(v); };
+  auto t1111 = [](const double v) { return quad_take<quad_perm(1, 1, 1, 1)>(v); };
+  double S[3], L[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { P[j] = t0022(w[j]); S[j] = t1133(w[j]); L[j] = t2222(w[j]); }   // (r r lv lv), (v v lr lr), lambda_v
+  const double mass = t1111(w[3]);
+  const double inv_m = rcp_nr(mass);
+  const double aL = tp.cT * inv_m;
+  const double w2 = 2.0 * tp.omega;
+  const double a0 = P[0] + Q.off1;
+  const double u0 = a0 + Q.off2, u0_o = a0 + Q.off2_o;
+  const double yz2 = __builtin_fma(P[1], P[1], P[2] * P[2]);
+  const double d = __builtin_fma(u0, u0, yz2);
+  const double i = rsqrt_nr(fmax(d, Q.floor));
+  const double is = i * i;
+  const double c = Q.kapb * (is * i);
+  const double e = 3.0 * c * is;
+  const double n2 = t2222(d), inv_n = t2222(i);
+  const double n = n2 * inv_n;
+  double m, ua, ub, un;
+  if constexpr (PM == PM_P1) {            // as rhs12_base_parts, with accelLimit = cT / m
+    const double zz = fmin(fmax((1.0 - n) * tp.inv_rho, -700.0), 690.0);
+    const double ez = exp_mid(zz);
+    const double qq = rcp_nr(1.0 + ez);
+    m = aL * qq;
+    ua = m * inv_n;
+    un = (aL * tp.inv_rho) * (ez * qq) * qq;
+    ub = ua - un;
+  } else {
+    m = aL; ua = aL * inv_n; ub = ua; un = 0.0;
+  }
+  const double yzl = __builtin_fma(P[1], L[1], P[2] * L[2]);
+  const double s = __builtin_fma(u0, L[0], yzl);
+  const double t = e * s;
+  const double c_o = t1032(c), t_o = t1032(t);
+  const double cs = c_o + c, omc = 1.0 - cs;
+  const double es = t_o + t;
+  const double tA = __builtin_fma(t_o, u0_o, t * u0);
+  const double x = P[0], yy = P[1], z = P[2];
+  const double ax = __builtin_fma(-ua, L[0], __builtin_fma(-c_o, u0_o, __builtin_fma(-c, u0, __builtin_fma(w2, S[1], x))));
+  const double ay = __builtin_fma(-ua, L[1], __builtin_fma(-cs, yy, __builtin_fma(-w2, S[0], yy)));
+  const double az = __builtin_fma(-ua, L[2], -cs * z);
+  const double gx = __builtin_fma(-omc, L[0], -tA);
+  const double gy = __builtin_fma(-omc, L[1], -es * yy);
+  const double gz = __builtin_fma(cs, L[2], -es * z);
+  const double g3x = t1111(gx), g3y = t1111(gy), g3z = t1111(gz);
+  const double lin0 = __builtin_fma(Q.kap_lin, P[1], Q.sg_lin * S[0]);
+  const double lin1 = __builtin_fma(-Q.kap_lin, P[0], Q.sg_lin * S[1]);
+  const double lin2 = Q.sg_lin * S[2];
+  k[0] = Q.lane1 ? ax : (Q.lane3 ? g3x : lin0);
+  k[1] = Q.lane1 ? ay : (Q.lane3 ? g3y : lin1);
+  k[2] = Q.lane1 ? az : (Q.lane3 ? g3z : lin2);
+  const double mdot = (-tp.kappa_td * m) * mass;                 // rhs14: dy[6]
+  const double lmdot = -((m * n) * inv_m);                       // rhs14: dy[13], thrust-limited laws
+  k[3] = Q.lane1 ? mdot : (Q.lane3 ? lmdot : 0.0);
+  bp.q.c = c; bp.q.is = is; bp.q.inv_n = inv_n; bp.q.n2 = n2; bp.q.ua = ua; bp.q.ub = ub;
+  bp.q.a0 = a0; bp.q.e = e; bp.q.q = 5.0 * t * is; bp.q.es = es; bp.q.omc = omc;
+  bp.inv_m = inv_m; bp.mass = mass; bp.un = un; bp.umag = m; bp.n = n;
+}
+
 }  // namespace lto

@@ -86,6 +86,9 @@ hipError_t launch_indirect14_stm(int pm, int method, int cols_per_lane, const In
 hipError_t launch_indirect_stm_coop(int ndim, int pm, int method, const IndirectArgs& a, hipStream_t st);
 // the same with every 12-component state split over two lanes (kernels_indirect_coop2.hip): 12-dim, DOP853 adaptive only
 hipError_t launch_indirect_stm_coop2(int pm, const IndirectArgs& a, hipStream_t st);
+// ... and its 14-dim form (kernels_indirect_coop2_14.hip): states split 7 + 7, thirteen columns; the always-thrust-limited laws (p = 0, 1) only
+hipError_t launch_indirect_stm_coop2_14(int pm, const IndirectArgs& a, hipStream_t st);
+bool indirect_stm_coop2_14_available(int pm);
 // defect-only sweep with two lanes per segment (kernels_indirect_defect2.hip): 12-dim, DOP853 adaptive only
 hipError_t launch_indirect_defect2(int pm, const IndirectArgs& a, hipStream_t st);
 // ... with four lanes per segment (same file): while the chip has a SIMD per 16 segments to spare

@@ -595,8 +595,8 @@ int lto_indirect_plan_set_kernel(lto_indirect_plan* p, int kernel) {
     return set_err(p->ctx, LTO_EINVAL, "kernel must be LTO_KERNEL_AUTO, _PER_LANE, _COOP, _PIPE8, _COOP2, _PIPE48, _PIPE32 or _LANE");
   if (kernel == LTO_KERNEL_LANE && !indirect_stm_lane_available(p->ndim, p->integ.method, p->S))
     return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_LANE is built for 12-dim RK4 plans");
-  if (kernel == LTO_KERNEL_COOP2 && (p->integ.method != LTO_DOP853_ADAPTIVE || p->ndim != 12))
-    return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_COOP2 is built for 12-dim DOP853_ADAPTIVE plans");
+  if (kernel == LTO_KERNEL_COOP2 && (p->integ.method != LTO_DOP853_ADAPTIVE || (p->ndim != 12 && !indirect_stm_coop2_14_available(p->pm))))
+    return set_err(p->ctx, LTO_EINVAL, "LTO_KERNEL_COOP2 is built for DOP853_ADAPTIVE plans: 12-dim, and 14-dim with p = 0 or p = 1");
   if ((kernel == LTO_KERNEL_PIPE8 || kernel == LTO_KERNEL_PIPE48 || kernel == LTO_KERNEL_PIPE32) && p->integ.method != LTO_RK4)
     return set_err(p->ctx, LTO_EINVAL, "the pipeline kernels are built for fixed-step RK4 plans");
   if (kernel == LTO_KERNEL_PIPE32 && !indirect_stm_pipe32_available(p->ndim, p->pm))
@@ -783,7 +783,8 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
 static int auto_stm_kernel(int ndim, int method, int steps, int pm, long S, long cus, bool ordered, int cols_per_lane, const double* cost,
                            double per_lane3_us, double lane_us) {
   const auto rounds = [&](long per_round) { return (double)((S + per_round - 1) / per_round); };
-  if (method != LTO_RK4) return (method == LTO_DOP853_ADAPTIVE && ndim == 12) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
+  if (method != LTO_RK4)      // DOP853: the two-lanes-per-state forms (12-dim; 14-dim for batches of the always-thrust-limited laws, round 6)
+    return (method == LTO_DOP853_ADAPTIVE && (ndim == 12 || indirect_stm_coop2_14_available(pm))) ? LTO_KERNEL_COOP2 : LTO_KERNEL_COOP;
   if (steps < 6) {
     if (steps >= 2 && indirect_stm_lane_available(ndim, method, S) && !ordered && cols_per_lane == 0 &&
         rounds(256 * cus) * lane_us < rounds(64 * cus) * per_lane3_us)
@@ -882,7 +883,7 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   if (blocks) { a.Pa = Phi; if (a.defect) a.Da = defect; }
   hipError_t e;
   if (kern == LTO_KERNEL_COOP) e = launch_indirect_stm_coop(p->ndim, p->pm, p->integ.method, a, st);
-  else if (kern == LTO_KERNEL_COOP2) e = launch_indirect_stm_coop2(p->pm, a, st);
+  else if (kern == LTO_KERNEL_COOP2) e = (p->ndim == 12) ? launch_indirect_stm_coop2(p->pm, a, st) : launch_indirect_stm_coop2_14(p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE8) e = launch_indirect_stm_pipe8(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, seg44, st);
   else if (kern == LTO_KERNEL_PIPE32) e = launch_indirect_stm_pipe32(p->ndim, p->pm, a, st);

@@ -24,7 +24,7 @@ BOUNDARY_CASES = [
     (12, 24576, lto.RK4, 6, "pipeline48"), (12, 45056, lto.RK4, 64, "pipeline48"), (12, 45057, lto.RK4, 64, "segment-lane"),
     (12, 65536, lto.RK4, 64, "segment-lane"), (12, 65537, lto.RK4, 64, "pipeline48"), (12, 90113, lto.RK4, 64, "segment-lane"),
     (12, 262144, lto.RK4, 64, "segment-lane"), (14, 262144, lto.RK4, 64, "pipeline32"),
-    (12, 29, lto.DOP853_ADAPTIVE, 0, "cooperative2"), (14, 29, lto.DOP853_ADAPTIVE, 0, "cooperative"),
+    (12, 29, lto.DOP853_ADAPTIVE, 0, "cooperative2"), (14, 29, lto.DOP853_ADAPTIVE, 0, "cooperative2"),
     (12, 29, lto.RKF78_ADAPTIVE, 0, "cooperative"), (14, 29, lto.RKF78_FIXED, 4, "cooperative"),
     (12, 65535, lto.RK4, 1, "per-lane"), (12, 1048576, lto.RK4, 1, "per-lane"), (12, 262144, lto.RK4, 3, "segment-lane"),
 ]
@@ -40,6 +40,9 @@ def test_auto_kernel_depends_on_what_the_families_are_built_for():
     assert lto.auto_kernel(14, lto.RK4, 64, 1.0, 8192) == "pipeline32" and lto.auto_kernel(14, lto.RK4, 64, 0.0, 8192) == "pipeline32"
     assert lto.auto_kernel(14, lto.RK4, 64, 2.0, 8192) == "pipeline8" and lto.auto_kernel(14, lto.RK4, 64, 1.5, 12288) == "pipeline48"
     assert lto.auto_kernel(12, lto.RK4, 64, 1.5, 8192) == "pipeline32"
+    # 14-dim DOP853: the two-lanes-per-state form for the always-thrust-limited laws, the one-piece cooperative kernel for the others
+    assert lto.auto_kernel(14, lto.DOP853_ADAPTIVE, 0, 0.0, 4096) == "cooperative2" and lto.auto_kernel(14, lto.DOP853_ADAPTIVE, 0, 2.0, 4096) == "cooperative"
+    assert lto.auto_kernel(14, lto.DOP853_ADAPTIVE, 0, 1.5, 4096) == "cooperative" and lto.auto_kernel(14, lto.RKF78_ADAPTIVE, 0, 1.0, 4096) == "cooperative"
     # ordered sweeps (a lane order from lto_indirect_plan_rebalance) keep the pipelines: the whole-segment lanes read nodes in place
     assert lto.auto_kernel(12, lto.RK4, 64, 1.0, 262144, ordered=True) == "pipeline48"
     # fewer compute units: the rounds shrink with the device

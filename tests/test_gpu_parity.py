@@ -220,10 +220,10 @@ def test_indirect_mixed_control_law_classes(gpu_ctx, ndim, mname, kernel):
     tuple, stateCostate_deriv.jl:36-53) with segments of different classes inside one wavefront / workgroup: defect,
     STM and step counts equal those of single-trajectory sweeps, for every integrator and both STM kernel families."""
     import torch
-    if kernel == "coop2" and ndim != 12:
-        pytest.skip("the two-lane cooperative kernel is built for the 12-dim system")
     method, steps = METHODS[mname]
     ps = [1.0, 0.0, 2.0, 1.5, 1.0, 2.0, 3.0]
+    if kernel == "coop2" and ndim == 14:
+        ps = [1.0, 0.0, 1.0, 0.0, 0.0, 1.0, 1.0]     # the 14-dim two-lane form is built for the always-thrust-limited laws: both of its classes
     B, n = len(ps), 8                                          # 7 segments per trajectory: classes interleave in a wave
     XC, T = synth.indirect_problem(n, n_batch=B, seed=31, dt_range=(0.05, 0.3))
     if ndim == 14:
@@ -1139,10 +1139,15 @@ def test_indirect_stm_kernel_variants_vs_oracle(gpu_ctx, oracle, ndim, mname, ke
     waves exchanging the variational coefficients through LDS) against the oracle's dual-number STM, for every
     integrator, ND = 12 and the 14-dim extension, ragged segment count (not a multiple of 16 or 64)."""
     import torch
-    if kernel == "coop2" and ndim != 12:
-        pytest.skip("the two-lane cooperative kernel is built for the 12-dim system")
     method, steps = METHODS[mname]
     n = 78
+    if kernel == "coop2" and ndim == 14 and pcase in ("p2_clamped", "p1.5"):
+        # the 14-dim two-lane form is built for the always-thrust-limited laws (p = 0, 1); the selector is refused elsewhere
+        plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(MU, DU, TU, 0.05, 2000.0, 1.0, P_CASES[pcase][0], 1.0), lto.integrator(method, steps=steps), ndim=14)
+        with pytest.raises(lto.LtoError):
+            plan.set_kernel(plan.KERNEL_COOP2)
+        plan.close()
+        return
     pp, rho, thr, lam = P_CASES[pcase]
     XC, T = synth.indirect_problem(n, seed=11, lam_sigma=lam)
     XC, t = XC[:, :, 0], T[:, 0]
@@ -1620,7 +1625,7 @@ def test_indirect_auto_kernel_choice(gpu_ctx):
              (14, 30, lto.RK4, 2, "per-lane"), (14, 12289, lto.RK4, 6, "pipeline48"), (14, 16385, lto.RK4, 6, "pipeline32"),
              (14, 20481, lto.RK4, 6, "pipeline8"), (12, 11265, lto.RK4, 6, "pipeline48"),
              (12, 32769, lto.RK4, 8, "pipeline48"), (14, 24577, lto.RK4, 6, "pipeline48"), (12, 24577, lto.RK4, 6, "pipeline48"),
-             (12, 30, lto.DOP853_ADAPTIVE, 0, "cooperative2"), (14, 30, lto.DOP853_ADAPTIVE, 0, "cooperative"),
+             (12, 30, lto.DOP853_ADAPTIVE, 0, "cooperative2"), (14, 30, lto.DOP853_ADAPTIVE, 0, "cooperative2"),
              (12, 30, lto.RKF78_ADAPTIVE, 0, "cooperative"), (14, 30, lto.RKF78_FIXED, 4, "cooperative")]
     for ndim, n, method, steps, want in cases:
         XC, T = synth.indirect_problem(n, seed=2)
