@@ -93,6 +93,8 @@ bool indirect_stm_coop2_14_available(int pm);
 hipError_t launch_indirect_defect2(int pm, const IndirectArgs& a, hipStream_t st);
 // ... with four lanes per segment (same file): while the chip has a SIMD per 16 segments to spare
 hipError_t launch_indirect_defect4(int pm, const IndirectArgs& a, hipStream_t st);
+// ... on the 14-dim system (same file; p = 0 / 1 batches, see indirect_stm_coop2_14_available)
+hipError_t launch_indirect14_defect4(int pm, const IndirectArgs& a, hipStream_t st);
 // three-role pipeline, fixed-step RK4 only: base wave, coefficient wave and column waves per 16 segments, skewed by one RK4 step.
 // Eight-wave form (kernels_indirect_pipe8.hip): one STM column per lane with the coefficients broadcast inside the FMA (v_fmac_f64_dpp
 // row_newbcast), two RK4 steps per phase, a fourth of the column work alternates between two SIMDs, base role with paired stages

@@ -610,8 +610,10 @@ int lto_indirect_plan_last_kernel(const lto_indirect_plan* p) { return p ? p->la
 int lto_indirect_plan_set_defect_lanes(lto_indirect_plan* p, int lanes) {
   if (!p) return LTO_ENULL;
   if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4) return set_err(p->ctx, LTO_EINVAL, "defect lanes must be 0 (choose), 1, 2 or 4");
-  if (lanes > 1 && !(p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE))
-    return set_err(p->ctx, LTO_EINVAL, "two and four lanes per segment are built for 12-dim DOP853_ADAPTIVE plans (the reference's integrator setting)");
+  const bool quad14 = p->ndim == 14 && p->integ.method == LTO_DOP853_ADAPTIVE && indirect_stm_coop2_14_available(p->pm);
+  if (lanes > 1 && !(p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE) && !(lanes == 4 && quad14))
+    return set_err(p->ctx, LTO_EINVAL, "two and four lanes per segment are built for 12-dim DOP853_ADAPTIVE plans (the reference's integrator setting); "
+                                       "four also for 14-dim DOP853_ADAPTIVE plans with p = 0 or p = 1");
   p->defect_lanes = lanes;
   return LTO_OK;
 }
@@ -703,7 +705,11 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
   // 90 -> 77 us, 65 536 ordered: 0.31 -> 0.27 ms, 131 072: 0.32 -> 0.30 ms; 262 144: 0.39 -> 0.52 ms, so two lanes there.
   // LTO_KERNEL_PER_LANE / LTO_KERNEL_COOP2 on the plan, or lto_indirect_plan_set_defect_lanes, force one form.
   const bool ref_setting = p->ndim == 12 && p->integ.method == LTO_DOP853_ADAPTIVE;
+  // the same integrator setting on the 14-dim system (always-thrust-limited laws): the quad form while the chip has a SIMD per 16
+  // segments to spare, as for 12-dim (round 6)
+  const bool quad14 = p->ndim == 14 && p->integ.method == LTO_DOP853_ADAPTIVE && indirect_stm_coop2_14_available(p->pm);
   int lanes = 1;
+  if (quad14) lanes = p->defect_lanes ? p->defect_lanes : ((p->kernel == LTO_KERNEL_AUTO || p->kernel == LTO_KERNEL_COOP2) && (long)(p->S + 15) / 16 <= 32L * c->cu_count) ? 4 : 1;
   if (ref_setting) {
     if (p->defect_lanes) lanes = p->defect_lanes;
     else if (p->kernel == LTO_KERNEL_COOP2) lanes = 2;
@@ -748,7 +754,7 @@ int lto_indirect_defect_dev(lto_indirect_plan* p, void* stream, const double* X,
     a.Xa = p->d_xa; a.Da = p->d_da;
   }
   if (blocks) a.Da = defect;
-  hipError_t e = lanes == 4        ? launch_indirect_defect4(p->pm, a, st)
+  hipError_t e = lanes == 4        ? (p->ndim == 12 ? launch_indirect_defect4(p->pm, a, st) : launch_indirect14_defect4(p->pm, a, st))
                  : lanes == 2      ? launch_indirect_defect2(p->pm, a, st)
                  : (p->ndim == 12) ? launch_indirect_defect(p->pm, p->integ.method, a, st)
                                    : launch_indirect14_defect(p->pm, p->integ.method, a, st);

@@ -1606,8 +1606,9 @@ def test_indirect_pipeline_kernel_is_rk4_only(gpu_ctx):
     plan.set_defect_lanes(1); plan.set_defect_lanes(0)
     plan.close()
     plan = lto.IndirectPlan(gpu_ctx, 8, 1, prm, lto.integrator(lto.DOP853_ADAPTIVE), ndim=14)
+    plan.set_defect_lanes(4)                     # round 6: the quad form exists for 14-dim plans of the always-thrust-limited laws (p = 1 here)
     with pytest.raises(lto.LtoError):
-        plan.set_defect_lanes(4)
+        plan.set_defect_lanes(2)                 # ... the pair form does not
     plan.close()
 
 

@@ -85,3 +85,56 @@ def test_gpu14_adaptive_and_reduction(gpu_ctx, oracle):
     Phi12, d12 = lto.indirect_stm(XC, t, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), integ, ctx=gpu_ctx)
     assert np.abs(d14[IDX12] - d12).max() < 1e-13
     assert np.abs(Phi14[np.ix_(IDX12, IDX12)] - Phi12).max() < 1e-11 * np.abs(Phi12).max()
+
+
+@pytest.mark.gpu
+def test_gpu14_reference_integrator_kernels_for_the_thrust_limited_laws(gpu_ctx, oracle):
+    """Round 6: the reference's integrator setting (adaptive order 8 @ 1e-13) on the 14-dim system runs the two-lanes-per-state
+    cooperative kernel (STM sweep: states split 7 + 7, thirteen columns, the lambda_m column the unit vector) and the four-lanes-per-
+    segment defect kernel for batches of the always-thrust-limited laws (p = 0, p = 1).  A ragged batch with both classes in one
+    workgroup: STM and defect against the oracle's dual-number flow (same error norm: 1e-9 of max |Phi|), the quad defect sweep
+    against the one-lane kernel, the lambda_m column exactly e_13, det Phi = 1; p = 2 keeps the one-piece cooperative kernel."""
+    import torch
+    n, B = 41, 3
+    S = (n - 1) * B
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=4, dt_range=(0.05, 0.35))
+    X = np.zeros((14, n, B), order="F")
+    X[:6] = XC[:6]; X[6] = 1000.0 - 0.03 * np.arange(n)[:, None]; X[7:13] = XC[6:]; X[13] = 0.25
+    ps, rhos = [1.0, 0.0, 1.0], [1.0, 1.0, 1e-2]
+    prm_l = [[MU, DU, TU, 0.05, 2000.0, 1.0, ps[b], rhos[b]] for b in range(B)]
+    plan = lto.IndirectPlan(gpu_ctx, n, B, [lto.make_params(*q) for q in prm_l], lto.integrator(), ndim=14)
+    Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    f64 = dict(dtype=torch.float64, device="cuda")
+    Phi = torch.zeros(196, S, **f64); d = torch.zeros(14, S, **f64); d4 = torch.zeros(14, S, **f64); d1 = torch.zeros(14, S, **f64)
+    plan.jacobian(Xd, n * B, td, B, Phi, S, d, S)
+    assert plan.last_kernel() == "cooperative2"
+    plan.defect(Xd, n * B, td, B, d4, S)                 # AUTO: four lanes per segment
+    plan.set_defect_lanes(1); plan.defect(Xd, n * B, td, B, d1, S)
+    plan.set_defect_lanes(4)
+    with pytest.raises(lto.LtoError):
+        plan.set_defect_lanes(2)                          # the pair form is 12-dim only
+    torch.cuda.synchronize()
+    acc, rej = plan.step_counts()
+    assert acc.min() >= 1 and (acc + rej).max() < 200
+    plan.close()
+    P = Phi.cpu().numpy().reshape(14, 14, S).transpose(1, 0, 2)
+    dn, d4n, d1n = d.cpu().numpy(), d4.cpu().numpy(), d1.cpu().numpy()
+    assert np.abs(d4n - d1n).max() < 1e-12 and np.abs(d4n - dn).max() < 1e-11
+    e13 = np.zeros(14); e13[13] = 1.0
+    assert np.array_equal(P[:, 13, :], np.repeat(e13[:, None], S, axis=1))
+    for b in range(B):
+        sl = slice(b * (n - 1), (b + 1) * (n - 1))
+        P_o, d_o, rc = oracle.indirect14(X[:, :, b], T[:, b], prm_l[b], oracle.DOP853_ADAPTIVE)
+        assert rc == 0
+        xn = np.linalg.norm(d_o + X[:, 1:, b])
+        assert np.linalg.norm(dn[:, sl] - d_o) / xn < 1e-10 and np.linalg.norm(d4n[:, sl] - d_o) / xn < 1e-10
+        assert np.abs(P[:, :, sl] - P_o).max() < 1e-9 * np.abs(P_o).max()
+    for s in (0, 17, S - 1):
+        assert abs(np.linalg.det(P[:, :, s]) - 1.0) < 1e-8
+    p2 = lto.IndirectPlan(gpu_ctx, 8, 1, lto.make_params(MU, DU, TU, 10.0, 2000.0, 1.0, 2.0, 1.0), lto.integrator(), ndim=14)
+    with pytest.raises(lto.LtoError):
+        p2.set_kernel(p2.KERNEL_COOP2)
+    with pytest.raises(lto.LtoError):
+        p2.set_defect_lanes(4)
+    p2.close()
