@@ -230,7 +230,12 @@ int lto_direct_jacobian(lto_ctx* ctx, int nstate, int n_nodes, int n_batch, cons
  *   X[c*ldx + j]  t[g*n_nodes + k]  defect[c*ldd + s]  Phi[(col*ndim+row)*ldp + s]  errors[s]
  *   U[c*ldu + j]  Jac[(col*nstate+row)*ldj + s]  dtf[c*ldd + s]
  * Launches are asynchronous on `stream`, a hipStream_t taken literally (NULL = HIP's default stream,
- * which is also PyTorch's default current stream); lto_ctx_stream() returns the context's own stream. */
+ * which is also PyTorch's default current stream); lto_ctx_stream() returns the context's own stream.
+ * One exception to "asynchronous": lto_indirect_defect_dev on an ndim = 12 DOP853_ADAPTIVE plan under LTO_KERNEL_AUTO with at
+ * least 64 x CUs segments may WAIT ON THE HOST for an event recorded behind an EARLIER defect sweep of the same plan (the trial-step
+ * statistics its lanes-per-segment choice reads: after the plan's first two sweeps, then every sixteenth) -- i.e. for work the
+ * caller enqueued before, never for the sweep being enqueued; lto_indirect_plan_set_defect_lanes(plan, 1 | 2 | 4) fixes the
+ * choice and removes the wait, and inside a stream capture nothing is waited for. */
 int lto_indirect_plan_create(lto_ctx* ctx, int ndim, int n_nodes, int n_batch, const lto_params* prm, int n_prm,
                              const lto_integrator* integ, lto_indirect_plan** out);
 void lto_indirect_plan_destroy(lto_indirect_plan* plan);
