@@ -12,12 +12,13 @@ if [ "$PART" = all ] || [ "$PART" = bench ]; then
 # progress goes straight into the log (a pipe into tail would hold it back until the end: the GPU box kills a run that stays silent for 7 minutes)
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
 tail -3 "$OUT/pytest_gpu.log"
-T0=$SECONDS; python bench.py --gpus 1 --steps 20 --warmup 5 2>"$OUT/bench_c2_driver.err" > "$OUT/bench_c2_driver.json"; echo "driver line: $((SECONDS - T0)) s wall"; last "$OUT/bench_c2_driver.json"
+T0=$SECONDS; python bench.py --gpus 1 --steps 20 --warmup 5 --detail "$OUT/bench_c2_verbose.json" 2>"$OUT/bench_c2_driver.err" > "$OUT/bench_c2_driver.json"; echo "driver line: $((SECONDS - T0)) s wall, $(tail -1 "$OUT/bench_c2_driver.json" | wc -c) bytes"; last "$OUT/bench_c2_driver.json"
 python bench.py --no-cpu-baseline --no-configs 2>/dev/null > "$OUT/bench_c2_200.json"; last "$OUT/bench_c2_200.json"
 python bench.py --workload hbm --ndim 12 --segments 1048576 --no-cpu-baseline --live-traffic on --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_hbm.json"; last "$OUT/bench_hbm.json"
 python bench.py --segments 8192 --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_8192.json"; last "$OUT/bench_c2_8192.json"    # 32-segment pipeline (AUTO above one round)
 python bench.py --workload c3 --cpu-seconds 5 2>/dev/null > "$OUT/bench_c3.json"; last "$OUT/bench_c3.json"
 python bench.py --ndim 12 --method dop853 --no-cpu-baseline --steps 50 2>/dev/null > "$OUT/bench_c2_dop853.json"; last "$OUT/bench_c2_dop853.json"
+python bench.py --ndim 14 --method dop853 --no-cpu-baseline --steps 50 2>/dev/null > "$OUT/bench_c2_ndim14_dop853.json"; last "$OUT/bench_c2_ndim14_dop853.json"   # round 6: the 7 + 7 two-lane form
 python bench.py --ndim 12 --method rkf78 --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_rkf78x4.json"; last "$OUT/bench_c2_rkf78x4.json"
 python bench.py --workload c4 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_c4.json"; last "$OUT/bench_c4.json"
 python bench.py --workload c5 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_c5.json"; last "$OUT/bench_c5.json"
@@ -34,6 +35,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_8192" -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c3" -- python bench.py --workload c3 --steps 2000 --warmup 5 --no-cpu-baseline > "$OUT/prof_c3.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c4" -- python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/prof_c4.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_dop853" -- python bench.py --ndim 12 --method dop853 --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2_dop853.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c2_ndim14_dop853" -- python bench.py --ndim 14 --method dop853 --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/prof_c2_ndim14_dop853.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5_stm" -- python bench.py --workload c5_stm --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_c5_stm.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5" -- python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_c5.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_newton" -- python bench.py --workload newton --pmc-child --steps 100 --warmup 5 > "$OUT/prof_newton.log" 2>&1
@@ -56,6 +58,7 @@ pmc_passes c4 --workload c4
 pmc_passes c5 --workload c5
 pmc_passes c5_stm --workload c5_stm
 pmc_passes c2_ndim12_dop853 --ndim 12 --method dop853
+pmc_passes c2_dop853 --ndim 14 --method dop853
 pmc_passes hbm_ndim12 --workload hbm --ndim 12 --segments 1048576
 pmc_passes newton --workload newton --pmc-child      # the Newton iteration's kernels: k_bvp_chunk / _tail / _backchunk, the sweeps, the norms
 fi
@@ -64,6 +67,7 @@ find "$OUT" -name "*.csv" | wc -l
 #   python tools/summarize_profile.py $OUT <tag> c2 "k_indirect_pipe8<14"
 #   python tools/summarize_profile.py $OUT <tag> c2_ndim12 "k_indirect_pipe8<12" c2
 #   python tools/summarize_profile.py $OUT <tag> c3 "k_direct_jacobian_pipe<6"
+#   (tools/condense_round.sh <run> <tag> runs all of these)
 #   python tools/summarize_profile.py $OUT <tag> c4 "k_indirect_lane"
 #   python tools/summarize_profile.py $OUT <tag> c5 "k_indirect_defect4"
 #   python tools/summarize_profile.py $OUT <tag> c5_stm "k_indirect_coop2"
