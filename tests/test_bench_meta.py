@@ -64,9 +64,9 @@ def test_roofline_object_quotes_the_profile_of_its_own_batch_size():
 
 
 def _canned_long_form():
-    """A long form with every leg the default run produces: the builder's round-5 driver line (profiles/, 21.9 KB -- the one the driver
-    could not parse), which has all of them."""
-    with open(os.path.join(ROOT, "profiles", "r05z_bench_c2_driver.json")) as fh:
+    """A long form with every leg the default run produces: the long form of the builder's round-6 run of the driver's command
+    (`--detail`), 20 KB -- the size of round 5's default line, which the driver could not parse."""
+    with open(os.path.join(ROOT, "profiles", "r06z_bench_c2_verbose.json")) as fh:
         return json.loads(fh.read().strip().splitlines()[-1])
 
 
@@ -74,7 +74,7 @@ def test_default_line_budget():
     """the default line is compact_line(long form) -- under LINE_BUDGET (6 000) bytes, a JSON object that
     round-trips, with the contract keys and roofline / cpu_baseline / parity at the top level, numbers and short tokens only."""
     long_form = _canned_long_form()
-    assert len(json.dumps(long_form)) > 20000
+    assert len(json.dumps(long_form)) > 15000
     line = bench.compact_line(long_form)
     text = json.dumps(line)
     assert len(text) < bench.LINE_BUDGET == 6000, len(text)
@@ -142,3 +142,24 @@ def test_multi_rank_line_stays_compact_and_names_both_transports():
     c = line["config"]
     assert c["collective"] == "windows" and c["rccl_ranks"] == 8 and c["transports"]["chosen"] == "windows" and c["policy"]["chosen"] == "overlap"
     assert c["stream"] == "side" and c["devices_token"] == "distinct" and c["slab_ok"] is True
+
+
+def test_design_table_is_the_one_generated_from_the_profiles():
+    """DESIGN.md section 6's table of measurements is generated from the committed profiles
+    (tools/design_table.py: bench lines, rocprofv3 kernel-trace averages, counter summaries) -- regenerate it and compare, so that the
+    prose cannot drift from the traces; and every fraction in it is reproducible from the kernel-stats average it names."""
+    spec_t = importlib.util.spec_from_file_location("design_table", os.path.join(ROOT, "tools", "design_table.py"))
+    dt = importlib.util.module_from_spec(spec_t)
+    spec_t.loader.exec_module(dt)
+    text = dt.table("r06z")
+    doc = open(os.path.join(ROOT, "DESIGN.md")).read()
+    block = doc[doc.index(dt.BEGIN) + len(dt.BEGIN):doc.index(dt.END)].strip()
+    assert block == text.strip()
+    assert open(os.path.join(ROOT, "profiles", "r06z_table.md")).read().strip() == text.strip()
+    rows = [ln for ln in text.splitlines()[2:]]
+    assert len(rows) == len(dt.ROWS) == 10 and all("--" not in r.split("|")[4] for r in rows)      # every row has its rocprofv3 average
+    # the contract row's fraction from its rocprofv3 average: 4 096 segments x 569 600 flops / average / 78.6 TFLOP/s
+    avg_us, calls, name = dt.kernel_avg("r06z", "c2", "k_indirect_pipe8<14")
+    assert calls > 1000 and "pipe8<14" in name
+    frac = 4096 * 569600 / (avg_us * 1e-6) / 78.6e12
+    assert ("FP64 %.3f" % frac) in rows[0]

@@ -31,7 +31,8 @@ def rows(pattern):
 def main():
     run, tag, workload, kname = sys.argv[1:5]
     src = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else workload      # prof_<src>/ holds the kernel trace (one trace, several kernels)
-    pmc_src = src if os.path.isdir(os.path.join(run, src)) else workload   # <run>/<pmc_src>/pmc_* hold the counter passes
+    # <run>/<pmc_src>/pmc_* hold the counter passes: the workload's own directory when there is one (bench.py's pmc_key), else the trace's
+    pmc_src = workload if os.path.isdir(os.path.join(run, workload)) else src
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     # kernel stats
     stats = list(rows(os.path.join(run, "prof_%s" % src, "**", "*_kernel_stats.csv")))
