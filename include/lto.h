@@ -412,7 +412,9 @@ int lto_line_search_pick_dev(lto_ctx* ctx, void* stream, const double* sumsq, co
                              double* maxabs_out, double* defect, long ldd);
 
 /* Dense output (device): segment s is sampled at t_samples[first[s] .. first[s+1]) (sorted, inside the segment);
- * Y[c*ldy + j] = x_c(t_samples[j]); final_state[c*n_batch + b] (or NULL) = x(t_n) of trajectory b. */
+ * Y[c*ldy + j] = x_c(t_samples[j]); final_state[c*n_batch + b] (or NULL) = x(t_n) of trajectory b.  Built for what densify
+ * (src/HelperFunctions.jl:51-101) needs -- ndim = 12 with LTO_DOP853_ADAPTIVE (for its Vern8) -- and for LTO_RK4; other plans:
+ * LTO_EUNSUPPORTED (round 6 removed the 14-dim and RKF7(8) instantiations, which nothing ran). */
 int lto_indirect_dense_dev(lto_indirect_plan* plan, void* stream, const double* X, long ldx, const double* t,
                            int n_tgrids, const int* first, const double* t_samples, double* Y, long ldy,
                            double* final_state);

@@ -35,15 +35,11 @@ hipError_t launch_indirect_stm(int pm, int method, int cols, const IndirectArgs&
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_indirect14_dense(int pm, int method, const IndirectArgs& a, const DenseArgs& d, hipStream_t st);
-
 hipError_t launch_indirect_dense(int ndim, int pm, int method, const IndirectArgs& a, const DenseArgs& d, hipStream_t st) {
   if (a.S <= 0) return hipSuccess;
-  if (ndim == 14) return launch_indirect14_dense(pm, method, a, d, st);
+  if (ndim != 12) return hipErrorInvalidValue;          // (lto_api.hip refuses these shapes with LTO_EUNSUPPORTED before it gets here)
   switch (method) {
     case M_RK4: return launch_dense_pm<12, M_RK4>(pm, a, d, st);
-    case M_RKF78_FIXED: return launch_dense_pm<12, M_RKF78_FIXED>(pm, a, d, st);
-    case M_RKF78_ADAPTIVE: return launch_dense_pm<12, M_RKF78_ADAPTIVE>(pm, a, d, st);
     case M_DOP853_ADAPTIVE: return launch_dense_pm<12, M_DOP853_ADAPTIVE>(pm, a, d, st);
   }
   return hipErrorInvalidValue;

@@ -28,14 +28,4 @@ hipError_t launch_indirect14_stm(int pm, int method, int cols, const IndirectArg
   return hipErrorInvalidValue;      // 13-stage methods: cooperative kernels only (see kernels_indirect.hip)
 }
 
-hipError_t launch_indirect14_dense(int pm, int method, const IndirectArgs& a, const DenseArgs& d, hipStream_t st) {
-  switch (method) {
-    case M_RK4: return launch_dense_pm<14, M_RK4>(pm, a, d, st);
-    case M_RKF78_FIXED: return launch_dense_pm<14, M_RKF78_FIXED>(pm, a, d, st);
-    case M_RKF78_ADAPTIVE: return launch_dense_pm<14, M_RKF78_ADAPTIVE>(pm, a, d, st);
-    case M_DOP853_ADAPTIVE: return launch_dense_pm<14, M_DOP853_ADAPTIVE>(pm, a, d, st);
-  }
-  return hipErrorInvalidValue;
-}
-
 }  // namespace lto

@@ -1500,6 +1500,10 @@ int lto_indirect_dense_dev(lto_indirect_plan* p, void* stream, const double* X, 
   int rc = fill_indirect_args(p, X, ldx, t, n_tgrids, &a);
   if (rc) return rc;
   if (!first || !t_samples || !Y) return set_err(c, LTO_ENULL, "first, t_samples or Y is NULL");
+  // dense output is built for what densify needs (HelperFunctions.jl:51-101 re-propagates with the solver of the sweep: the 12-dim
+  // system, DOP853 for Vern8) and for the contract's RK4; round 6 removed the 24 other instantiations, which nothing ran
+  if (p->ndim != 12 || (p->integ.method != LTO_RK4 && p->integ.method != LTO_DOP853_ADAPTIVE))
+    return set_err(c, LTO_EUNSUPPORTED, "dense output is built for ndim = 12 with LTO_RK4 or LTO_DOP853_ADAPTIVE");
   rc = bind_device(c);
   if (rc) return rc;
   DenseArgs d;

@@ -387,6 +387,8 @@ def test_bench_under_the_launcher_times_both_transports_and_reports_what_rccl_sa
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
            str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-configs"]
+    # the N > 1 default on distinct devices: collective on a side stream, wait policy measured, both transports in play
+    env["LTO_BENCH_COLLECTIVE_STREAM"] = "auto"
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert p.returncode == 0, p.stderr[-4000:]
     last = p.stdout.strip().splitlines()[-1]
@@ -397,16 +399,10 @@ def test_bench_under_the_launcher_times_both_transports_and_reports_what_rccl_sa
     tr = c["transports"]
     assert tr["windows_ms"] > 0 and tr["rccl_ms"] > 0 and tr["chosen"] in ("windows", "rccl") and c["collective"] == tr["chosen"], c
     assert (tr["chosen"] == "windows") == (tr["windows_ms"] <= tr["rccl_ms"])
+    assert c["stream"] == "side" and c["policy"]["chosen"] in ("serial", "overlap"), c
     assert c["slab_ok"] is True and c["devices_token"] == "distinct" and out["ok"] is True
-    # the N > 1 default on distinct devices -- collective on a side stream, wait policy measured -- with both transports in play
-    env["LTO_BENCH_COLLECTIVE_STREAM"] = "auto"
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
-    assert p.returncode == 0, p.stderr[-4000:]
-    c = json.loads(p.stdout.strip().splitlines()[-1])["config"]
-    assert c["stream"] == "side" and c["policy"]["chosen"] in ("serial", "overlap") and c["transports"]["chosen"] == c["collective"], c
-    assert c["rccl_ranks"] == 1 and c["slab_ok"] is True
     del env["LTO_BENCH_COLLECTIVE_STREAM"]
-    # and with the transport named: RCCL carries the timed legs
+    # and with the transport named, on the sweep's own stream: RCCL carries the timed legs
     env["LTO_BENCH_TRANSPORT"] = "rccl"
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert p.returncode == 0, p.stderr[-4000:]

@@ -1206,6 +1206,22 @@ def test_densify_vs_oracle(gpu_ctx, oracle, mname):
     assert np.abs(XD[:, -1] - ref).max() < tol * max(1.0, np.abs(ref).max())
 
 
+def test_densify_is_refused_where_it_is_not_built(gpu_ctx):
+    """Dense output exists for the 12-dim system with DOP853 (what densify needs) and RK4; the 14-dim and RKF7(8) instantiations
+    were removed in round 6 (nothing ran them): LTO_EUNSUPPORTED, not a wrong result."""
+    XC, T = synth.indirect_problem(9, seed=3)
+    XC, t = XC[:, :, 0], T[:, 0]
+    prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    for method in (lto.RKF78_FIXED, lto.RKF78_ADAPTIVE):
+        with pytest.raises(lto.LtoError) as ei:
+            lto.densify(XC, t, prm, 40, lto.integrator(method, steps=4), ctx=gpu_ctx)
+        assert ei.value.code == -3
+    X14 = np.zeros((14, 9), order="F"); X14[:6] = XC[:6]; X14[6] = 1000.0; X14[7:13] = XC[6:]
+    with pytest.raises(lto.LtoError) as ei:
+        lto.densify(X14, t, lto.make_params(MU, DU, TU, 0.05, 2000.0, 1.0, 1.0, 1.0), 40, lto.integrator(), ctx=gpu_ctx)
+    assert ei.value.code == -3
+
+
 @pytest.mark.parametrize("n_nodes,n_batch", [(2, 1), (3, 1), (30, 1), (31, 2), (200, 3)])
 def test_device_newton_solve_vs_dense(gpu_ctx, oracle, n_nodes, n_batch):
     """Structured orthogonal cyclic reduction on the device == the reference's linear algebra
