@@ -1569,18 +1569,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds, ndim=a.ndim)
             if wl == "c2":
                 # the same sweep the way the reference executes it (adaptive order 8 @ 1e-13 + dual numbers, 12-dim)
-                out["cpu_baseline_reference_algorithm"] = cpu_baseline("c2", max(3.0, a.cpu_seconds / 2), ndim=12, reference_algorithm=True)
+                out["cpu_baseline_reference_algorithm"] = cpu_baseline("c2", max(min(3.0, a.cpu_seconds), a.cpu_seconds / 2), ndim=12, reference_algorithm=True)
             if wl == "c2":
                 # the metric's second half: defect L2 error of this very run against the oracle (checker), 256-segment sample
                 out["parity"] = parity_vs_oracle(a.ndim, XC, T, defect, Phi, S)
             ncpu = os.cpu_count() or 1
             if ncpu > 1:   # same restatement with the segment loop spread over every host core (reported, not the target)
-                out["cpu_baseline_all_cores"] = cpu_baseline("c3" if wl == "c3" else "c2", max(3.0, a.cpu_seconds / 3), threads=ncpu,
+                out["cpu_baseline_all_cores"] = cpu_baseline("c3" if wl == "c3" else "c2", max(min(3.0, a.cpu_seconds), a.cpu_seconds / 3), threads=ncpu,
                                                              ndim=a.ndim)
         if world == 1 and not a.no_cpu_baseline and not a.method and (wl in ("c3", "c4", "c5", "c5_stm") or (wl == "hbm" and a.ndim == 12)):
             # the single-workload lines carry what their `configs` legs carry: an oracle sample of this run's own last sweep and the
             # oracle timed on one core on that sample
-            par, cpu = config_parity_and_cpu(w, lto, max(1.0, a.cpu_seconds / 4))
+            par, cpu = config_parity_and_cpu(w, lto, max(min(1.0, a.cpu_seconds), a.cpu_seconds / 4))
             out["parity"] = par
             if wl == "c3":
                 out.setdefault("cpu_baseline", cpu)         # (the leg above timed the same thing on a larger sample)
@@ -1608,7 +1608,7 @@ def main():
                 rf["traffic_live"] = "not measured in this run (%s): the stored profile's figure stands" % how
         if world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
             # what a user of the reference's driver waits for per iteration
-            out["newton_iteration"] = leg_newton(lto, synth, ctx, st, torch, [29, 4096], 0.0 if a.no_cpu_baseline else max(2.0, a.cpu_seconds / 4))
+            out["newton_iteration"] = leg_newton(lto, synth, ctx, st, torch, [29, 4096], 0.0 if a.no_cpu_baseline else max(min(2.0, a.cpu_seconds), a.cpu_seconds / 4))
         if world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments and not a.no_configs:
             # BASELINE configs[2..4] and the HBM evidence point, each at its full single-GPU size, in this same line
             plan.close(); plan = None
@@ -1616,7 +1616,7 @@ def main():
             for key, cwl, ksteps, kwarm in CONFIG_LEGS:
                 try:
                     cfgs[key] = leg_config(key, cwl, ksteps, kwarm, lto, synth, torch, ctx, st, dev, a.device_warmup_ms,
-                                           0.0 if a.no_cpu_baseline else max(1.0, a.cpu_seconds / 6))
+                                           0.0 if a.no_cpu_baseline else max(min(1.0, a.cpu_seconds), a.cpu_seconds / 6))
                 except Exception as ex:      # noqa: BLE001 -- one leg's failure is reported in its place, the line is kept
                     cfgs[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
                 torch.cuda.empty_cache()

@@ -74,7 +74,7 @@ def test_default_bench_line_is_compact_complete_and_every_leg_within_tolerance()
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1",
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0.4",
                         "--live-traffic", "off", "--strict"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = p.stdout.strip().splitlines()
