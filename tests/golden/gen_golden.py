@@ -12,6 +12,9 @@ restatements that are INDEPENDENT of both the C++ oracle (oracle/lto_oracle.cpp)
   rhs_prop_ep.json         CRTBP_prop_EP_deriv (src/CRTBP_prop_EP_deriv.jl:8-61), mpmath 40 digits.
   flows_taylor.json        final states (and one STM by central differences) of a few demo-sized segments
                            integrated with mpmath's Taylor-series ODE solver at 30 digits.
+  stm_taylor.json          (round 6) the 12x12 STM of one demo segment per control-law class -- p = 2 unclamped and clamped, p = 0,
+                           p = 1.5, p = 1 at rho = 1e-2 -- by 4th-order central differences of the same 30-digit Taylor flow: the
+                           independent pin of jacobianCalc's blocks (indirect.jl:121) for every branch of :36-53.
   flows_scipy.json         32 segments with scipy DOP853 at rtol = atol = 1e-13 (the reference's tolerance,
                            src/multiShoot_CRTBP_indirect.jl:79).
   direct_numpy.json        mid-point defects and maxErr of 8 segments from a numpy transliteration of ode7_8
@@ -212,6 +215,46 @@ def gen_flows_taylor():
                "cases": cases}, open(os.path.join(HERE, "flows_taylor.json"), "w"), indent=0)
 
 
+def taylor_flow_and_stm(y0, prm, span, d=1e-6):
+    """(final state, 12x12 STM) of one segment: mpmath Taylor flow at the working precision, STM by Richardson-extrapolated central
+    differences of that flow (perturbations are exact doubles)."""
+    def flow(yy):
+        sol = mp.odefun(lambda t, y: mp_rhs_state_costate(y, prm, numeric_hessian=False), 0, [mp.mpf(float(v)) for v in yy], tol=mp.mpf(10) ** -26)
+        return sol(mp.mpf(span))
+    yf = flow(y0)
+    Phi = np.zeros((12, 12))
+    for c in range(12):
+        fs = {}
+        for k in (-2, -1, 1, 2):
+            yp = np.array(y0, dtype=np.float64)
+            yp[c] = yp[c] + k * d
+            fs[k] = (flow(yp), mp.mpf(float(yp[c])) - mp.mpf(float(y0[c])))
+        for r in range(12):
+            d1 = (fs[1][0][r] - fs[-1][0][r]) / (fs[1][1] - fs[-1][1])
+            d2 = (fs[2][0][r] - fs[-2][0][r]) / (fs[2][1] - fs[-2][1])
+            Phi[r, c] = float((4 * d1 - d2) / 3)
+    return yf, Phi
+
+
+def gen_stm_taylor():
+    """One segment per branch of the control law (stateCostate_deriv.jl:36-53) away from its kinks: the clamp of p > 1 is either far
+    off (thrust limit 10 N, the demo's first setting, indirect_demo.jl:179) or firmly on (0.05 N with |lambda_v| ~ 1)."""
+    mp.mp.dps = 30
+    cases = []
+    for (name, node, p, rho, thr, lam) in (("p2_unclamped", 7, 2.0, 1.0, 10.0, 0.1), ("p2_clamped", 9, 2.0, 1.0, 0.05, 1.0), ("p0", 13, 0.0, 1.0, 0.05, 0.1),
+                                           ("p1.5_unclamped", 16, 1.5, 1.0, 10.0, 0.3), ("p1_rho1e-2", 23, 1.0, 1e-2, 0.05, 1.0)):
+        XC, T = synth.indirect_problem(30, seed=5, lam_sigma=lam)
+        span = float(T[1, 0] - T[0, 0])
+        y0 = XC[:, node, 0]
+        prm = [MU, DU, TU, thr, 1000.0, 1.0, p, rho]
+        yf, Phi = taylor_flow_and_stm(y0, prm, span)
+        cases.append({"name": name, "y0": f64(y0), "prm": prm, "span": span, "yf": [mp.nstr(v, 22) for v in yf], "Phi_rowmajor": Phi.reshape(-1).tolist()})
+        print("taylor STM", name, "done", flush=True)
+    mp.mp.dps = 40
+    json.dump({"doc": "mpmath Taylor-series flow and STM (Richardson central differences of the flow) of CRTBP_stateCostate_deriv! over one demo "
+                      "segment per control-law class", "cases": cases}, open(os.path.join(HERE, "stm_taylor.json"), "w"), indent=0)
+
+
 def np_rhs_state_costate(y, prm):
     """numpy restatement through the pseudo-potential Hessian (independent of the oracle's longhand rows)."""
     MUq, DUq, TUq, thrustLimit, mass, td, p, rho = prm
@@ -406,3 +449,5 @@ if __name__ == "__main__":
         gen_halo(); print("halo done", flush=True)
     if "taylor" in which:
         gen_flows_taylor(); print("taylor done", flush=True)
+    if "stm_taylor" in which:          # (round 6; not part of the default list: the older files are not regenerated)
+        gen_stm_taylor(); print("stm_taylor done", flush=True)

@@ -137,6 +137,36 @@ def test_indirect_stm_adaptive_vs_oracle(gpu_ctx, oracle, mname, pcase):
     assert np.abs(Phi - Phi_o).max() < tol_p * np.abs(Phi_o).max()
 
 
+def test_indirect_stm_vs_taylor_goldens_per_control_law_class(gpu_ctx):
+    """Round 6: the 12x12 STM of one demo segment per branch of the control law (p = 2 unclamped / clamped, p = 0, p = 1.5, p = 1 at
+    rho = 1e-2) against an INDEPENDENT reference -- 4th-order central differences of a 30-digit mpmath Taylor flow of the RHS restated
+    in mpmath (tests/golden/stm_taylor.json; neither the oracle's nor the kernels' formulas).  Every STM kernel family that can run
+    the case: the reference's integrator setting (two-lane cooperative kernel) to 1e-9 of max |Phi|, the RK4 pipelines with 256 steps
+    (discretisation ~1e-11) to 1e-8."""
+    import torch
+    for c in load("stm_taylor.json")["cases"]:
+        XC = np.zeros((12, 2)); XC[:, 0] = c["y0"]
+        t = [0.0, c["span"]]
+        prm = lto.make_params(*c["prm"])
+        ref = np.array([float(v) for v in c["yf"]])
+        Phi_ref = np.array(c["Phi_rowmajor"]).reshape(12, 12)
+        scale = np.abs(Phi_ref).max()
+        Phi, d = lto.indirect_stm(XC, t, prm, lto.integrator(lto.DOP853_ADAPTIVE), ctx=gpu_ctx)
+        assert np.abs(d[:, 0] - ref).max() < 3e-13, c["name"]
+        assert np.abs(Phi[:, :, 0] - Phi_ref).max() < 1e-9 * scale, c["name"]
+        Phi4, d4 = lto.indirect_stm(XC, t, prm, lto.integrator(lto.RK4, steps=256), ctx=gpu_ctx)       # AUTO: the eight-wave pipeline
+        assert np.abs(d4[:, 0] - ref).max() < 1e-10 and np.abs(Phi4[:, :, 0] - Phi_ref).max() < 1e-8 * scale, c["name"]
+        plan = lto.IndirectPlan(gpu_ctx, 2, 1, prm, lto.integrator(lto.RK4, steps=256))
+        Xd = torch.from_numpy(synth.to_soa_nodes(XC[:, :, None])).cuda(); td = torch.tensor(t, dtype=torch.float64, device="cuda")
+        for kern in (plan.KERNEL_PER_LANE, plan.KERNEL_PIPE48, plan.KERNEL_PIPE32, plan.KERNEL_LANE):
+            plan.set_kernel(kern)
+            P = torch.zeros(144, 1, dtype=torch.float64, device="cuda"); dd = torch.zeros(12, 1, dtype=torch.float64, device="cuda")
+            plan.jacobian(Xd, 2, td, 1, P, 1, dd, 1)
+            torch.cuda.synchronize()
+            assert np.abs(P.cpu().numpy().reshape(12, 12).T - Phi_ref).max() < 1e-8 * scale, (c["name"], kern)
+        plan.close()
+
+
 @pytest.mark.parametrize("pp", [1.0, 2.0, 1.5, 0.0])
 @pytest.mark.parametrize("cols", [1, 2, 3])
 def test_indirect_stm_cols_per_lane_agree(gpu_ctx, cols, pp):

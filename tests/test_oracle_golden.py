@@ -108,6 +108,25 @@ def test_flows_vs_taylor(oracle):
             assert np.abs(Phi - Phi_ref).max() < 1e-9 * np.abs(Phi_ref).max()
 
 
+def test_stm_vs_taylor_per_control_law_class(oracle):
+    """Round 6: the oracle's STM (the same solve on dual numbers, what ForwardDiff.jacobian does at indirect.jl:121) for one demo
+    segment per branch of the control law against tests/golden/stm_taylor.json -- central differences of a 30-digit mpmath Taylor flow of
+    an independent mpmath restatement of the RHS."""
+    cases = load("stm_taylor.json")["cases"]
+    assert [c["name"] for c in cases] == ["p2_unclamped", "p2_clamped", "p0", "p1.5_unclamped", "p1_rho1e-2"]
+    for c in cases:
+        ref = np.array([float(v) for v in c["yf"]])
+        Phi_ref = np.array(c["Phi_rowmajor"]).reshape(12, 12)
+        ya, Phi, rc, _, _ = oracle.flow_stm_state_costate(c["y0"], c["prm"], c["span"], oracle.DOP853_ADAPTIVE)
+        assert rc == 0 and np.abs(ya - ref).max() < 3e-13
+        assert np.abs(Phi - Phi_ref).max() < 1e-9 * np.abs(Phi_ref).max(), c["name"]
+        y4, Phi4, rc, _, _ = oracle.flow_stm_state_costate(c["y0"], c["prm"], c["span"], oracle.RK4, 256)
+        assert np.abs(Phi4 - Phi_ref).max() < 1e-8 * np.abs(Phi_ref).max(), c["name"]
+        # the flow is symplectic for every branch away from its kinks: Phi^T Omega Phi = Omega
+        Om = np.zeros((12, 12)); Om[:6, 6:] = np.eye(6); Om[6:, :6] = -np.eye(6)
+        assert np.abs(Phi_ref.T @ Om @ Phi_ref - Om).max() < 1e-7 * max(1.0, np.abs(Phi_ref).max() ** 2)
+
+
 def test_rk4_order(oracle):
     """RK4 (ode.jl:64-68) shows 4th-order convergence on a demo segment."""
     c = load("flows_scipy.json")["cases"][0]
