@@ -119,7 +119,7 @@ def test_stm_vs_taylor_per_control_law_class(oracle):
         Phi_ref = np.array(c["Phi_rowmajor"]).reshape(12, 12)
         ya, Phi, rc, _, _ = oracle.flow_stm_state_costate(c["y0"], c["prm"], c["span"], oracle.DOP853_ADAPTIVE)
         assert rc == 0 and np.abs(ya - ref).max() < 3e-13
-        assert np.abs(Phi - Phi_ref).max() < 1e-9 * np.abs(Phi_ref).max(), c["name"]
+        assert np.abs(Phi - Phi_ref).max() < 1e-12 * np.abs(Phi_ref).max(), c["name"]          # measured: 9e-15 ... 4e-14
         y4, Phi4, rc, _, _ = oracle.flow_stm_state_costate(c["y0"], c["prm"], c["span"], oracle.RK4, 256)
         assert np.abs(Phi4 - Phi_ref).max() < 1e-8 * np.abs(Phi_ref).max(), c["name"]
         # the flow is symplectic for every branch away from its kinks: Phi^T Omega Phi = Omega
