@@ -15,6 +15,9 @@ restatements that are INDEPENDENT of both the C++ oracle (oracle/lto_oracle.cpp)
   stm_taylor.json          (round 6) the 12x12 STM of one demo segment per control-law class -- p = 2 unclamped and clamped, p = 0,
                            p = 1.5, p = 1 at rho = 1e-2 -- by 4th-order central differences of the same 30-digit Taylor flow: the
                            independent pin of jacobianCalc's blocks (indirect.jl:121) for every branch of :36-53.
+  direct_jacobian_ld.json  (round 6) the direct path's 6 x 18 Jacobian blocks and tf column of 8 segments: the numpy Fehlberg march in
+                           80-bit precision, Richardson central differences -- the independent pin of jacobianCalc
+                           (multiShoot_CRTBP_direct.jl:111-166) and of the tf partial (:503-516).
   flows_scipy.json         32 segments with scipy DOP853 at rtol = atol = 1e-13 (the reference's tolerance,
                            src/multiShoot_CRTBP_indirect.jl:79).
   direct_numpy.json        mid-point defects and maxErr of 8 segments from a numpy transliteration of ode7_8
@@ -418,6 +421,79 @@ def gen_direct():
     json.dump(out, open(os.path.join(HERE, "direct_numpy.json"), "w"), indent=0)
 
 
+def gen_direct_jacobian():
+    """(round 6) The direct path's Jacobian blocks and tf column, independently: the numpy restatement above run in 80-bit extended
+    precision (np.longdouble, eps 1.1e-19) and differentiated by Richardson-extrapolated central differences (steps 1e-5 and 2e-5 in
+    every variable: truncation ~1e-15, rounding ~1e-14) -- jacobianCalc's 18 columns (src/multiShoot_CRTBP_direct.jl:111-166; the
+    reference itself uses forward differences with pert 1e-8, i.e. ~1e-8 of noise) and the tf partial (:503-516; there a central
+    difference of +-1e-3).  Same inputs as direct_numpy.json's 6-state case."""
+    LD = np.longdouble
+    X, U, T = synth.direct_problem(9, seed=0, nstate=6)
+    X, U, t = X[:, :, 0], U[:, :, 0], T[:, 0]
+    U[:, 3] = 0.0
+    n, S = 9, 8
+
+    def march(x0, grid, Isp, ctrl, td):
+        x = x0.astype(LD)
+        for k in range(1, len(grid)):
+            h = grid[k] - grid[k - 1]
+            K = np.zeros((6, 13), dtype=LD)
+            K[:, 0] = np_prop_ep_ld(x, ctrl, td)
+            for s_ in range(1, 13):
+                K[:, s_] = np_prop_ep_ld(x + (h * K) @ _RKF78.lower[:, s_].astype(LD), ctrl, td)
+            x = x + (h * K) @ _RKF78.weights.astype(LD)
+        return x
+
+    def np_prop_ep_ld(state, control, td):
+        x, y, z, xdot, ydot, zdot = state
+        MUq, DUq, TUq = LD(MU), LD(DU), LD(TU)
+        m = LD(1000.0)
+        r1 = np.sqrt((x + MUq) ** 2 + y ** 2 + z ** 2)
+        r2 = np.sqrt((x + MUq - 1) ** 2 + y ** 2 + z ** 2)
+        Tacc = control / m / LD(1e3) * TUq ** 2 / DUq          # = control / |control| * T_mag of prop_EP_deriv.jl:32-39, which is linear in control
+        xdd = -(1 - MUq) * (x + MUq) / r1 ** 3 - MUq * (x - 1 + MUq) / r2 ** 3 + 2 * td * ydot + x + Tacc[0]
+        ydd = -(1 - MUq) * y / r1 ** 3 - MUq * y / r2 ** 3 - 2 * td * xdot + y + Tacc[1]
+        zdd = -(1 - MUq) * z / r1 ** 3 - MUq * z / r2 ** 3 + Tacc[2]
+        return np.array([xdot, ydot, zdot, xdd, ydd, zdd], dtype=LD)
+
+    def seg_defect(xi, xj, ui, uj, ti, tj):
+        grid = np.linspace(LD(ti), LD(ti) + (LD(tj) - LD(ti)) / 2, 10, dtype=LD)
+        xf = march(xi, grid, 2000.0, ui.astype(LD), LD(1.0))
+        x0 = xj.astype(LD).copy(); x0[3:6] = -x0[3:6]
+        xb = march(x0, grid, 2000.0, uj.astype(LD), LD(-1.0))
+        xb[3:6] = -xb[3:6]
+        return xf - xb
+
+    jac = np.zeros((S, 6, 18)); dtf = np.zeros((S, 6)); dfc = np.zeros((S, 6))
+    span = LD(t[-1]) - LD(t[0])
+    for i in range(S):
+        base = [X[:, i].astype(LD), X[:, i + 1].astype(LD), U[:, i].astype(LD), U[:, i + 1].astype(LD)]
+        dfc[i] = seg_defect(*base, t[i], t[i + 1]).astype(np.float64)
+        col = 0
+        for blk, size, h in ((0, 6, LD(1e-5)), (1, 6, LD(1e-5)), (2, 3, LD(1e-5)), (3, 3, LD(1e-5))):
+            for c in range(size):
+                def at(k):
+                    v = [b.copy() for b in base]
+                    v[blk][c] = v[blk][c] + k * h
+                    return seg_defect(*v, t[i], t[i + 1])
+                d1 = (at(1) - at(-1)) / (2 * h)
+                d2 = (at(2) - at(-2)) / (4 * h)
+                jac[i, :, col] = ((4 * d1 - d2) / 3).astype(np.float64)
+                col += 1
+        # tf partial: every interval scales with (tf - t0); d defect / d tf by the same Richardson scheme on the scale factor
+        def at_tf(k, e=LD(1e-5)):
+            sc = (span + k * e) / span
+            ti, tj = LD(t[0]) + (LD(t[i]) - LD(t[0])) * sc, LD(t[0]) + (LD(t[i + 1]) - LD(t[0])) * sc
+            return seg_defect(*base, ti, tj)
+        d1 = (at_tf(1) - at_tf(-1)) / (2 * LD(1e-5)); d2 = (at_tf(2) - at_tf(-2)) / (4 * LD(1e-5))
+        dtf[i] = ((4 * d1 - d2) / 3).astype(np.float64)
+        print("direct jacobian segment", i, "done", flush=True)
+    json.dump({"doc": "direct two-sided defect (nsteps = 10, Isp 2000, 6-state), its 6 x 18 Jacobian wrt [x_i; x_{i+1}; u_i; u_{i+1}] and its tf partial "
+                      "from the numpy Fehlberg march in 80-bit precision + Richardson central differences",
+               "nsteps": 10, "Isp": 2000.0, "X": X.T.tolist(), "U": U.T.tolist(), "t": t.tolist(), "defect": dfc.tolist(), "jac": jac.tolist(),
+               "dtf": dtf.tolist()}, open(os.path.join(HERE, "direct_jacobian_ld.json"), "w"), indent=0)
+
+
 def gen_halo():
     H = synth.halo_orbits()
     out = {"doc": "facts about the reference's L2_Anderson_{1,2}.txt", "orbits": []}
@@ -449,5 +525,7 @@ if __name__ == "__main__":
         gen_halo(); print("halo done", flush=True)
     if "taylor" in which:
         gen_flows_taylor(); print("taylor done", flush=True)
+    if "direct_jacobian" in which:     # (round 6; likewise)
+        gen_direct_jacobian(); print("direct_jacobian done", flush=True)
     if "stm_taylor" in which:          # (round 6; not part of the default list: the older files are not regenerated)
         gen_stm_taylor(); print("stm_taylor done", flush=True)

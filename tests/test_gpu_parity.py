@@ -1023,6 +1023,34 @@ def test_direct_jacobian_vs_oracle(gpu_ctx, oracle, nstate):
     assert np.abs(J - J_o).max() < 1e-9
 
 
+def test_direct_jacobian_vs_extended_precision_golden(gpu_ctx):
+    """Round 6: the direct path's Jacobian blocks against an INDEPENDENT reference -- the numpy restatement of the fixed-grid Fehlberg
+    march (tests/golden/gen_golden.py; neither the oracle's nor the kernels' code) run in 80-bit precision and differentiated by
+    Richardson central differences (tests/golden/direct_jacobian_ld.json): every one of the 18 columns of jacobianCalc
+    (direct.jl:111-166) to 1e-11, the tf column (:503-516; the kernels' is the analytic one) to the RKF7(8) truncation, both kernel forms."""
+    import torch
+    g = load("direct_jacobian_ld.json")
+    X, U, t = np.array(g["X"]).T, np.array(g["U"]).T, np.array(g["t"])
+    J_ref = np.array(g["jac"]).transpose(1, 2, 0)                 # [row][var][segment]
+    Jt, dtf, d, e = lto.direct_jacobian_blocks(X, U, t, g["nsteps"], MU, DU, TU, g["Isp"], ctx=gpu_ctx)
+    assert np.abs(d - np.array(g["defect"]).T).max() < 1e-13
+    assert np.abs(Jt - J_ref).max() < 1e-11 * np.abs(J_ref).max()
+    assert np.abs(dtf - np.array(g["dtf"]).T).max() < 1e-9
+    S = 8
+    plan = lto.DirectPlan(gpu_ctx, 6, 9, 1, g["nsteps"], MU, DU, TU, g["Isp"])
+    Xd = torch.from_numpy(synth.to_soa_nodes(X[:, :, None])).cuda(); Ud = torch.from_numpy(synth.to_soa_nodes(U[:, :, None])).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(t)).cuda()
+    f64 = dict(dtype=torch.float64, device="cuda")
+    for kern in (1, 3):                                           # LTO_KERNEL_PER_LANE, LTO_KERNEL_DIRECT_PIPE
+        plan.set_kernel(kern)
+        Jac = torch.zeros(108, S, **f64); dt_ = torch.zeros(6, S, **f64); dd = torch.zeros(6, S, **f64); er = torch.zeros(S, **f64)
+        plan.jacobian(Xd, 9, Ud, 9, td, 1, Jac, S, dt_, dd, S, er)
+        torch.cuda.synchronize()
+        J = Jac.cpu().numpy().reshape(18, 6, S).transpose(1, 0, 2)
+        assert np.abs(J - J_ref).max() < 1e-11 * np.abs(J_ref).max(), kern
+    plan.close()
+
+
 @pytest.mark.parametrize("nstate", [6, 7])
 def test_direct_endpoint_partials_vs_reference_finite_differences(gpu_ctx, oracle, nstate):
     """endpointPartials (direct.jl:168-246): its finite-difference blocks (pert = 1e-5) reproduced with the oracle and

@@ -231,6 +231,23 @@ def test_direct_jacobian_fd_vs_dual(oracle):
         assert np.abs(dtf - dtf_exact).max() < 1e-6
 
 
+def test_direct_jacobian_vs_extended_precision_golden(oracle):
+    """Round 6: the oracle's derivative of the direct two-sided defect (dual numbers through the RKF7(8) march) and its tf partial
+    (d/dh) against tests/golden/direct_jacobian_ld.json -- an independent numpy restatement run in 80-bit precision and differentiated
+    by Richardson central differences.  The reference's own forward differences (pert 1e-8, direct.jl:123-143) sit 1e-7 from both."""
+    g = load("direct_jacobian_ld.json")
+    X, U, t = np.array(g["X"]).T, np.array(g["U"]).T, np.array(g["t"])
+    d, e = oracle.direct_defect(X, U, t, g["nsteps"], MU, DU, TU, g["Isp"])
+    assert np.abs(d - np.array(g["defect"]).T).max() < 1e-14
+    J_ref = np.array(g["jac"]).transpose(1, 2, 0)
+    Jd, dh, _ = oracle.direct_jacobian_dual(X, U, t, g["nsteps"], MU, DU, TU, g["Isp"])
+    assert np.abs(Jd - J_ref).max() < 1e-12 * np.abs(J_ref).max()              # measured 1.4e-14
+    dtf = dh * (np.diff(t) / (t[-1] - t[0]))[None, :]
+    assert np.abs(dtf - np.array(g["dtf"]).T).max() < 1e-12                    # measured 1.2e-14
+    Jfd = oracle.direct_jacobian_fd(X, U, t, d, g["nsteps"], MU, DU, TU, g["Isp"])
+    assert 1e-10 < np.abs(Jfd - J_ref).max() < 2e-6 * np.abs(J_ref).max()      # the reference's method: FD noise
+
+
 def test_indirect_scatter_dense_shape_and_mask(oracle):
     """jacobianCalc band scatter (indirect.jl:128-142): shape, [Phi | -I] placement, zeroed end-state columns."""
     XC, T = synth.indirect_problem(5, seed=1)
