@@ -54,6 +54,12 @@ def make_case(seed):
     prm_l = [[MU, DU, TU, thr[b], slot, td, ps[b], rhos[b]] for b in range(B)]
     # lanes per segment of the defect-only sweep with the reference's setting (own generator: the other draws stay put)
     lanes = int(np.random.default_rng(9000 + seed).choice([0, 1, 2, 4])) if (ndim == 12 and method == lto.DOP853_ADAPTIVE) else 0
+    # round 6 (own generator): 14-dim DOP853 batches of the always-thrust-limited laws have the quad defect kernel and the 7 + 7
+    # two-lane cooperative kernel (AUTO's choice there; selector 6 names it)
+    if ndim == 14 and method == lto.DOP853_ADAPTIVE and all(p in (0.0, 1.0) for p in ps):
+        g14 = np.random.default_rng(13000 + seed)
+        lanes = int(g14.choice([0, 1, 4]))
+        kernel = int(g14.choice([kernel, 6, 0]))
     return dict(ndim=ndim, method=method, steps=steps, adaptive=adaptive, B=B, n=n, X=X, T=T, prm_l=prm_l, kernel=kernel,
                 cols=cols, lanes=lanes)
 
