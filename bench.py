@@ -915,6 +915,51 @@ def config_parity_and_cpu(w, lto, seconds):
     return parity, _time_oracle(run, cnt, seconds, what, {"c4": "rk4x64 duals", "c5": "dop853", "c5_stm": "dop853 duals", "hbm": "rk4x1 duals"}[wl])
 
 
+def leg_c1(lto, synth, torch, ctx, st, cpu_seconds):
+    """BASELINE configs[0] -- the reference demo's size (CRTBP_Multishoot_indirect_demo.jl: 30 nodes, 29 segments; there on the CPU) --
+    on the device: what one sweep costs when nothing fills the chip ("report time per sweep at S = 29").  jacobianCalc and
+    defectCalc with the reference's integrator setting, the RK4 x 64 STM sweep, all 29 segments against the oracle, the oracle timed."""
+    from oracle import oracle as O
+    n, S = 30, 29
+    XC, T = synth.indirect_problem(n, seed=0)
+    X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+    prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    Phi = torch.zeros(144, S, **f64); d = torch.zeros(12, S, **f64); d0 = torch.zeros(12, S, **f64)
+    pa = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator())
+    pr = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(lto.RK4, steps=64))
+    try:
+        def burst(fn, reps=200):
+            for _ in range(20):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); e1.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        rk4_us = burst(lambda: pr.jacobian(X, n, t, 1, Phi, S, d, S, stream=st))
+        stm_us = burst(lambda: pa.jacobian(X, n, t, 1, Phi, S, d, S, stream=st))
+        def_us = burst(lambda: pa.defect(X, n, t, 1, d0, S, stream=st))
+        torch.cuda.synchronize()
+        out = {"segments": S, "stm_us": stm_us, "defect_us": def_us, "rk4_stm_us": rk4_us, "kernel": pa.last_kernel(),
+               "ms_per_step": stm_us * 1e-3, "value": S / (stm_us * 1e-6)}
+        if cpu_seconds > 0:
+            prm_o = [lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, 1.0]
+            P_o, d_o, rc = O.indirect_jacobian(XC[:, :, 0], T[:, 0], prm_o, O.DOP853_ADAPTIVE, 0)
+            P_g = Phi.cpu().numpy().reshape(12, 12, S).transpose(1, 0, 2)
+            xn = np.linalg.norm(d_o + XC[:, 1:, 0])
+            out["parity"] = {"defect_rel_l2": float(max(np.linalg.norm(d.cpu().numpy() - d_o), np.linalg.norm(d0.cpu().numpy() - d_o)) / xn),
+                             "stm_rel_max": float(np.abs(P_g - P_o).max() / np.abs(P_o).max()), "sample_segments": S, "oracle_rc": int(rc), "tolerance": 1e-10,
+                             "against": "CPU oracle, adaptive order 8 @ 1e-13 on dual numbers, all 29 segments"}
+            out["cpu_baseline"] = _time_oracle(lambda: O.indirect_jacobian(XC[:, :, 0], T[:, 0], prm_o, O.DOP853_ADAPTIVE, 0), S, cpu_seconds,
+                                               "jacobianCalc of the demo's 29 segments as the reference computes it", "dop853 duals")
+        return out
+    finally:
+        pa.close(); pr.close()
+
+
 def leg_config(key, wl, steps, warmup, lto, synth, torch, ctx, st, dev, device_warmup_ms, cpu_seconds):
     """One BASELINE config as a compact leg (see CONFIG_LEGS)."""
     w = make_workload(wl, lto, synth, torch, ctx, st, dev)
@@ -1032,6 +1077,9 @@ def _leg_compact(leg, S=None):
          "cpu_value": _num((leg.get("cpu_baseline") or {}).get("value"))}
     if "errors_rel_max" in par:
         o["parity_errors"] = _num(par["errors_rel_max"], 3)
+    if "stm_us" in leg:          # configs[0] (29 segments): latencies of the three sweeps instead of a roofline
+        o = {"segments": leg["segments"], "stm_us": _num(leg["stm_us"], 4), "defect_us": _num(leg["defect_us"], 4), "rk4_stm_us": _num(leg["rk4_stm_us"], 4),
+             "kernel": leg.get("kernel"), "parity_defect": o["parity_defect"], "parity_stm": o["parity_stm"], "cpu_value": o["cpu_value"]}
     ad = leg.get("adaptive")
     if ad:
         o["trial_steps"] = [_num(ad.get("trial_steps_mean", ad.get("steps_accepted_mean", 0.0) + ad.get("steps_rejected_mean", 0.0)), 4),
@@ -1613,6 +1661,10 @@ def main():
             # BASELINE configs[2..4] and the HBM evidence point, each at its full single-GPU size, in this same line
             plan.close(); plan = None
             cfgs = {}
+            try:                 # configs[0]: the demo's size, where a sweep is pure latency
+                cfgs["c1"] = leg_c1(lto, synth, torch, ctx, st, 0.0 if a.no_cpu_baseline else max(min(1.0, a.cpu_seconds), a.cpu_seconds / 12))
+            except Exception as ex:      # noqa: BLE001
+                cfgs["c1"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             for key, cwl, ksteps, kwarm in CONFIG_LEGS:
                 try:
                     cfgs[key] = leg_config(key, cwl, ksteps, kwarm, lto, synth, torch, ctx, st, dev, a.device_warmup_ms,

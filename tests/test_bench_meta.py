@@ -91,7 +91,9 @@ def test_default_line_budget():
     assert r["algorithmic"] == 1920 * 4096 and r["traffic"] > 0
     cb = back["cpu_baseline"]
     assert set(cb) >= {"value", "unit", "cores", "kind", "sample"} and cb["kind"] == "port" and cb["cores"] == 1
-    assert list(back["configs"]) == ["c3", "c4", "c5", "c5_stm", "hbm"]
+    assert list(back["configs"]) == ["c1", "c3", "c4", "c5", "c5_stm", "hbm"]
+    c1 = back["configs"].pop("c1")
+    assert c1["segments"] == 29 and c1["ok"] is True and c1["stm_us"] > c1["defect_us"] > 0
     for key, leg in back["configs"].items():
         assert set(leg) >= {"ms_per_step", "value", "kernel", "kernel_ms", "frac", "bound", "traffic", "algorithmic", "parity_defect",
                             "parity_stm", "cpu_value", "ok"}, key

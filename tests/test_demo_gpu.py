@@ -85,7 +85,9 @@ def test_default_bench_line_is_compact_complete_and_every_leg_within_tolerance()
     assert out["parity"]["ok"] is True and out["parity"]["defect_rel_l2"] < 1e-10
     assert out["roofline"]["bound"] == "mfma" and 0.2 < out["roofline"]["frac"] < 1.0 and out["roofline"]["traffic"] > 0
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
-    assert list(out["configs"]) == ["c3", "c4", "c5", "c5_stm", "hbm"]
+    assert list(out["configs"]) == ["c1", "c3", "c4", "c5", "c5_stm", "hbm"]
+    c1 = out["configs"].pop("c1")                    # configs[0]: the demo's 29 segments -- latencies, all segments against the oracle
+    assert c1["segments"] == 29 and c1["ok"] is True and 20 < c1["defect_us"] < c1["stm_us"] < 400 and c1["rk4_stm_us"] > 20 and c1["cpu_value"] > 0
     for key, leg in out["configs"].items():
         assert leg["ok"] is True and leg["frac"] > 0 and leg["kernel_ms"] > 0 and leg["cpu_value"] > 0, (key, leg)
     assert out["configs"]["hbm"]["bound"] == "hbm"
