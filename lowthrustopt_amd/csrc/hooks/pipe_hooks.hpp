@@ -28,6 +28,11 @@ struct Counter {
   __device__ __forceinline__ void bump() {}
   __device__ __forceinline__ void report(double*, long, int, long) const {}
 };
+// wall-clock stamps of a workgroup's life (entry, loop start, loop end, exit) and the compute unit it ran on (tools/probe_c5_turnover.py)
+struct Stamps {
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void report(double*, long, int, long) const {}
+};
 // role switches of the pipeline kernels (probe build: bits of IndirectArgs::max_steps switch roles off)
 template <class Args>
 __device__ __forceinline__ constexpr bool role_on(const Args&, int) { return true; }

@@ -73,6 +73,8 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   constexpr bool BASE = (ROLE == C2_BASE);
   constexpr int NS = 12;
   constexpr int NC = BASE ? 3 : 6;       // components per lane: a base lane owns one triple, a column lane half a column
+  hook::Stamps c2_life;                  // probe build: when this workgroup entered, looped and left, and where (no-ops in the product)
+  c2_life.mark(0);
   // ---- who is this lane
   int seg, col = 0;
   const int q4 = lane & 3;               // base wave: the quad's lane (r, v, lambda_v, lambda_r)
@@ -288,6 +290,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
   hook::RegionClock c2_loop;
   hook::Counter c2_trials;
   c2_loop.start();
+  c2_life.mark(1);
   for (int trial = 0; trial < a.max_steps; ++trial) {
     c2_trials.bump();
     // every lane of a segment holds identical (t, h_abs, done): they are updated from identical data below
@@ -432,6 +435,7 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
     }
     // (the exit vote rides on the next trial step's first stage barrier)
   }
+  c2_life.mark(2);
   if ((lane & 15) == 0 && (BASE ? lane == 0 : (cwave == 0 && lane == 0))) {      // probe build only: the hooks write nothing otherwise
     const int r0 = BASE ? 16 : (ROLE == C2_TOP ? 20 : 22);
     const long at = (long)blockIdx.x * C2_SEG;
@@ -463,6 +467,8 @@ __device__ __forceinline__ void coop2_run(const IndirectArgs& a, C2Shared& sh, c
       for (int j = 0; j < NC; ++j) put_phi(a, col, grow[j], s, y[j]);
     }
   }
+  c2_life.mark(3);
+  if (BASE && lane == 0) c2_life.report(a.defect, a.ldd, 24, (long)blockIdx.x * C2_SEG);     // (rows 24 .. 28 of the probe's buffer)
 }
 
 template <int PM>
