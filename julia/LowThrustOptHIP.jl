@@ -25,6 +25,13 @@ const LTO_RK4 = Cint(0)
 const LTO_RKF78_FIXED = Cint(1)
 const LTO_RKF78_ADAPTIVE = Cint(2)
 const LTO_DOP853_ADAPTIVE = Cint(3)
+# error codes (include/lto.h): < 0 = misuse, > 0 = run time
+const LTO_EINVAL, LTO_ENULL, LTO_EUNSUPPORTED = Cint(-1), Cint(-2), Cint(-3)
+const LTO_EHIP, LTO_EBADP, LTO_ENODEVICE, LTO_ENOMEM = Cint(1), Cint(2), Cint(3), Cint(4)
+# kernel families of an indirect plan's STM sweep (lto_indirect_plan_set_kernel; 0 = let the library choose)
+const LTO_KERNEL_AUTO, LTO_KERNEL_PER_LANE, LTO_KERNEL_COOP, LTO_KERNEL_DIRECT_PIPE = Cint(0), Cint(1), Cint(2), Cint(3)
+const LTO_KERNEL_PIPE8, LTO_KERNEL_COOP2, LTO_KERNEL_PIPE48, LTO_KERNEL_PIPE32, LTO_KERNEL_LANE = Cint(5), Cint(6), Cint(7), Cint(8), Cint(9)
+const LTO_LAYOUT_SOA, LTO_LAYOUT_BLOCKS = Cint(0), Cint(1)
 
 # isbits mirrors of the C structs (include/lto.h)
 struct LtoIntegrator
@@ -87,8 +94,9 @@ last_error(g::LtoGroup) = unsafe_string(ccall((:lto_group_last_error, liblto), C
 function check(ctx::LtoHandle, rc::Cint)
     rc == 0 && return
     msg = last_error(ctx)
-    # code 2 is the reference's own error("Invalid value of p!") (CRTBP_stateCostate_deriv.jl:52)
-    error(rc == 2 ? msg : "lto error $rc: $msg")
+    # code 2 is the reference's own error("Invalid value of p!") (CRTBP_stateCostate_deriv.jl:52); code 4 = host memory / threads ran out inside the call
+    rc == LTO_ENOMEM && throw(OutOfMemoryError())
+    error(rc == LTO_EBADP ? msg : "lto error $rc: $msg")
 end
 
 # ---------------------------------------------------------------------------------------------- indirect
@@ -302,6 +310,9 @@ last_call_order(ctx::LtoContext) = Int(ccall((:lto_last_call_order, liblto), Cin
 "Measure the cost table LTO_KERNEL_AUTO chooses the RK4 STM kernel family by (microseconds per round) on this context's device."
 calibrate_kernels!(ctx::LtoContext) = check(ctx, ccall((:lto_calibrate_kernels, liblto), Cint, (Ptr{Cvoid},), ctx.handle))
 
+"Microseconds per round (256 x CUs segments, 64 steps) of the whole-segment lanes (LTO_KERNEL_LANE, 12-dim): the default or this device's (calibrate_kernels!)."
+kernel_lane_round_us(ctx::LtoContext) = ccall((:lto_kernel_lane_round_us, liblto), Cdouble, (Ptr{Cvoid},), ctx.handle)
+
 "(`[pipeline8, pipeline48 with 48 segments per workgroup, per-lane, pipeline48 with 44, pipeline32]` microseconds per round at 64 steps, calibrated?) for `ndim` = 12 or 14."
 function kernel_round_costs(ctx::LtoContext, ndim::Integer)
     us = zeros(Float64, 5)
@@ -400,6 +411,10 @@ end
 set_warm_start!(pl::LtoIndirectPlan, on::Bool = true) = check(pl.ctx, ccall((:lto_indirect_plan_set_warm_start, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, on ? 1 : 0))
 "Output layout of the plan's sweeps: 0 = struct of arrays, 1 = one block per segment (defect [S][ndim], Phi [S][ndim*ndim] column-major: Julia's own layout; 12-dim DOP853 plans)."
 set_output_layout!(pl::LtoIndirectPlan, layout::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_output_layout, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, layout))
+"Record staging of the plan's ordered sweeps, a bit mask: 1 node / defect records in place, 2 Phi records too, 4 an allocation failed and staging is off (lto.h)."
+plan_staging(pl::LtoIndirectPlan) = Int(ccall((:lto_indirect_plan_staging, liblto), Cint, (Ptr{Cvoid},), pl.handle))
+"STM columns per lane of the per-lane RK4 kernel: 0 auto, 1-3, or 12 = the whole STM in the segment's lane (one-step plans)."
+set_cols_per_lane!(pl::LtoIndirectPlan, cols::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_cols_per_lane, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, cols))
 "Lanes per segment of the defect-only sweep of a 12-dim DOP853 plan: 0 = choose (four up to 131 072 segments, then two, then one), 1, 2 or 4."
 set_defect_lanes!(pl::LtoIndirectPlan, lanes::Integer = 0) = check(pl.ctx, ccall((:lto_indirect_plan_set_defect_lanes, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, lanes))
 
