@@ -221,6 +221,9 @@ def parse():
                     help="print the long form of the line (every leg's full roofline object, the prose notes on how each figure was obtained); "
                          "default: the compact line of compact_line() -- numbers and short tokens only, under LINE_BUDGET bytes")
     ap.add_argument("--detail", default="", help="also write the long form to this file (the compact line's `detail` then names it)")
+    ap.add_argument("--time-budget", type=float, default=240.0,
+                    help="seconds after which the OPTIONAL legs of the line (12-dim legs, host API, Newton iteration, config legs, counter passes) "
+                         "are skipped instead of started: the contract leg and its roofline / cpu_baseline / parity always run")
     ap.add_argument("--strict", action="store_true", help="exit 1 when a leg failed or a parity figure exceeds its tolerance (the line's `ok` says so either way)")
     ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
                     help="roofline.traffic from counter passes of THIS run: rank 0 at N = 1 starts `rocprofv3 --pmc FETCH_SIZE` and "
@@ -1064,8 +1067,8 @@ def _leg_compact(leg, S=None):
     cpu_value, ok}."""
     if leg is None:
         return None
-    if "error" in leg:
-        return {"error": str(leg["error"])[:120], "ok": False}
+    if "error" in leg:       # the leg raised (ok: false) or was not started because the run's time budget was used up (ok: null)
+        return {"error": str(leg["error"])[:120], "ok": None if str(leg["error"]).startswith("skipped:") else False}
     r = leg.get("roofline") or {}
     S = S or leg.get("segments")
     par = leg.get("parity") or {}
@@ -1099,11 +1102,14 @@ def legs_failed(out):
         if leg is not None and leg.get("parity") is not None and not parity_ok(leg["parity"]):
             bad.append(name)
     for key, leg in (out.get("configs") or {}).items():
-        if "error" in leg or (leg.get("parity") is not None and not parity_ok(leg["parity"])):
+        if ("error" in leg and not str(leg["error"]).startswith("skipped:")) or (leg.get("parity") is not None and not parity_ok(leg["parity"])):
             bad.append(key)
     for it in ((out.get("newton_iteration") or {}).get("sizes") or []):
         if not it.get("finite", True):
             bad.append("newton_%d" % it["segments"])
+    for name, why in (out.get("leg_errors") or {}).items():          # optional legs that raised (legs skipped for time are listed in `skipped`;
+        if name not in bad and not why.startswith("skipped:") and name != "live_traffic":   # the counter passes are an extra: the stored profile stands)
+            bad.append(name)
     return bad
 
 
@@ -1161,6 +1167,9 @@ def compact_line(out, detail=None):
     line["ok"] = not bad
     if bad:
         line["failed"] = bad
+    skipped = [k for k, why in (out.get("leg_errors") or {}).items() if why.startswith("skipped:")]
+    if skipped:
+        line["skipped"] = skipped
     line["detail"] = detail or DETAIL_DEFAULT
     return line
 
@@ -1243,6 +1252,22 @@ def main():
     ctl = torch.device("cpu") if share else dev           # where torch.distributed's control tensors live
     ctx = lto.Context(dev_index)
     st = lto.current_stream_ptr()
+
+    t_start = time.perf_counter()
+    leg_errors = {}
+
+    def optional(name, fn, fallback=None):
+        """An optional leg of the line: never lose the headline to it.  Past --time-budget it is not started; an exception is recorded
+        (`failed` in the line names the leg) and the fallback returned."""
+        if time.perf_counter() - t_start > a.time_budget:
+            leg_errors[name] = "skipped: --time-budget %.0f s used up" % a.time_budget
+            return fallback
+        try:
+            return fn()
+        except Exception as ex:      # noqa: BLE001
+            leg_errors[name] = "%s: %s" % (type(ex).__name__, str(ex)[:160])
+            sys.stderr.write("bench.py: leg %s failed: %s\n" % (name, leg_errors[name]))
+            return fallback
 
     wl = a.workload
     if wl == "newton":
@@ -1510,8 +1535,8 @@ def main():
     if rank == 0 and world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
         # the reference's own system (12-dim, constant mass): the sweep reference parity is claimed for, and the reference's own
         # integrator setting on it -- same run, timed the same way (W warm-up + K timed steps), BEFORE the contract leg's warm-up
-        ref12 = leg_12dim(lto, synth, ctx, st, torch, a)
-        refint = leg_12dim(lto, synth, ctx, st, torch, a, reference_integrator=True)
+        ref12 = optional("ref12", lambda: leg_12dim(lto, synth, ctx, st, torch, a))
+        refint = optional("refint", lambda: leg_12dim(lto, synth, ctx, st, torch, a, reference_integrator=True))
 
     if a.device_warmup_ms > 0 and not c5:
         # untimed sweeps of THIS workload straight before its timed region (the other legs leave the clocks wherever their own
@@ -1616,15 +1641,18 @@ def main():
         if world == 1 and not a.no_cpu_baseline and wl in ("c2", "c3", "c2_defect") and not a.method:
             out["cpu_baseline"] = cpu_baseline("c3" if wl == "c3" else "c2", a.cpu_seconds, ndim=a.ndim)
             if wl == "c2":
-                # the same sweep the way the reference executes it (adaptive order 8 @ 1e-13 + dual numbers, 12-dim)
-                out["cpu_baseline_reference_algorithm"] = cpu_baseline("c2", max(min(3.0, a.cpu_seconds), a.cpu_seconds / 2), ndim=12, reference_algorithm=True)
-            if wl == "c2":
                 # the metric's second half: defect L2 error of this very run against the oracle (checker), 256-segment sample
                 out["parity"] = parity_vs_oracle(a.ndim, XC, T, defect, Phi, S)
+            if wl == "c2":
+                # the same sweep the way the reference executes it (adaptive order 8 @ 1e-13 + dual numbers, 12-dim)
+                r = optional("cpu_ref_alg", lambda: cpu_baseline("c2", max(min(3.0, a.cpu_seconds), a.cpu_seconds / 2), ndim=12, reference_algorithm=True))
+                if r:
+                    out["cpu_baseline_reference_algorithm"] = r
             ncpu = os.cpu_count() or 1
             if ncpu > 1:   # same restatement with the segment loop spread over every host core (reported, not the target)
-                out["cpu_baseline_all_cores"] = cpu_baseline("c3" if wl == "c3" else "c2", max(min(3.0, a.cpu_seconds), a.cpu_seconds / 3), threads=ncpu,
-                                                             ndim=a.ndim)
+                r = optional("cpu_all_cores", lambda: cpu_baseline("c3" if wl == "c3" else "c2", max(min(3.0, a.cpu_seconds), a.cpu_seconds / 3), threads=ncpu, ndim=a.ndim))
+                if r:
+                    out["cpu_baseline_all_cores"] = r
         if world == 1 and not a.no_cpu_baseline and not a.method and (wl in ("c3", "c4", "c5", "c5_stm") or (wl == "hbm" and a.ndim == 12)):
             # the single-workload lines carry what their `configs` legs carry: an oracle sample of this run's own last sweep and the
             # oracle timed on one core on that sample
@@ -1635,7 +1663,9 @@ def main():
             else:
                 out["cpu_baseline"] = cpu
         if world == 1 and wl == "c2" and not a.method and not a.segments:
-            out["host_api"] = leg_host_api(lto, ctx, XC, T, prm, integ, a.ndim, S)
+            r = optional("host_api", lambda: leg_host_api(lto, ctx, XC, T, prm, integ, a.ndim, S))
+            if r:
+                out["host_api"] = r
         want_live = a.live_traffic == "on" or (a.live_traffic == "auto" and not a.no_cpu_baseline)
         if world == 1 and want_live and "roofline" in out and wl in ("c2", "c2_defect", "c3", "c4", "hbm"):   # (the C5 sweeps order their lanes first)
             argv_wl = ["--workload", wl, "--ndim", str(a.ndim)]
@@ -1644,10 +1674,7 @@ def main():
             if a.kernel: argv_wl += ["--kernel", str(a.kernel)]
             if a.cols: argv_wl += ["--cols", str(a.cols)]
             if a.no_rebalance: argv_wl += ["--no-rebalance"]
-            try:
-                live, how = live_traffic(argv_wl)
-            except Exception as ex:      # noqa: BLE001 -- the counter passes are an extra: never lose the line to them
-                live, how = None, "%s: %s" % (type(ex).__name__, ex)
+            live, how = optional("live_traffic", lambda: live_traffic(argv_wl), (None, "skipped or failed"))   # an extra: never lose the line to it
             rf = out["roofline"]
             if live is not None:
                 rf["traffic_stored"], rf["traffic_stored_from"] = rf.get("traffic"), rf.get("traffic_from")
@@ -1656,29 +1683,27 @@ def main():
                 rf["traffic_live"] = "not measured in this run (%s): the stored profile's figure stands" % how
         if world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments:
             # what a user of the reference's driver waits for per iteration
-            out["newton_iteration"] = leg_newton(lto, synth, ctx, st, torch, [29, 4096], 0.0 if a.no_cpu_baseline else max(min(2.0, a.cpu_seconds), a.cpu_seconds / 4))
+            r = optional("newton", lambda: leg_newton(lto, synth, ctx, st, torch, [29, 4096], 0.0 if a.no_cpu_baseline else max(min(2.0, a.cpu_seconds), a.cpu_seconds / 4)))
+            if r:
+                out["newton_iteration"] = r
         if world == 1 and wl == "c2" and a.ndim == 14 and not a.method and not a.segments and not a.no_configs:
             # BASELINE configs[2..4] and the HBM evidence point, each at its full single-GPU size, in this same line
             plan.close(); plan = None
             cfgs = {}
-            try:                 # configs[0]: the demo's size, where a sweep is pure latency
-                cfgs["c1"] = leg_c1(lto, synth, torch, ctx, st, 0.0 if a.no_cpu_baseline else max(min(1.0, a.cpu_seconds), a.cpu_seconds / 12))
-            except Exception as ex:      # noqa: BLE001
-                cfgs["c1"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-            for key, cwl, ksteps, kwarm in CONFIG_LEGS:
-                try:
-                    cfgs[key] = leg_config(key, cwl, ksteps, kwarm, lto, synth, torch, ctx, st, dev, a.device_warmup_ms,
-                                           0.0 if a.no_cpu_baseline else max(min(1.0, a.cpu_seconds), a.cpu_seconds / 6))
-                except Exception as ex:      # noqa: BLE001 -- one leg's failure is reported in its place, the line is kept
-                    cfgs[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            # configs[0]: the demo's size, where a sweep is pure latency
+            cfgs["c1"] = optional("c1", lambda: leg_c1(lto, synth, torch, ctx, st, 0.0 if a.no_cpu_baseline else max(min(1.0, a.cpu_seconds), a.cpu_seconds / 12)))
+            for key, cwl, ksteps, kwarm in CONFIG_LEGS:      # one leg's failure is reported in its place, the line is kept
+                cfgs[key] = optional(key, lambda: leg_config(key, cwl, ksteps, kwarm, lto, synth, torch, ctx, st, dev, a.device_warmup_ms,
+                                                             0.0 if a.no_cpu_baseline else max(min(1.0, a.cpu_seconds), a.cpu_seconds / 6)))
                 torch.cuda.empty_cache()
-            out["configs"] = cfgs
-        if ref12 is not None:
-            out["reference_system_12dim"] = ref12[0]
-            out["reference_integrator"] = refint[0]
-            if not a.no_cpu_baseline:
-                ref12[1]()
-                refint[1]()
+            out["configs"] = {k: (v if v is not None else {"error": leg_errors.get(k, "failed")}) for k, v in cfgs.items()}
+        for name, leg in (("reference_system_12dim", ref12), ("reference_integrator", refint)):
+            if leg is not None:
+                out[name] = leg[0]
+                if not a.no_cpu_baseline:
+                    optional(name + "_parity", leg[1])
+        if leg_errors:
+            out["leg_errors"] = leg_errors
         exit_code = emit(out, a)
     if use_coll:
         dist.barrier()              # nobody unmaps a window a peer may still be pushing into

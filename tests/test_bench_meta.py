@@ -165,3 +165,26 @@ def test_design_table_is_the_one_generated_from_the_profiles():
     assert calls > 1000 and "pipe8<14" in name
     frac = 4096 * 569600 / (avg_us * 1e-6) / 78.6e12
     assert ("FP64 %.3f" % frac) in rows[0]
+
+
+def test_optional_legs_that_raise_or_run_out_of_time_do_not_cost_the_headline():
+    """one exception path was all that protected the headline.  Every optional leg now runs behind
+    `optional()`: a leg that raises is named in `failed` with `ok: false` in its place, a leg not started because --time-budget was
+    used up is named in `skipped` (its `ok` is null and the line's `ok` is not touched), a failed counter pass is neither."""
+    long_form = _canned_long_form()
+    long_form["configs"]["c4"] = {"error": "RuntimeError: planted"}
+    long_form["configs"]["hbm"] = {"error": "skipped: --time-budget 240 s used up"}
+    long_form.pop("newton_iteration")
+    long_form["leg_errors"] = {"c4": "RuntimeError: planted", "hbm": "skipped: --time-budget 240 s used up", "newton": "ValueError: planted",
+                               "live_traffic": "OSError: no rocprofv3"}
+    assert bench.legs_failed(long_form) == ["c4", "newton"]
+    line = bench.compact_line(long_form)
+    assert line["ok"] is False and line["failed"] == ["c4", "newton"] and line["skipped"] == ["hbm"]
+    assert line["configs"]["c4"]["ok"] is False and line["configs"]["hbm"]["ok"] is None and "newton_us" not in line
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0 and line["parity"]["ok"] is True
+    assert len(json.dumps(line)) < bench.LINE_BUDGET
+    long_form = _canned_long_form()
+    long_form["leg_errors"] = {"hbm": "skipped: --time-budget 240 s used up"}
+    long_form["configs"]["hbm"] = {"error": "skipped: --time-budget 240 s used up"}
+    line = bench.compact_line(long_form)
+    assert line["ok"] is True and "failed" not in line and line["skipped"] == ["hbm"]

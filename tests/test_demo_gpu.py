@@ -92,3 +92,22 @@ def test_default_bench_line_is_compact_complete_and_every_leg_within_tolerance()
         assert leg["ok"] is True and leg["frac"] > 0 and leg["kernel_ms"] > 0 and leg["cpu_value"] > 0, (key, leg)
     assert out["configs"]["hbm"]["bound"] == "hbm"
     assert out["ref12"]["ok"] is True and out["refint"]["ok"] is True
+
+
+@pytest.mark.gpu
+def test_bench_headline_survives_a_spent_time_budget():
+    """`--time-budget 0`: every optional leg is skipped (named in `skipped`), the contract leg with its roofline, cpu_baseline and
+    parity still runs and the line is printed -- what protects the headline on a slow box."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0.3",
+                        "--time-budget", "0", "--strict"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["ok"] is True and out["value"] > 1e7 and out["roofline"]["frac"] > 0.2 and out["cpu_baseline"]["value"] > 0 and out["parity"]["ok"] is True
+    assert set(out["skipped"]) >= {"ref12", "refint", "host_api", "newton", "c1", "c3", "c4", "c5", "c5_stm", "hbm"}
+    assert all(leg["ok"] is None for leg in out["configs"].values()) and "ref12" not in out and "newton_us" not in out
