@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Cooperative kernels with the reference's integrator setting (DOP853, rtol = atol = 1e-13, 12-dim + STM): one-piece lanes
-(LTO_KERNEL_COOP) against two lanes per state (LTO_KERNEL_COOP2): results, step counts, time per sweep."""
+"""Cooperative kernels with the reference's integrator setting (DOP853, rtol = atol = 1e-13, + STM): one-piece lanes
+(LTO_KERNEL_COOP) against two lanes per state (LTO_KERNEL_COOP2): results, step counts, time per sweep.  Round 6: the 12-dim one-piece
+form is gone (its selector runs the two-lane kernel), so the comparison is made on the 14-dim system (NDIM=14, the default), where both
+exist for the always-thrust-limited laws; NDIM=12 times the two-lane kernel alone."""
 import os
 import sys
 import time
@@ -15,21 +17,26 @@ from lowthrustopt_amd import synth
 def main():
     ctx = lto.Context(0)
     st = lto.current_stream_ptr()
+    ndim = int(os.environ.get("NDIM", "14"))
     for S in [int(x) for x in os.environ.get("SEGS", "29,4096,65536").split(",")]:
         n = S + 1
         if S == 65536:
             XC, T = synth.indirect_problem(n, seed=5, dt_range=(0.05, 0.5)); rho = 1e-3
         else:
             XC, T = synth.indirect_problem(n); rho = 1.0
-        prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 1000.0, 1.0, 1.0, rho)
+        prm = lto.make_params(lto.MU, lto.DU, lto.TU, 0.05, 2000.0 if ndim == 14 else 1000.0, 1.0, 1.0, rho)
+        if ndim == 14:
+            X14 = np.zeros((14,) + XC.shape[1:], order="F")
+            X14[:6] = XC[:6]; X14[6] = 1000.0; X14[7:13] = XC[6:]; X14[13] = 0.1
+            XC = X14
         X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
         t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
         res = {}
         for name, kern in (("coop", 2), ("coop2", 6)):
-            plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator())
+            plan = lto.IndirectPlan(ctx, n, 1, prm, lto.integrator(), ndim=ndim)
             plan.set_kernel(kern)
-            d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
-            Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
+            d = torch.zeros(ndim, S, dtype=torch.float64, device="cuda")
+            Phi = torch.zeros(ndim * ndim, S, dtype=torch.float64, device="cuda")
             for _ in range(3):
                 plan.jacobian(X, n, t, 1, Phi, S, d, S, stream=st)
             if S > 8192:
@@ -45,13 +52,13 @@ def main():
             ms = (time.perf_counter() - t0) / reps * 1e3
             acc, rej = plan.step_counts(stream=st)
             res[name] = (Phi.cpu().numpy(), d.cpu().numpy(), acc.copy(), rej.copy())
-            print("S=%6d %-6s %.4f ms per sweep; steps accepted %.2f (max %d), rejected %.2f; finite %s" % (
-                S, name, ms, acc.mean(), acc.max(), rej.mean(), bool(np.isfinite(res[name][0]).all())), flush=True)
+            print("ndim %d S=%6d %-6s (ran %s) %.4f ms per sweep; steps accepted %.2f (max %d), rejected %.2f; finite %s" % (
+                ndim, S, name, plan.last_kernel(), ms, acc.mean(), acc.max(), rej.mean(), bool(np.isfinite(res[name][0]).all())), flush=True)
             plan.close()
         P1, d1, a1, r1 = res["coop"]; P2, d2, a2, r2 = res["coop2"]
         print("   coop2 vs coop: max |dPhi| / max |Phi| = %.2e, max |ddefect| = %.2e, step counts equal: %s" % (
             np.abs(P1 - P2).max() / np.abs(P1).max(), np.abs(d1 - d2).max(), bool(np.array_equal(a1, a2) and np.array_equal(r1, r2))), flush=True)
-    if os.environ.get("LTO_HIP_LIB", "").endswith("liblto_probe.so"):
+    if os.environ.get("LTO_HIP_LIB", "").endswith("liblto_probe.so") and ndim == 12:
         # probe build: barrier-wait and loop ticks per role (rows 16-23 of a 24-row defect buffer), 4 096 segments
         S = 4096; n = S + 1
         XC, T = synth.indirect_problem(n)
