@@ -23,6 +23,17 @@ static int self_check(void) {
   int rc;
   if (lto_version() != LTO_VERSION) return fail("lto_version", lto_version(), NULL);
   if (lto_create(NULL, 0) != LTO_ENULL) return fail("lto_create(NULL)", 0, NULL);
+  /* host logic that needs no device (round 6): what LTO_KERNEL_AUTO resolves to, by the MI355X cost table */
+  if (lto_indirect_auto_kernel(14, LTO_RK4, 64, 1.0, 4096, 256, 0) != LTO_KERNEL_PIPE8) return fail("auto kernel, contract size", 0, NULL);
+  if (lto_indirect_auto_kernel(14, LTO_RK4, 64, 1.0, 262144, 256, 0) != LTO_KERNEL_PIPE32) return fail("auto kernel, 14-dim C4 size", 0, NULL);
+  if (lto_indirect_auto_kernel(12, LTO_RK4, 64, 1.0, 262144, 256, 0) != LTO_KERNEL_LANE) return fail("auto kernel, C4", 0, NULL);
+  if (lto_indirect_auto_kernel(12, LTO_RK4, 64, 1.0, 32768, 256, 0) != LTO_KERNEL_PIPE48) return fail("auto kernel, C4 per rank of eight", 0, NULL);
+  if (lto_indirect_auto_kernel(12, LTO_DOP853_ADAPTIVE, 0, 1.0, 65536, 256, 1) != LTO_KERNEL_COOP2) return fail("auto kernel, C5", 0, NULL);
+  if (lto_indirect_auto_kernel(14, LTO_DOP853_ADAPTIVE, 0, 2.0, 4096, 256, 0) != LTO_KERNEL_COOP) return fail("auto kernel, 14-dim p = 2", 0, NULL);
+  if (lto_indirect_auto_kernel(13, LTO_RK4, 64, 1.0, 4096, 256, 0) != LTO_EINVAL) return fail("auto kernel accepted ndim 13", 0, NULL);
+  if (lto_indirect_auto_kernel(12, LTO_RK4, 64, 0.5, 4096, 256, 0) != LTO_EINVAL) return fail("auto kernel accepted p = 0.5", 0, NULL);
+  if (lto_comm_rccl_ranks(NULL) != LTO_ENULL || lto_last_call_order(NULL) != LTO_ENULL) return fail("NULL handles accepted", 0, NULL);
+  printf("host logic: LTO_KERNEL_AUTO resolves as documented\n");
   rc = lto_create(&c, 0);
   if (rc == LTO_ENODEVICE) { printf("no device: lto_create refused (LTO_ENODEVICE), no CPU fallback\n"); return 0; }
   if (rc != LTO_OK) return fail("lto_create", rc, c);

@@ -30,6 +30,7 @@ def test_header_is_c99_and_library_refuses_without_a_device(harness):
     import torch
     r = subprocess.run([harness], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "LTO_KERNEL_AUTO resolves as documented" in r.stdout          # the pure host logic of the ABI, called from C without a device
     if torch.cuda.device_count() == 0:
         assert "LTO_ENODEVICE" in r.stdout
     else:
