@@ -126,7 +126,7 @@ int lto_last_call_order(const lto_ctx* ctx);
 int lto_calibrate_kernels(lto_ctx* ctx);
 int lto_kernel_round_costs(const lto_ctx* ctx, int ndim, double* us_per_round, int* calibrated);
 /* The sixth family AUTO weighs for ndim = 12 (round 5; kept out of the five-entry table so that its callers' arrays stay valid):
- * microseconds per round of 256 x CUs segments at 64 steps of the whole-segment lanes (LTO_KERNEL_LANE) -- 590 on MI355X by
+ * microseconds per round of 256 x CUs segments at 64 steps of the whole-segment lanes (LTO_KERNEL_LANE) -- 505 on MI355X by
  * default, this device's figure after lto_calibrate_kernels (which then also sweeps one such round: ~5 ms more, and the context's
  * work arena grows to ~110 MB). */
 double lto_kernel_lane_round_us(const lto_ctx* ctx);
@@ -325,12 +325,13 @@ int lto_indirect_plan_set_warm_start(lto_indirect_plan* plan, int on);
  * (AUTO does not consider it there).  Results equal LTO_KERNEL_PIPE8's bit for bit. */
 #define LTO_KERNEL_PIPE32 8
 /* RK4, ndim = 12 plans only (others: LTO_EINVAL): a lane owns a whole segment -- its base trajectory, the four stage matrices of
- * every step and all twelve STM columns, which it sends through those matrices one after the other (six columns parked in
- * accumulation registers, six in LDS).  No DPP row with idle lanes, no barrier, no hand-over: ~75 wave-instructions per segment
+ * every step and all twelve STM columns, which it sends through those matrices one after the other (eight columns parked in
+ * accumulation registers, four in LDS).  No DPP row with idle lanes, no barrier, no hand-over: ~61 wave-instructions per segment
  * and RK4 step against ~118 of LTO_KERNEL_PIPE48 -- but one wavefront of 64 segments per SIMD, so it only pays once the batch
- * fills the chip: AUTO compares its rounds of 256 x CUs segments (590 us at 64 steps on MI355X) with the pipelines' rounds and
- * takes it from about 48 000 segments on MI355X (not for the sizes just above a multiple of a pipeline's smaller round).  Phi
- * and defect equal the pipeline kernels' bit for bit. */
+ * fills the chip: AUTO compares its rounds of 256 x CUs segments (505 us at 64 steps on MI355X) with the pipelines' rounds and
+ * takes it from 36 865 segments on MI355X (not for the sizes just above a multiple of a pipeline's smaller round: 65 537 ...
+ * 78 848).  The defect equals the pipeline kernels' bit for bit; Phi agrees with theirs to round-off (~1e-15 of max |Phi|: since
+ * round 6 the stage matrices come from the base evaluations' by-products, not from a second evaluation of the control law). */
 #define LTO_KERNEL_LANE 9
 int lto_indirect_plan_set_kernel(lto_indirect_plan* plan, int kernel);
 /* What LTO_KERNEL_AUTO resolves to for the STM sweep of a plan of this shape on a device with `n_cus` compute units, by the MI355X

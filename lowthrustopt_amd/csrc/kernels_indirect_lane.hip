@@ -6,22 +6,27 @@
 // carries the 12 columns of a segment (a quarter of the column lanes idle), the roles meet at a barrier per step, coefficients
 // travel through LDS.  Here a lane owns its segment outright:
 //
-//   per RK4 step   base trajectory, four stage evaluations (rhs12_base: the pipelines' base role, same operations, same bits)
-//                  -> the four stage matrices G, H, U from the stage arguments' position and lambda_v (rhs12<PM, true>: the
-//                     pipelines' coefficient role), scaled by the stage weights, 68 doubles in registers
+//   per RK4 step   base trajectory, four stage evaluations (rhs12_base_parts: the pipelines' base role, same operations, same bits,
+//                     keeping of every evaluation the by-products the variational coefficients are made of)
+//                  -> the four stage matrices G, H, U from the stage arguments' position and lambda_v and those by-products
+//                     (coef12_from_parts: no second set of reciprocal square roots, no second control law), scaled by the stage
+//                     weights, 68 doubles in addressable registers
 //                  -> the twelve STM columns one after the other through those four matrices (col_reg_step: col_dpp_step of
-//                     pipe_common.hpp with the coefficient in a register instead of a DPP broadcast -- the same FMAs in the same
-//                     order, so Phi equals the pipelines' bit for bit).
-//   No LDS, no barrier, no idle lane, nothing computed twice: ~60 wave-instructions per segment and step.
+//                     pipe_common.hpp with the coefficient in a register instead of a DPP broadcast -- the same FMAs in the same order).
+//   No barrier, no idle lane, nothing computed twice: 61 wave-instructions per segment and step (3 913 per wavefront).
+//   The defect equals the pipelines' bit for bit (same base arithmetic); Phi agrees with theirs to round-off (~1e-15 of max |Phi|):
+//   the pipelines' coefficient role re-evaluates the control law with another exponential routine, this kernel reuses the base
+//   evaluation's (round 5's form, which re-evaluated like the pipelines, was bit-identical and 11 % slower).
 //
-// The price is state: Phi is 144 doubles per lane, next to 68 doubles of stage matrices and ~50 of a column in flight.  The kernel
-// runs ONE wavefront per SIMD (512 registers per lane: 256 addressable + 256 accumulation registers): six columns live in
-// registers -- the compiler parks them in the accumulation registers and moves one in and out per step, ~830 v_accvgpr moves per
-// step against ~3 800 FP64 instructions -- and six in LDS (36 KB per wavefront, four wavefronts per CU; 16-byte pieces, one per lane
-// and access).  More register columns spill to scratch, more LDS columns do not fit four wavefronts per CU (LANE_COLS_IN_REGISTERS).
-// So it needs 64 segments per SIMD to fill the chip: AUTO compares its rounds of 256 x CUs segments with the pipelines' (lto_api.hip).
-// The stage arguments pass through an empty asm before the matrices are built from them: otherwise the compiler merges that
-// evaluation into the base stage's and keeps ~20 by-products per stage alive across the step (+110 registers).
+// The price is state: Phi is 144 doubles per lane, next to 68 doubles of stage matrices and four 12-vectors of a column in flight.
+// The kernel runs ONE wavefront per SIMD (512 registers per lane: 256 addressable + 256 accumulation registers) and says where
+// everything lives (round 6; before, the allocator chose, parked matrices as well as Phi and spilled to scratch inside the loop):
+// EIGHT columns of Phi in the accumulation registers by inline asm (192 of 256), moved in and out around their own RK4 step; the base
+// state parked there too during the column phase (24); four columns in LDS (24 KB per wavefront, four wavefronts per CU; 16-byte
+// pieces, one per lane and access).  490 registers, no scratch, no spill in any control-law class; nine columns would spill
+// (LANE_COLS_IN_REGISTERS).  It needs 64 segments per SIMD to fill the chip: AUTO compares its rounds of 256 x CUs segments with the
+// pipelines' (lto_api.hip).  The stage arguments pass through an empty asm before the matrices are built from them: otherwise the
+// compiler keeps ~20 more by-products per stage alive across the step.
 // 12-dim; every control-law class; RK4 with any number of steps.
 #include "kernels.hpp"
 #include "pipe_common.hpp"
@@ -74,7 +79,36 @@ __device__ __forceinline__ void col_reg_step(const VarCoef12 (&vc)[4], const Col
   col_reg_stage(vc[3], k.h2w, k.h2, V3, B, y);
 }
 
-constexpr int LANE_COLS_IN_REGISTERS = 6;
+#ifndef LANE_NREG
+#define LANE_NREG 8
+#endif
+constexpr int LANE_COLS_IN_REGISTERS = LANE_NREG;
+
+// Explicit parking (round 6; LANE_EXPLICIT_PARK, default 3 -- the lower levels are kept for A/B builds, profiles/r06_probe_lane_parking.txt):
+//   1  the register columns of Phi live in the ACCUMULATION registers by inline asm with "a" constraints and pass through the
+//      addressable registers only for their own RK4 step (24 reads before it, 24 writes behind it);
+//   2  the base state is parked the same way across the column phase (without that the allocator keeps it addressable through the
+//      phase and spills ~100 registers elsewhere);
+//   3  the four stage matrices are built from the by-products of the base evaluations (rhs12_base_parts -> coef12_from_parts: no
+//      second set of reciprocal square roots and exponentials per step, 270 instructions fewer) -- affordable only now that nothing
+//      spills: 28 more doubles live across the base phase.
+// Left to itself (level 0) the allocator parks whatever it happens to choose -- stage matrices and work values as well as Phi -- and
+// spills four doubles to scratch inside the loop; a lone wavefront per SIMD cannot hide those round trips.  C4: 2.41 -> 2.16 ms on the
+// same box with eight columns in registers (level 2: 2.31; level 3 with six columns: 2.19).
+#ifndef LANE_EXPLICIT_PARK
+#define LANE_EXPLICIT_PARK 3
+#endif
+struct AccDouble { int lo, hi; };
+__device__ __forceinline__ void acc_put(AccDouble& a, const double v) {
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.lo) : "v"(__double2loint(v)));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.hi) : "v"(__double2hiint(v)));
+}
+__device__ __forceinline__ double acc_get(const AccDouble& a) {
+  int lo, hi;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(a.lo));
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(a.hi));
+  return __hiloint2double(hi, lo);
+}
 
 template <int PM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_indirect_lane(const IndirectArgs a) {
@@ -94,46 +128,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   double y[12];
 #pragma unroll
   for (int c = 0; c < 12; ++c) y[c] = a.X[c * a.ldx + node];
-  // Phi: columns 0 .. NREG-1 in registers (the compiler parks them in the accumulation registers), the others in LDS, one 16-byte
-  // piece per lane and access (conflict-free), read back through an offset the compiler cannot see through (it would otherwise
-  // forward the stored registers across the loop and keep them alive -- 144 + 68 + 36 doubles do not fit 512 registers)
+  // Phi: columns 0 .. NREG-1 in the accumulation registers (PHI_PUT / PHI_GET), the others in LDS, one 16-byte piece per lane and
+  // access (conflict-free), read back through an offset the compiler cannot see through (it would otherwise forward the stored
+  // registers across the loop and keep them alive)
   constexpr int NREG = LANE_COLS_IN_REGISTERS, NLDS = 12 - NREG;
   __shared__ double2 s_park[(NLDS > 0 ? NLDS : 1) * 6][64];
   int lane_opaque = threadIdx.x;
   asm volatile("" : "+v"(lane_opaque));
+#if LANE_EXPLICIT_PARK
+  AccDouble phi[NREG > 0 ? NREG : 1][12];
+#define PHI_PUT(col, r, v) acc_put(phi[col][r], (v))
+#define PHI_GET(col, r) acc_get(phi[col][r])
+#else
   double phi[NREG > 0 ? NREG : 1][12];
+#define PHI_PUT(col, r, v) (phi[col][r] = (v))
+#define PHI_GET(col, r) (phi[col][r])
+#endif
 #pragma unroll
   for (int col = 0; col < 12; ++col)
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const double e0 = (2 * q == col) ? 1.0 : 0.0, e1 = (2 * q + 1 == col) ? 1.0 : 0.0;
-      if (col < NREG) { phi[col][2 * q] = e0; phi[col][2 * q + 1] = e1; }
+      if (col < NREG) { PHI_PUT(col, 2 * q, e0); PHI_PUT(col, 2 * q + 1, e1); }
       else s_park[(col - NREG) * 6 + q][threadIdx.x] = make_double2(e0, e1);
     }
 
   for (int step = 0; step < steps; ++step) {
     // base trajectory (the pipelines' base role): one RK4 step; of every stage argument the position and lambda_v are kept
     double arg[4][6];
+#if LANE_EXPLICIT_PARK >= 3
+    BaseParts12 bparts[4];
+#endif
     {
       double k[12], yt[12], acc[12];
 #pragma unroll
       for (int c = 0; c < 3; ++c) { arg[0][c] = y[c]; arg[0][3 + c] = y[9 + c]; }
+#if LANE_EXPLICIT_PARK >= 3
+      rhs12_base_parts<PM>(y, tp, k, bparts[0]);
+#else
       rhs12_base<PM>(y, tp, k);
+#endif
 #pragma unroll
       for (int c = 0; c < 12; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
 #pragma unroll
       for (int c = 0; c < 3; ++c) { arg[1][c] = yt[c]; arg[1][3 + c] = yt[9 + c]; }
+#if LANE_EXPLICIT_PARK >= 3
+      rhs12_base_parts<PM>(yt, tp, k, bparts[1]);
+#else
       rhs12_base<PM>(yt, tp, k);
+#endif
 #pragma unroll
       for (int c = 0; c < 12; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
 #pragma unroll
       for (int c = 0; c < 3; ++c) { arg[2][c] = yt[c]; arg[2][3 + c] = yt[9 + c]; }
+#if LANE_EXPLICIT_PARK >= 3
+      rhs12_base_parts<PM>(yt, tp, k, bparts[2]);
+#else
       rhs12_base<PM>(yt, tp, k);
+#endif
 #pragma unroll
       for (int c = 0; c < 12; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
 #pragma unroll
       for (int c = 0; c < 3; ++c) { arg[3][c] = yt[c]; arg[3][3 + c] = yt[9 + c]; }
+#if LANE_EXPLICIT_PARK >= 3
+      rhs12_base_parts<PM>(yt, tp, k, bparts[3]);
+#else
       rhs12_base<PM>(yt, tp, k);
+#endif
 #pragma unroll
       for (int c = 0; c < 12; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
     }
@@ -151,16 +212,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
       for (int c = 0; c < 3; ++c) { ya[c] = arg[j][c]; ya[9 + c] = arg[j][3 + c]; }
       __builtin_amdgcn_sched_barrier(0);           // one stage's matrices at a time
+#if LANE_EXPLICIT_PARK >= 3
+      coef12_from_parts(ya[0], ya[1], ya[2], ya[9], ya[10], ya[11], bparts[j], tp.MU, vc[j]);
+      (void)dead;
+#else
       rhs12<PM, true>(ya, tp, dead, vc[j]);
+#endif
       const double as = (j == 2) ? h : h2;
       double* o = reinterpret_cast<double*>(&vc[j]);
 #pragma unroll
       for (int e = 0; e < 14; ++e) o[e] = o[e] * as;
     }
+#ifndef LANE_PARK_BASE
+#define LANE_PARK_BASE (LANE_EXPLICIT_PARK >= 2)
+#endif
+#if LANE_PARK_BASE
+    AccDouble ypark[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) acc_put(ypark[c], y[c]);
+#endif
 #pragma unroll
     for (int col = 0; col < 12; ++col) {
       __builtin_amdgcn_sched_barrier(0);           // one column at a time: interleaving two of them costs more registers than there are
+#if LANE_EXPLICIT_PARK
+      if (col < NREG) {
+        double u[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) u[c] = PHI_GET(col, c);
+        col_reg_step(vc, kc, u);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) PHI_PUT(col, c, u[c]);
+      }
+#else
       if (col < NREG) col_reg_step(vc, kc, phi[col]);
+#endif
       else {
         double u[12];
 #pragma unroll
@@ -170,11 +255,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int q = 0; q < 6; ++q) s_park[(col - NREG) * 6 + q][threadIdx.x] = make_double2(u[2 * q], u[2 * q + 1]);
       }
     }
+#if LANE_PARK_BASE
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 12; ++c) y[c] = acc_get(ypark[c]);
+#endif
     if (((step + 1) & (COL_RESCALE_EVERY - 1)) == 0) {       // every 256 steps: u <- 3^-256 u, all columns (pipe_common.hpp COL_RESCALE)
 #pragma unroll
       for (int col = 0; col < NREG; ++col)
 #pragma unroll
-        for (int c = 0; c < 12; ++c) phi[col][c] *= COL_RESCALE;
+        for (int c = 0; c < 12; ++c) PHI_PUT(col, c, PHI_GET(col, c) * COL_RESCALE);
 #pragma unroll
       for (int j = 0; j < NLDS * 6; ++j) {
         double2 t = s_park[j][lane_opaque];
@@ -200,7 +290,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       double2 t;
-      if (col < NREG) t = make_double2(phi[col][2 * q], phi[col][2 * q + 1]);
+      if (col < NREG) t = make_double2(PHI_GET(col, 2 * q), PHI_GET(col, 2 * q + 1));
       else t = s_park[(col - NREG) * 6 + q][lane_opaque];
       *(double*)(prow + off) = t.x * a.stm_scale;
       prow += row_bytes;

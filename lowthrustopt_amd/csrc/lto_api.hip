@@ -26,7 +26,7 @@ using namespace lto;
 // RK4 STM sweeps with >= 6 steps, 12-dim: microseconds per round of the form whose lane is a whole segment (kernels_indirect_lane.hip;
 // a round = 256 segments per CU) at 64 steps on MI355X, for AUTO's comparison with the pipelines' round costs (default of
 // lto_ctx::lane_round_us; lto_calibrate_kernels measures it on the context's own device).
-static const double kLaneRoundUs = 590.0;
+static const double kLaneRoundUs = 505.0;      // round 6 (explicit register parking, matrices from the base evaluations' by-products): was 590
 // us per round at 64 steps, MI355X: [12-dim | 14-dim][eight-wave (16 x CUs) | 48-segment (48 x CUs) | per-lane with 3 columns (64 x CUs) |
 // 44-segment (44 x CUs) | 32-segment (32 x CUs)]; lto_calibrate_kernels replaces them with the context's own device's
 static const double kRoundCostDefault[2][5] = {{63.0, 165.0, 246.0, 139.0, 111.0}, {72.0, 191.0, 1e300, 1e300, 128.0}};

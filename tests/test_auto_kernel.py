@@ -21,8 +21,9 @@ BOUNDARY_CASES = [
     (12, 12288, lto.RK4, 8, "pipeline48"), (12, 16384, lto.RK4, 8, "pipeline32"), (14, 29, lto.RK4, 2, "per-lane"),
     (14, 12288, lto.RK4, 6, "pipeline48"), (14, 16384, lto.RK4, 6, "pipeline32"), (14, 20480, lto.RK4, 6, "pipeline8"),
     (12, 11264, lto.RK4, 6, "pipeline48"), (12, 32768, lto.RK4, 8, "pipeline48"), (14, 24576, lto.RK4, 6, "pipeline48"),
-    (12, 24576, lto.RK4, 6, "pipeline48"), (12, 45056, lto.RK4, 64, "pipeline48"), (12, 45057, lto.RK4, 64, "segment-lane"),
-    (12, 65536, lto.RK4, 64, "segment-lane"), (12, 65537, lto.RK4, 64, "pipeline48"), (12, 90113, lto.RK4, 64, "segment-lane"),
+    (12, 24576, lto.RK4, 6, "pipeline48"), (12, 36864, lto.RK4, 64, "pipeline48"), (12, 36865, lto.RK4, 64, "segment-lane"),
+    (12, 45057, lto.RK4, 64, "segment-lane"), (12, 65536, lto.RK4, 64, "segment-lane"), (12, 65537, lto.RK4, 64, "pipeline48"),
+    (12, 78848, lto.RK4, 64, "pipeline48"), (12, 78849, lto.RK4, 64, "segment-lane"), (12, 90113, lto.RK4, 64, "segment-lane"),
     (12, 262144, lto.RK4, 64, "segment-lane"), (14, 262144, lto.RK4, 64, "pipeline32"),
     (12, 29, lto.DOP853_ADAPTIVE, 0, "cooperative2"), (14, 29, lto.DOP853_ADAPTIVE, 0, "cooperative2"),
     (12, 29, lto.RKF78_ADAPTIVE, 0, "cooperative"), (14, 29, lto.RKF78_FIXED, 4, "cooperative"),

@@ -1770,9 +1770,9 @@ def test_kernel_cost_table_calibration():
         d12, cal = ctx.kernel_round_costs(12)
         d14, _ = ctx.kernel_round_costs(14)
         assert not cal and d12 == [63.0, 165.0, 246.0, 139.0, 111.0] and d14 == [72.0, 191.0, -1.0, -1.0, 128.0]
-        assert ctx.kernel_lane_round_us() == 590.0                       # the sixth family (12-dim): whole-segment lanes, rounds of 256 x CUs
+        assert ctx.kernel_lane_round_us() == 505.0                       # the sixth family (12-dim): whole-segment lanes, rounds of 256 x CUs
         got = ctx.calibrate_kernels()
-        assert 0.6 * 590.0 < ctx.kernel_lane_round_us() < 1.6 * 590.0 and ctx.kernel_lane_round_us() != 590.0
+        assert 0.6 * 505.0 < ctx.kernel_lane_round_us() < 1.6 * 505.0 and ctx.kernel_lane_round_us() != 505.0
         m12, cal = ctx.kernel_round_costs(12)
         m14, _ = ctx.kernel_round_costs(14)
         assert cal and got[12] == m12 and got[14] == m14
@@ -1997,9 +1997,12 @@ def test_one_step_whole_segment_lanes_choice_and_misuse(gpu_ctx):
 @pytest.mark.parametrize("pp,steps", [(1.0, 9), (0.0, 3), (2.0, 64), (1.5, 7), (1.0, 258)])
 def test_segment_lane_kernel_equals_the_pipelines_bitwise(gpu_ctx, oracle, pp, steps):
     """LTO_KERNEL_LANE (kernels_indirect_lane.hip: a lane owns a whole segment -- base trajectory, stage matrices, all twelve STM
-    columns): the same FMAs in the same order as the three-role pipelines, so Phi and defect equal LTO_KERNEL_PIPE48's bit for bit
-    -- every control-law class, a ragged batch (3 trajectories x 1 111 segments with their own grids), step counts on both sides
-    of the columns' rescaling period (256) -- and the oracle's dual-number STM of the same discrete map to round-off."""
+    columns): the base trajectory is the pipelines' base role operation for operation, so the DEFECT equals LTO_KERNEL_PIPE48's bit for
+    bit; the columns run the same FMAs in the same order through stage matrices that, since round 6, are built from the base
+    evaluations' own by-products instead of a second evaluation of the control law (the pipelines' coefficient role): Phi agrees with
+    the pipelines' to round-off (1e-13 of max |Phi|; measured ~1e-15) -- every control-law class, a ragged batch (3 trajectories x
+    1 111 segments with their own grids), step counts on both sides of the columns' rescaling period (256) -- and both agree with the
+    oracle's dual-number STM of the same discrete map."""
     import torch
     n, B = 1112, 3
     XC, T = synth.indirect_problem(n, n_batch=B, seed=17, dt_seg=0.12)
@@ -2021,7 +2024,8 @@ def test_segment_lane_kernel_equals_the_pipelines_bitwise(gpu_ctx, oracle, pp, s
     plan.close()
     assert bool(torch.isfinite(out["lane"][0]).all())
     assert torch.equal(out["lane"][1], out["pipe48"][1])
-    assert torch.equal(out["lane"][0], out["pipe48"][0])
+    pscale = float(out["pipe48"][0].abs().max())
+    assert float((out["lane"][0] - out["pipe48"][0]).abs().max()) < 1e-13 * pscale
     b = B - 1
     P_o, d_o, rc = oracle.indirect_jacobian(XC[:, :65, b], T[:65, b], [MU, DU, TU, thr, 1000.0, 1.0, pp, 1.0], oracle.RK4, steps)
     assert rc == 0
@@ -2053,7 +2057,8 @@ def test_segment_lane_kernel_choice_mixed_classes_and_misuse(gpu_ctx):
         res[kernel] = (Phi, d, plan.last_kernel())
     plan.close()
     assert res["auto"][2] == "segment-lane" and res["pipe48"][2] == "pipeline48"
-    assert torch.equal(res["auto"][0], res["pipe48"][0]) and torch.equal(res["auto"][1], res["pipe48"][1])
+    assert torch.equal(res["auto"][1], res["pipe48"][1])                    # same base arithmetic: the defect bit for bit
+    assert float((res["auto"][0] - res["pipe48"][0]).abs().max()) < 1e-13 * float(res["pipe48"][0].abs().max())     # Phi: round-off (lane kernel's header)
     assert torch.equal(res["auto"][0][:, :S1], res["auto"][0][:, 12 * S1:13 * S1])       # trajectory 12 = a copy of trajectory 0 (same p, same rho)
     # RK4 with 2 ... 5 steps on a full chip: AUTO's per-lane family gives way to the whole-segment lanes too (no fill or drain,
     # no base stage run twice); the per-lane kernel with three columns per lane agrees within rounding
