@@ -164,7 +164,9 @@ def test_design_table_is_the_one_generated_from_the_profiles():
     avg_us, calls, name = dt.kernel_avg("r06z", "c2", "k_indirect_pipe8<14")
     assert calls > 1000 and "pipe8<14" in name
     frac = 4096 * 569600 / (avg_us * 1e-6) / 78.6e12
-    assert ("FP64 %.3f" % frac) in rows[0]
+    import re
+    shown = float(re.search(r"FP64 ([0-9.]+)", rows[0]).group(1))
+    assert abs(shown - frac) < 2e-3, (shown, frac)              # (the table rescales the bench line's rounded fraction by the two times)
 
 
 def test_optional_legs_that_raise_or_run_out_of_time_do_not_cost_the_headline():
