@@ -281,23 +281,68 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
   // ten column waves and the mass couplings the compiler otherwise hoists the 64-bit literals of the unrolled stage loop, runs out
   // of scalar registers and parks two dozen of them in scratch (48 dwords, reloaded every step).
   constexpr bool BY_SLOPE = (NS == 7);
+  // NS = 7 also forms the arguments of the last three stages, the weighted sum and the error term EAGERLY: with seven components
+  // ten slopes are alive at stage 12 (K0, K3 ... K11; 182 registers with y and the argument, against 168 per lane at three waves
+  // per SIMD -- 13 dwords went to scratch).  From stage EAGER - 1 on every sum that still needs an old slope is carried as an
+  // accumulator instead: behind stage 8's argument the sums of stages 9 ... 12, of the weights and of the error term take K0 ... K7 (in
+  // the tableau's order, so every chain of FMAs is the one it was: bit-identical), then each new slope is fed to them as it appears
+  // and dies.  Scratch per lane by threshold: 7: 20 B, 8 and 9: none, 10: 12 B, 11: 20 B, none of it (before): 56 B.
+  constexpr int EAGER = 9;
   auto rk_step = [&](auto&& slope) {
+    double accE[13 - EAGER][NS], accB[NS], gerr[NS];
+    const double cerr = __ddiv_rn(__dmul_rn(h, 41.0), 840.0);             // rkf78_err_term's scale (ode.jl:940)
+    auto feed = [&](const int k) {                                        // slope k enters every eager sum that uses it
+#pragma unroll
+      for (int t = EAGER; t < 13; ++t)
+        if (t > k && TabRKF78::A[t][k] != 0.0) {
+          const double w = coef_here(TabRKF78::A[t][k]);
+#pragma unroll
+          for (int c = 0; c < NS; ++c) accE[t - EAGER][c] = __builtin_fma(w, K[k][c], accE[t - EAGER][c]);
+        }
+      if (TabRKF78::B[k] != 0.0) {
+        const double w = coef_here(TabRKF78::B[k]);
+#pragma unroll
+        for (int c = 0; c < NS; ++c) accB[c] = __builtin_fma(w, K[k][c], accB[c]);
+      }
+      if (TabRKF78::E[k] != 0.0 && is_base) {                            // the four terms of rkf78_err_term, one at a time in its order
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+          const double term = __dmul_rn(cerr, K[k][c]);
+          gerr[c] = (k == 0) ? term : __dadd_rn(gerr[c], TabRKF78::E[k] > 0.0 ? term : -term);
+        }
+      }
+    };
 #pragma unroll
     for (int st = 0; st < 13; ++st) {
       double arg[NS];
       if constexpr (BY_SLOPE) {
-        double acc[NS];
+        if (st < EAGER) {
+          double acc[NS];
 #pragma unroll
-        for (int c = 0; c < NS; ++c) acc[c] = 0.0;
+          for (int c = 0; c < NS; ++c) acc[c] = 0.0;
 #pragma unroll
-        for (int k = 0; k < st; ++k)
-          if (TabRKF78::A[st][k] != 0.0) {
-            const double w = coef_here(TabRKF78::A[st][k]);
+          for (int k = 0; k < st; ++k)
+            if (TabRKF78::A[st][k] != 0.0) {
+              const double w = coef_here(TabRKF78::A[st][k]);
 #pragma unroll
-            for (int c = 0; c < NS; ++c) acc[c] = __builtin_fma(w, K[k][c], acc[c]);
-          }
+              for (int c = 0; c < NS; ++c) acc[c] = __builtin_fma(w, K[k][c], acc[c]);
+            }
 #pragma unroll
-        for (int c = 0; c < NS; ++c) arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc[c], y[c]);
+          for (int c = 0; c < NS; ++c) arg[c] = (st == 0) ? y[c] : __builtin_fma(h, acc[c], y[c]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < NS; ++c) arg[c] = __builtin_fma(h, accE[st - EAGER][c], y[c]);
+        }
+        if (st == EAGER - 1) {
+#pragma unroll
+          for (int t = 0; t < 13 - EAGER; ++t)
+#pragma unroll
+            for (int c = 0; c < NS; ++c) accE[t][c] = 0.0;
+#pragma unroll
+          for (int c = 0; c < NS; ++c) { accB[c] = 0.0; gerr[c] = 0.0; }
+#pragma unroll
+          for (int k = 0; k < EAGER - 1; ++k) feed(k);
+        }
       } else {
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
@@ -309,22 +354,15 @@ __global__ __launch_bounds__(768) void k_direct_jacobian_pipe(const DirectArgs a
         }
       }
       slope(st, arg, K[st]);
+      if constexpr (BY_SLOPE) {
+        if (st >= EAGER - 1) feed(st);
+      }
     }
     if constexpr (BY_SLOPE) {
-      double acc[NS];
-#pragma unroll
-      for (int c = 0; c < NS; ++c) acc[c] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 13; ++k)
-        if (TabRKF78::B[k] != 0.0) {
-          const double w = coef_here(TabRKF78::B[k]);
-#pragma unroll
-          for (int c = 0; c < NS; ++c) acc[c] = __builtin_fma(w, K[k][c], acc[c]);
-        }
 #pragma unroll
       for (int c = 0; c < NS; ++c) {
-        if (is_base) maxErr = fmax(maxErr, fabs(rkf78_err_term(h, K[0][c], K[10][c], K[11][c], K[12][c])));
-        y[c] = __builtin_fma(h, acc[c], y[c]);
+        if (is_base) maxErr = fmax(maxErr, fabs(gerr[c]));
+        y[c] = __builtin_fma(h, accB[c], y[c]);
       }
     } else {
 #pragma unroll

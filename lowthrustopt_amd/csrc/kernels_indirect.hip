@@ -19,13 +19,14 @@ hipError_t launch_indirect_stm(int pm, int method, int cols, const IndirectArgs&
   if (method == M_RK4) {
     if (cols == 0) {
       // Fill the chip first (1024 SIMDs): fewer columns per lane = more waves but more redundant base
-      // work; more columns per lane amortise the base RHS once the machine is full.
+      // work; more columns per lane amortise the base RHS once the machine is full.  (Round 6: the two-column form is gone -- it won
+      // only around 8 192 segments, 18.5 against 21.5 us, and AUTO ran it up to 43 690 where three columns are 20 % faster:
+      // tools/probe_cols.py, profiles/r06_probe_cols.txt.)
       const long waves1 = ((long)a.S + 63) / 64 * 12;
-      cols = (waves1 <= 2048) ? 1 : (waves1 <= 8192 ? 2 : 3);
+      cols = (waves1 <= 1536) ? 1 : 3;
     }
     switch (cols) {
       case 1: return launch_pm<12, M_RK4, 1>(pm, a, st);
-      case 2: return launch_pm<12, M_RK4, 2>(pm, a, st);
       case 3: return launch_pm<12, M_RK4, 3>(pm, a, st);
     }
     return hipErrorInvalidValue;

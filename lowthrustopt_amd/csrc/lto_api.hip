@@ -661,6 +661,7 @@ int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
       return set_err(p->ctx, LTO_EINVAL, "cols_per_lane = 12 (the whole STM in the segment's lane) is built for 12-dim RK4 plans with ONE step per segment");
   } else if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2, 3 or 12");
   if (p->ndim == 14 && cols == 3) return set_err(p->ctx, LTO_EUNSUPPORTED, "14 STM columns do not split into groups of 3: use 0 (auto), 1 or 2");
+  if (p->ndim == 12 && cols == 2) return set_err(p->ctx, LTO_EUNSUPPORTED, "two columns per lane are not built for 12-dim plans (removed in round 6: one column wins up to 8 192 segments, three above): use 0 (auto), 1 or 3");
   p->cols_per_lane = cols;
   return LTO_OK;
 }

@@ -316,9 +316,9 @@ def _run_bench(extra_env, args, timeout=420):
     return p.returncode, out, p.stderr[-8000:]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [4])          # (two ranks: test_bench_collective_on_a_side_stream and the c5 case below)
 def test_bench_multi_rank_path_runs_with_ranks_sharing_the_device(world):
-    """`bench.py --gpus N` WITHOUT a launcher (N = 2 and 4: the window transport with more than one peer): it starts
+    """`bench.py --gpus N` WITHOUT a launcher (N = 4: the window transport with more than one peer): it starts
     torch.distributed.run itself (as a child process, before touching the GPU), all ranks take device 0 (LTO_BENCH_SHARE_DEVICE=1), negotiate the window transport, double-buffer the all-gather of the defect
     slabs inside the timed steps, check their slabs and reduce the timing over ranks -- the code path the driver's 8-GPU run takes,
     on the one device this box has."""
@@ -335,7 +335,9 @@ def test_bench_multi_rank_path_runs_with_ranks_sharing_the_device(world):
     assert out["value"] > 0 and out["scaling"] == "weak"
 
 
-@pytest.mark.parametrize("wl,world,per_rank", [("c4", 2, 128 * 1024), ("c4", 4, 64 * 1024), ("c5", 2, 32768)])
+# (c4 with two ranks -- 131 072 segments per rank -- is one of test_gpu_baseline_shapes.py's per-rank batches; every case here is a
+# process launch of ~3 s, and the suite has a time budget)
+@pytest.mark.parametrize("wl,world,per_rank", [("c4", 4, 64 * 1024), ("c5", 2, 32768)])
 def test_bench_sharded_configs_with_ranks_sharing_the_device(wl, world, per_rank):
     """BASELINE configs[3] / [4] through the N > 1 path: `--workload c4` gives every rank 256 / N homotopy levels of 1 024 segments,
     `--workload c5` 65 536 / N segments (ordered lanes after the warm-up sweep) -- a FIXED global size, so the line says "strong" --

@@ -73,9 +73,10 @@ def test_indirect_random_configuration_vs_oracle(gpu_ctx, oracle, seed):
                             ndim=ndim)
     plan.set_kernel(c["kernel"])
     plan.set_defect_lanes(c["lanes"])
-    if ndim == 14 and c["cols"] == 3:                # 14 columns do not split into groups of 3: refused, auto is kept
+    if (ndim == 14 and c["cols"] == 3) or (ndim == 12 and c["cols"] == 2):
+        # 14 columns do not split into groups of 3, and the 12-dim pairs left the library in round 6: refused, auto is kept
         with pytest.raises(lto.LtoError) as ei:
-            plan.set_cols_per_lane(3)
+            plan.set_cols_per_lane(c["cols"])
         assert ei.value.code == -3
     else:
         plan.set_cols_per_lane(c["cols"])
@@ -215,7 +216,8 @@ def test_device_newton_solve_random_sizes_vs_dense(gpu_ctx, seed):
                     keep[12 * k:12 * k + 6] = False
             rhs = -dn[:, :, b].reshape(-1, order="F")
             ref = np.zeros(Jd.shape[1])
-            ref[keep] = np.linalg.lstsq(Jd[:, keep], rhs, rcond=None)[0]
+            A = Jd[:, keep]                                                                  # square without the adjoints-only rows: LU
+            ref[keep] = np.linalg.solve(A, rhs) if A.shape[0] == A.shape[1] else (lambda q, r: np.linalg.solve(r, q.T @ rhs))(*np.linalg.qr(A))
             got = den[:, :, b].reshape(-1, order="F")
             assert np.all(got[~keep] == 0.0), what
             assert np.abs(got - ref).max() < 1e-7 * max(1.0, np.abs(ref).max()), what

@@ -168,10 +168,10 @@ def test_indirect_stm_vs_taylor_goldens_per_control_law_class(gpu_ctx):
 
 
 @pytest.mark.parametrize("pp", [1.0, 2.0, 1.5, 0.0])
-@pytest.mark.parametrize("cols", [1, 2, 3])
+@pytest.mark.parametrize("cols", [3])
 def test_indirect_stm_cols_per_lane_agree(gpu_ctx, cols, pp):
-    """All column-group mappings (1, 2, 3 STM columns per lane) produce the same Phi to round-off, for every
-    control-law class."""
+    """Both column-group mappings (1 or 3 STM columns per lane) produce the same Phi to round-off, for every
+    control-law class; the two-column grouping left the 12-dim library in round 6 (refused, the plan keeps its setting)."""
     import torch
     n = 200
     XC, T = synth.indirect_problem(n, seed=4)
@@ -181,6 +181,9 @@ def test_indirect_stm_cols_per_lane_agree(gpu_ctx, cols, pp):
     prm = lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, pp, 1.0)
     plan = lto.IndirectPlan(gpu_ctx, n, 1, prm, lto.integrator(lto.RK4, steps=32))
     out = {}
+    with pytest.raises(lto.LtoError) as ei:
+        plan.set_cols_per_lane(2)
+    assert ei.value.code == -3
     for c in (1, cols):
         plan.set_cols_per_lane(c)
         Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda")
@@ -1305,7 +1308,12 @@ def test_device_newton_solve_vs_dense(gpu_ctx, oracle, n_nodes, n_batch):
     for b in range(n_batch):
         Jd = lto.indirect_scatter(np.asfortranarray(Pn[:, :, :, b]))
         rhs = -dn[:, :, b].reshape(-1, order="F")
-        ref = np.linalg.lstsq(Jd, rhs, rcond=None)[0].reshape(12, n_nodes, order="F")
+        keep = np.ones(Jd.shape[1], bool)                                         # fixed end states (indirect.jl:141-142): their columns
+        keep[:6] = False; keep[12 * (n_nodes - 1):12 * (n_nodes - 1) + 6] = False  # are empty, what is left is square -> LU, not an SVD
+        assert not Jd[:, ~keep].any()
+        ref = np.zeros(Jd.shape[1])
+        ref[keep] = np.linalg.solve(Jd[:, keep], rhs)
+        ref = ref.reshape(12, n_nodes, order="F")
         assert np.all(de[:6, 0, b] == 0.0) and np.all(de[:6, -1, b] == 0.0)       # fixed end states
         # residual of the linear system and agreement with the dense solve
         res = Jd @ de[:, :, b].reshape(-1, order="F") - rhs
@@ -1480,7 +1488,8 @@ def test_device_adjoints_only_least_squares_vs_dense(gpu_ctx, n_nodes, n_batch):
             keep[12 * (n_nodes - 1):12 * (n_nodes - 1) + 6] = False   # zero columns of the fixed final state
             rhs = -dn[:, :, b].reshape(-1, order="F")
             ref = np.zeros(12 * n_nodes)
-            ref[keep] = np.linalg.lstsq(Jd[:, keep], rhs, rcond=None)[0]
+            q, r = np.linalg.qr(Jd[:, keep])                 # full column rank: Householder QR least squares (an SVD of the same matrix takes 10 x as long)
+            ref[keep] = np.linalg.solve(r, q.T @ rhs)
             ref = ref.reshape(12, n_nodes, order="F")
             assert np.all(de[:6, :, b] == 0.0)            # states untouched
             assert np.abs(de[:, :, b] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())

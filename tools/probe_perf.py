@@ -41,7 +41,7 @@ def main():
             print("S=%7d %-8s stm COOP      %9.3f ms  %10.3e seg/s" % (S, name, ms, S / ms * 1e3), flush=True)
             plan.set_kernel(1)
             if method == lto.RK4:
-                for cols in (1, 2, 3):
+                for cols in (1, 3):
                     plan.set_cols_per_lane(cols)
                     ms = timeit(lambda: plan.jacobian(X, n, t, 1, Phi, S, defect, S, stream=st), iters=10)
                     print("S=%7d %-8s stm cols=%d    %9.3f ms  %10.3e seg/s  (%.2f TFLOP/s model)" % (
