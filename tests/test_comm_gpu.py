@@ -360,7 +360,8 @@ def test_bench_collective_on_a_side_stream(mode):
     """The N > 1 default on distinct devices: the all-gather of step k on a second stream beside the sweep of step k + 1, the wait
     policy (next sweep behind the gather, or only buffer reuse) measured before the timed legs and agreed by all ranks (`auto`),
     or overlap as given (`side`).  Rehearsed here with two ranks on the one device: the window communicator is bound to the side
-    stream by the test gather, events order sweep -> gather -> buffer reuse, the slab check passes."""
+    stream by the test gather, events order sweep -> gather -> buffer reuse, the slab check passes.  (One launch at a time: a
+    launch is three processes with the GPU open -- the launcher's agent and two ranks -- and the box allows six, this one included.)"""
     rc, out, err = _run_bench({"LTO_BENCH_SHARE_DEVICE": "1", "LTO_BENCH_COLLECTIVE_STREAM": mode},
                               ["--gpus", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--segments", "1024"])
     assert rc == 0 and out is not None, err
@@ -387,13 +388,25 @@ def test_bench_under_the_launcher_times_both_transports_and_reports_what_rccl_sa
     env = dict(os.environ, LTO_BENCH_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-configs"]
+    def launch(extra):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+               str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-configs"]
+        return subprocess.Popen(cmd, env=dict(env, **extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # (two launches side by side -- two agents and two ranks with the GPU open, five processes with this one, the box allows six:
+    # a launch is ~4.5 s of start-up and the suite has a time budget)
     # the N > 1 default on distinct devices: collective on a side stream, wait policy measured, both transports in play
-    env["LTO_BENCH_COLLECTIVE_STREAM"] = "auto"
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
-    assert p.returncode == 0, p.stderr[-4000:]
-    last = p.stdout.strip().splitlines()[-1]
+    pa = launch({"LTO_BENCH_COLLECTIVE_STREAM": "auto"})
+    # and with the transport named, on the sweep's own stream: RCCL carries the timed legs
+    pb = launch({"LTO_BENCH_TRANSPORT": "rccl"})
+    try:
+        oa, ea = pa.communicate(timeout=420)
+        ob, eb = pb.communicate(timeout=420)
+    finally:
+        for q in (pa, pb):
+            if q.poll() is None:
+                q.kill()
+    assert pa.returncode == 0, ea[-4000:]
+    last = oa.strip().splitlines()[-1]
     assert len(last) < 6000
     out = json.loads(last)
     c = out["config"]
@@ -403,12 +416,8 @@ def test_bench_under_the_launcher_times_both_transports_and_reports_what_rccl_sa
     assert (tr["chosen"] == "windows") == (tr["windows_ms"] <= tr["rccl_ms"])
     assert c["stream"] == "side" and c["policy"]["chosen"] in ("serial", "overlap"), c
     assert c["slab_ok"] is True and c["devices_token"] == "distinct" and out["ok"] is True
-    del env["LTO_BENCH_COLLECTIVE_STREAM"]
-    # and with the transport named, on the sweep's own stream: RCCL carries the timed legs
-    env["LTO_BENCH_TRANSPORT"] = "rccl"
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
-    assert p.returncode == 0, p.stderr[-4000:]
-    c = json.loads(p.stdout.strip().splitlines()[-1])["config"]
+    assert pb.returncode == 0, eb[-4000:]
+    c = json.loads(ob.strip().splitlines()[-1])["config"]
     assert c["collective"] == "rccl" and c["rccl_ranks"] == 1 and c.get("transports") is None, c
 
 
