@@ -371,10 +371,11 @@ int lto_indirect_plan_set_output_layout(lto_indirect_plan* plan, int layout);
 /* LTO_KERNEL_* family the last STM sweep of this plan ran (what AUTO resolved to); LTO_KERNEL_AUTO before any sweep. */
 int lto_indirect_plan_last_kernel(const lto_indirect_plan* plan);
 /* Per-lane kernel only: STM columns integrated per lane (12-dim: 1 or 3, 14-dim: 1 or 2 -- LTO_EUNSUPPORTED for the other
- * grouping; every lane re-integrates the base state with its columns); 0 = choose from S.  12 = the whole 12x12 STM in the segment's own lane (kernels_indirect_stream.hip): built for ndim = 12 RK4
- * plans with ONE step per segment (LTO_EINVAL otherwise) -- the HBM-bound corner of the sweep, where the lane of a segment runs
- * the four stage evaluations once and sends the twelve columns through the four stage matrices; 0 chooses it for such plans from
- * 65 536 segments. */
+ * grouping; every lane re-integrates the base state with its columns); 0 = choose from S.  cols = the plan's dimension (12 or 14) = the
+ * whole STM in the segment's own lane (kernels_indirect_stream.hip): built for RK4 plans with ONE step per segment (LTO_EINVAL
+ * otherwise, and for the other dimension's value) -- the HBM-bound corner of the sweep, where the lane of a segment runs the four
+ * stage evaluations once and sends the columns through the four stage matrices; 0 chooses it for such plans from 65 536 segments.
+ * One kernel per dimension whatever the batch's control laws (the law is chosen per trajectory at run time; round 6). */
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* plan, int cols);
 
 /* Newton step of the indirect method solved on the device: delta = -Jac_full \ defect for the block-bidiagonal

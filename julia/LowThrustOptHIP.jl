@@ -413,7 +413,7 @@ set_warm_start!(pl::LtoIndirectPlan, on::Bool = true) = check(pl.ctx, ccall((:lt
 set_output_layout!(pl::LtoIndirectPlan, layout::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_output_layout, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, layout))
 "Record staging of the plan's ordered sweeps, a bit mask: 1 node / defect records in place, 2 Phi records too, 4 an allocation failed and staging is off (lto.h)."
 plan_staging(pl::LtoIndirectPlan) = Int(ccall((:lto_indirect_plan_staging, liblto), Cint, (Ptr{Cvoid},), pl.handle))
-"STM columns per lane of the per-lane RK4 kernel: 0 auto, 1-3, or 12 = the whole STM in the segment's lane (one-step plans)."
+"STM columns per lane of the per-lane RK4 kernel: 0 auto, 1 or 3 (12-dim) / 1 or 2 (14-dim), or the plan's dimension (12 / 14) = the whole STM in the segment's lane (one-step plans)."
 set_cols_per_lane!(pl::LtoIndirectPlan, cols::Integer) = check(pl.ctx, ccall((:lto_indirect_plan_set_cols_per_lane, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, cols))
 "Lanes per segment of the defect-only sweep of a 12-dim DOP853 plan: 0 = choose (four up to 131 072 segments, then two, then one), 1, 2 or 4."
 set_defect_lanes!(pl::LtoIndirectPlan, lanes::Integer = 0) = check(pl.ctx, ccall((:lto_indirect_plan_set_defect_lanes, liblto), Cint, (Ptr{Cvoid}, Cint), pl.handle, lanes))

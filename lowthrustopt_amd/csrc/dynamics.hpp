@@ -14,6 +14,9 @@ namespace lto {
 
 // Control-law modes of CRTBP_stateCostate_deriv! (stateCostate_deriv.jl:36-53).
 enum PMode : int { PM_P0 = 0, PM_P1 = 1, PM_P2 = 2, PM_PGEN = 3, PM_NCLASS = 4 };
+// Not a class: "whatever law the trajectory has", a run-time switch over the four class bodies (control_dispatch).  For kernels that
+// HBM bounds (kernels_indirect_stream.hip): there a kernel per class buys no time and costs four instantiations per dimension.
+constexpr int PM_ANY = PM_NCLASS;
 // Control-law class of an exponent p (valid p only: 0, 1 or > 1).  Every kernel is compiled for ONE class, so the law
 // is straight-line code; a batch that mixes classes is swept by one launch per class present, each launch skipping the
 // other classes' trajectories (IndirectArgs::class_filter).
@@ -138,8 +141,18 @@ __device__ __forceinline__ void control_law(const TrajParams& tp, const double a
 template <int PM, bool VAR, bool SHORT = false>
 __device__ __forceinline__ void control_dispatch(const TrajParams& tp, const double aL, double n, double inv_n, double& m,
                                                  double& ua, double& ub, double& un, bool& tlim) {
-  static_assert(PM >= PM_P0 && PM < PM_NCLASS, "kernels are compiled per control-law class");
-  control_law<PM, VAR, SHORT>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+  static_assert(PM >= PM_P0 && PM <= PM_ANY, "kernels are compiled per control-law class (or PM_ANY)");
+  if constexpr (PM == PM_ANY) {
+    // the law of THIS trajectory, chosen at run time: the same control_law<class> code, so the same bits as the per-class kernels
+    switch (p_class(tp.p)) {
+      case PM_P0: control_law<PM_P0, VAR, SHORT>(tp, aL, n, inv_n, m, ua, ub, un, tlim); break;
+      case PM_P1: control_law<PM_P1, VAR, SHORT>(tp, aL, n, inv_n, m, ua, ub, un, tlim); break;
+      case PM_P2: control_law<PM_P2, VAR, SHORT>(tp, aL, n, inv_n, m, ua, ub, un, tlim); break;
+      default: control_law<PM_PGEN, VAR, SHORT>(tp, aL, n, inv_n, m, ua, ub, un, tlim); break;
+    }
+  } else {
+    control_law<PM, VAR, SHORT>(tp, aL, n, inv_n, m, ua, ub, un, tlim);
+  }
 }
 
 // A1: ydot for y = (r, v, lambda_r, lambda_v); optionally the column coefficients.

@@ -103,7 +103,7 @@ hipError_t launch_indirect_stm_pipe8(int ndim, int pm, const IndirectArgs& a, hi
 hipError_t launch_indirect_stm_pipe48(int ndim, int pm, const IndirectArgs& a, bool seg44, hipStream_t st);
 hipError_t launch_indirect_stm_pipe32(int ndim, int pm, const IndirectArgs& a, hipStream_t st);   // kernels_indirect_pipe32.hip
 // one RK4 step, lane = whole segment with all twelve STM columns (kernels_indirect_stream.hip): the HBM-bound corner of the sweep
-hipError_t launch_indirect_stm_stream(int pm, const IndirectArgs& a, hipStream_t st);
+hipError_t launch_indirect_stm_stream(int ndim, int pm, const IndirectArgs& a, hipStream_t st);
 bool indirect_stm_stream_available(int ndim, int method, int steps, long S);
 // RK4, any number of steps, lane = whole segment with the full STM (kernels_indirect_lane.hip): batches that fill the chip many times over
 hipError_t launch_indirect_stm_lane(int pm, const IndirectArgs& a, hipStream_t st);

@@ -22,13 +22,32 @@
 //
 // A column starts at the unit vector only because steps == 1; plans with 2 ... 5 RK4 steps keep the per-column-group kernel.
 // Arithmetic per entry = rhs12<PM, true> / var_col12 / the RK4 update of rk4_step, in the same order as k_indirect<12,PM,RK4,COLS>.
+//
+// ND = 14 (round 6; BASELINE configs[1]'s system, 1 680 bytes of Phi and defect per segment): the same mapping with rhs14 / var_col14.
+// Four VarCoef14 are 100 doubles and a column in flight 42, so the lane takes the whole register file of its SIMD (one wavefront per
+// SIMD, 512 registers -- for the 12-dim form measured to cost nothing, see above); of a stage argument the coefficients need position,
+// mass, lambda_v and lambda_m (8 doubles).
 #include "kernels.hpp"
 #include "rk.hpp"
 
 namespace lto {
 
-template <int PM, int WPE>
+// rows of a stage argument that the variational coefficients depend on (rhs12 / rhs14 with VAR)
+template <int ND> struct StreamKeep;
+template <> struct StreamKeep<12> { static constexpr int N = 6;  static constexpr int idx[6] = {0, 1, 2, 9, 10, 11}; };
+template <> struct StreamKeep<14> { static constexpr int N = 8;  static constexpr int idx[8] = {0, 1, 2, 6, 10, 11, 12, 13}; };
+
+template <int ND, int WPE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_indirect_stream(const IndirectArgs a) {
+  constexpr int PM = PM_ANY;                           // the law is chosen per trajectory at run time: one kernel per dimension (round 6)
+  using Keep = StreamKeep<ND>;
+  using Coef = typename std::conditional<ND == 12, VarCoef12, VarCoef14>::type;
+  constexpr int NK = Keep::N;
+  auto rhs = [](auto var, const double (&yy)[ND], const TrajParams& tp, double (&dy)[ND], Coef& vc) {
+    constexpr bool VAR = decltype(var)::value;
+    if constexpr (ND == 12) rhs12<PM, VAR>(yy, tp, dy, vc);
+    else rhs14<PM, VAR>(yy, tp, dy, vc);
+  };
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= a.S) return;
   const int traj = s / a.seg_per_traj;
@@ -36,44 +55,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
   const long node = (long)traj * a.n_nodes + i;
   const long tg = (long)traj * a.t_stride + i;
   const TrajParams tp = a.tp[(long)traj * a.tp_stride];
-  if (a.class_filter && p_class(tp.p) != PM) return;   // mixed-class batch: another launch owns this trajectory
   const double w2 = 2.0 * tp.omega;
 
-  double y[12];
+  double y[ND];
 #pragma unroll
-  for (int c = 0; c < 12; ++c) y[c] = a.X[c * a.ldx + node];
+  for (int c = 0; c < ND; ++c) y[c] = a.X[c * a.ldx + node];
   const double span = a.t[tg + 1] - a.t[tg];
   const double h = span / (double)a.steps;             // steps == 1 (the launcher checks)
   const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
 
   // Base trajectory: one RK4 step.  Only what the variational coefficients depend on is kept of every stage argument -- its
-  // position and lambda_v, 6 doubles -- and the coefficients are built from those AFTER the step (rhs12<PM, true> once more per
-  // stage with its slopes dead: the same instructions on the same operands, so the same bits as one fused evaluation): with the
-  // coefficients of earlier stages live across the later evaluations the base phase needs ~280 registers, this way ~200.
-  double arg[4][6];
+  // position and lambda_v, 6 doubles (ND = 14: + mass and lambda_m) -- and the coefficients are built from those AFTER the step (the
+  // right-hand side once more per stage with its slopes dead: the same instructions on the same operands, so the same bits as one
+  // fused evaluation): with the coefficients of earlier stages live across the later evaluations the base phase needs ~280
+  // registers (ND = 12), this way ~200.
+  double arg[4][NK];
   {
-    double k[12], yt[12], acc[12];
-    VarCoef12 none;
+    double k[ND], yt[ND], acc[ND];
+    Coef none;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { arg[0][c] = y[c]; arg[0][3 + c] = y[9 + c]; }
-    rhs12<PM, false>(y, tp, k, none);
+    for (int c = 0; c < NK; ++c) arg[0][c] = y[Keep::idx[c]];
+    rhs(std::false_type{}, y, tp, k, none);
 #pragma unroll
-    for (int c = 0; c < 12; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
+    for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h6, k[c], y[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { arg[1][c] = yt[c]; arg[1][3 + c] = yt[9 + c]; }
-    rhs12<PM, false>(yt, tp, k, none);
+    for (int c = 0; c < NK; ++c) arg[1][c] = yt[Keep::idx[c]];
+    rhs(std::false_type{}, yt, tp, k, none);
 #pragma unroll
-    for (int c = 0; c < 12; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
+    for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h2, k[c], y[c]); }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { arg[2][c] = yt[c]; arg[2][3 + c] = yt[9 + c]; }
-    rhs12<PM, false>(yt, tp, k, none);
+    for (int c = 0; c < NK; ++c) arg[2][c] = yt[Keep::idx[c]];
+    rhs(std::false_type{}, yt, tp, k, none);
 #pragma unroll
-    for (int c = 0; c < 12; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
+    for (int c = 0; c < ND; ++c) { acc[c] = __builtin_fma(h3, k[c], acc[c]); yt[c] = __builtin_fma(h, k[c], y[c]); }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { arg[3][c] = yt[c]; arg[3][3 + c] = yt[9 + c]; }
-    rhs12<PM, false>(yt, tp, k, none);
+    for (int c = 0; c < NK; ++c) arg[3][c] = yt[Keep::idx[c]];
+    rhs(std::false_type{}, yt, tp, k, none);
 #pragma unroll
-    for (int c = 0; c < 12; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
+    for (int c = 0; c < ND; ++c) y[c] = __builtin_fma(h6, k[c], acc[c]);
   }
   const unsigned off = (unsigned)s << 3;               // byte offset of this lane inside a row of a struct-of-arrays output (S < 2^29)
   if (a.defect) {
@@ -81,71 +100,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     // base stages would not fit two wavefronts per SIMD
     char* drow = (char*)a.defect;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) __builtin_nontemporal_store(y[c] - a.X[c * a.ldx + node + 1], (double*)(drow + (long)c * a.ldd * 8 + off));
+    for (int c = 0; c < ND; ++c) __builtin_nontemporal_store(y[c] - a.X[c * a.ldx + node + 1], (double*)(drow + (long)c * a.ldd * 8 + off));
   }
   if (a.errors) a.errors[s] = 0.0;
   if (a.nacc) a.nacc[s] = a.steps;
   if (a.nrej) a.nrej[s] = 0;
 
   // the four stage matrices
-  VarCoef12 vc[4];
+  Coef vc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    double ya[12], dead[12];
+    double ya[ND], dead[ND];
 #pragma unroll
-    for (int c = 0; c < 12; ++c) ya[c] = 0.0;
+    for (int c = 0; c < ND; ++c) ya[c] = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(arg[j][c]));   // opaque: or the compiler merges this evaluation back into the step's
+    for (int c = 0; c < NK; ++c) asm volatile("" : "+v"(arg[j][c]));   // opaque: or the compiler merges this evaluation back into the step's
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { ya[c] = arg[j][c]; ya[9 + c] = arg[j][3 + c]; }
-    rhs12<PM, true>(ya, tp, dead, vc[j]);
+    for (int c = 0; c < NK; ++c) ya[Keep::idx[c]] = arg[j][c];
+    rhs(std::true_type{}, ya, tp, dead, vc[j]);
   }
-  // the twelve columns, one after the other, through them
-  char* prow = (char*)a.Phi;                            // row (col * 12 + r) of Phi starts at prow: uniform, advanced by scalar adds
+  // the columns, one after the other, through them
+  char* prow = (char*)a.Phi;                            // row (col * ND + r) of Phi starts at prow: uniform, advanced by scalar adds
   const long row_bytes = a.ldp * 8;
-  for (int col = 0; col < 12; ++col) {
-    double c0[12], ct[12], dc[12], acc[12];
+  auto var_col = [&](const Coef& v, const double (&c)[ND], double (&dc)[ND]) {
+    if constexpr (ND == 12) var_col12(v, w2, c, dc);
+    else var_col14(v, w2, c, dc);
+  };
+  for (int col = 0; col < ND; ++col) {
+    double c0[ND], ct[ND], dc[ND], acc[ND];
 #pragma unroll
-    for (int r = 0; r < 12; ++r) c0[r] = (r == col) ? 1.0 : 0.0;
-    var_col12(vc[0], w2, c0, dc);
+    for (int r = 0; r < ND; ++r) c0[r] = (r == col) ? 1.0 : 0.0;
+    var_col(vc[0], c0, dc);
 #pragma unroll
-    for (int r = 0; r < 12; ++r) { acc[r] = __builtin_fma(h6, dc[r], c0[r]); ct[r] = __builtin_fma(h2, dc[r], c0[r]); }
-    var_col12(vc[1], w2, ct, dc);
+    for (int r = 0; r < ND; ++r) { acc[r] = __builtin_fma(h6, dc[r], c0[r]); ct[r] = __builtin_fma(h2, dc[r], c0[r]); }
+    var_col(vc[1], ct, dc);
 #pragma unroll
-    for (int r = 0; r < 12; ++r) { acc[r] = __builtin_fma(h3, dc[r], acc[r]); ct[r] = __builtin_fma(h2, dc[r], c0[r]); }
-    var_col12(vc[2], w2, ct, dc);
+    for (int r = 0; r < ND; ++r) { acc[r] = __builtin_fma(h3, dc[r], acc[r]); ct[r] = __builtin_fma(h2, dc[r], c0[r]); }
+    var_col(vc[2], ct, dc);
 #pragma unroll
-    for (int r = 0; r < 12; ++r) { acc[r] = __builtin_fma(h3, dc[r], acc[r]); ct[r] = __builtin_fma(h, dc[r], c0[r]); }
-    var_col12(vc[3], w2, ct, dc);
+    for (int r = 0; r < ND; ++r) { acc[r] = __builtin_fma(h3, dc[r], acc[r]); ct[r] = __builtin_fma(h, dc[r], c0[r]); }
+    var_col(vc[3], ct, dc);
 #pragma unroll
-    for (int r = 0; r < 12; ++r) {
+    for (int r = 0; r < ND; ++r) {
       __builtin_nontemporal_store(__builtin_fma(h6, dc[r], acc[r]), (double*)(prow + off));
       prow += row_bytes;
     }
   }
 }
 
-template <int PM>
-static hipError_t launch_stream_one(const IndirectArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((k_indirect_stream<PM, 2>), dim3((a.S + 63) / 64), dim3(64), 0, st, a);
-  return hipGetLastError();
-}
-
 bool indirect_stm_stream_available(int ndim, int method, int steps, long S) {
-  return ndim == 12 && method == M_RK4 && steps == 1 && S < (1L << 29);
+  return (ndim == 12 || ndim == 14) && method == M_RK4 && steps == 1 && S < (1L << 29);
 }
 
-hipError_t launch_indirect_stm_stream(int pm, const IndirectArgs& a0, hipStream_t st) {
-  if (a0.S <= 0) return hipSuccess;
-  if (a0.steps != 1 || !a0.Phi) return hipErrorInvalidValue;
-  IndirectArgs a = a0;
-  a.class_filter = single_class(pm) ? 0 : 1;
-  hipError_t e = hipSuccess;
-  if (e == hipSuccess && (pm & (1 << PM_P0))) e = launch_stream_one<PM_P0>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_P1))) e = launch_stream_one<PM_P1>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_P2))) e = launch_stream_one<PM_P2>(a, st);
-  if (e == hipSuccess && (pm & (1 << PM_PGEN))) e = launch_stream_one<PM_PGEN>(a, st);
-  return e;
+// One launch whatever the batch's control laws (PM_ANY): mixed-class batches used to be one launch per class.
+hipError_t launch_indirect_stm_stream(int ndim, int pm, const IndirectArgs& a, hipStream_t st) {
+  (void)pm;
+  if (a.S <= 0) return hipSuccess;
+  if (a.steps != 1 || !a.Phi || (ndim != 12 && ndim != 14)) return hipErrorInvalidValue;
+  const dim3 grid((a.S + 63) / 64);
+  if (ndim == 12) hipLaunchKernelGGL((k_indirect_stream<12, 2>), grid, dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((k_indirect_stream<14, 1>), grid, dim3(64), 0, st, a);
+  return hipGetLastError();
 }
 
 }  // namespace lto

@@ -656,10 +656,10 @@ static void warm_filled(lto_indirect_plan* p, int which, const IndirectArgs& a) 
 
 int lto_indirect_plan_set_cols_per_lane(lto_indirect_plan* p, int cols) {
   if (!p) return LTO_ENULL;
-  if (cols == 12) {
-    if (!indirect_stm_stream_available(p->ndim, p->integ.method, p->integ.steps, p->S))
-      return set_err(p->ctx, LTO_EINVAL, "cols_per_lane = 12 (the whole STM in the segment's lane) is built for 12-dim RK4 plans with ONE step per segment");
-  } else if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2, 3 or 12");
+  if (cols == 12 || cols == 14) {
+    if (cols != p->ndim || !indirect_stm_stream_available(p->ndim, p->integ.method, p->integ.steps, p->S))
+      return set_err(p->ctx, LTO_EINVAL, "cols_per_lane = ndim (12 or 14: the whole STM in the segment's lane) is built for RK4 plans with ONE step per segment");
+  } else if (cols != 0 && cols != 1 && cols != 2 && cols != 3) return set_err(p->ctx, LTO_EINVAL, "cols_per_lane must be 0, 1, 2, 3 or the plan's dimension");
   if (p->ndim == 14 && cols == 3) return set_err(p->ctx, LTO_EUNSUPPORTED, "14 STM columns do not split into groups of 3: use 0 (auto), 1 or 2");
   if (p->ndim == 12 && cols == 2) return set_err(p->ctx, LTO_EUNSUPPORTED, "two columns per lane are not built for 12-dim plans (removed in round 6: one column wins up to 8 192 segments, three above): use 0 (auto), 1 or 3");
   p->cols_per_lane = cols;
@@ -895,9 +895,9 @@ int lto_indirect_jacobian_dev(lto_indirect_plan* p, void* stream, const double* 
   else if (kern == LTO_KERNEL_PIPE48) e = launch_indirect_stm_pipe48(p->ndim, p->pm, a, seg44, st);
   else if (kern == LTO_KERNEL_PIPE32) e = launch_indirect_stm_pipe32(p->ndim, p->pm, a, st);
   else if (kern == LTO_KERNEL_LANE) e = launch_indirect_stm_lane(p->pm, a, st);
-  else if (p->ndim == 12 && !a.order && (p->cols_per_lane == 12 || (p->cols_per_lane == 0 && p->S >= kStreamMinSegments &&
-                                                          indirect_stm_stream_available(12, p->integ.method, p->integ.steps, p->S))))
-    e = launch_indirect_stm_stream(p->pm, a, st);      // one RK4 step on a full chip: lane = segment, HBM-bound (kernels_indirect_stream.hip)
+  else if (!a.order && (p->cols_per_lane == p->ndim || (p->cols_per_lane == 0 && p->S >= kStreamMinSegments &&
+                                                        indirect_stm_stream_available(p->ndim, p->integ.method, p->integ.steps, p->S))))
+    e = launch_indirect_stm_stream(p->ndim, p->pm, a, st);   // one RK4 step on a full chip: lane = segment, HBM-bound (kernels_indirect_stream.hip)
   else e = (p->ndim == 12) ? launch_indirect_stm(p->pm, p->integ.method, p->cols_per_lane, a, st)
                            : launch_indirect14_stm(p->pm, p->integ.method, p->cols_per_lane, a, st);
   if (e == hipSuccess && staged && !blocks) e = launch_pack_soa(p->d_pa, 144, p->S, a.Phi, a.ldp, st);

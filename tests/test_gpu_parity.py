@@ -1973,7 +1973,7 @@ def test_one_step_whole_segment_lanes_vs_oracle_and_column_groups(gpu_ctx, oracl
 
 def test_one_step_whole_segment_lanes_choice_and_misuse(gpu_ctx):
     """AUTO takes the whole-segment lanes for one-step RK4 plans from 65 536 segments (checked through the results: they are the
-    forced form's bit for bit); cols_per_lane = 12 is refused for plans it is not built for (more than one step, 14-dim, 13-stage
+    forced form's bit for bit); cols_per_lane = 12 is refused for plans it is not built for (more than one step, 14-dim -- 14 there --, 13-stage
     integrators); a mixed-class batch is swept by one launch per class."""
     import torch
     n, B = 1025, 64                                    # 65 536 segments
@@ -1996,6 +1996,7 @@ def test_one_step_whole_segment_lanes_choice_and_misuse(gpu_ctx):
     S1 = n - 1                                                                                # copies of a trajectory: same bits wherever they sit
     assert torch.equal(res[1][0][:, :S1], res[1][0][:, 4 * S1:5 * S1])
     plan.close()
+    # (14-dim one-step plans have their own whole-segment form since round 6, named by cols_per_lane = 14: 12 is refused for them)
     for kw, ndim in ((dict(method=lto.RK4, steps=2), 12), (dict(method=lto.RK4, steps=1), 14), (dict(method=lto.DOP853_ADAPTIVE), 12)):
         pl = lto.IndirectPlan(gpu_ctx, 30, 1, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), lto.integrator(**kw), ndim=ndim)
         with pytest.raises(lto._lib.LtoError):

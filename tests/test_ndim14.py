@@ -138,3 +138,47 @@ def test_gpu14_reference_integrator_kernels_for_the_thrust_limited_laws(gpu_ctx,
     with pytest.raises(lto.LtoError):
         p2.set_defect_lanes(4)
     p2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pcase", ["p1_rho1", "p1_rho1e-2", "p2_unclamped", "p2_clamped", "p1.5", "p0"])
+def test_gpu14_one_step_whole_segment_lanes(gpu_ctx, oracle, pcase):
+    """Round 6: RK4 with ONE step per segment and the whole 14x14 STM in the segment's own lane (k_indirect_stream<14, PM>,
+    cols_per_lane = 14) -- the 14-dim form of SURVEY 8d's HBM-bound corner.  Defect and Phi equal the oracle's dual-number
+    derivative of the same one-step map and the per-(segment, column group) kernel's (same functions on the same operands: round-off),
+    on a ragged batch of three trajectories x 333 segments with a mixed law in one of them; every control-law class."""
+    import torch
+    p, rho, thr, lam = CASES[pcase]
+    n, B = 334, 3
+    XC, T = synth.indirect_problem(n, n_batch=B, seed=31, dt_seg=0.01, lam_sigma=lam)
+    S1, S = n - 1, (n - 1) * B
+    X = np.zeros((14, n, B), order="F")
+    X[:6] = XC[:6]; X[6] = 1000.0 - 0.03 * np.arange(n)[:, None]; X[7:13] = XC[6:]; X[13] = 0.25
+    ps = [p, p, 1.0]                                              # the third trajectory always smooth-switch: two classes in one launch unless p = 1
+    prm_l = [[MU, DU, TU, thr, 2000.0, 1.0, ps[b], rho] for b in range(B)]
+    plan = lto.IndirectPlan(gpu_ctx, n, B, [lto.make_params(*q) for q in prm_l], lto.integrator(lto.RK4, steps=1), ndim=14)
+    Xd = torch.from_numpy(synth.to_soa_nodes(X)).cuda()
+    td = torch.from_numpy(np.ascontiguousarray(T.T.reshape(-1))).cuda()
+    out = {}
+    with pytest.raises(lto.LtoError):
+        plan.set_cols_per_lane(12)                               # the 12-dim plans' value
+    for cols in (14, 2):
+        plan.set_cols_per_lane(cols)
+        Phi = torch.full((196, S), float("nan"), dtype=torch.float64, device="cuda")
+        d = torch.full((14, S), float("nan"), dtype=torch.float64, device="cuda")
+        plan.jacobian(Xd, n * B, td, B, Phi, S, d, S)
+        torch.cuda.synchronize()
+        assert plan.last_kernel() == "per-lane"
+        out[cols] = (Phi.cpu().numpy(), d.cpu().numpy())
+    plan.close()
+    P14, d14 = out[14]
+    assert np.all(np.isfinite(P14)) and np.all(np.isfinite(d14))
+    assert np.abs(P14 - out[2][0]).max() <= 1e-14 * np.abs(out[2][0]).max()
+    assert np.abs(d14 - out[2][1]).max() <= 1e-13                # (the mass row is O(1000))
+    for b in range(B):
+        P_o, d_o, rc = oracle.indirect14(X[:, :, b], T[:, b], prm_l[b], oracle.RK4, 1)
+        assert rc == 0
+        sl = slice(b * S1, (b + 1) * S1)
+        Pg = P14[:, sl].reshape(14, 14, S1).transpose(1, 0, 2)
+        assert np.linalg.norm(d14[:, sl] - d_o) / np.linalg.norm(d_o + X[:, 1:, b]) < 1e-13
+        assert np.abs(Pg - P_o).max() < 1e-12 * np.abs(P_o).max()
