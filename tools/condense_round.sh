@@ -21,7 +21,8 @@ q $S c5 "k_indirect_defect4<1, 12>"
 q $S c5_stm "k_indirect_coop2<" - "k_node_records"
 q $S c2_ndim12_dop853 "k_indirect_coop2<" c2_dop853
 q $S c2_dop853 "k_indirect_coop2_14" c2_ndim14_dop853
-q $S hbm_ndim12 "k_indirect_stream" hbm
+q $S hbm_ndim12 "k_indirect_stream<12" hbm
+q $S hbm "k_indirect_stream<14" hbm14
 q $S newton_bvp_chunk_first "k_bvp_chunk<12, true" newton
 q $S newton_bvp_chunk "k_bvp_chunk<12, false" newton
 q $S newton_bvp_tail "k_bvp_tail<12" newton

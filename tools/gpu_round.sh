@@ -15,6 +15,7 @@ tail -3 "$OUT/pytest_gpu.log"
 T0=$SECONDS; python bench.py --gpus 1 --steps 20 --warmup 5 --detail "$OUT/bench_c2_verbose.json" 2>"$OUT/bench_c2_driver.err" > "$OUT/bench_c2_driver.json"; echo "driver line: $((SECONDS - T0)) s wall, $(tail -1 "$OUT/bench_c2_driver.json" | wc -c) bytes"; last "$OUT/bench_c2_driver.json"
 python bench.py --no-cpu-baseline --no-configs 2>/dev/null > "$OUT/bench_c2_200.json"; last "$OUT/bench_c2_200.json"
 python bench.py --workload hbm --ndim 12 --segments 1048576 --no-cpu-baseline --live-traffic on --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_hbm.json"; last "$OUT/bench_hbm.json"
+python bench.py --workload hbm --ndim 14 --segments 1048576 --no-cpu-baseline --live-traffic on --steps 20 --warmup 3 2>/dev/null > "$OUT/bench_hbm14.json"; last "$OUT/bench_hbm14.json"   # round 6: the 14-dim form of the whole-segment one-step kernel
 python bench.py --segments 8192 --no-cpu-baseline 2>/dev/null > "$OUT/bench_c2_8192.json"; last "$OUT/bench_c2_8192.json"    # 32-segment pipeline (AUTO above one round)
 python bench.py --workload c3 --cpu-seconds 5 2>/dev/null > "$OUT/bench_c3.json"; last "$OUT/bench_c3.json"
 python bench.py --ndim 12 --method dop853 --no-cpu-baseline --steps 50 2>/dev/null > "$OUT/bench_c2_dop853.json"; last "$OUT/bench_c2_dop853.json"
@@ -40,6 +41,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5_stm" -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c5" -- python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_c5.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_newton" -- python bench.py --workload newton --pmc-child --steps 100 --warmup 5 > "$OUT/prof_newton.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_hbm" -- python bench.py --workload hbm --ndim 12 --segments 1048576 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_hbm.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_hbm14" -- python bench.py --workload hbm --ndim 14 --segments 1048576 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_hbm14.log" 2>&1
 fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
 # PMC passes for EVERY workload that has a roofline row, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one
@@ -60,6 +62,7 @@ pmc_passes c5_stm --workload c5_stm
 pmc_passes c2_ndim12_dop853 --ndim 12 --method dop853
 pmc_passes c2_dop853 --ndim 14 --method dop853
 pmc_passes hbm_ndim12 --workload hbm --ndim 12 --segments 1048576
+pmc_passes hbm --workload hbm --ndim 14 --segments 1048576
 pmc_passes newton --workload newton --pmc-child      # the Newton iteration's kernels: k_bvp_chunk / _tail / _backchunk, the sweeps, the norms
 fi
 find "$OUT" -name "*.csv" | wc -l
