@@ -159,7 +159,7 @@ def test_design_table_is_the_one_generated_from_the_profiles():
     assert block == text.strip()
     assert open(os.path.join(ROOT, "profiles", "r06z_table.md")).read().strip() == text.strip()
     rows = [ln for ln in text.splitlines()[2:]]
-    assert len(rows) == len(dt.ROWS) == 10 and all("--" not in r.split("|")[4] for r in rows)      # every row has its rocprofv3 average
+    assert len(rows) == len(dt.ROWS) == 11 and all("--" not in r.split("|")[4] for r in rows)      # every row has its rocprofv3 average
     # the contract row's fraction from its rocprofv3 average: 4 096 segments x 569 600 flops / average / 78.6 TFLOP/s
     avg_us, calls, name = dt.kernel_avg("r06z", "c2", "k_indirect_pipe8<14")
     assert calls > 1000 and "pipe8<14" in name
