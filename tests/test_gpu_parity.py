@@ -195,6 +195,31 @@ def test_indirect_stm_cols_per_lane_agree(gpu_ctx, cols, pp):
     assert np.abs(out[cols][1] - out[1][1]).max() < 1e-13
 
 
+def test_per_lane_auto_goes_from_one_column_to_three_above_8192_segments(gpu_ctx):
+    """Round 6: the per-lane RK4 STM kernel (plans with fewer than six steps) runs one column per lane up to 8 192 segments and three
+    above (tools/probe_cols.py, profiles/r06_probe_cols.txt: the two-column form in between was dominated and is gone) -- checked
+    through the results: AUTO's are the forced grouping's bit for bit on either side of the boundary, and differ from the other's."""
+    import torch
+    for S, auto_cols, other in ((8192, 1, 3), (8193, 3, 1)):
+        n = S + 1
+        XC, T = synth.indirect_problem(n, seed=6)
+        X = torch.from_numpy(synth.to_soa_nodes(XC)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(T[:, 0])).cuda()
+        plan = lto.IndirectPlan(gpu_ctx, n, 1, lto.make_params(MU, DU, TU, 0.05, 1000.0, 1.0, 1.0, 1.0), lto.integrator(lto.RK4, steps=3))
+        res = {}
+        for cols in (0, auto_cols, other):
+            plan.set_cols_per_lane(cols)
+            Phi = torch.zeros(144, S, dtype=torch.float64, device="cuda"); d = torch.zeros(12, S, dtype=torch.float64, device="cuda")
+            plan.jacobian(X, n, t, 1, Phi, S, d, S)
+            torch.cuda.synchronize()
+            assert plan.last_kernel() == "per-lane"
+            res[cols] = Phi
+        plan.close()
+        assert torch.equal(res[0], res[auto_cols]), S
+        assert not torch.equal(res[0], res[other]), S                       # (the groupings differ in the last bits: fused vs built matrices)
+        assert float((res[0] - res[other]).abs().max()) <= 1e-12 * float(res[0].abs().max())
+
+
 def test_indirect_golden_scipy_flows(gpu_ctx):
     """HIP adaptive integrators vs the committed scipy DOP853 (1e-13) vectors: 5e-13 absolute."""
     cases = load("flows_scipy.json")["cases"]
