@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks, lto_last_call_order, lto_indirect_auto_kernel, lto_indirect_plan_set_output_layout; LTO_KERNEL_PIPE is now LTO_KERNEL_DIRECT_PIPE (same value), LTO_KERNEL_PIPE6_REMOVED is gone (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
+#define LTO_VERSION 102 /* 0.1.2: round 6 added lto_comm_rccl_ranks, lto_last_call_order, lto_indirect_auto_kernel, lto_indirect_plan_set_output_layout; LTO_KERNEL_PIPE is now LTO_KERNEL_DIRECT_PIPE (same value), LTO_KERNEL_PIPE6_REMOVED is gone; lto_indirect_plan_set_cols_per_lane: 14 names the whole-segment one-step form of 14-dim plans, 2 is refused for 12-dim plans (0.1.1, round 5: LTO_ENOMEM, LTO_KERNEL_LANE, lto_indirect_plan_staging, lto_comm_set_kernel_payload, lto_kernel_lane_round_us) */
 
 /* error codes */
 #define LTO_OK 0
